@@ -1,0 +1,236 @@
+"""CPU tests: the oracle restatement vs the golden vectors the reference itself produced, and vs the
+known-answer values KAT-1..KAT-11 of SURVEY.md §8c.  This is what pins the oracle."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import golden, T, state_from_fixture, assert_close
+import closed_form as CF
+from oracle import blocks as OB, nets as ON, losses as OL, metrics as OM, specs as OS
+
+TOL = 2e-5
+
+
+def _run(fn, sd, x, extras=()):
+    x = x.clone().requires_grad_(True)
+    extras = [e.clone().requires_grad_(True) for e in extras]
+    leaves = {k: v for k, v in sd.items() if v.dtype.is_floating_point and not k.endswith(('running_mean', 'running_var'))}
+    for v in leaves.values():
+        v.requires_grad_(True)
+    y = fn(x, *extras)
+    return x, extras, leaves, y
+
+
+BLOCKS = {
+    'F1_conv2dbnrelu_k33': lambda sd, tr: (lambda x: OB.conv2d_bn_relu(sd, '', x, tr)),
+    'F1_conv2dbnrelu_k31': lambda sd, tr: (lambda x: OB.conv2d_bn_relu(sd, '', x, tr)),
+    'F1_conv2dbnrelu_k13': lambda sd, tr: (lambda x: OB.conv2d_bn_relu(sd, '', x, tr)),
+    'F2_convbnrelu': lambda sd, tr: (lambda x: OB.conv_bn_relu(sd, '', x, tr)),
+    'F3_decoderv1': lambda sd, tr: (lambda x: OB.decoder_block_v1(sd, '', x, tr)),
+    'F3_decoderv2_deconv': lambda sd, tr: (lambda x: OB.decoder_block_v2(sd, '', x, tr, True)),
+    'F3_decoderv2_upsample': lambda sd, tr: (lambda x: OB.decoder_block_v2(sd, '', x, tr, False)),
+    'F3_deconvconv2dbnrelu': lambda sd, tr: (lambda x: OB.deconv_conv2d_bn_relu(sd, '', x, tr)),
+    'F4_decoderblock_skip': lambda sd, tr: (lambda x, e: OB.decoder_block(sd, '', x, e, tr)),
+    'F4_decoderblock_noskip': lambda sd, tr: (lambda x: OB.decoder_block(sd, '', x, None, tr)),
+    'F4_channel_se': lambda sd, tr: (lambda x: OB.channel_se(sd, '', x)),
+    'F4_spatial_se': lambda sd, tr: (lambda x: OB.spatial_se(sd, '', x)),
+}
+
+
+@pytest.mark.parametrize('name', sorted(BLOCKS))
+@pytest.mark.parametrize('mode', ['train', 'eval'])
+def test_block_matches_reference(name, mode):
+    fx = golden('%s_%s' % (name, mode))
+    sd = state_from_fixture(fx)
+    extras = [T(fx['e0'])] if 'e0' in fx else []
+    x, ex, leaves, y = _run(BLOCKS[name](sd, mode == 'train'), sd, T(fx['x']), extras)
+    assert_close(y, fx['y'], TOL, 'y')
+    y.backward(T(fx['gy']))
+    assert_close(x.grad, fx['gx'], 5e-5, 'gx')
+    for i, e in enumerate(ex):
+        assert_close(e.grad, fx['ge%d' % i], 5e-5, 'ge%d' % i)
+    for k, v in leaves.items():
+        if ('g:' + k) in fx and v.grad is not None:
+            ref = fx['g:' + k]
+            if np.abs(ref).max() < 1e-5:      # conv bias in front of train-mode BN: mathematically zero
+                assert float(v.grad.abs().max()) < 1e-4, k
+            else:
+                assert_close(v.grad, ref, 2e-4, 'g:' + k)
+    for k in sd:                               # running statistics after the pass
+        if k.endswith(('running_mean', 'running_var')):
+            assert_close(sd[k], fx['s:' + k], TOL, k)
+
+
+def test_pool_upsample_ops():
+    fx = golden('F5_pool_upsample')
+    x = T(fx['x'])
+    for tag, fn in (('max2', lambda t: F.max_pool2d(t, 2, 2)), ('max3s2', lambda t: F.max_pool2d(t, 3, 2, 1)),
+                    ('avg2', lambda t: F.avg_pool2d(t, 2, 2))):
+        t = x.clone().requires_grad_(True)
+        y = fn(t)
+        y.backward(T(fx[tag + '_gy']))
+        assert_close(y, fx[tag + '_y'], 0, tag)
+        assert_close(t.grad, fx[tag + '_gx'], 1e-6, tag + ' grad')
+    for r in (2, 4, 8, 16):
+        t = T(fx['xb']).clone().requires_grad_(True)
+        y = OB.upsample_bilinear(t, r)
+        y.backward(T(fx['up%d_gy' % r]))
+        assert_close(y, fx['up%d_y' % r], 1e-6, 'up%d' % r)
+        assert_close(t.grad, fx['up%d_gx' % r], 1e-5, 'up%d grad' % r)
+
+
+@pytest.mark.parametrize('case', ['random', 'all0', 'all1', 'p1', 'ties', 'big'])
+def test_lovasz_matches_reference(case):
+    fx = golden('F6_lovasz')
+    z = T(fx[case + '_z']).clone().requires_grad_(True)
+    t = T(fx[case + '_t'])
+    loss = OL.lovasz_loss(z, t)
+    loss.backward()
+    assert abs(float(loss) - float(fx[case + '_loss'])) <= 2e-6 * max(1, abs(float(fx[case + '_loss'])))
+    if case != 'ties':
+        assert_close(z.grad, fx[case + '_gz'], 1e-5, 'grad')
+    else:   # per-element gradients are order dependent among ties; compare sums per (image, error value, label)
+        e = (1 - fx[case + '_z'] * (2 * fx[case + '_t'] - 1)).reshape(3, -1)
+        g1 = z.grad.numpy().reshape(3, -1)
+        g2 = fx[case + '_gz'].reshape(3, -1)
+        for b in range(3):
+            for v in np.unique(e[b]):
+                m = e[b] == v
+                assert abs(g1[b][m].sum() - g2[b][m].sum()) < 1e-6
+    lb = OL.lovasz_hinge(T(fx[case + '_z']), T(fx[case + '_t']).long(), per_image=False)
+    assert abs(float(lb) - float(fx[case + '_loss_batch'])) <= 3e-6 * max(1, abs(float(lb)))
+    # closed-form gradient agrees with autograd (no ties)
+    if case in ('random', 'big', 'all0', 'all1'):
+        lv, g = OL.lovasz_hinge_grad_closed_form(T(fx[case + '_z']), T(fx[case + '_t']))
+        assert abs(lv - float(fx[case + '_loss'])) < 1e-5
+        assert_close(g.float(), fx[case + '_gz'], 1e-5, 'closed form grad')
+
+
+def test_bce_dice_matches_reference():
+    fx = golden('F7_bce_dice')
+    z = T(fx['z']).clone().requires_grad_(True)
+    loss = OL.mixed_dice_bce_loss(z, T(fx['t']))
+    loss.backward()
+    assert abs(float(loss) - float(fx['loss'])) < 2e-6
+    assert_close(z.grad, fx['gz'], 1e-5, 'grad')
+    assert abs(float(OL.dice_loss(torch.sigmoid(T(fx['z'])), T(fx['t']))) - float(fx['dice'])) < 2e-6
+    assert abs(float(OL.multiclass_dice_loss(T(fx['z']), T(fx['t']))) - float(fx['mc_dice'])) < 2e-6
+
+
+def test_kat_values():
+    """KAT-1..KAT-11: RNG-free known answers captured from the reference."""
+    np.testing.assert_allclose(OL.lovasz_grad(torch.tensor([1, 0, 1, 1, 0])).numpy(), [1 / 3, 1 / 6, 1 / 4, 1 / 4, 0], atol=1e-7)
+    logits = torch.linspace(-2, 2, 64).view(2, 2, 4, 4).clone().requires_grad_(True)
+    labels = (torch.arange(64) % 3 == 0).float().view(2, 2, 4, 4)
+    l2 = OL.lovasz_hinge(logits, labels.long(), per_image=True)
+    l2.backward()
+    assert abs(float(l2) - 1.79754961) < 2e-6
+    assert abs(float(logits.grad.sum()) + 0.30850735) < 2e-6
+    assert abs(float(logits.grad.abs().sum()) - 0.96475732) < 2e-6
+    np.testing.assert_allclose(logits.grad[0, 0, 0].numpy(), [-0.0454545, 0, 0, -0.0454546], atol=2e-6)
+    assert abs(float(OL.lovasz_hinge(logits.detach(), labels.long(), per_image=False)) - 1.70986664) < 2e-6
+    assert abs(float(OL.lovasz_hinge(logits.detach(), torch.zeros_like(labels).long())) - 1.98412704) < 2e-6
+    assert abs(float(OL.mixed_dice_bce_loss(logits.detach(), labels)) - 0.88487631) < 2e-6
+    assert abs(float(OL.dice_loss(torch.sigmoid(logits.detach()), labels)) - 0.59259260) < 2e-6
+    assert abs(float(OL.multiclass_dice_loss(logits.detach(), labels)) - 0.59855360) < 2e-6
+    x = torch.arange(16.).view(1, 1, 4, 4)
+    w = torch.arange(1., 10.).view(1, 1, 3, 3)
+    bn = {'weight': torch.ones(1), 'bias': torch.zeros(1), 'running_mean': torch.zeros(1), 'running_var': torch.ones(1)}
+    sd = {'conv.weight': w, 'conv.bias': torch.zeros(1)}
+    sd.update({'batch_norm.' + k: v.clone() for k, v in bn.items()})
+    k8 = OB.conv2d_bn_relu(sd, '', x, False).flatten() * (1 + 1e-5) ** 0.5
+    np.testing.assert_allclose(k8.numpy(), [51, 96, 123, 135, 147, 192, 219, 231, 303, 348, 375, 387, 483, 528, 555, 567], rtol=1e-6)
+    sd = {'conv.0.weight': w, 'conv.0.bias': torch.zeros(1)}
+    sd.update({'conv.1.' + k: v.clone() for k, v in bn.items()})
+    k9 = OB.conv_bn_relu(sd, '', x, False).flatten() * (1 + 1e-5) ** 0.5
+    np.testing.assert_allclose(k9.numpy(), [83, 139, 178, 121, 198, 303, 348, 225, 330, 483, 528, 333, 181, 253, 274, 163], rtol=1e-6)
+    x2 = torch.arange(4.).view(1, 1, 2, 2)
+    k10 = F.conv_transpose2d(x2, w, None, 2, 1, 1).flatten()
+    np.testing.assert_allclose(k10.numpy(), [0, 4, 5, 6, 4, 16, 14, 18, 10, 24, 15, 18, 16, 39, 24, 27])
+    k11 = F.conv_transpose2d(x2, torch.arange(1., 17.).view(1, 1, 4, 4), None, 2, 1).flatten()
+    np.testing.assert_allclose(k11.numpy(), [0, 5, 6, 7, 4, 18, 24, 20, 12, 42, 48, 36, 20, 49, 54, 33])
+
+
+NETS = {'unet_resnet34_hyper': ('UNetResNet', {}), 'ternaus_resnet34_deconv': ('TernausUNetResNet', {'is_deconv': True}),
+        'ternaus_resnet34_upsample': ('TernausUNetResNet', {'is_deconv': False}),
+        'salt_unet': ('SaltUNet', {}), 'salt_linknet': ('SaltLinkNet', {})}
+
+
+@pytest.mark.parametrize('tag', sorted(NETS))
+def test_whole_model_matches_reference(tag):
+    fx = golden('F8_' + tag)
+    arch, kw = NETS[tag]
+    spec = OS.SPECS[arch](with_fc=True)
+    # key set (with aliases) equals the reference's state_dict
+    assert set(OS.expand_aliases(arch, {k: None for k in spec})) == set(fx['keys'].tolist())
+    sd = CF.state_for((k, s) for k, (s, _) in spec.items())
+    x, t = T(fx['x']), T(fx['t'])
+    with torch.no_grad():
+        logits = ON.FORWARDS[arch](sd, x, False, **kw)
+    assert_close(logits, fx['eval_logits'], 1e-4, 'eval logits')
+    assert np.array_equal((logits[:, 1] > 0).numpy().astype(np.uint8), fx['eval_mask'])
+    # one training step: loss, gradient norms, post-Adam parameter sums, BN running stats
+    train_keys = OS.trainable_keys(spec)
+    for k in train_keys:
+        sd[k].requires_grad_(True)
+    out = ON.FORWARDS[arch](sd, x, True, **kw)
+    loss = OL.lovasz_loss(out, t)
+    loss.backward()
+    assert abs(float(loss) - float(fx['train_loss'])) < 1e-4 * max(1.0, abs(float(fx['train_loss'])))
+    names = fx['param_names'].tolist()
+    amap = OS.alias_map(arch)
+    idx = {n: i for i, n in enumerate(names)}
+    checked = 0
+    for k in train_keys:
+        i = idx[k]
+        has = bool(fx['param_has_grad'][i])
+        assert (sd[k].grad is not None) == has, k
+        if has and fx['grad_norm'][i] > 1e-4:
+            gn = float(sd[k].grad.double().norm())
+            assert abs(gn - fx['grad_norm'][i]) <= 2e-3 * fx['grad_norm'][i], (k, gn, fx['grad_norm'][i])
+            checked += 1
+    assert checked > 20
+    for k in fx:
+        if k.startswith('fullgrad:'):
+            assert_close(sd[k[9:]].grad, fx[k], 2e-3, k)
+    params = [sd[k] for k in train_keys]
+    grads = [p.grad for p in params]
+    with torch.no_grad():
+        ps = [p.detach() for p in params]
+        OL.adam_l2_step(ps, grads, [torch.zeros_like(p) for p in ps], [torch.zeros_like(p) for p in ps], 1)
+    for k, p in zip(train_keys, params):
+        i = idx[k]
+        if fx['param_has_grad'][i] and fx['grad_norm'][i] > 1e-4:
+            assert abs(float(p.detach().double().norm()) - fx['post_norm'][i]) <= 1e-5 * max(fx['post_norm'][i], 1e-3), k
+    for k, s in zip(fx['bn_keys'].tolist(), fx['bn_sum'].tolist()):
+        assert abs(float(sd[k].double().sum()) - s) <= 1e-4 * max(1.0, abs(s)), k
+
+
+def test_tta_post_metric():
+    fx = golden('F9_tta')
+    for i, (ud, lr, rot) in enumerate(fx['specs'].tolist()):
+        s = {'ud_flip': bool(ud), 'lr_flip': bool(lr), 'rotation': int(rot)}
+        np.testing.assert_array_equal(OM.tta_transform(fx['img'], s), fx['fwd%d' % i])
+        np.testing.assert_array_equal(OM.tta_inverse(fx['pred'][i % 4], s), fx['inv%d' % i])
+    assert [tuple(sorted(d.items())) for d in OM.tta_specs(True, True)] == \
+        [tuple(sorted(d.items())) for d in [{'ud_flip': False, 'lr_flip': False, 'rotation': 0},
+                                            {'ud_flip': True, 'lr_flip': True, 'rotation': 0},
+                                            {'ud_flip': True, 'lr_flip': False, 'rotation': 0},
+                                            {'ud_flip': False, 'lr_flip': True, 'rotation': 0}]]
+    fx = golden('F10_post_metric')
+    np.testing.assert_array_equal(OM.crop_image(fx['p128'], (101, 101)), fx['crop101'])
+    assert OM.crop_image(fx['p128'], (101, 101)).shape == (2, 101, 101)
+    np.testing.assert_array_equal(np.array(OM.crop_pad_sequence(27, 27)), fx['crop_seq_27'])
+    np.testing.assert_array_equal(np.array(OM.crop_pad_sequence(155, 155)), fx['crop_seq_155'])
+    np.testing.assert_allclose(OM.sigmoid(fx['p128'][:, :4, :4]), fx['sigmoid'], rtol=1e-7)
+    np.testing.assert_array_equal(OM.binarize(OM.sigmoid(fx['p128'])), fx['binarize'])
+    np.testing.assert_array_equal(OM.binarize(OM.sigmoid(fx['p128'])), (fx['p128'][1] > 0).astype(np.uint8))
+    np.testing.assert_allclose(OM.add_depth_channels(fx['depth_in'].copy()), fx['depth_out'], rtol=1e-6)
+    for v, it in zip(fx['iou_values'], fx['iout_values']):
+        assert abs(sum(1.0 if v >= th else 0.0 for th in OM.THRESHOLDS) / 10 - it) < 1e-12
+    e = np.zeros((5, 5), np.uint8)
+    a = e.copy(); a[:2] = 1
+    b = e.copy(); b[1:3] = 1
+    assert OM.iou_single(e, e) == 1.0 and OM.iou_single(a, e) == 0.0 and OM.iou_single(e, a) == 0.0
+    assert abs(OM.iou_single(a, b) - 5 / 15) < 1e-12
