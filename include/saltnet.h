@@ -1,0 +1,518 @@
+/* saltnet.h — C-ABI of the MI355X-native U-Net hot path (libsaltnet_hip.so, gfx950).
+ *
+ * The reference (neptune-ai/open-solution-salt-identification) is pure Python on PyTorch; the
+ * arithmetic this library replaces is reached from it through torch operator calls inside the
+ * nn.Module classes cited next to each entry point (paths relative to the reference's
+ * common_blocks/).  A maintainer binds these symbols with ctypes; there are no
+ * torch types in any signature: plain pointers to device memory, sizes and a HIP stream.
+ *
+ * Conventions
+ *   - Every operator is `int salt_<op>(const salt_<op>_args*, void* stream)`; 0 = success,
+ *     otherwise a SALT_E_* code or a hipError_t (> 0).  `stream` is a hipStream_t (NULL = default).
+ *   - The library never allocates or frees device memory; workspaces are passed in.
+ *   - Activations are NHWC, element type given by `dtype` (SALT_F32 / SALT_BF16).  A `salt_view`
+ *     describes a [B,H,W,C] tensor whose pixels are `cs` elements apart (cs >= C), so a channel
+ *     slice of a wider buffer (a "concat-free" skip connection) is a view, not a copy.
+ *   - Parameters, gradients, statistics and losses are fp32.
+ *   - This header is parsed by the Python host (salt_amd/_abi.py) to build the ctypes structures:
+ *     keep one field per line, only the scalar/array/view forms used below.
+ */
+#ifndef SALTNET_H
+#define SALTNET_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SALT_F32 0
+#define SALT_BF16 1
+
+#define SALT_OK 0
+#define SALT_E_BADARG -1
+#define SALT_E_UNSUPPORTED -2
+#define SALT_E_LDS -3
+
+#define SALT_MAX_TAPS 16
+
+typedef struct {
+    void* p;      /* device pointer to element [0,0,0,0] of the view */
+    int B;
+    int H;
+    int W;
+    int C;        /* channels in the view */
+    int cs;       /* pixel stride in elements */
+} salt_view;
+
+/* ------------------------------------------------------------------ library / device info */
+int salt_abi_version(void);                 /* bumps when any struct below changes */
+int salt_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name_len);
+int salt_abi_struct_sizes(int* out, int n); /* sizeof of every struct below, declaration order */
+const char* salt_last_error(void);          /* text for the last non-zero return on this thread */
+
+/* ------------------------------------------------------------------ implicit-GEMM convolution
+ * One kernel family serves nn.Conv2d 3x3/1x1 (stride 1|2, zero pad: unet_models.py:24, torchvision
+ * BasicBlock/Bottleneck; replicate pad top/right: architectures/base.py:21-27), one output-parity
+ * phase of nn.ConvTranspose2d k3/k4 s2 (unet_models.py:44,60; base.py:48-49), and their
+ * data-gradients (same kernel, transposed packed weights, mirrored taps).
+ *   out[b, oy*out_step+out_oy, ox*out_step+out_ox, n] (+)= epi( sum_t sum_c
+ *        X[b, pad(oy*in_step + tap_dy[t]), pad(ox*in_step + tap_dx[t]), c] * Wp[t][n][c] )
+ *   epi(v) = relu?( (v + bias[n]) * scale[n] + shift[n] )        (each part optional)
+ * Wp is the packed layout produced by salt_pack_conv_weight: [ceil(Cin/KC)][ntaps][Cout][KC],
+ * KC = 64 bytes of channels (16 f32 / 32 bf16), zero padded.
+ * stats (optional): per output-tile-wave partial (sum, M2 about the partial's own mean, count) of
+ * the stored value per channel, for train-mode BatchNorm (deterministic: no atomics).
+ */
+typedef struct {
+    int dtype;
+    salt_view x;
+    const void* w;            /* packed weights */
+    int ntaps;
+    int tap_dy[SALT_MAX_TAPS];
+    int tap_dx[SALT_MAX_TAPS];
+    int in_step;              /* 1 | 2 */
+    int pad_mode;             /* 0 zero, 1 clamp (replicate) */
+    salt_view y;              /* FULL output buffer view [B,OHf,OWf,Cout] */
+    int OH;                   /* logical output grid of this launch */
+    int OW;
+    int out_step;             /* 1 | 2 */
+    int out_oy;
+    int out_ox;
+    const float* bias;        /* [Cout] or NULL */
+    const float* scale;       /* [Cout] or NULL */
+    const float* shift;       /* [Cout] or NULL */
+    int relu;
+    int accumulate;           /* y += result */
+    float* stats;             /* [nparts][2][Cout] or NULL */
+    float* stats_cnt;         /* [nparts] */
+    int stats_part0;          /* first partial index written by this launch (ConvT phases) */
+    int cfg;                  /* 0 = auto; else tile-config id (tests / tuning) */
+} salt_conv_args;
+int salt_conv(const salt_conv_args*, void* stream);
+/* number of stats partials a launch with these args writes (host sizes the workspace with it) */
+int salt_conv_stats_parts(const salt_conv_args*);
+
+/* weight gradient of the same family:
+ *   dW[t][a][b] = sum_{pixels p of P} P[p, a] * Q[pad(p*q_step + tap[t]), b]
+ * conv:  P = dY (a = cout), Q = X (b = cin);   convT: P = X (a = cin), Q = dY (b = cout).
+ * Writes nsplit partial slabs [nsplit][ntaps][Ca][Cb] fp32 into `partials`;
+ * salt_wgrad_reduce sums them in fixed order into the reference parameter layout. */
+typedef struct {
+    int dtype;
+    salt_view p;
+    salt_view q;
+    int ntaps;
+    int tap_dy[SALT_MAX_TAPS];
+    int tap_dx[SALT_MAX_TAPS];
+    int q_step;
+    int pad_mode;
+    float* partials;
+    int nsplit;               /* as returned by salt_conv_wgrad_nsplit */
+} salt_conv_wgrad_args;
+int salt_conv_wgrad(const salt_conv_wgrad_args*, void* stream);
+int salt_conv_wgrad_nsplit(const salt_conv_wgrad_args*);
+
+typedef struct {
+    const float* partials;    /* [nsplit][ntaps][Ca][Cb] */
+    int nsplit;
+    int ntaps;
+    int Ca;
+    int Cb;
+    int KH;                   /* reference weight tensor is [Ca][Cb][KH][KW] */
+    int KW;
+    int tap_kh[SALT_MAX_TAPS];
+    int tap_kw[SALT_MAX_TAPS];
+    float* grad;              /* fp32, reference layout */
+    int accumulate;
+} salt_wgrad_reduce_args;
+int salt_wgrad_reduce(const salt_wgrad_reduce_args*, void* stream);
+
+/* fp32 master weight (reference layout) -> packed compute layout.
+ * transpose=0: Wp[chunk][t][n=d0][c=d1]  from W[d0][d1][kh][kw]   (conv forward; convT dgrad)
+ * transpose=1: Wp[chunk][t][n=d1][c=d0]                           (conv dgrad;   convT forward) */
+typedef struct {
+    int dtype;                /* of the packed copy */
+    const float* w;           /* [D0][D1][KH][KW] */
+    int D0;
+    int D1;
+    int KH;
+    int KW;
+    int ntaps;
+    int tap_kh[SALT_MAX_TAPS];
+    int tap_kw[SALT_MAX_TAPS];
+    int transpose;
+    void* wp;
+} salt_pack_conv_weight_args;
+int salt_pack_conv_weight(const salt_pack_conv_weight_args*, void* stream);
+int64_t salt_packed_weight_elems(int dtype, int ntaps, int n, int c);
+
+/* ------------------------------------------------------------------ thin-channel direct convolutions
+ * First layer (Cin <= 4: ResNet stem conv7x7 s2 p3, encoders.py:23-31 / torchvision; vanilla U-Net's
+ * first 3x3) and heads with Cout <= 4 (final 1x1 unet.py:84-87, unet_models.py:138; sSE base.py:110).
+ * These are not dense contractions; they run on the vector ALUs. */
+typedef struct {
+    int dtype;                /* dtype of y */
+    const float* x;           /* input image batch, fp32 NCHW [B,Cin,H,W] (the reference batch contract) */
+    int B;
+    int Cin;
+    int H;
+    int W;
+    const float* w;           /* fp32 master weight [Cout][Cin][K][K] */
+    int K;
+    int stride;
+    int pad;                  /* zero padding */
+    salt_view y;              /* [B,OH,OW,Cout] */
+    const float* bias;
+    const float* scale;
+    const float* shift;
+    int relu;
+    float* stats;
+    float* stats_cnt;
+} salt_conv_first_args;
+int salt_conv_first(const salt_conv_first_args*, void* stream);
+int salt_conv_first_stats_parts(const salt_conv_first_args*);
+
+typedef struct {
+    int dtype;                /* dtype of dy */
+    const float* x;
+    int B;
+    int Cin;
+    int H;
+    int W;
+    int K;
+    int stride;
+    int pad;
+    salt_view dy;
+    float* partials;          /* [nparts][Cout*Cin*K*K] */
+    int nparts;               /* as returned by salt_conv_first_wgrad_parts */
+    float* grad;              /* [Cout][Cin][K][K] */
+    int accumulate;
+} salt_conv_first_wgrad_args;
+int salt_conv_first_wgrad(const salt_conv_first_wgrad_args*, void* stream);
+int salt_conv_first_wgrad_parts(const salt_conv_first_wgrad_args*);
+
+typedef struct {
+    int dtype;
+    salt_view x;
+    const float* w;           /* [Cout][Cin] fp32, Cout <= 4 */
+    const float* bias;        /* [Cout] or NULL */
+    int Cout;
+    float* y_nchw;            /* fp32 [B,Cout,H,W] or NULL */
+    salt_view y;              /* NHWC output (used when y_nchw == NULL) */
+} salt_head1x1_args;
+int salt_head1x1(const salt_head1x1_args*, void* stream);
+
+typedef struct {
+    int dtype;
+    salt_view x;
+    const float* w;
+    int Cout;
+    const float* dy_nchw;     /* fp32 [B,Cout,H,W] */
+    salt_view dx;             /* grad wrt x */
+    int accumulate;
+    float* partials;          /* [nparts][Cout*(Cin+1)] */
+    int nparts;               /* as returned by salt_head1x1_bwd_parts */
+    float* gw;                /* [Cout][Cin] */
+    float* gb;                /* [Cout] or NULL */
+} salt_head1x1_bwd_args;
+int salt_head1x1_bwd(const salt_head1x1_bwd_args*, void* stream);
+int salt_head1x1_bwd_parts(const salt_head1x1_bwd_args*);
+
+/* ------------------------------------------------------------------ BatchNorm2d (+ReLU, +residual)
+ * torch semantics (eps 1e-5, momentum 0.1, biased batch variance for normalisation, unbiased for the
+ * running estimate): unet_models.py:25,45,61; base.py:23; torchvision BasicBlock/Bottleneck. */
+typedef struct {
+    const float* stats;       /* [nparts][2][C] */
+    const float* stats_cnt;   /* [nparts] */
+    int nparts;
+    int C;
+    const float* gamma;
+    const float* beta;
+    float* running_mean;
+    float* running_var;
+    int64_t* num_batches_tracked;   /* may be NULL */
+    float momentum;
+    float eps;
+    float* mean;              /* out [C] */
+    float* invstd;            /* out [C] */
+    float* scale;             /* out [C]: gamma*invstd */
+    float* shift;             /* out [C]: beta - mean*scale */
+} salt_bn_finalize_args;
+int salt_bn_finalize(const salt_bn_finalize_args*, void* stream);
+
+typedef struct {              /* eval mode: scale/shift from running statistics */
+    int C;
+    const float* gamma;
+    const float* beta;
+    const float* running_mean;
+    const float* running_var;
+    float eps;
+    float* scale;
+    float* shift;
+} salt_bn_fold_args;
+int salt_bn_fold(const salt_bn_fold_args*, void* stream);
+
+typedef struct {              /* a = relu?( y*scale + shift (+ res) ) */
+    int dtype;
+    salt_view y;
+    const float* scale;       /* NULL = identity */
+    const float* shift;
+    salt_view res;            /* res.p == NULL: none */
+    int relu;
+    salt_view a;
+} salt_affine_act_args;
+int salt_affine_act(const salt_affine_act_args*, void* stream);
+
+typedef struct {              /* backward of a = relu?(bn(y) (+res)) in train mode */
+    int dtype;
+    salt_view da;             /* grad wrt a */
+    salt_view a;              /* forward output (ReLU mask); a.p == NULL when relu == 0 */
+    salt_view y;              /* conv output (pre-BN) */
+    int relu;
+    const float* mean;
+    const float* invstd;
+    const float* gamma;
+    float* partials;          /* [nparts][2][C] workspace */
+    int nparts;               /* as returned by salt_bn_bwd_parts */
+    float* dgamma;            /* [C] */
+    float* dbeta;             /* [C] */
+    int accumulate_param_grads;
+    float* coef;              /* [3][C] workspace: k, c1, c2 */
+    salt_view dy;             /* out: grad wrt y */
+    salt_view dres;           /* out: grad wrt residual (masked da); dres.p == NULL: none */
+    int accumulate_dres;
+} salt_bn_bwd_args;
+int salt_bn_bwd(const salt_bn_bwd_args*, void* stream);
+int salt_bn_bwd_parts(const salt_bn_bwd_args*);
+
+typedef struct {              /* backward of a = relu(y (+res)) without BN, or plain masked copy */
+    int dtype;
+    salt_view da;
+    salt_view a;
+    salt_view dy;
+    int accumulate;
+} salt_relu_bwd_args;
+int salt_relu_bwd(const salt_relu_bwd_args*, void* stream);
+
+/* ------------------------------------------------------------------ pooling / resize / layout */
+typedef struct {              /* nn.MaxPool2d(2,2) (unet_models.py:119) */
+    int dtype;
+    salt_view x;
+    salt_view y;
+} salt_maxpool2_args;
+int salt_maxpool2(const salt_maxpool2_args*, void* stream);
+
+typedef struct {              /* gradient to the first maximal element of each window (torch rule) */
+    int dtype;
+    salt_view x;
+    salt_view dy;
+    salt_view dx;
+    int accumulate;
+} salt_maxpool2_bwd_args;
+int salt_maxpool2_bwd(const salt_maxpool2_bwd_args*, void* stream);
+
+typedef struct {              /* nn.AvgPool2d(2,2) (unet.py:62); bwd: dx = dy/4 */
+    int dtype;
+    salt_view x;
+    salt_view y;
+    int backward;             /* 0: y = avg(x);  1: x(+)= y/4 broadcast (x is the grad output) */
+    int accumulate;
+} salt_avgpool2_args;
+int salt_avgpool2(const salt_avgpool2_args*, void* stream);
+
+typedef struct {              /* bilinear xR, align_corners=False (base.py:70, unet.py:103-106 on torch 2.10) */
+    int dtype;
+    salt_view x;              /* low resolution  [B,H,W,C] */
+    salt_view y;              /* high resolution [B,H*R,W*R,C] */
+    int R;
+    int backward;             /* 0: y = up(x);  1: x (+)= up^T(y) */
+    int accumulate;
+} salt_bilinear_args;
+int salt_bilinear(const salt_bilinear_args*, void* stream);
+
+typedef struct {              /* adjoint of replicate padding: fold an extended grad back (base.py:21-27) */
+    int dtype;
+    salt_view xp;             /* [B,H+top+bottom,W+left+right,C] */
+    int top;
+    int bottom;
+    int left;
+    int right;
+    salt_view x;              /* [B,H,W,C] */
+    int accumulate;
+} salt_pad_fold_args;
+int salt_pad_fold(const salt_pad_fold_args*, void* stream);
+
+typedef struct {              /* y = a + b (or y += a when b.p == NULL); also plain copy/cast between views */
+    int dtype;
+    salt_view a;
+    salt_view b;
+    salt_view y;
+    int accumulate;
+} salt_add_args;
+int salt_add(const salt_add_args*, void* stream);
+
+typedef struct {              /* fp32 NCHW [B,C,H,W] <-> NHWC view (dtype) */
+    int dtype;
+    float* nchw;
+    salt_view nhwc;
+    int to_nhwc;              /* 1: nchw -> nhwc, 0: nhwc -> nchw */
+} salt_layout_args;
+int salt_layout(const salt_layout_args*, void* stream);
+
+/* ------------------------------------------------------------------ squeeze-excitation (base.py:82-117)
+ * out = relu( x*cSE(x) + x*sSE(x) ),  cSE = sigmoid(W2 relu(W1 gap(x)+b1)+b2),  sSE = sigmoid(w.x+b) */
+typedef struct {
+    int dtype;
+    salt_view x;
+    const float* w1;          /* [R][C] */
+    const float* b1;          /* [R] */
+    const float* w2;          /* [C][R] */
+    const float* b2;          /* [C] */
+    int R;
+    const float* ws;          /* [C] (sSE 1x1 conv weight) */
+    const float* bs;          /* [1] */
+    float* gap_partials;      /* [B][nparts][C] workspace */
+    int nparts;               /* as returned by salt_scse_parts */
+    float* gap;               /* [B][C]  (saved for backward) */
+    float* hidden;            /* [B][R]  (saved, post-ReLU) */
+    float* gate_c;            /* [B][C]  (saved) */
+    float* gate_s;            /* [B][H*W] (saved) */
+    salt_view y;
+} salt_scse_args;
+int salt_scse(const salt_scse_args*, void* stream);
+int salt_scse_parts(const salt_scse_args*);
+
+typedef struct {
+    int dtype;
+    salt_view x;
+    salt_view y;              /* forward output (ReLU mask) */
+    salt_view dy;
+    const float* w1;
+    const float* w2;
+    int R;
+    const float* ws;
+    const float* gap;
+    const float* hidden;
+    const float* gate_c;
+    const float* gate_s;
+    float* partials;          /* [B][nparts][2C+1] workspace */
+    int nparts;
+    float* g_w1;
+    float* g_b1;
+    float* g_w2;
+    float* g_b2;
+    float* g_ws;
+    float* g_bs;
+    float* dgap;              /* [B][C] workspace */
+    salt_view dx;
+    int accumulate;
+} salt_scse_bwd_args;
+int salt_scse_bwd(const salt_scse_bwd_args*, void* stream);
+
+/* ------------------------------------------------------------------ losses
+ * Lovasz hinge, per image, both channels flattened together, F.elu variant
+ * (lovasz_losses.py:81-115,21-33; models.py:326-328).  One workgroup per image: LSD radix sort of
+ * the hinge errors (stable; ties keep flat-index order), label scan, Jaccard gradient, dot. */
+typedef struct {
+    const float* logits;      /* fp32 NCHW [B,C,H,W] */
+    const float* target;      /* fp32 NCHW [B,C,H,W] in {0,1} */
+    int B;
+    int P;                    /* elements per image = C*H*W */
+    uint32_t* ws_keys;        /* [2][B][P] workspace */
+    uint32_t* ws_vals;        /* [2][B][P] workspace */
+    float* loss_per_image;    /* [B] */
+    float* loss;              /* [1]: mean over images * loss_scale */
+    float* dlogits;           /* fp32 NCHW or NULL (forward only) */
+    float loss_scale;         /* loss weight (models.py:194) and 1/world for data parallel */
+} salt_lovasz_args;
+int salt_lovasz_hinge(const salt_lovasz_args*, void* stream);
+
+/* 0.2*mean_c dice(sigmoid) + 0.9*BCEWithLogits (models.py:315-340,361-388), sums over the whole batch */
+typedef struct {
+    const float* logits;
+    const float* target;
+    int B;
+    int C;
+    int HW;
+    float dice_weight;
+    float bce_weight;
+    float* partials;          /* [nparts][4] workspace */
+    int nparts;               /* as returned by salt_bce_dice_parts */
+    float* sums;              /* [3C+1] workspace (kept for backward) */
+    float* loss;              /* [1] */
+    float* dlogits;           /* or NULL */
+    float loss_scale;
+} salt_bce_dice_args;
+int salt_bce_dice(const salt_bce_dice_args*, void* stream);
+int salt_bce_dice_parts(const salt_bce_dice_args*);
+
+/* ------------------------------------------------------------------ optimizer (models.py:74-75,289-297)
+ * torch.optim.Adam with L2-in-gradient weight decay over one flat fp32 parameter buffer. */
+typedef struct {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t n;
+    const float* hyper;       /* device [8]: lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, grad_scale */
+} salt_adam_args;
+int salt_adam(const salt_adam_args*, void* stream);
+
+typedef struct {              /* advance step counter and bias corrections on device (graph-replay safe) */
+    float* hyper;             /* as above */
+    int64_t* step;            /* device [1] */
+} salt_adam_tick_args;
+int salt_adam_tick(const salt_adam_tick_args*, void* stream);
+
+typedef struct {
+    void* p;
+    int64_t bytes;
+} salt_zero_args;
+int salt_zero(const salt_zero_args*, void* stream);
+
+/* ------------------------------------------------------------------ inference epilogue
+ * sigmoid -> inverse flip (TTA) -> mean over variants (models.py:143-144, augmentation.py:156-163,
+ * loaders.py:722-760);  flips are index permutations. */
+typedef struct {
+    const float* logits;      /* fp32 NCHW [V*B, C, H, W]: variant-major */
+    int V;
+    int B;
+    int C;
+    int H;
+    int W;
+    const int* flip_ud;       /* host arrays [V] */
+    const int* flip_lr;
+    float* prob;              /* fp32 NCHW [B,C,H,W] */
+} salt_tta_mean_args;
+int salt_tta_mean(const salt_tta_mean_args*, void* stream);
+
+typedef struct {              /* x_out[b] = flip(x[b]) for NCHW fp32 batches (TTA forward transform) */
+    const float* x;
+    int B;
+    int C;
+    int H;
+    int W;
+    int flip_ud;
+    int flip_lr;
+    float* y;
+} salt_flip_args;
+int salt_flip(const salt_flip_args*, void* stream);
+
+/* ------------------------------------------------------------------ program executor
+ * A training/inference step is a static list of the operators above.  The host builds it once per
+ * (model, batch shape); running it is one call.  capture/replay wraps it in a hipGraph. */
+typedef int (*salt_op_fn)(const void* args, void* stream);
+typedef struct {
+    salt_op_fn fn;
+    const void* args;
+} salt_program_entry;
+int salt_program_run(const salt_program_entry* entries, int n, void* stream);
+int salt_program_run_range(const salt_program_entry* entries, int begin, int end, void* stream);
+int salt_graph_capture(const salt_program_entry* entries, int n, void* stream, void** graph_exec_out);
+int salt_graph_launch(void* graph_exec, void* stream);
+int salt_graph_destroy(void* graph_exec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SALTNET_H */

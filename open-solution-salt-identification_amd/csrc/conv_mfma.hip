@@ -1,0 +1,683 @@
+// conv_mfma.hip — im2col-free direct convolution on the CDNA4 matrix cores (gfx950).
+//
+// One kernel family, parameterised by a tap list, serves every dense convolution of the path:
+//   nn.Conv2d 3x3 / 1x1, stride 1|2, zero pad           (unet_models.py:24, torchvision ResNet blocks)
+//   replicate-pad top/right 3x3 (and (k,1)/(1,k))       (architectures/base.py:21-27)
+//   one output-parity phase of ConvTranspose2d k3/k4 s2 (unet_models.py:44,60; base.py:48-49)
+//   the data-gradients of all of the above (transposed packed weights, mirrored taps)
+//   the weight-gradients (conv_wgrad_kernel below).
+//
+// Data movement (forward/dgrad): per workgroup one output tile of BM pixels x BN channels.  Per 64-byte
+// channel chunk the NHWC input HALO tile (all pixels any tap of the tile touches) and the chunk's
+// weights for all taps are staged ONCE in LDS as 64-byte rows (XOR-swizzled 16-byte slots, conflict-free
+// for ds_read_b128 A/B fragment reads); the 9 taps then re-read the same LDS pixels at shifted
+// addresses, so HBM/L2 sees each input element once per tile instead of 9 times and no im2col
+// matrix ever exists.  The inner contraction over (tap, channel) runs on MFMA:
+//   bf16: v_mfma_f32_32x32x16_bf16 (one per 16-byte k-step),  f32: 4 x v_mfma_f32_32x32x2_f32
+//   (exact f32, bitwise an fmaf chain) with the k-slots permuted so both operands are 16-byte LDS reads.
+// Epilogue: bias, optional folded-BN affine + ReLU (eval), optional accumulate, and deterministic
+// per-wave BatchNorm partial statistics (sum, M2) for train mode.
+#include "common.h"
+
+namespace {
+
+struct ConvKP {
+    const void* x; const void* w; void* y;
+    const float* bias; const float* scale; const float* shift;
+    float* stats; float* stats_cnt;
+    int B, H, W, Cin, x_cs;
+    int Cout, y_cs, OHf, OWf, OH, OW, out_step, out_oy, out_ox;
+    int ntaps; int tap_off[SALT_MAX_TAPS];
+    int in_step, pad_mode, min_dy, min_dx;
+    int th_log2, tw_log2, nb;
+    int hh, hw;
+    int tiles_y, tiles_x;
+    int nchunk, a_bytes;
+    int relu, accumulate, stats_part0;
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<float> {
+    static __device__ __forceinline__ void step(const u32x4& a, const u32x4& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<bf16_t> {
+    static __device__ __forceinline__ void step(const u32x4& a, const u32x4& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+
+// 16-byte piece load from global with channel-tail / alignment handling.
+template <typename T>
+__device__ __forceinline__ u32x4 load_piece(const T* base, int64_t off, int ch0, int C, bool vec_ok) {
+    constexpr int VE = Elem<T>::VE;
+    if (vec_ok && ch0 + VE <= C) return *reinterpret_cast<const u32x4*>(base + off);
+    float f[VE];
+#pragma unroll
+    for (int j = 0; j < VE; ++j) f[j] = (ch0 + j < C) ? Elem<T>::ld(base + off + j) : 0.f;
+    if (sizeof(T) == 4) return pack16<T>(f);
+    // bf16: repack exactly (values came from bf16, conversion is lossless)
+    return pack16<T>(f);
+}
+
+__device__ __forceinline__ int swz_addr(int row, int slot) {        // 64-byte rows, 4 x 16-byte slots
+    return row * 64 + (((slot ^ (row >> 2)) & 3) << 4);
+}
+
+constexpr int MAXA = 9;     // halo pieces per thread: P_halo*4 <= 9*256
+
+template <typename T, int MI, int NI, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvKP p) {
+    constexpr int BN = 32 * NI * WN;
+    constexpr int KCE = 64 / (int)sizeof(T);
+    constexpr int VE = Elem<T>::VE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sA = smem;
+    unsigned char* sB = smem + p.a_bytes;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int khalf = lane >> 5, l31 = lane & 31;
+
+    int tile = blockIdx.x;
+    const int txi = tile % p.tiles_x; tile /= p.tiles_x;
+    const int tyi = tile % p.tiles_y;
+    const int tbi = tile / p.tiles_y;
+    const int oy0 = tyi << p.th_log2, ox0 = txi << p.tw_log2, b0 = tbi * p.nb;
+    const int n0 = blockIdx.y * BN;
+    const int hhw = p.hh * p.hw;
+    const int phalo = p.nb * hhw;
+    const int iy0 = oy0 * p.in_step + p.min_dy, ix0 = ox0 * p.in_step + p.min_dx;
+    const T* xg = reinterpret_cast<const T*>(p.x);
+    const T* wg = reinterpret_cast<const T*>(p.w);
+    const bool x_vec = ((p.x_cs % VE) == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
+
+    // ---- per-thread halo staging pieces (fixed for the whole chunk loop)
+    int64_t a_goff[MAXA];
+    const int npa = (phalo * 4 + 255) >> 8;
+#pragma unroll
+    for (int k = 0; k < MAXA; ++k) {
+        a_goff[k] = -2;
+        if (k < npa) {
+            const int q = tid + (k << 8);
+            const int pix = q >> 2;
+            if (pix < phalo) {
+                const int bl = pix / hhw;
+                const int r = pix - bl * hhw;
+                const int hy = r / p.hw;
+                const int hx = r - hy * p.hw;
+                int iy = iy0 + hy, ix = ix0 + hx;
+                const int b = b0 + bl;
+                bool valid = b < p.B;
+                if (p.pad_mode) {
+                    iy = min(max(iy, 0), p.H - 1);
+                    ix = min(max(ix, 0), p.W - 1);
+                } else {
+                    valid = valid && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                }
+                a_goff[k] = valid ? (((int64_t)b * p.H + iy) * p.W + ix) * p.x_cs + (q & 3) * VE : -1;
+            }
+        }
+    }
+    // ---- per-lane A fragment rows (halo pixel index of the lane's output pixel, per M sub-tile)
+    int pbase[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = (wm * MI + i) * 32 + l31;
+        const int tx = m & ((1 << p.tw_log2) - 1);
+        const int ty = (m >> p.tw_log2) & ((1 << p.th_log2) - 1);
+        const int bl = m >> (p.tw_log2 + p.th_log2);
+        pbase[i] = bl * hhw + ty * p.in_step * p.hw + tx * p.in_step;
+    }
+    int nrow[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) nrow[j] = (wn * NI + j) * 32 + l31;
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nbp = p.ntaps * BN * 4;          // weight pieces per chunk
+    for (int c = 0; c < p.nchunk; ++c) {
+        const int ch_base = c * KCE;
+        __syncthreads();                        // previous chunk's fragment reads are done
+        // stage halo tile
+#pragma unroll
+        for (int k = 0; k < MAXA; ++k) {
+            if (k < npa && a_goff[k] != -2) {
+                const int q = tid + (k << 8);
+                u32x4 v = {0u, 0u, 0u, 0u};
+                const int ch0 = ch_base + (q & 3) * VE;
+                if (a_goff[k] >= 0 && ch0 < p.Cin) v = load_piece<T>(xg, a_goff[k] + ch_base, ch0, p.Cin, x_vec);
+                *reinterpret_cast<u32x4*>(sA + swz_addr(q >> 2, q & 3)) = v;
+            }
+        }
+        // stage weights of this chunk: Wp[c][t][n][KCE]
+        for (int q = tid; q < nbp; q += 256) {
+            const int row = q >> 2;                       // t*BN + n
+            const int t = row / BN, n = row - t * BN;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (n0 + n < p.Cout)
+                v = *reinterpret_cast<const u32x4*>(wg + (((int64_t)c * p.ntaps + t) * p.Cout + n0 + n) * KCE + (q & 3) * VE);
+            *reinterpret_cast<u32x4*>(sB + swz_addr(row, q & 3)) = v;
+        }
+        __syncthreads();
+        for (int t = 0; t < p.ntaps; ++t) {
+            const int toff = p.tap_off[t];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int slot = (s << 1) | khalf;
+                u32x4 a[MI], b[NI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const u32x4*>(sA + swz_addr(pbase[i] + toff, slot));
+#pragma unroll
+                for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const u32x4*>(sB + swz_addr(t * BN + nrow[j], slot));
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) Mma<T>::step(a[i], b[j], acc[i][j]);
+            }
+        }
+    }
+
+    // ---- epilogue.  C layout (32x32): col n = lane&31, row m = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    T* yg = reinterpret_cast<T*>(p.y);
+    float ssum[NI], cntf = 0.f;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) ssum[j] = 0.f;
+    int64_t yoff[MI][16];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+            const int tx = m & ((1 << p.tw_log2) - 1);
+            const int ty = (m >> p.tw_log2) & ((1 << p.th_log2) - 1);
+            const int bl = m >> (p.tw_log2 + p.th_log2);
+            const int oy = oy0 + ty, ox = ox0 + tx, b = b0 + bl;
+            const bool valid = (b < p.B) && (oy < p.OH) && (ox < p.OW) && (bl < p.nb);
+            yoff[i][r] = valid ? (((int64_t)b * p.OHf + oy * p.out_step + p.out_oy) * p.OWf + ox * p.out_step + p.out_ox) * p.y_cs : -1;
+            if (valid) cntf += 1.f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int n = n0 + nrow[j];
+        const bool nok = n < p.Cout;
+        const float bias = (nok && p.bias) ? p.bias[n] : 0.f;
+        const float sc = (nok && p.scale) ? p.scale[n] : 1.f;
+        const float sh = (nok && p.shift) ? p.shift[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = (acc[i][j][r] + bias) * sc + sh;
+                if (p.relu) v = fmaxf(v, 0.f);
+                acc[i][j][r] = v;
+                if (yoff[i][r] >= 0) {
+                    ssum[j] += v;
+                    if (nok) {
+                        T* dst = yg + yoff[i][r] + n;
+                        if (p.accumulate) v += Elem<T>::ld(dst);
+                        Elem<T>::st(dst, v);
+                    }
+                }
+            }
+        }
+    }
+    if (p.stats) {
+        cntf += __shfl_xor(cntf, 32);
+        const int part = p.stats_part0 + blockIdx.x * WM + wm;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            float s = ssum[j] + __shfl_xor(ssum[j], 32);
+            const float mean = cntf > 0.f ? s / cntf : 0.f;
+            float m2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (yoff[i][r] >= 0) { const float d = acc[i][j][r] - mean; m2 += d * d; }
+            m2 += __shfl_xor(m2, 32);
+            const int n = n0 + nrow[j];
+            if (khalf == 0 && n < p.Cout) {
+                p.stats[((int64_t)part * 2 + 0) * p.Cout + n] = s;
+                p.stats[((int64_t)part * 2 + 1) * p.Cout + n] = m2;
+            }
+        }
+        if (lane == 0 && wn == 0 && blockIdx.y == 0) p.stats_cnt[part] = cntf;
+    }
+}
+
+struct TileCfg { int id, MI, NI, WM, WN; };
+// id -> (BM, BN): 1: 128x64, 2: 256x64, 3: 128x128, 4: 128x32, 5: 64x64
+const TileCfg kCfgs[] = {{1, 2, 1, 2, 2}, {2, 2, 2, 4, 1}, {3, 2, 2, 2, 2}, {4, 1, 1, 4, 1}, {5, 1, 1, 2, 2}};
+
+struct Plan {
+    TileCfg cfg; ConvKP kp; dim3 grid; size_t lds; int parts;
+};
+
+int make_plan(const salt_conv_args* a, Plan* pl) {
+    if (!a) SALT_FAIL(SALT_E_BADARG, "null args");
+    if (!view_ok(a->x) || !view_ok(a->y) || !a->w) SALT_FAIL(SALT_E_BADARG, "conv: bad view");
+    if (a->ntaps < 1 || a->ntaps > SALT_MAX_TAPS) SALT_FAIL(SALT_E_BADARG, "conv: ntaps %d", a->ntaps);
+    if (a->in_step < 1 || a->in_step > 2 || a->out_step < 1 || a->out_step > 2) SALT_FAIL(SALT_E_BADARG, "conv: steps");
+    if (a->OH < 1 || a->OW < 1) SALT_FAIL(SALT_E_BADARG, "conv: empty output grid");
+    if ((a->OH - 1) * a->out_step + a->out_oy >= a->y.H || (a->OW - 1) * a->out_step + a->out_ox >= a->y.W)
+        SALT_FAIL(SALT_E_BADARG, "conv: output grid exceeds buffer");
+    if (a->x.B != a->y.B) SALT_FAIL(SALT_E_BADARG, "conv: batch mismatch");
+    const int Cout = a->y.C;
+    int min_dy = 1 << 30, max_dy = -(1 << 30), min_dx = 1 << 30, max_dx = -(1 << 30);
+    for (int t = 0; t < a->ntaps; ++t) {
+        min_dy = a->tap_dy[t] < min_dy ? a->tap_dy[t] : min_dy; max_dy = a->tap_dy[t] > max_dy ? a->tap_dy[t] : max_dy;
+        min_dx = a->tap_dx[t] < min_dx ? a->tap_dx[t] : min_dx; max_dx = a->tap_dx[t] > max_dx ? a->tap_dx[t] : max_dx;
+    }
+    const int64_t pixels = (int64_t)a->x.B * a->OH * a->OW;
+    // ---- tile config heuristic (overridable for tests/tuning)
+    int id = a->cfg;
+    if (id == 0) {
+        if (Cout <= 32) id = 4;
+        else if (Cout <= 64) id = (a->in_step == 1 && a->OH >= 16 && a->OW >= 16 && pixels >= 256 * 256 * 2) ? 2 : 1;
+        else id = 1;
+        const int64_t wgs = ((pixels + 127) / 128) * cdiv(Cout, 64);
+        if (id == 1 && wgs < 256) id = 5;
+    }
+    const TileCfg* cfg = nullptr;
+    for (const auto& c : kCfgs) if (c.id == id) cfg = &c;
+    if (!cfg) SALT_FAIL(SALT_E_BADARG, "conv: unknown cfg %d", id);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const int BM = 32 * cfg->MI * cfg->WM;
+        ConvKP& k = pl->kp;
+        k.tw_log2 = ilog2_ceil(a->OW) < 4 ? ilog2_ceil(a->OW) : 4;
+        int rem = ilog2_ceil(BM) - k.tw_log2;
+        k.th_log2 = ilog2_ceil(a->OH) < rem ? ilog2_ceil(a->OH) : rem;
+        k.nb = BM >> (k.tw_log2 + k.th_log2);
+        const int th = 1 << k.th_log2, tw = 1 << k.tw_log2;
+        k.hh = (th - 1) * a->in_step + (max_dy - min_dy) + 1;
+        k.hw = (tw - 1) * a->in_step + (max_dx - min_dx) + 1;
+        const int phalo = k.nb * k.hh * k.hw;
+        if (phalo * 4 > MAXA * 256) {
+            if (attempt == 0 && cfg->id != 5) { for (const auto& c : kCfgs) if (c.id == 5) cfg = &c; continue; }
+            SALT_FAIL(SALT_E_UNSUPPORTED, "conv: halo tile of %d pixels too large", phalo);
+        }
+        break;
+    }
+    pl->cfg = *cfg;
+    ConvKP& k = pl->kp;
+    const int BN = 32 * cfg->NI * cfg->WN;
+    const int KCE = a->dtype == SALT_F32 ? 16 : 32;
+    k.x = a->x.p; k.w = a->w; k.y = a->y.p;
+    k.bias = a->bias; k.scale = a->scale; k.shift = a->shift; k.stats = a->stats; k.stats_cnt = a->stats_cnt;
+    k.B = a->x.B; k.H = a->x.H; k.W = a->x.W; k.Cin = a->x.C; k.x_cs = a->x.cs;
+    k.Cout = Cout; k.y_cs = a->y.cs; k.OHf = a->y.H; k.OWf = a->y.W; k.OH = a->OH; k.OW = a->OW;
+    k.out_step = a->out_step; k.out_oy = a->out_oy; k.out_ox = a->out_ox;
+    k.ntaps = a->ntaps; k.in_step = a->in_step; k.pad_mode = a->pad_mode; k.min_dy = min_dy; k.min_dx = min_dx;
+    for (int t = 0; t < a->ntaps; ++t) k.tap_off[t] = (a->tap_dy[t] - min_dy) * k.hw + (a->tap_dx[t] - min_dx);
+    k.tiles_y = cdiv(a->OH, 1 << k.th_log2); k.tiles_x = cdiv(a->OW, 1 << k.tw_log2);
+    const int tiles_b = cdiv(a->x.B, k.nb);
+    k.nchunk = cdiv(a->x.C, KCE);
+    k.a_bytes = k.nb * k.hh * k.hw * 64;
+    k.relu = a->relu; k.accumulate = a->accumulate; k.stats_part0 = a->stats_part0;
+    pl->grid = dim3((unsigned)(tiles_b * k.tiles_y * k.tiles_x), (unsigned)cdiv(Cout, BN), 1);
+    pl->lds = (size_t)k.a_bytes + (size_t)a->ntaps * BN * 64;
+    pl->parts = tiles_b * k.tiles_y * k.tiles_x * cfg->WM;
+    if (pl->lds > 160 * 1024) SALT_FAIL(SALT_E_LDS, "conv: needs %zu bytes of LDS", pl->lds);
+    return SALT_OK;
+}
+
+template <typename T, int MI, int NI, int WM, int WN>
+int launch_cfg(const Plan& pl, hipStream_t st) {
+    auto kern = conv_mfma_kernel<T, MI, NI, WM, WN>;
+    static size_t attr_set = 0;
+    if (pl.lds > 64 * 1024 && pl.lds > attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) SALT_FAIL((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = 160 * 1024;
+    }
+    hipLaunchKernelGGL(kern, pl.grid, dim3(256), pl.lds, st, pl.kp);
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}
+
+template <typename T>
+int launch_T(const Plan& pl, hipStream_t st) {
+    switch (pl.cfg.id) {
+        case 1: return launch_cfg<T, 2, 1, 2, 2>(pl, st);
+        case 2: return launch_cfg<T, 2, 2, 4, 1>(pl, st);
+        case 3: return launch_cfg<T, 2, 2, 2, 2>(pl, st);
+        case 4: return launch_cfg<T, 1, 1, 4, 1>(pl, st);
+        case 5: return launch_cfg<T, 1, 1, 2, 2>(pl, st);
+    }
+    SALT_FAIL(SALT_E_BADARG, "conv: cfg");
+}
+
+// ------------------------------------------------------------------------------------------ weight packing
+struct PackKP {
+    const float* w; void* wp; int D0, D1, KH, KW, ntaps, transpose, N, C, nchunk;
+    int tap_kh[SALT_MAX_TAPS], tap_kw[SALT_MAX_TAPS];
+};
+template <typename T>
+__global__ void pack_weight_kernel(PackKP p) {
+    constexpr int KCE = 64 / (int)sizeof(T);
+    const int64_t total = (int64_t)p.nchunk * p.ntaps * p.N * KCE;
+    T* out = reinterpret_cast<T*>(p.wp);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int kc = (int)(i % KCE);
+        int64_t r = i / KCE;
+        const int n = (int)(r % p.N); r /= p.N;
+        const int t = (int)(r % p.ntaps);
+        const int ch = (int)(r / p.ntaps) * KCE + kc;
+        float v = 0.f;
+        if (ch < p.C) {
+            const int d0 = p.transpose ? ch : n, d1 = p.transpose ? n : ch;
+            v = p.w[(((int64_t)d0 * p.D1 + d1) * p.KH + p.tap_kh[t]) * p.KW + p.tap_kw[t]];
+        }
+        Elem<T>::st(out + i, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ weight gradient
+// dW[t][a][b] = sum_p P[p,a] * Q[pad(p*q_step + tap_t), b].  Workgroup = 64(a) x 64(b) block for all taps of
+// the launch over a slice of the pixel tiles (split-K); 4 waves as 2(a) x 2(b), each 32x32 per tap.
+struct WgradKP {
+    const void* P; const void* Q; float* partials;
+    int B, PH, PW, Ca, p_cs;        // P view (output-grid pixels)
+    int QH, QW, Cb, q_cs;
+    int ntaps; int tap_off[SALT_MAX_TAPS];
+    int q_step, pad_mode, min_dy, min_dx;
+    int th_log2, tw_log2, nb, hh, hw;
+    int tiles_y, tiles_x, ntiles, nsplit;
+    int a_blocks, b_blocks;
+};
+
+template <typename T> struct WRow { static constexpr int BYTES = 64 * (int)sizeof(T); };   // 64 channels per pixel row
+
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradKP p) {
+    constexpr int VE = Elem<T>::VE;
+    constexpr int PPR = 64 / VE;                                // 16-byte pieces per pixel row
+    constexpr int ROWB = (sizeof(T) == 2) ? 192 : 256;           // bf16 rows padded to 192 B: conflict-free tr reads
+    constexpr int BMP = 128;                                     // pixels per tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sP = smem;
+    unsigned char* sQ = smem + BMP * ROWB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wa = wave >> 1, wb = wave & 1;
+    const int blk = blockIdx.x;
+    const int ab = blk % p.a_blocks;
+    const int bb = (blk / p.a_blocks) % p.b_blocks;
+    const int split = blk / (p.a_blocks * p.b_blocks);
+    const int a0 = ab * 64, c0 = bb * 64;
+    const int hhw = p.hh * p.hw, phalo = p.nb * hhw;
+    const T* Pg = reinterpret_cast<const T*>(p.P);
+    const T* Qg = reinterpret_cast<const T*>(p.Q);
+    const bool p_vec = ((p.p_cs % VE) == 0) && ((reinterpret_cast<uintptr_t>(p.P) & 15) == 0);
+    const bool q_vec = ((p.q_cs % VE) == 0) && ((reinterpret_cast<uintptr_t>(p.Q) & 15) == 0);
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    for (int tile = split; tile < p.ntiles; tile += p.nsplit) {
+        int tt = tile;
+        const int txi = tt % p.tiles_x; tt /= p.tiles_x;
+        const int tyi = tt % p.tiles_y;
+        const int tbi = tt / p.tiles_y;
+        const int oy0 = tyi << p.th_log2, ox0 = txi << p.tw_log2, b0 = tbi * p.nb;
+        const int iy0 = oy0 * p.q_step + p.min_dy, ix0 = ox0 * p.q_step + p.min_dx;
+        __syncthreads();
+        // stage P tile: BMP pixels x 64 channels (zero outside the grid / channel range)
+        for (int q = tid; q < BMP * PPR; q += 256) {
+            const int m = q / PPR, pc = q - m * PPR;
+            const int tx = m & ((1 << p.tw_log2) - 1);
+            const int ty = (m >> p.tw_log2) & ((1 << p.th_log2) - 1);
+            const int bl = m >> (p.tw_log2 + p.th_log2);
+            const int oy = oy0 + ty, ox = ox0 + tx, b = b0 + bl;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            const int ch0 = a0 + pc * VE;
+            if (b < p.B && oy < p.PH && ox < p.PW && ch0 < p.Ca)
+                v = load_piece<T>(Pg, (((int64_t)b * p.PH + oy) * p.PW + ox) * p.p_cs + ch0, ch0, p.Ca, p_vec);
+            *reinterpret_cast<u32x4*>(sP + m * ROWB + pc * 16) = v;
+        }
+        // stage Q halo tile
+        for (int q = tid; q < phalo * PPR; q += 256) {
+            const int pix = q / PPR, pc = q - pix * PPR;
+            const int bl = pix / hhw;
+            const int r = pix - bl * hhw;
+            const int hy = r / p.hw, hx = r - hy * p.hw;
+            int iy = iy0 + hy, ix = ix0 + hx;
+            const int b = b0 + bl;
+            bool valid = b < p.B;
+            if (p.pad_mode) { iy = min(max(iy, 0), p.QH - 1); ix = min(max(ix, 0), p.QW - 1); }
+            else valid = valid && iy >= 0 && iy < p.QH && ix >= 0 && ix < p.QW;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            const int ch0 = c0 + pc * VE;
+            if (valid && ch0 < p.Cb)
+                v = load_piece<T>(Qg, (((int64_t)b * p.QH + iy) * p.QW + ix) * p.q_cs + ch0, ch0, p.Cb, q_vec);
+            *reinterpret_cast<u32x4*>(sQ + pix * ROWB + pc * 16) = v;
+        }
+        __syncthreads();
+        if constexpr (sizeof(T) == 4) {
+            // f32: v_mfma_f32_32x32x2_f32, A[i=a][k=pixel], B[k=pixel][j=b]; one dword per lane per operand.
+            const int khalf = lane >> 5, l31 = lane & 31;
+            for (int k0 = 0; k0 < BMP; k0 += 2) {
+                const int m = k0 + khalf;
+                const int tx = m & ((1 << p.tw_log2) - 1);
+                const int ty = (m >> p.tw_log2) & ((1 << p.th_log2) - 1);
+                const int bl = m >> (p.tw_log2 + p.th_log2);
+                const int qpix = bl * hhw + ty * p.q_step * p.hw + tx * p.q_step;
+                const float av = *reinterpret_cast<const float*>(sP + m * ROWB + (wa * 32 + l31) * 4);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    if (t < p.ntaps) {
+                        const float bv = *reinterpret_cast<const float*>(sQ + (qpix + p.tap_off[t]) * ROWB + (wb * 32 + l31) * 4);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        } else {
+            // bf16: v_mfma_f32_32x32x16_bf16 needs 8 k(=pixel)-consecutive values per lane while LDS rows are
+            // channel-contiguous: ds_read_b64_tr_b16 transposes a [4 pixel][16 channel] block per 16-lane group.
+            typedef short s16x4 __attribute__((ext_vector_type(4)));
+            typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+            const int khalf = lane >> 5;
+            const int g16 = (lane >> 4) & 1;                     // which 16-row half of the 32-row operand
+            const int i16 = lane & 15;
+            const int prow = i16 >> 2;                           // pixel within the k-quad this lane fetches
+            const int pcol = (i16 & 3) * 4;                      // channel offset of its 4 contiguous elements
+            for (int k0 = 0; k0 < BMP; k0 += 16) {
+                int mq[2], qpix[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int m = k0 + khalf * 8 + h * 4 + prow;
+                    mq[h] = m;
+                    const int tx = m & ((1 << p.tw_log2) - 1);
+                    const int ty = (m >> p.tw_log2) & ((1 << p.th_log2) - 1);
+                    const int bl = m >> (p.tw_log2 + p.th_log2);
+                    qpix[h] = bl * hhw + ty * p.q_step * p.hw + tx * p.q_step;
+                }
+                const int acol = (wa * 32 + g16 * 16 + pcol) * 2;
+                const int bcol = (wb * 32 + g16 * 16 + pcol) * 2;
+                s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sP + mq[0] * ROWB + acol));
+                s16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sP + mq[1] * ROWB + acol));
+                typedef short s16x8 __attribute__((ext_vector_type(8)));
+                s16x8 av = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    if (t < p.ntaps) {
+                        s16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sQ + (qpix[0] + p.tap_off[t]) * ROWB + bcol));
+                        s16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sQ + (qpix[1] + p.tap_off[t]) * ROWB + bcol));
+                        s16x8 bv = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // write the partial slab: partials[split][t][a][b]
+    const int khalf = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (t < p.ntaps) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int a = a0 + wa * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                const int b = c0 + wb * 32 + l31;
+                if (a < p.Ca && b < p.Cb)
+                    p.partials[(((int64_t)split * p.ntaps + t) * p.Ca + a) * p.Cb + b] = acc[t][r];
+            }
+        }
+    }
+}
+
+int wgrad_plan(const salt_conv_wgrad_args* a, WgradKP* k, int* nsplit_out) {
+    if (!a || !view_ok(a->p) || !view_ok(a->q)) SALT_FAIL(SALT_E_BADARG, "wgrad: bad view");
+    if (a->ntaps < 1 || a->ntaps > 9) SALT_FAIL(SALT_E_BADARG, "wgrad: ntaps %d (max 9 per launch)", a->ntaps);
+    if (a->p.B != a->q.B) SALT_FAIL(SALT_E_BADARG, "wgrad: batch mismatch");
+    int min_dy = 1 << 30, max_dy = -(1 << 30), min_dx = 1 << 30, max_dx = -(1 << 30);
+    for (int t = 0; t < a->ntaps; ++t) {
+        min_dy = a->tap_dy[t] < min_dy ? a->tap_dy[t] : min_dy; max_dy = a->tap_dy[t] > max_dy ? a->tap_dy[t] : max_dy;
+        min_dx = a->tap_dx[t] < min_dx ? a->tap_dx[t] : min_dx; max_dx = a->tap_dx[t] > max_dx ? a->tap_dx[t] : max_dx;
+    }
+    const int BM = 128;
+    k->tw_log2 = ilog2_ceil(a->p.W) < 4 ? ilog2_ceil(a->p.W) : 4;
+    int rem = 7 - k->tw_log2;
+    k->th_log2 = ilog2_ceil(a->p.H) < rem ? ilog2_ceil(a->p.H) : rem;
+    k->nb = BM >> (k->tw_log2 + k->th_log2);
+    const int th = 1 << k->th_log2, tw = 1 << k->tw_log2;
+    k->hh = (th - 1) * a->q_step + (max_dy - min_dy) + 1;
+    k->hw = (tw - 1) * a->q_step + (max_dx - min_dx) + 1;
+    k->P = a->p.p; k->Q = a->q.p; k->partials = a->partials;
+    k->B = a->p.B; k->PH = a->p.H; k->PW = a->p.W; k->Ca = a->p.C; k->p_cs = a->p.cs;
+    k->QH = a->q.H; k->QW = a->q.W; k->Cb = a->q.C; k->q_cs = a->q.cs;
+    k->ntaps = a->ntaps; k->q_step = a->q_step; k->pad_mode = a->pad_mode; k->min_dy = min_dy; k->min_dx = min_dx;
+    for (int t = 0; t < a->ntaps; ++t) k->tap_off[t] = (a->tap_dy[t] - min_dy) * k->hw + (a->tap_dx[t] - min_dx);
+    k->tiles_y = cdiv(a->p.H, th); k->tiles_x = cdiv(a->p.W, tw);
+    k->ntiles = cdiv(a->p.B, k->nb) * k->tiles_y * k->tiles_x;
+    k->a_blocks = cdiv(a->p.C, 64); k->b_blocks = cdiv(a->q.C, 64);
+    int ns = 512 / (k->a_blocks * k->b_blocks);
+    if (ns < 1) ns = 1;
+    if (ns > k->ntiles) ns = k->ntiles;
+    *nsplit_out = ns;
+    k->nsplit = ns;
+    return SALT_OK;
+}
+
+struct ReduceKP {
+    const float* partials; float* grad; int nsplit, ntaps, Ca, Cb, KH, KW, accumulate;
+    int tap_kh[SALT_MAX_TAPS], tap_kw[SALT_MAX_TAPS];
+};
+__global__ void wgrad_reduce_kernel(ReduceKP p) {
+    const int64_t slab = (int64_t)p.ntaps * p.Ca * p.Cb;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < slab; i += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < p.nsplit; ++k) s += p.partials[k * slab + i];
+        const int b = (int)(i % p.Cb);
+        int64_t r = i / p.Cb;
+        const int a = (int)(r % p.Ca);
+        const int t = (int)(r / p.Ca);
+        float* dst = p.grad + (((int64_t)a * p.Cb + b) * p.KH + p.tap_kh[t]) * p.KW + p.tap_kw[t];
+        *dst = p.accumulate ? (*dst + s) : s;
+    }
+}
+
+}  // namespace
+
+extern "C" int salt_conv(const salt_conv_args* a, void* stream) {
+    Plan pl;
+    int rc = make_plan(a, &pl);
+    if (rc) return rc;
+    if (a->stats && !a->stats_cnt) SALT_FAIL(SALT_E_BADARG, "conv: stats without stats_cnt");
+    if (a->dtype == SALT_F32) return launch_T<float>(pl, (hipStream_t)stream);
+    if (a->dtype == SALT_BF16) return launch_T<bf16_t>(pl, (hipStream_t)stream);
+    SALT_FAIL(SALT_E_BADARG, "conv: dtype %d", a->dtype);
+}
+
+extern "C" int salt_conv_stats_parts(const salt_conv_args* a) {
+    Plan pl;
+    if (make_plan(a, &pl)) return -1;
+    return pl.parts;
+}
+
+extern "C" int64_t salt_packed_weight_elems(int dtype, int ntaps, int n, int c) {
+    const int KCE = dtype == SALT_F32 ? 16 : 32;
+    return (int64_t)cdiv(c, KCE) * ntaps * n * KCE;
+}
+
+extern "C" int salt_pack_conv_weight(const salt_pack_conv_weight_args* a, void* stream) {
+    if (!a || !a->w || !a->wp || a->ntaps < 1 || a->ntaps > SALT_MAX_TAPS) SALT_FAIL(SALT_E_BADARG, "pack: bad args");
+    PackKP p;
+    p.w = a->w; p.wp = a->wp; p.D0 = a->D0; p.D1 = a->D1; p.KH = a->KH; p.KW = a->KW; p.ntaps = a->ntaps; p.transpose = a->transpose;
+    p.N = a->transpose ? a->D1 : a->D0; p.C = a->transpose ? a->D0 : a->D1;
+    const int KCE = a->dtype == SALT_F32 ? 16 : 32;
+    p.nchunk = cdiv(p.C, KCE);
+    for (int t = 0; t < a->ntaps; ++t) {
+        if (a->tap_kh[t] < 0 || a->tap_kh[t] >= a->KH || a->tap_kw[t] < 0 || a->tap_kw[t] >= a->KW) SALT_FAIL(SALT_E_BADARG, "pack: tap");
+        p.tap_kh[t] = a->tap_kh[t]; p.tap_kw[t] = a->tap_kw[t];
+    }
+    const int64_t total = (int64_t)p.nchunk * p.ntaps * p.N * KCE;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    if (a->dtype == SALT_F32) hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    else if (a->dtype == SALT_BF16) hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    else SALT_FAIL(SALT_E_BADARG, "pack: dtype");
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}
+
+extern "C" int salt_conv_wgrad_nsplit(const salt_conv_wgrad_args* a) {
+    WgradKP k; int ns = 0;
+    if (wgrad_plan(a, &k, &ns)) return -1;
+    return ns;
+}
+
+template <typename T>
+static int launch_wgrad(const WgradKP& k, hipStream_t st) {
+    constexpr int ROWB = (sizeof(T) == 2) ? 192 : 256;
+    const size_t lds = (size_t)(128 + k.nb * k.hh * k.hw) * ROWB;
+    if (lds > 160 * 1024) SALT_FAIL(SALT_E_LDS, "wgrad: needs %zu bytes of LDS", lds);
+    const dim3 grid((unsigned)(k.a_blocks * k.b_blocks * k.nsplit));
+#define SALT_WG(NT) { auto kern = conv_wgrad_kernel<T, NT>; \
+        if (lds > 64 * 1024) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            if (e != hipSuccess) SALT_FAIL((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e)); } \
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, k); }
+    if (k.ntaps == 1) SALT_WG(1)
+    else if (k.ntaps <= 3) SALT_WG(3)
+    else if (k.ntaps == 4) SALT_WG(4)
+    else SALT_WG(9)
+#undef SALT_WG
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}
+
+extern "C" int salt_conv_wgrad(const salt_conv_wgrad_args* a, void* stream) {
+    WgradKP k; int ns = 0;
+    int rc = wgrad_plan(a, &k, &ns);
+    if (rc) return rc;
+    if (!a->partials) SALT_FAIL(SALT_E_BADARG, "wgrad: partials workspace missing");
+    if (a->nsplit != ns) SALT_FAIL(SALT_E_BADARG, "wgrad: nsplit %d, expected %d", a->nsplit, ns);
+    if (a->dtype == SALT_F32) return launch_wgrad<float>(k, (hipStream_t)stream);
+    if (a->dtype == SALT_BF16) return launch_wgrad<bf16_t>(k, (hipStream_t)stream);
+    SALT_FAIL(SALT_E_BADARG, "wgrad: dtype");
+}
+
+extern "C" int salt_wgrad_reduce(const salt_wgrad_reduce_args* a, void* stream) {
+    if (!a || !a->partials || !a->grad || a->ntaps < 1 || a->ntaps > SALT_MAX_TAPS) SALT_FAIL(SALT_E_BADARG, "wgrad_reduce: bad args");
+    ReduceKP p;
+    p.partials = a->partials; p.grad = a->grad; p.nsplit = a->nsplit; p.ntaps = a->ntaps; p.Ca = a->Ca; p.Cb = a->Cb;
+    p.KH = a->KH; p.KW = a->KW; p.accumulate = a->accumulate;
+    for (int t = 0; t < a->ntaps; ++t) { p.tap_kh[t] = a->tap_kh[t]; p.tap_kw[t] = a->tap_kw[t]; }
+    const int64_t slab = (int64_t)a->ntaps * a->Ca * a->Cb;
+    const int blocks = (int)((slab + 255) / 256 < 4096 ? (slab + 255) / 256 : 4096);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}

@@ -1,0 +1,418 @@
+// conv_small.hip — thin-channel convolutions that are NOT dense contractions and therefore run on the
+// vector ALUs instead of MFMA:
+//   salt_conv_first      : first layer, Cin <= 4 straight from the fp32 NCHW batch the reference's loader
+//                          hands over (ResNet stem conv7x7 s2 p3: encoders.py:23-31 / torchvision resnet.py;
+//                          vanilla U-Net's first 3x3).  K*K*Cin <= 147 taps: input halo tile + weights in LDS.
+//   salt_conv_first_wgrad: its weight gradient (the input image needs no data gradient).
+//   salt_head1x1(_bwd)   : 1x1 convolution to <= 4 output channels (logit head: unet.py:84-87,
+//                          unet_models.py:138), writing the fp32 NCHW logits the reference's loss and
+//                          SegmentationModel.transform expect (models.py:121-126,164-167).
+#include "common.h"
+
+namespace {
+
+constexpr int FT = 16;            // output tile edge (16x16 pixels per 256-thread workgroup)
+
+struct FirstKP {
+    const float* x; const float* w; void* y;
+    const float* bias; const float* scale; const float* shift; float* stats; float* stats_cnt;
+    int B, Cin, H, W, K, stride, pad, OH, OW, Cout, y_cs, relu, tiles_y, tiles_x, halo;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv_first_kernel(FirstKP p) {
+    extern __shared__ __attribute__((aligned(16))) float smf[];
+    const int KKC = p.K * p.K * p.Cin;
+    const int CoutP = (p.Cout + 15) & ~15;
+    float* s_in = smf;                                   // [Cin][halo][halo]
+    float* s_w = smf + p.Cin * p.halo * p.halo;          // [KKC][CoutP]
+    float* s_red = s_w + KKC * CoutP;                    // [4][16]
+    const int tid = threadIdx.x;
+    int tile = blockIdx.x;
+    const int txi = tile % p.tiles_x; tile /= p.tiles_x;
+    const int tyi = tile % p.tiles_y; const int b = tile / p.tiles_y;
+    const int oy0 = tyi * FT, ox0 = txi * FT;
+    const int iy0 = oy0 * p.stride - p.pad, ix0 = ox0 * p.stride - p.pad;
+    for (int i = tid; i < p.Cin * p.halo * p.halo; i += 256) {
+        const int hx = i % p.halo; int r = i / p.halo; const int hy = r % p.halo; const int ci = r / p.halo;
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        s_in[i] = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? p.x[(((int64_t)b * p.Cin + ci) * p.H + iy) * p.W + ix] : 0.f;
+    }
+    for (int i = tid; i < KKC * CoutP; i += 256) {
+        const int co = i % CoutP, kk = i / CoutP;         // kk = (ci*K + kh)*K + kw
+        s_w[i] = co < p.Cout ? p.w[(int64_t)co * KKC + kk] : 0.f;
+    }
+    __syncthreads();
+    const int ty = tid >> 4, tx = tid & 15;
+    const int oy = oy0 + ty, ox = ox0 + tx;
+    const bool valid = oy < p.OH && ox < p.OW;
+    float cnt = valid ? 1.f : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if ((tid & 63) == 0) s_red[tid >> 6] = cnt;
+    __syncthreads();
+    cnt = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    __syncthreads();
+    T* yrow = (T*)p.y + (((int64_t)b * p.OH + (valid ? oy : 0)) * p.OW + (valid ? ox : 0)) * p.y_cs;
+    for (int co0 = 0; co0 < p.Cout; co0 += 16) {
+        float acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+        for (int ci = 0; ci < p.Cin; ++ci)
+            for (int kh = 0; kh < p.K; ++kh)
+                for (int kw = 0; kw < p.K; ++kw) {
+                    const float xv = s_in[(ci * p.halo + ty * p.stride + kh) * p.halo + tx * p.stride + kw];
+                    const float4* wr = reinterpret_cast<const float4*>(s_w + ((ci * p.K + kh) * p.K + kw) * CoutP + co0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 w4 = wr[q];
+                        acc[q * 4 + 0] += xv * w4.x; acc[q * 4 + 1] += xv * w4.y; acc[q * 4 + 2] += xv * w4.z; acc[q * 4 + 3] += xv * w4.w;
+                    }
+                }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int co = co0 + j;
+            if (co < p.Cout) {
+                float v = acc[j] + (p.bias ? p.bias[co] : 0.f);
+                if (p.scale) v = v * p.scale[co] + p.shift[co];
+                if (p.relu) v = fmaxf(v, 0.f);
+                acc[j] = v;
+                if (valid) Elem<T>::st(yrow + co, v);
+            }
+        }
+        if (p.stats) {
+            // tile statistics for 16 channels: sum, then M2 about the tile mean (two block reductions)
+            float mean[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                float s = valid ? acc[j] : 0.f;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+                if ((tid & 63) == 0) s_red[(tid >> 6) * 16 + j] = s;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 16; ++j) mean[j] = (s_red[j] + s_red[16 + j] + s_red[32 + j] + s_red[48 + j]);   // tile SUM
+            if (tid < 16 && co0 + tid < p.Cout)
+                p.stats[((int64_t)blockIdx.x * 2) * p.Cout + co0 + tid] = s_red[tid] + s_red[16 + tid] + s_red[32 + tid] + s_red[48 + tid];
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float d = valid ? acc[j] - mean[j] / cnt : 0.f;
+                float s = d * d;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+                if ((tid & 63) == 0) s_red[(tid >> 6) * 16 + j] = s;
+            }
+            __syncthreads();
+            if (tid < 16 && co0 + tid < p.Cout)
+                p.stats[((int64_t)blockIdx.x * 2 + 1) * p.Cout + co0 + tid] = s_red[tid] + s_red[16 + tid] + s_red[32 + tid] + s_red[48 + tid];
+            __syncthreads();
+        }
+    }
+    if (p.stats && tid == 0) p.stats_cnt[blockIdx.x] = cnt;
+}
+
+int first_geom(int H, int W, int K, int stride, int pad, int* OH, int* OW) {
+    *OH = (H + 2 * pad - K) / stride + 1;
+    *OW = (W + 2 * pad - K) / stride + 1;
+    return (FT - 1) * stride + K;
+}
+
+constexpr int MAXKK = 40;
+struct FirstWgKP {
+    const float* x; const void* dy; float* partials;
+    int B, Cin, H, W, K, stride, pad, OH, OW, Cout, dy_cs, tiles_y, tiles_x, halo, groups, per;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstWgKP p) {
+    extern __shared__ __attribute__((aligned(16))) float smf[];
+    const int KKC = p.K * p.K * p.Cin;
+    float* s_in = smf;                                   // [Cin][halo][halo]
+    float* s_dy = smf + p.Cin * p.halo * p.halo;         // [256][Cout]
+    const int tid = threadIdx.x;
+    int tile = blockIdx.x;
+    const int txi = tile % p.tiles_x; tile /= p.tiles_x;
+    const int tyi = tile % p.tiles_y; const int b = tile / p.tiles_y;
+    const int oy0 = tyi * FT, ox0 = txi * FT;
+    const int iy0 = oy0 * p.stride - p.pad, ix0 = ox0 * p.stride - p.pad;
+    for (int i = tid; i < p.Cin * p.halo * p.halo; i += 256) {
+        const int hx = i % p.halo; int r = i / p.halo; const int hy = r % p.halo; const int ci = r / p.halo;
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        s_in[i] = (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) ? p.x[(((int64_t)b * p.Cin + ci) * p.H + iy) * p.W + ix] : 0.f;
+    }
+    for (int i = tid; i < 256 * p.Cout; i += 256) {
+        const int co = i % p.Cout, px = i / p.Cout;
+        const int oy = oy0 + (px >> 4), ox = ox0 + (px & 15);
+        s_dy[i] = (oy < p.OH && ox < p.OW) ? Elem<T>::ld((const T*)p.dy + (((int64_t)b * p.OH + oy) * p.OW + ox) * p.dy_cs + co) : 0.f;
+    }
+    __syncthreads();
+    const int co = tid % p.Cout, grp = tid / p.Cout;
+    if (grp >= p.groups) return;
+    float acc[MAXKK];
+    int koff[MAXKK];
+#pragma unroll
+    for (int j = 0; j < MAXKK; ++j) {
+        acc[j] = 0.f;
+        const int kk = grp + j * p.groups;
+        int off = 0;
+        if (j < p.per && kk < KKC) { const int kw = kk % p.K; int r = kk / p.K; const int kh = r % p.K; const int ci = r / p.K; off = (ci * p.halo + kh) * p.halo + kw; }
+        koff[j] = off;
+    }
+    for (int px = 0; px < 256; ++px) {
+        const float g = s_dy[px * p.Cout + co];
+        const int base = ((px >> 4) * p.stride) * p.halo + (px & 15) * p.stride;
+#pragma unroll
+        for (int j = 0; j < MAXKK; ++j)
+            if (j < p.per) acc[j] += g * s_in[base + koff[j]];
+    }
+#pragma unroll
+    for (int j = 0; j < MAXKK; ++j) {
+        const int kk = grp + j * p.groups;
+        if (j < p.per && kk < KKC) p.partials[(int64_t)blockIdx.x * p.Cout * KKC + (int64_t)co * KKC + kk] = acc[j];
+    }
+}
+
+__global__ void partial_sum_kernel(const float* partials, int nparts, int64_t n, float* out, int accumulate) {
+    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < n; i += gridDim.x * 256LL) {
+        float s = 0.f;
+        for (int k = 0; k < nparts; ++k) s += partials[(int64_t)k * n + i];
+        out[i] = accumulate ? out[i] + s : s;
+    }
+}
+
+// ---------------------------------------------------------------- 1x1 head, Cout <= 4
+template <typename T>
+__global__ void head1x1_kernel(salt_view x, const float* w, const float* bias, int Cout, float* y_nchw, salt_view y) {
+    const int64_t hw = (int64_t)x.H * x.W, npix = (int64_t)x.B * hw;
+    for (int64_t pix = blockIdx.x * 256LL + threadIdx.x; pix < npix; pix += gridDim.x * 256LL) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const T* row = (const T*)x.p + pix * x.cs;
+        for (int c = 0; c < x.C; ++c) {
+            const float v = Elem<T>::ld(row + c);
+#pragma unroll
+            for (int o = 0; o < 4; ++o) if (o < Cout) acc[o] += v * w[o * x.C + c];
+        }
+        const int64_t b = pix / hw, s = pix - b * hw;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) if (o < Cout) {
+            const float v = acc[o] + (bias ? bias[o] : 0.f);
+            if (y_nchw) y_nchw[(b * Cout + o) * hw + s] = v; else Elem<T>::st((T*)y.p + pix * y.cs + o, v);
+        }
+    }
+}
+
+// vectorised: C/VE lanes cooperate on one pixel (each reads one 16-byte piece), butterfly-reduce the dots.
+template <typename T>
+__global__ void head1x1_vec_kernel(salt_view x, const float* w, const float* bias, int Cout, float* y_nchw, salt_view y, int cpv_log2) {
+    constexpr int VE = Elem<T>::VE;
+    const int cpv = 1 << cpv_log2;
+    const int64_t hw = (int64_t)x.H * x.W, npix = (int64_t)x.B * hw;
+    const int64_t units = npix << cpv_log2;
+    const int64_t units_pad = (units + 255) & ~255LL;
+    for (int64_t u = blockIdx.x * 256LL + threadIdx.x; u < units_pad; u += gridDim.x * 256LL) {
+        const int64_t pix = u >> cpv_log2; const int cv = (int)(u & (cpv - 1));
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (pix < npix) {
+            float f[VE];
+            unpack16<T>(*reinterpret_cast<const u32x4*>((const T*)x.p + pix * x.cs + cv * VE), f);
+#pragma unroll
+            for (int o = 0; o < 4; ++o) if (o < Cout) {
+#pragma unroll
+                for (int j = 0; j < VE; ++j) acc[o] += f[j] * w[o * x.C + cv * VE + j];
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+            for (int s = 1; s < cpv; s <<= 1) acc[o] += __shfl_xor(acc[o], s);
+        if (pix < npix && cv == 0) {
+            const int64_t b = pix / hw, s = pix - b * hw;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) if (o < Cout) {
+                const float v = acc[o] + (bias ? bias[o] : 0.f);
+                if (y_nchw) y_nchw[(b * Cout + o) * hw + s] = v; else Elem<T>::st((T*)y.p + pix * y.cs + o, v);
+            }
+        }
+    }
+}
+
+// backward: dx[pix][c] = sum_o dy[o][pix] w[o][c];  gw[o][c] = sum_pix dy[o][pix] x[pix][c];  gb[o] = sum_pix dy[o][pix]
+template <typename T>
+__global__ __launch_bounds__(256) void head1x1_bwd_kernel(salt_view x, const float* w, int Cout, const float* dy_nchw, salt_view dx,
+                                                          int accumulate, float* partials, int64_t pix_per_block) {
+    extern __shared__ float sm[];
+    const int C = x.C;
+    const int64_t hw = (int64_t)x.H * x.W, npix = (int64_t)x.B * hw;
+    const int64_t p0 = blockIdx.x * pix_per_block;
+    const int64_t p1 = p0 + pix_per_block < npix ? p0 + pix_per_block : npix;
+    const int PW = Cout * (C + 1);
+    for (int i = threadIdx.x; i < PW; i += 256) sm[i] = 0.f;
+    __syncthreads();
+    for (int c0 = 0; c0 < C; c0 += 256) {
+        const int cn = C - c0 < 256 ? C - c0 : 256;
+        const int R = 256 / cn;
+        const int row = threadIdx.x / cn, c = c0 + threadIdx.x % cn;
+        float gw[4] = {0.f, 0.f, 0.f, 0.f}, gb[4] = {0.f, 0.f, 0.f, 0.f};
+        if (row < R) {
+            float wv[4];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) wv[o] = o < Cout ? w[o * C + c] : 0.f;
+            for (int64_t pix = p0 + row; pix < p1; pix += R) {
+                const int64_t b = pix / hw, s = pix - b * hw;
+                const float xv = Elem<T>::ld((const T*)x.p + pix * x.cs + c);
+                float d = 0.f;
+#pragma unroll
+                for (int o = 0; o < 4; ++o) if (o < Cout) {
+                    const float g = dy_nchw[(b * Cout + o) * hw + s];
+                    d += g * wv[o]; gw[o] += g * xv; gb[o] += g;
+                }
+                T* dst = (T*)dx.p + pix * dx.cs + c;
+                if (accumulate) d += Elem<T>::ld(dst);
+                Elem<T>::st(dst, d);
+            }
+        }
+        // deterministic in-block combine: rows add in fixed order
+        for (int r = 0; r < R; ++r) {
+            if (row == r) {
+#pragma unroll
+                for (int o = 0; o < 4; ++o) if (o < Cout) { sm[o * (C + 1) + c] += gw[o]; if (c == 0) sm[o * (C + 1) + C] += gb[o]; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < PW; i += 256) partials[(int64_t)blockIdx.x * PW + i] = sm[i];
+}
+
+__global__ void head1x1_bwd_finalize(const float* partials, int nparts, int Cout, int C, float* gw, float* gb) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int PW = Cout * (C + 1);
+    if (i >= PW) return;
+    float s = 0.f;
+    for (int k = 0; k < nparts; ++k) s += partials[(int64_t)k * PW + i];
+    const int o = i / (C + 1), c = i - o * (C + 1);
+    if (c < C) gw[o * C + c] = s; else if (gb) gb[o] = s;
+}
+
+int head_parts(const salt_view& x, int64_t* per) {
+    const int64_t npix = view_pixels(x);
+    int64_t parts = (npix + 255) / 256;
+    if (parts > 512) parts = 512;
+    if (parts < 1) parts = 1;
+    const int64_t pp = (npix + parts - 1) / parts;
+    if (per) *per = pp;
+    return (int)((npix + pp - 1) / pp);
+}
+
+}  // namespace
+
+extern "C" int salt_conv_first_stats_parts(const salt_conv_first_args* a) {
+    if (!a) return -1;
+    int OH, OW; first_geom(a->H, a->W, a->K, a->stride, a->pad, &OH, &OW);
+    return a->B * cdiv(OH, FT) * cdiv(OW, FT);
+}
+
+extern "C" int salt_conv_first(const salt_conv_first_args* a, void* stream) {
+    if (!a || !a->x || !a->w || !view_ok(a->y) || a->Cin < 1 || a->Cin > 4 || a->K < 1 || a->K > 7 || a->stride < 1 || a->stride > 2)
+        SALT_FAIL(SALT_E_BADARG, "conv_first: bad args");
+    FirstKP p;
+    int OH, OW;
+    p.halo = first_geom(a->H, a->W, a->K, a->stride, a->pad, &OH, &OW);
+    if (a->y.H != OH || a->y.W != OW || a->y.B != a->B) SALT_FAIL(SALT_E_BADARG, "conv_first: output view is %dx%d, expected %dx%d", a->y.H, a->y.W, OH, OW);
+    if ((a->scale == nullptr) != (a->shift == nullptr)) SALT_FAIL(SALT_E_BADARG, "conv_first: scale/shift");
+    p.x = a->x; p.w = a->w; p.y = a->y.p; p.bias = a->bias; p.scale = a->scale; p.shift = a->shift; p.stats = a->stats; p.stats_cnt = a->stats_cnt;
+    p.B = a->B; p.Cin = a->Cin; p.H = a->H; p.W = a->W; p.K = a->K; p.stride = a->stride; p.pad = a->pad; p.OH = OH; p.OW = OW;
+    p.Cout = a->y.C; p.y_cs = a->y.cs; p.relu = a->relu; p.tiles_y = cdiv(OH, FT); p.tiles_x = cdiv(OW, FT);
+    const int CoutP = (p.Cout + 15) & ~15;
+    const size_t lds = sizeof(float) * ((size_t)p.Cin * p.halo * p.halo + (size_t)p.K * p.K * p.Cin * CoutP + 64);
+    if (lds > 160 * 1024) SALT_FAIL(SALT_E_LDS, "conv_first: needs %zu bytes of LDS", lds);
+    const dim3 grid((unsigned)(p.B * p.tiles_y * p.tiles_x));
+    SALT_DISPATCH_DTYPE(a->dtype, T, {
+        auto kern = conv_first_kernel<T>;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, (hipStream_t)stream, p);
+    })
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}
+
+extern "C" int salt_conv_first_wgrad_parts(const salt_conv_first_wgrad_args* a) {
+    if (!a) return -1;
+    int OH, OW; first_geom(a->H, a->W, a->K, a->stride, a->pad, &OH, &OW);
+    return a->B * cdiv(OH, FT) * cdiv(OW, FT);
+}
+
+extern "C" int salt_conv_first_wgrad(const salt_conv_first_wgrad_args* a, void* stream) {
+    if (!a || !a->x || !view_ok(a->dy) || !a->partials || !a->grad || a->Cin < 1 || a->Cin > 4 || a->K < 1 || a->K > 7)
+        SALT_FAIL(SALT_E_BADARG, "conv_first_wgrad: bad args");
+    FirstWgKP p;
+    int OH, OW;
+    p.halo = first_geom(a->H, a->W, a->K, a->stride, a->pad, &OH, &OW);
+    if (a->dy.H != OH || a->dy.W != OW || a->dy.B != a->B) SALT_FAIL(SALT_E_BADARG, "conv_first_wgrad: dy view shape");
+    const int Cout = a->dy.C;
+    if (Cout > 256) SALT_FAIL(SALT_E_UNSUPPORTED, "conv_first_wgrad: Cout %d > 256", Cout);
+    p.x = a->x; p.dy = a->dy.p; p.partials = a->partials;
+    p.B = a->B; p.Cin = a->Cin; p.H = a->H; p.W = a->W; p.K = a->K; p.stride = a->stride; p.pad = a->pad; p.OH = OH; p.OW = OW;
+    p.Cout = Cout; p.dy_cs = a->dy.cs; p.tiles_y = cdiv(OH, FT); p.tiles_x = cdiv(OW, FT);
+    const int KKC = a->K * a->K * a->Cin;
+    p.groups = 256 / Cout;
+    p.per = cdiv(KKC, p.groups);
+    if (p.per > MAXKK) SALT_FAIL(SALT_E_UNSUPPORTED, "conv_first_wgrad: %d taps per thread > %d", p.per, MAXKK);
+    const int nparts = a->B * p.tiles_y * p.tiles_x;
+    if (a->nparts != nparts) SALT_FAIL(SALT_E_BADARG, "conv_first_wgrad: nparts %d, expected %d", a->nparts, nparts);
+    const size_t lds = sizeof(float) * ((size_t)p.Cin * p.halo * p.halo + (size_t)256 * Cout);
+    if (lds > 160 * 1024) SALT_FAIL(SALT_E_LDS, "conv_first_wgrad: needs %zu bytes of LDS", lds);
+    SALT_DISPATCH_DTYPE(a->dtype, T, {
+        auto kern = conv_first_wgrad_kernel<T>;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(kern, dim3(nparts), dim3(256), lds, (hipStream_t)stream, p);
+    })
+    SALT_CHECK_LAUNCH();
+    const int64_t n = (int64_t)Cout * KKC;
+    hipLaunchKernelGGL(partial_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a->partials, nparts, n, a->grad, a->accumulate);
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}
+
+extern "C" int salt_head1x1(const salt_head1x1_args* a, void* stream) {
+    if (!a || !view_ok(a->x) || !a->w || a->Cout < 1 || a->Cout > 4) SALT_FAIL(SALT_E_BADARG, "head1x1: bad args");
+    if (!a->y_nchw && (!view_ok(a->y) || a->y.C != a->Cout)) SALT_FAIL(SALT_E_BADARG, "head1x1: no output");
+    const int64_t npix = view_pixels(a->x);
+    SALT_DISPATCH_DTYPE(a->dtype, T, {
+        constexpr int VE = Elem<T>::VE;
+        const int cpv = a->x.C / VE;
+        const bool vec = (a->x.C % VE) == 0 && (a->x.cs % VE) == 0 && ((reinterpret_cast<uintptr_t>(a->x.p) & 15) == 0) && cpv >= 1 && cpv <= 64 && (cpv & (cpv - 1)) == 0;
+        if (vec) {
+            const int64_t units = npix * cpv;
+            const int blocks = (int)((units + 255) / 256 < 4096 ? (units + 255) / 256 : 4096);
+            hipLaunchKernelGGL(head1x1_vec_kernel<T>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a->x, a->w, a->bias, a->Cout, a->y_nchw, a->y, ilog2_ceil(cpv));
+        } else {
+            const int blocks = (int)((npix + 255) / 256 < 4096 ? (npix + 255) / 256 : 4096);
+            hipLaunchKernelGGL(head1x1_kernel<T>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a->x, a->w, a->bias, a->Cout, a->y_nchw, a->y);
+        }
+    })
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}
+
+extern "C" int salt_head1x1_bwd_parts(const salt_head1x1_bwd_args* a) {
+    if (!a || !view_ok(a->x)) return -1;
+    return head_parts(a->x, nullptr);
+}
+
+extern "C" int salt_head1x1_bwd(const salt_head1x1_bwd_args* a, void* stream) {
+    if (!a || !view_ok(a->x) || !view_ok(a->dx) || !a->w || !a->dy_nchw || !a->partials || !a->gw || a->Cout < 1 || a->Cout > 4)
+        SALT_FAIL(SALT_E_BADARG, "head1x1_bwd: bad args");
+    int64_t per = 0;
+    const int nparts = head_parts(a->x, &per);
+    if (a->nparts != nparts) SALT_FAIL(SALT_E_BADARG, "head1x1_bwd: nparts %d, expected %d", a->nparts, nparts);
+    const int PW = a->Cout * (a->x.C + 1);
+    SALT_DISPATCH_DTYPE(a->dtype, T, {
+        hipLaunchKernelGGL(head1x1_bwd_kernel<T>, dim3(nparts), dim3(256), PW * sizeof(float), (hipStream_t)stream,
+                           a->x, a->w, a->Cout, a->dy_nchw, a->dx, a->accumulate, a->partials, per);
+    })
+    SALT_CHECK_LAUNCH();
+    hipLaunchKernelGGL(head1x1_bwd_finalize, dim3(cdiv(PW, 64)), dim3(64), 0, (hipStream_t)stream, a->partials, nparts, a->Cout, a->x.C, a->gw, a->gb);
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}

@@ -1,0 +1,633 @@
+// elementwise.hip — the HBM-bound operators of the path: BatchNorm finalize/apply/backward, ReLU,
+// residual add, 2x2 max/avg pooling, bilinear xR resize, replicate-pad adjoint, layout conversion.
+// All are single-pass NHWC streaming kernels: 16-byte accesses per lane (8 bf16 / 4 f32 channels of one
+// pixel, so a wave reads whole 128-B+ lines), fp32 math, deterministic two-level reductions (no atomics).
+// Reference anchors are listed per entry point in include/saltnet.h.
+#include "common.h"
+
+namespace {
+
+// A "unit" is one 16-byte piece (VEC) or one element (!VEC) of one pixel of a view.
+template <typename T, bool VEC> struct Unit {
+    static constexpr int N = VEC ? Elem<T>::VE : 1;
+    static __device__ __forceinline__ void ld(const T* p, float* f) {
+        if constexpr (VEC) { u32x4 v = *reinterpret_cast<const u32x4*>(p); unpack16<T>(v, f); }
+        else f[0] = Elem<T>::ld(p);
+    }
+    static __device__ __forceinline__ void st(T* p, const float* f) {
+        if constexpr (VEC) *reinterpret_cast<u32x4*>(p) = pack16<T>(f);
+        else Elem<T>::st(p, f[0]);
+    }
+};
+
+inline bool vec_ok(const salt_view& v, int ve) {
+    return v.p == nullptr || ((v.C % ve) == 0 && (v.cs % ve) == 0 && (reinterpret_cast<uintptr_t>(v.p) & 15) == 0);
+}
+inline int ew_blocks(int64_t units) { int64_t b = (units + 255) / 256; return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b)); }
+
+#define EW_LAUNCH(KERN, T, allvec, units, stream, ...) \
+    do { if (allvec) hipLaunchKernelGGL((KERN<T, true>), dim3(ew_blocks(units)), dim3(256), 0, stream, __VA_ARGS__); \
+         else hipLaunchKernelGGL((KERN<T, false>), dim3(ew_blocks(units)), dim3(256), 0, stream, __VA_ARGS__); } while (0)
+
+// ---------------------------------------------------------------- affine + act (+ residual)
+template <typename T, bool VEC>
+__global__ void affine_act_kernel(salt_view y, const float* scale, const float* shift, salt_view res, int relu, salt_view a) {
+    constexpr int N = Unit<T, VEC>::N;
+    const int cpv = y.C / N;
+    const int64_t units = (int64_t)y.B * y.H * y.W * cpv;
+    for (int64_t u = blockIdx.x * 256LL + threadIdx.x; u < units; u += gridDim.x * 256LL) {
+        const int64_t pix = u / cpv; const int c0 = (int)(u - pix * cpv) * N;
+        float f[N], r[N];
+        Unit<T, VEC>::ld((const T*)y.p + pix * y.cs + c0, f);
+        if (res.p) Unit<T, VEC>::ld((const T*)res.p + pix * res.cs + c0, r);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            float v = f[j];
+            if (scale) v = v * scale[c0 + j] + shift[c0 + j];
+            if (res.p) v += r[j];
+            if (relu) v = fmaxf(v, 0.f);
+            f[j] = v;
+        }
+        Unit<T, VEC>::st((T*)a.p + pix * a.cs + c0, f);
+    }
+}
+
+// ---------------------------------------------------------------- BN finalize (Chan combine, fp64, fixed order)
+__global__ void bn_finalize_kernel(salt_bn_finalize_args a) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && a.num_batches_tracked) *a.num_batches_tracked += 1;
+    if (c >= a.C) return;
+    double n = 0.0, mean = 0.0, m2 = 0.0;
+    for (int k = 0; k < a.nparts; ++k) {
+        const double nk = (double)a.stats_cnt[k];
+        if (nk <= 0.0) continue;
+        const double sk = (double)a.stats[((int64_t)k * 2 + 0) * a.C + c];
+        const double m2k = (double)a.stats[((int64_t)k * 2 + 1) * a.C + c];
+        const double mk = sk / nk;
+        const double d = mk - mean;
+        const double nn = n + nk;
+        mean += d * nk / nn;
+        m2 += m2k + d * d * n * nk / nn;
+        n = nn;
+    }
+    const double var = n > 0 ? m2 / n : 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
+    const float sc = a.gamma[c] * invstd;
+    a.mean[c] = (float)mean; a.invstd[c] = invstd; a.scale[c] = sc; a.shift[c] = a.beta[c] - (float)mean * sc;
+    if (a.running_mean) {
+        const double unb = n > 1 ? m2 / (n - 1) : var;
+        a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)mean;
+        a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unb;
+    }
+}
+
+__global__ void bn_fold_kernel(salt_bn_fold_args a) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.C) return;
+    const float sc = a.gamma[c] / sqrtf(a.running_var[c] + a.eps);
+    a.scale[c] = sc; a.shift[c] = a.beta[c] - a.running_mean[c] * sc;
+}
+
+// ---------------------------------------------------------------- BN backward
+// pass 1: per-block partial sums of dyh = da*mask and dyh*xhat per channel.
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(salt_view da, salt_view a, salt_view y, int relu,
+                                                            const float* mean, const float* invstd, float* partials, int64_t pix_per_block) {
+    constexpr int N = Unit<T, VEC>::N;
+    extern __shared__ float sm[];
+    const int C = y.C, cpv = C / N;
+    const int64_t npix = (int64_t)y.B * y.H * y.W;
+    const int64_t p0 = blockIdx.x * pix_per_block;
+    const int64_t p1 = p0 + pix_per_block < npix ? p0 + pix_per_block : npix;
+    for (int cv0 = 0; cv0 < cpv; cv0 += 256) {
+        const int cvn = cpv - cv0 < 256 ? cpv - cv0 : 256;
+        const int R = 256 / cvn;
+        const int row = threadIdx.x / cvn, cv = cv0 + threadIdx.x % cvn;
+        float s1[N], s2[N], mu[N], is[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+        if (row < R) {
+            const int c0 = cv * N;
+#pragma unroll
+            for (int j = 0; j < N; ++j) { mu[j] = mean[c0 + j]; is[j] = invstd[c0 + j]; }
+            for (int64_t pix = p0 + row; pix < p1; pix += R) {
+                float g[N], yy[N], aa[N];
+                Unit<T, VEC>::ld((const T*)da.p + pix * da.cs + c0, g);
+                Unit<T, VEC>::ld((const T*)y.p + pix * y.cs + c0, yy);
+                if (relu) Unit<T, VEC>::ld((const T*)a.p + pix * a.cs + c0, aa);
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const float gg = (relu && !(aa[j] > 0.f)) ? 0.f : g[j];
+                    s1[j] += gg; s2[j] += gg * (yy[j] - mu[j]) * is[j];
+                }
+            }
+        }
+        __syncthreads();
+        if (row < R) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) { sm[((row * cvn + (cv - cv0)) * N + j) * 2] = s1[j]; sm[((row * cvn + (cv - cv0)) * N + j) * 2 + 1] = s2[j]; }
+        }
+        __syncthreads();
+        if (row == 0) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                float t1 = 0.f, t2 = 0.f;
+                for (int r = 0; r < R; ++r) { t1 += sm[((r * cvn + (cv - cv0)) * N + j) * 2]; t2 += sm[((r * cvn + (cv - cv0)) * N + j) * 2 + 1]; }
+                partials[((int64_t)blockIdx.x * 2 + 0) * C + cv * N + j] = t1;
+                partials[((int64_t)blockIdx.x * 2 + 1) * C + cv * N + j] = t2;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* partials, int nparts, int C, double M, const float* gamma, const float* invstd,
+                                       float* dgamma, float* dbeta, int accumulate, float* coef) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < nparts; ++k) { s1 += (double)partials[((int64_t)k * 2) * C + c]; s2 += (double)partials[((int64_t)k * 2 + 1) * C + c]; }
+    if (dgamma) { dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2; dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1; }
+    coef[c] = gamma[c] * invstd[c];
+    coef[C + c] = (float)(s1 / M);
+    coef[2 * C + c] = (float)(s2 / M);
+}
+
+template <typename T, bool VEC>
+__global__ void bn_bwd_apply_kernel(salt_view da, salt_view a, salt_view y, int relu, const float* mean, const float* invstd,
+                                    const float* coef, salt_view dy, salt_view dres, int acc_dres) {
+    constexpr int N = Unit<T, VEC>::N;
+    const int C = y.C, cpv = C / N;
+    const int64_t units = (int64_t)y.B * y.H * y.W * cpv;
+    for (int64_t u = blockIdx.x * 256LL + threadIdx.x; u < units; u += gridDim.x * 256LL) {
+        const int64_t pix = u / cpv; const int c0 = (int)(u - pix * cpv) * N;
+        float g[N], yy[N], aa[N], o[N];
+        Unit<T, VEC>::ld((const T*)da.p + pix * da.cs + c0, g);
+        Unit<T, VEC>::ld((const T*)y.p + pix * y.cs + c0, yy);
+        if (relu) Unit<T, VEC>::ld((const T*)a.p + pix * a.cs + c0, aa);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const float gg = (relu && !(aa[j] > 0.f)) ? 0.f : g[j];
+            g[j] = gg;
+            const float xh = (yy[j] - mean[c0 + j]) * invstd[c0 + j];
+            o[j] = coef[c0 + j] * (gg - coef[C + c0 + j] - xh * coef[2 * C + c0 + j]);
+        }
+        Unit<T, VEC>::st((T*)dy.p + pix * dy.cs + c0, o);
+        if (dres.p) {
+            if (acc_dres) {
+                float old[N];
+                Unit<T, VEC>::ld((const T*)dres.p + pix * dres.cs + c0, old);
+#pragma unroll
+                for (int j = 0; j < N; ++j) g[j] += old[j];
+            }
+            Unit<T, VEC>::st((T*)dres.p + pix * dres.cs + c0, g);
+        }
+    }
+}
+
+template <typename T, bool VEC>
+__global__ void relu_bwd_kernel(salt_view da, salt_view a, salt_view dy, int accumulate) {
+    constexpr int N = Unit<T, VEC>::N;
+    const int cpv = da.C / N;
+    const int64_t units = (int64_t)da.B * da.H * da.W * cpv;
+    for (int64_t u = blockIdx.x * 256LL + threadIdx.x; u < units; u += gridDim.x * 256LL) {
+        const int64_t pix = u / cpv; const int c0 = (int)(u - pix * cpv) * N;
+        float g[N], aa[N], old[N];
+        Unit<T, VEC>::ld((const T*)da.p + pix * da.cs + c0, g);
+        if (a.p) Unit<T, VEC>::ld((const T*)a.p + pix * a.cs + c0, aa);
+        if (accumulate) Unit<T, VEC>::ld((const T*)dy.p + pix * dy.cs + c0, old);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            float v = (a.p && !(aa[j] > 0.f)) ? 0.f : g[j];
+            if (accumulate) v += old[j];
+            g[j] = v;
+        }
+        Unit<T, VEC>::st((T*)dy.p + pix * dy.cs + c0, g);
+    }
+}
+
+// ---------------------------------------------------------------- pooling
+template <typename T, bool VEC>
+__global__ void maxpool2_kernel(salt_view x, salt_view y) {
+    constexpr int N = Unit<T, VEC>::N;
+    const int cpv = x.C / N;
+    const int64_t units = (int64_t)y.B * y.H * y.W * cpv;
+    for (int64_t u = blockIdx.x * 256LL + threadIdx.x; u < units; u += gridDim.x * 256LL) {
+        int64_t pix = u / cpv; const int c0 = (int)(u - pix * cpv) * N;
+        const int ox = (int)(pix % y.W); int64_t r = pix / y.W; const int oy = (int)(r % y.H); const int b = (int)(r / y.H);
+        const T* base = (const T*)x.p + (((int64_t)b * x.H + 2 * oy) * x.W + 2 * ox) * x.cs + c0;
+        float m[N], f[N];
+        Unit<T, VEC>::ld(base, m);
+        Unit<T, VEC>::ld(base + x.cs, f);
+#pragma unroll
+        for (int j = 0; j < N; ++j) m[j] = fmaxf(m[j], f[j]);
+        Unit<T, VEC>::ld(base + (int64_t)x.W * x.cs, f);
+#pragma unroll
+        for (int j = 0; j < N; ++j) m[j] = fmaxf(m[j], f[j]);
+        Unit<T, VEC>::ld(base + (int64_t)x.W * x.cs + x.cs, f);
+#pragma unroll
+        for (int j = 0; j < N; ++j) m[j] = fmaxf(m[j], f[j]);
+        Unit<T, VEC>::st((T*)y.p + pix * y.cs + c0, m);
+    }
+}
+
+template <typename T, bool VEC>
+__global__ void maxpool2_bwd_kernel(salt_view x, salt_view dy, salt_view dx, int accumulate) {
+    constexpr int N = Unit<T, VEC>::N;
+    const int cpv = x.C / N;
+    const int64_t units = (int64_t)x.B * x.H * x.W * cpv;
+    for (int64_t u = blockIdx.x * 256LL + threadIdx.x; u < units; u += gridDim.x * 256LL) {
+        int64_t pix = u / cpv; const int c0 = (int)(u - pix * cpv) * N;
+        const int ix = (int)(pix % x.W); int64_t r = pix / x.W; const int iy = (int)(r % x.H); const int b = (int)(r / x.H);
+        const int oy = iy >> 1, ox = ix >> 1;
+        float o[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) o[j] = 0.f;
+        if (oy < dy.H && ox < dy.W) {
+            const T* base = (const T*)x.p + (((int64_t)b * x.H + 2 * oy) * x.W + 2 * ox) * x.cs + c0;
+            float w[4][N], g[N];
+            Unit<T, VEC>::ld(base, w[0]);
+            Unit<T, VEC>::ld(base + x.cs, w[1]);
+            Unit<T, VEC>::ld(base + (int64_t)x.W * x.cs, w[2]);
+            Unit<T, VEC>::ld(base + (int64_t)x.W * x.cs + x.cs, w[3]);
+            Unit<T, VEC>::ld((const T*)dy.p + (((int64_t)b * dy.H + oy) * dy.W + ox) * dy.cs + c0, g);
+            const int me = ((iy & 1) << 1) | (ix & 1);
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                int arg = 0; float m = w[0][j];
+#pragma unroll
+                for (int k = 1; k < 4; ++k) if (w[k][j] > m) { m = w[k][j]; arg = k; }     // first maximum wins
+                o[j] = (arg == me) ? g[j] : 0.f;
+            }
+        }
+        T* dst = (T*)dx.p + pix * dx.cs + c0;
+        if (accumulate) { float old[N]; Unit<T, VEC>::ld(dst, old);
+#pragma unroll
+            for (int j = 0; j < N; ++j) o[j] += old[j]; }
+        Unit<T, VEC>::st(dst, o);
+    }
+}
+
+template <typename T, bool VEC>
+__global__ void avgpool2_kernel(salt_view x, salt_view y, int backward, int accumulate) {
+    constexpr int N = Unit<T, VEC>::N;
+    const int cpv = x.C / N;
+    if (!backward) {
+        const int64_t units = (int64_t)y.B * y.H * y.W * cpv;
+        for (int64_t u = blockIdx.x * 256LL + threadIdx.x; u < units; u += gridDim.x * 256LL) {
+            int64_t pix = u / cpv; const int c0 = (int)(u - pix * cpv) * N;
+            const int ox = (int)(pix % y.W); int64_t r = pix / y.W; const int oy = (int)(r % y.H); const int b = (int)(r / y.H);
+            const T* base = (const T*)x.p + (((int64_t)b * x.H + 2 * oy) * x.W + 2 * ox) * x.cs + c0;
+            float s[N], f[N];
+            Unit<T, VEC>::ld(base, s);
+            Unit<T, VEC>::ld(base + x.cs, f);
+#pragma unroll
+            for (int j = 0; j < N; ++j) s[j] += f[j];
+            Unit<T, VEC>::ld(base + (int64_t)x.W * x.cs, f);
+#pragma unroll
+            for (int j = 0; j < N; ++j) s[j] += f[j];
+            Unit<T, VEC>::ld(base + (int64_t)x.W * x.cs + x.cs, f);
+#pragma unroll
+            for (int j = 0; j < N; ++j) s[j] = (s[j] + f[j]) * 0.25f;
+            Unit<T, VEC>::st((T*)y.p + pix * y.cs + c0, s);
+        }
+    } else {
+        const int64_t units = (int64_t)x.B * x.H * x.W * cpv;
+        for (int64_t u = blockIdx.x * 256LL + threadIdx.x; u < units; u += gridDim.x * 256LL) {
+            int64_t pix = u / cpv; const int c0 = (int)(u - pix * cpv) * N;
+            const int ix = (int)(pix % x.W); int64_t r = pix / x.W; const int iy = (int)(r % x.H); const int b = (int)(r / x.H);
+            float o[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) o[j] = 0.f;
+            if ((iy >> 1) < y.H && (ix >> 1) < y.W) {
+                Unit<T, VEC>::ld((const T*)y.p + (((int64_t)b * y.H + (iy >> 1)) * y.W + (ix >> 1)) * y.cs + c0, o);
+#pragma unroll
+                for (int j = 0; j < N; ++j) o[j] *= 0.25f;
+            }
+            T* dst = (T*)x.p + pix * x.cs + c0;
+            if (accumulate) { float old[N]; Unit<T, VEC>::ld(dst, old);
+#pragma unroll
+                for (int j = 0; j < N; ++j) o[j] += old[j]; }
+            Unit<T, VEC>::st(dst, o);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- bilinear xR (align_corners=False)
+__device__ __forceinline__ void bil_src(int d, int R, int n, int& i0, int& i1, float& lam) {
+    float s = ((float)d + 0.5f) * (1.0f / (float)R) - 0.5f;
+    s = s < 0.f ? 0.f : s;
+    i0 = (int)s;
+    i1 = i0 + 1 < n ? i0 + 1 : n - 1;
+    lam = s - (float)i0;
+}
+
+template <typename T, bool VEC>
+__global__ void bilinear_fwd_kernel(salt_view x, salt_view y, int R) {
+    constexpr int N = Unit<T, VEC>::N;
+    const int cpv = x.C / N;
+    const int64_t units = (int64_t)y.B * y.H * y.W * cpv;
+    for (int64_t u = blockIdx.x * 256LL + threadIdx.x; u < units; u += gridDim.x * 256LL) {
+        int64_t pix = u / cpv; const int c0 = (int)(u - pix * cpv) * N;
+        const int ox = (int)(pix % y.W); int64_t r = pix / y.W; const int oy = (int)(r % y.H); const int b = (int)(r / y.H);
+        int y0, y1, x0, x1; float ly, lx;
+        bil_src(oy, R, x.H, y0, y1, ly);
+        bil_src(ox, R, x.W, x0, x1, lx);
+        const T* base = (const T*)x.p + (int64_t)b * x.H * x.W * x.cs + c0;
+        float a[N], bq[N], c[N], d[N], o[N];
+        Unit<T, VEC>::ld(base + ((int64_t)y0 * x.W + x0) * x.cs, a);
+        Unit<T, VEC>::ld(base + ((int64_t)y0 * x.W + x1) * x.cs, bq);
+        Unit<T, VEC>::ld(base + ((int64_t)y1 * x.W + x0) * x.cs, c);
+        Unit<T, VEC>::ld(base + ((int64_t)y1 * x.W + x1) * x.cs, d);
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+            o[j] = (1.f - ly) * ((1.f - lx) * a[j] + lx * bq[j]) + ly * ((1.f - lx) * c[j] + lx * d[j]);
+        Unit<T, VEC>::st((T*)y.p + pix * y.cs + c0, o);
+    }
+}
+
+// adjoint as a gather over the (<= 2R x 2R) outputs that reference each input pixel: deterministic.
+template <typename T, bool VEC>
+__global__ void bilinear_bwd_kernel(salt_view x, salt_view y, int R, int accumulate) {
+    constexpr int N = Unit<T, VEC>::N;
+    const int cpv = x.C / N;
+    const int64_t units = (int64_t)x.B * x.H * x.W * cpv;
+    for (int64_t u = blockIdx.x * 256LL + threadIdx.x; u < units; u += gridDim.x * 256LL) {
+        int64_t pix = u / cpv; const int c0 = (int)(u - pix * cpv) * N;
+        const int ix = (int)(pix % x.W); int64_t r = pix / x.W; const int iy = (int)(r % x.H); const int b = (int)(r / x.H);
+        const int oy_lo = max(0, R * iy - R / 2), oy_hi = min(y.H - 1, R * iy + (3 * R) / 2 - 1);
+        const int ox_lo = max(0, R * ix - R / 2), ox_hi = min(y.W - 1, R * ix + (3 * R) / 2 - 1);
+        float o[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) o[j] = 0.f;
+        const T* base = (const T*)y.p + (int64_t)b * y.H * y.W * y.cs + c0;
+        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+            int y0, y1; float ly;
+            bil_src(oy, R, x.H, y0, y1, ly);
+            const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+            if (wy == 0.f) continue;
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                int x0, x1; float lx;
+                bil_src(ox, R, x.W, x0, x1, lx);
+                const float w = wy * ((x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f));
+                if (w == 0.f) continue;
+                float g[N];
+                Unit<T, VEC>::ld(base + ((int64_t)oy * y.W + ox) * y.cs, g);
+#pragma unroll
+                for (int j = 0; j < N; ++j) o[j] += w * g[j];
+            }
+        }
+        T* dst = (T*)x.p + pix * x.cs + c0;
+        if (accumulate) { float old[N]; Unit<T, VEC>::ld(dst, old);
+#pragma unroll
+            for (int j = 0; j < N; ++j) o[j] += old[j]; }
+        Unit<T, VEC>::st(dst, o);
+    }
+}
+
+// ---------------------------------------------------------------- replicate-pad adjoint
+template <typename T, bool VEC>
+__global__ void pad_fold_kernel(salt_view xp, int top, int bottom, int left, int right, salt_view x, int accumulate) {
+    constexpr int N = Unit<T, VEC>::N;
+    const int cpv = x.C / N;
+    const int64_t units = (int64_t)x.B * x.H * x.W * cpv;
+    for (int64_t u = blockIdx.x * 256LL + threadIdx.x; u < units; u += gridDim.x * 256LL) {
+        int64_t pix = u / cpv; const int c0 = (int)(u - pix * cpv) * N;
+        const int ix = (int)(pix % x.W); int64_t r = pix / x.W; const int iy = (int)(r % x.H); const int b = (int)(r / x.H);
+        const int py0 = iy == 0 ? 0 : iy + top, py1 = iy == x.H - 1 ? iy + top + bottom : iy + top;
+        const int px0 = ix == 0 ? 0 : ix + left, px1 = ix == x.W - 1 ? ix + left + right : ix + left;
+        float o[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) o[j] = 0.f;
+        for (int py = py0; py <= py1; ++py)
+            for (int px = px0; px <= px1; ++px) {
+                float g[N];
+                Unit<T, VEC>::ld((const T*)xp.p + (((int64_t)b * xp.H + py) * xp.W + px) * xp.cs + c0, g);
+#pragma unroll
+                for (int j = 0; j < N; ++j) o[j] += g[j];
+            }
+        T* dst = (T*)x.p + pix * x.cs + c0;
+        if (accumulate) { float old[N]; Unit<T, VEC>::ld(dst, old);
+#pragma unroll
+            for (int j = 0; j < N; ++j) o[j] += old[j]; }
+        Unit<T, VEC>::st(dst, o);
+    }
+}
+
+template <typename T, bool VEC>
+__global__ void add_kernel(salt_view a, salt_view b, salt_view y, int accumulate) {
+    constexpr int N = Unit<T, VEC>::N;
+    const int cpv = a.C / N;
+    const int64_t units = (int64_t)a.B * a.H * a.W * cpv;
+    for (int64_t u = blockIdx.x * 256LL + threadIdx.x; u < units; u += gridDim.x * 256LL) {
+        const int64_t pix = u / cpv; const int c0 = (int)(u - pix * cpv) * N;
+        float f[N], g[N];
+        Unit<T, VEC>::ld((const T*)a.p + pix * a.cs + c0, f);
+        if (b.p) { Unit<T, VEC>::ld((const T*)b.p + pix * b.cs + c0, g);
+#pragma unroll
+            for (int j = 0; j < N; ++j) f[j] += g[j]; }
+        if (accumulate) { Unit<T, VEC>::ld((const T*)y.p + pix * y.cs + c0, g);
+#pragma unroll
+            for (int j = 0; j < N; ++j) f[j] += g[j]; }
+        Unit<T, VEC>::st((T*)y.p + pix * y.cs + c0, f);
+    }
+}
+
+template <typename T>
+__global__ void layout_kernel(float* nchw, salt_view v, int to_nhwc) {
+    const int64_t hw = (int64_t)v.H * v.W;
+    const int64_t npix = (int64_t)v.B * hw;
+    for (int64_t pix = blockIdx.x * 256LL + threadIdx.x; pix < npix; pix += gridDim.x * 256LL) {
+        const int64_t b = pix / hw, s = pix - b * hw;
+        T* row = (T*)v.p + pix * v.cs;
+        for (int c = 0; c < v.C; ++c) {
+            float* q = nchw + (b * v.C + c) * hw + s;
+            if (to_nhwc) Elem<T>::st(row + c, *q); else *q = Elem<T>::ld(row + c);
+        }
+    }
+}
+
+inline bool same_shape(const salt_view& a, const salt_view& b) { return a.B == b.B && a.H == b.H && a.W == b.W && a.C == b.C; }
+
+}  // namespace
+
+extern "C" int salt_affine_act(const salt_affine_act_args* a, void* stream) {
+    if (!a || !view_ok(a->y) || !view_ok(a->a) || !same_shape(a->y, a->a)) SALT_FAIL(SALT_E_BADARG, "affine_act: bad views");
+    if (a->res.p && !same_shape(a->y, a->res)) SALT_FAIL(SALT_E_BADARG, "affine_act: residual shape");
+    if ((a->scale == nullptr) != (a->shift == nullptr)) SALT_FAIL(SALT_E_BADARG, "affine_act: scale/shift");
+    SALT_DISPATCH_DTYPE(a->dtype, T, {
+        const int ve = Elem<T>::VE;
+        const bool v = vec_ok(a->y, ve) && vec_ok(a->a, ve) && vec_ok(a->res, ve);
+        const int64_t units = view_pixels(a->y) * (a->y.C / (v ? ve : 1));
+        EW_LAUNCH(affine_act_kernel, T, v, units, (hipStream_t)stream, a->y, a->scale, a->shift, a->res, a->relu, a->a);
+    })
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}
+
+extern "C" int salt_bn_finalize(const salt_bn_finalize_args* a, void* stream) {
+    if (!a || !a->stats || !a->stats_cnt || a->C < 1 || a->nparts < 1 || !a->gamma || !a->beta || !a->mean || !a->invstd || !a->scale || !a->shift)
+        SALT_FAIL(SALT_E_BADARG, "bn_finalize: bad args");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(a->C, 64)), dim3(64), 0, (hipStream_t)stream, *a);
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}
+
+extern "C" int salt_bn_fold(const salt_bn_fold_args* a, void* stream) {
+    if (!a || a->C < 1 || !a->gamma || !a->beta || !a->running_mean || !a->running_var || !a->scale || !a->shift) SALT_FAIL(SALT_E_BADARG, "bn_fold: bad args");
+    hipLaunchKernelGGL(bn_fold_kernel, dim3(cdiv(a->C, 64)), dim3(64), 0, (hipStream_t)stream, *a);
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}
+
+static int bn_bwd_nparts(const salt_bn_bwd_args* a, int64_t* ppb) {
+    const int64_t npix = view_pixels(a->y);
+    int64_t parts = (npix + 127) / 128;
+    if (parts > 1024) parts = 1024;
+    if (parts < 1) parts = 1;
+    const int64_t per = (npix + parts - 1) / parts;
+    if (ppb) *ppb = per;
+    return (int)((npix + per - 1) / per);
+}
+
+extern "C" int salt_bn_bwd_parts(const salt_bn_bwd_args* a) {
+    if (!a || !view_ok(a->y)) return -1;
+    return bn_bwd_nparts(a, nullptr);
+}
+
+extern "C" int salt_bn_bwd(const salt_bn_bwd_args* a, void* stream) {
+    if (!a || !view_ok(a->da) || !view_ok(a->y) || !view_ok(a->dy) || !same_shape(a->da, a->y) || !same_shape(a->dy, a->y))
+        SALT_FAIL(SALT_E_BADARG, "bn_bwd: bad views");
+    if (a->relu && (!view_ok(a->a) || !same_shape(a->a, a->y))) SALT_FAIL(SALT_E_BADARG, "bn_bwd: relu needs the forward output");
+    if (a->dres.p && !same_shape(a->dres, a->y)) SALT_FAIL(SALT_E_BADARG, "bn_bwd: dres shape");
+    if (!a->mean || !a->invstd || !a->gamma || !a->partials || !a->coef) SALT_FAIL(SALT_E_BADARG, "bn_bwd: missing buffers");
+    int64_t per = 0;
+    const int nparts = bn_bwd_nparts(a, &per);
+    if (a->nparts != nparts) SALT_FAIL(SALT_E_BADARG, "bn_bwd: nparts %d, expected %d", a->nparts, nparts);
+    hipStream_t st = (hipStream_t)stream;
+    const int C = a->y.C;
+    SALT_DISPATCH_DTYPE(a->dtype, T, {
+        const int ve = Elem<T>::VE;
+        const bool v = vec_ok(a->da, ve) && vec_ok(a->y, ve) && vec_ok(a->dy, ve) && vec_ok(a->dres, ve) && (!a->relu || vec_ok(a->a, ve));
+        const int N = v ? ve : 1;
+        const int cpv = C / N;
+        const int cvn = cpv < 256 ? cpv : 256;
+        const size_t lds = (size_t)(256 / cvn) * cvn * N * 2 * sizeof(float);
+        if (v) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), dim3(nparts), dim3(256), lds, st, a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->partials, per);
+        else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), dim3(nparts), dim3(256), lds, st, a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->partials, per);
+        SALT_CHECK_LAUNCH();
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, a->partials, nparts, C, (double)view_pixels(a->y),
+                           a->gamma, a->invstd, a->dgamma, a->dbeta, a->accumulate_param_grads, a->coef);
+        SALT_CHECK_LAUNCH();
+        const int64_t units = view_pixels(a->y) * cpv;
+        EW_LAUNCH(bn_bwd_apply_kernel, T, v, units, st, a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->coef, a->dy, a->dres, a->accumulate_dres);
+    })
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}
+
+extern "C" int salt_relu_bwd(const salt_relu_bwd_args* a, void* stream) {
+    if (!a || !view_ok(a->da) || !view_ok(a->dy) || !same_shape(a->da, a->dy)) SALT_FAIL(SALT_E_BADARG, "relu_bwd: bad views");
+    if (a->a.p && !same_shape(a->a, a->da)) SALT_FAIL(SALT_E_BADARG, "relu_bwd: mask shape");
+    SALT_DISPATCH_DTYPE(a->dtype, T, {
+        const int ve = Elem<T>::VE;
+        const bool v = vec_ok(a->da, ve) && vec_ok(a->dy, ve) && vec_ok(a->a, ve);
+        const int64_t units = view_pixels(a->da) * (a->da.C / (v ? ve : 1));
+        EW_LAUNCH(relu_bwd_kernel, T, v, units, (hipStream_t)stream, a->da, a->a, a->dy, a->accumulate);
+    })
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}
+
+extern "C" int salt_maxpool2(const salt_maxpool2_args* a, void* stream) {
+    if (!a || !view_ok(a->x) || !view_ok(a->y) || a->y.H != a->x.H / 2 || a->y.W != a->x.W / 2 || a->y.C != a->x.C || a->y.B != a->x.B)
+        SALT_FAIL(SALT_E_BADARG, "maxpool2: bad views");
+    SALT_DISPATCH_DTYPE(a->dtype, T, {
+        const int ve = Elem<T>::VE;
+        const bool v = vec_ok(a->x, ve) && vec_ok(a->y, ve);
+        const int64_t units = view_pixels(a->y) * (a->y.C / (v ? ve : 1));
+        EW_LAUNCH(maxpool2_kernel, T, v, units, (hipStream_t)stream, a->x, a->y);
+    })
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}
+
+extern "C" int salt_maxpool2_bwd(const salt_maxpool2_bwd_args* a, void* stream) {
+    if (!a || !view_ok(a->x) || !view_ok(a->dy) || !view_ok(a->dx) || !same_shape(a->x, a->dx) || a->dy.H != a->x.H / 2 || a->dy.W != a->x.W / 2 || a->dy.C != a->x.C)
+        SALT_FAIL(SALT_E_BADARG, "maxpool2_bwd: bad views");
+    SALT_DISPATCH_DTYPE(a->dtype, T, {
+        const int ve = Elem<T>::VE;
+        const bool v = vec_ok(a->x, ve) && vec_ok(a->dy, ve) && vec_ok(a->dx, ve);
+        const int64_t units = view_pixels(a->x) * (a->x.C / (v ? ve : 1));
+        EW_LAUNCH(maxpool2_bwd_kernel, T, v, units, (hipStream_t)stream, a->x, a->dy, a->dx, a->accumulate);
+    })
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}
+
+extern "C" int salt_avgpool2(const salt_avgpool2_args* a, void* stream) {
+    if (!a || !view_ok(a->x) || !view_ok(a->y) || a->y.H != a->x.H / 2 || a->y.W != a->x.W / 2 || a->y.C != a->x.C || a->y.B != a->x.B)
+        SALT_FAIL(SALT_E_BADARG, "avgpool2: bad views");
+    SALT_DISPATCH_DTYPE(a->dtype, T, {
+        const int ve = Elem<T>::VE;
+        const bool v = vec_ok(a->x, ve) && vec_ok(a->y, ve);
+        const int64_t units = (a->backward ? view_pixels(a->x) : view_pixels(a->y)) * (a->y.C / (v ? ve : 1));
+        EW_LAUNCH(avgpool2_kernel, T, v, units, (hipStream_t)stream, a->x, a->y, a->backward, a->accumulate);
+    })
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}
+
+extern "C" int salt_bilinear(const salt_bilinear_args* a, void* stream) {
+    if (!a || !view_ok(a->x) || !view_ok(a->y) || a->R < 1 || a->y.H != a->x.H * a->R || a->y.W != a->x.W * a->R || a->y.C != a->x.C || a->y.B != a->x.B)
+        SALT_FAIL(SALT_E_BADARG, "bilinear: bad views");
+    SALT_DISPATCH_DTYPE(a->dtype, T, {
+        const int ve = Elem<T>::VE;
+        const bool v = vec_ok(a->x, ve) && vec_ok(a->y, ve);
+        if (!a->backward) {
+            const int64_t units = view_pixels(a->y) * (a->y.C / (v ? ve : 1));
+            EW_LAUNCH(bilinear_fwd_kernel, T, v, units, (hipStream_t)stream, a->x, a->y, a->R);
+        } else {
+            const int64_t units = view_pixels(a->x) * (a->x.C / (v ? ve : 1));
+            EW_LAUNCH(bilinear_bwd_kernel, T, v, units, (hipStream_t)stream, a->x, a->y, a->R, a->accumulate);
+        }
+    })
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}
+
+extern "C" int salt_pad_fold(const salt_pad_fold_args* a, void* stream) {
+    if (!a || !view_ok(a->x) || !view_ok(a->xp) || a->xp.H != a->x.H + a->top + a->bottom || a->xp.W != a->x.W + a->left + a->right || a->xp.C != a->x.C || a->xp.B != a->x.B)
+        SALT_FAIL(SALT_E_BADARG, "pad_fold: bad views");
+    SALT_DISPATCH_DTYPE(a->dtype, T, {
+        const int ve = Elem<T>::VE;
+        const bool v = vec_ok(a->x, ve) && vec_ok(a->xp, ve);
+        const int64_t units = view_pixels(a->x) * (a->x.C / (v ? ve : 1));
+        EW_LAUNCH(pad_fold_kernel, T, v, units, (hipStream_t)stream, a->xp, a->top, a->bottom, a->left, a->right, a->x, a->accumulate);
+    })
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}
+
+extern "C" int salt_add(const salt_add_args* a, void* stream) {
+    if (!a || !view_ok(a->a) || !view_ok(a->y) || !same_shape(a->a, a->y)) SALT_FAIL(SALT_E_BADARG, "add: bad views");
+    if (a->b.p && !same_shape(a->a, a->b)) SALT_FAIL(SALT_E_BADARG, "add: b shape");
+    SALT_DISPATCH_DTYPE(a->dtype, T, {
+        const int ve = Elem<T>::VE;
+        const bool v = vec_ok(a->a, ve) && vec_ok(a->b, ve) && vec_ok(a->y, ve);
+        const int64_t units = view_pixels(a->a) * (a->a.C / (v ? ve : 1));
+        EW_LAUNCH(add_kernel, T, v, units, (hipStream_t)stream, a->a, a->b, a->y, a->accumulate);
+    })
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}
+
+extern "C" int salt_layout(const salt_layout_args* a, void* stream) {
+    if (!a || !a->nchw || !view_ok(a->nhwc)) SALT_FAIL(SALT_E_BADARG, "layout: bad args");
+    const int64_t npix = view_pixels(a->nhwc);
+    SALT_DISPATCH_DTYPE(a->dtype, T, {
+        hipLaunchKernelGGL(layout_kernel<T>, dim3(ew_blocks(npix)), dim3(256), 0, (hipStream_t)stream, a->nchw, a->nhwc, a->to_nhwc);
+    })
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}

@@ -1,0 +1,354 @@
+// loss.hip — Lovasz hinge and BCE+Dice on the GPU.
+//
+// Lovasz hinge (lovasz_losses.py:81-115,21-33 via models.py:326-328): the reference loops over the B
+// images in Python and issues ~10 small torch kernels per image (sort, gather, cumsum x2, ...).  Here
+// ONE launch does the whole batch: one 1024-thread workgroup per image runs a stable LSD radix sort
+// (4 x 8-bit digits) of the hinge errors with a (flat index, label) payload through a ping-pong
+// workspace that stays L2-resident (P = 2*H*W = 32768 keys = 256 KB per image), then a single fused
+// pass does the label scan, the Jaccard gradient g_k, the dot with elu(errors) and the scatter of
+// d loss / d logit back to NCHW order.  Ties keep flat-index order (stable sort), so results are
+// deterministic; the loss value itself is tie-order invariant.
+#include "common.h"
+
+namespace {
+
+constexpr int LT = 1024;                 // threads per image
+constexpr int LW = LT / 64;              // waves
+
+__device__ __forceinline__ unsigned desc_key(float e) {          // ascending uint order == descending float order
+    unsigned u = __float_as_uint(e);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ~u;
+}
+__device__ __forceinline__ float key_to_float(unsigned k) {
+    unsigned u = ~k;
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return __uint_as_float(u);
+}
+
+__global__ __launch_bounds__(LT) void lovasz_kernel(salt_lovasz_args a) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned base[256];
+    __shared__ unsigned wcount[LW][256];
+    __shared__ float red[LW];
+    __shared__ unsigned scan_w[LW];
+    __shared__ unsigned carry_s;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int P = a.P;
+    const float* z = a.logits + (int64_t)b * P;
+    const float* y = a.target + (int64_t)b * P;
+    unsigned* k0 = a.ws_keys + (int64_t)b * P;
+    unsigned* v0 = a.ws_vals + (int64_t)b * P;
+    unsigned* k1 = a.ws_keys + ((int64_t)a.B + b) * P;
+    unsigned* v1 = a.ws_vals + ((int64_t)a.B + b) * P;
+
+    // ---- keys + total positives
+    float gsum = 0.f;
+    for (int i = tid; i < P; i += LT) {
+        const float lab = y[i] > 0.5f ? 1.f : 0.f;              // target.long() of a {0.,1.} mask
+        const float e = 1.f - z[i] * (2.f * lab - 1.f);
+        k0[i] = desc_key(e);
+        v0[i] = ((unsigned)i << 1) | (lab > 0.5f ? 1u : 0u);
+        gsum += lab;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) gsum += __shfl_xor(gsum, o);
+    if (lane == 0) red[wave] = gsum;
+    __syncthreads();
+    float G = 0.f;
+    for (int w = 0; w < LW; ++w) G += red[w];
+    __syncthreads();
+
+    // ---- stable LSD radix sort, 8 bits per pass
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int pass = 0; pass < 4; ++pass) {
+        const unsigned* ki = (pass & 1) ? k1 : k0; const unsigned* vi = (pass & 1) ? v1 : v0;
+        unsigned* ko = (pass & 1) ? k0 : k1; unsigned* vo = (pass & 1) ? v0 : v1;
+        const int shift = pass * 8;
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < P; i += LT) atomicAdd(&hist[(ki[i] >> shift) & 255u], 1u);
+        __syncthreads();
+        if (tid < 64) {                                           // exclusive scan of 256 counters by one wave
+            unsigned c[4], s = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { c[j] = hist[tid * 4 + j]; s += c[j]; }
+            unsigned incl = s;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+            unsigned run = incl - s;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { base[tid * 4 + j] = run; run += c[j]; }
+        }
+        __syncthreads();
+        for (int c0 = 0; c0 < P; c0 += LT) {
+            for (int i = tid; i < LW * 256; i += LT) (&wcount[0][0])[i] = 0;
+            __syncthreads();
+            const int i = c0 + tid;
+            const bool ok = i < P;
+            unsigned key = 0, val = 0, d = 256;
+            if (ok) { key = ki[i]; val = vi[i]; d = (key >> shift) & 255u; }
+            // lanes of this wave holding the same digit
+            unsigned long long m = __ballot(ok);
+#pragma unroll
+            for (int bit = 0; bit < 8; ++bit) {
+                const unsigned long long bm = __ballot((d >> bit) & 1u);
+                m &= ((d >> bit) & 1u) ? bm : ~bm;
+            }
+            const unsigned rank = (unsigned)__popcll(m & lt_mask);
+            if (ok && rank == 0) wcount[wave][d] = (unsigned)__popcll(m);
+            __syncthreads();
+            if (tid < 256) {                                      // digit tid: prefix over waves, advance base
+                unsigned run = base[tid];
+                for (int w = 0; w < LW; ++w) { const unsigned c = wcount[w][tid]; wcount[w][tid] = run; run += c; }
+                base[tid] = run;
+            }
+            __syncthreads();
+            if (ok) { const unsigned dst = wcount[wave][d] + rank; ko[dst] = key; vo[dst] = val; }
+            __syncthreads();
+        }
+    }
+    // after 4 passes the sorted sequence is back in (k0, v0)
+
+    // ---- fused scan + Jaccard gradient + dot + scatter
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    float lsum = 0.f;
+    const float gscale = a.loss_scale / (float)a.B;
+    float* dz = a.dlogits ? a.dlogits + (int64_t)b * P : nullptr;
+    for (int c0 = 0; c0 < P; c0 += LT) {
+        const int i = c0 + tid;
+        const bool ok = i < P;
+        unsigned val = ok ? v0[i] : 0u;
+        const unsigned lab = val & 1u;
+        unsigned incl = ok ? lab : 0u;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        if (lane == 63) scan_w[wave] = incl;
+        __syncthreads();
+        unsigned woff = carry_s;
+        for (int w = 0; w < wave; ++w) woff += scan_w[w];
+        const unsigned c_k = woff + incl;                         // inclusive count of positives up to rank k
+        __syncthreads();
+        if (tid == LT - 1) carry_s = c_k;
+        if (ok) {
+            const float e = key_to_float(k0[i]);
+            const float kf = (float)(i + 1), ck = (float)c_k, ckm = (float)(c_k - lab);
+            const float jk = 1.f - (G - ck) / (G + (kf - ck));
+            float jm = 0.f;
+            if (i > 0) jm = 1.f - (G - ckm) / (G + ((kf - 1.f) - ckm));
+            const float g = (i > 0) ? jk - jm : jk;
+            const float el = e > 0.f ? e : expm1f(e);
+            lsum += el * g;
+            if (dz) {
+                const float d = e > 0.f ? 1.f : __expf(e);
+                const float s = lab ? 1.f : -1.f;
+                dz[val >> 1] = -s * d * g * gscale;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
+    if (lane == 0) red[wave] = lsum;
+    __syncthreads();
+    if (tid == 0) {
+        float t = 0.f;
+        for (int w = 0; w < LW; ++w) t += red[w];
+        if (P == 0) t = 0.f;
+        a.loss_per_image[b] = t;
+    }
+}
+
+__global__ void mean_kernel(const float* v, int n, float scale, float* out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < n; ++i) s += v[i];
+        out[0] = s * scale / (float)n;
+    }
+}
+
+// ---------------------------------------------------------------- BCE + Dice
+__global__ __launch_bounds__(256) void bce_dice_partial_kernel(const float* z, const float* t, int HW, int ppp, int per, float* partials) {
+    __shared__ float sm4[4];
+    const int plane = blockIdx.x / ppp, part = blockIdx.x % ppp;
+    const int i0 = part * per, i1 = min(i0 + per, HW);
+    float s_pt = 0.f, s_p = 0.f, s_t = 0.f, s_b = 0.f;
+    for (int i = i0 + threadIdx.x; i < i1; i += 256) {
+        const float zz = z[(int64_t)plane * HW + i], tt = t[(int64_t)plane * HW + i];
+        const float p = 1.f / (1.f + expf(-zz));
+        s_pt += p * tt; s_p += p; s_t += tt;
+        s_b += fmaxf(zz, 0.f) - zz * tt + log1pf(expf(-fabsf(zz)));
+    }
+    const float r0 = block_sum_256(s_pt, sm4), r1 = block_sum_256(s_p, sm4), r2 = block_sum_256(s_t, sm4), r3 = block_sum_256(s_b, sm4);
+    if (threadIdx.x == 0) { float* o = partials + (int64_t)blockIdx.x * 4; o[0] = r0; o[1] = r1; o[2] = r2; o[3] = r3; }
+}
+
+__global__ void bce_dice_finalize_kernel(const float* partials, int B, int C, int ppp, int HW, float dw, float bw, float scale, float* sums, float* loss) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double bce = 0.0, dice = 0.0;
+    for (int c = 0; c < C; ++c) {
+        double pt = 0.0, p = 0.0, t = 0.0;
+        for (int b = 0; b < B; ++b)
+            for (int k = 0; k < ppp; ++k) {
+                const float* o = partials + ((int64_t)(b * C + c) * ppp + k) * 4;
+                pt += o[0]; p += o[1]; t += o[2]; bce += o[3];
+            }
+        sums[c * 3 + 0] = (float)pt; sums[c * 3 + 1] = (float)p; sums[c * 3 + 2] = (float)t;
+        dice += 1.0 - 2.0 * pt / (p + t + 1e-7);
+    }
+    sums[3 * C] = (float)bce;
+    loss[0] = (float)((dw * dice / C + bw * bce / ((double)B * C * HW)) * scale);
+}
+
+__global__ void bce_dice_grad_kernel(const float* z, const float* t, int B, int C, int HW, const float* sums, float dw, float bw, float scale, float* dz) {
+    const int64_t n = (int64_t)B * C * HW;
+    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < n; i += gridDim.x * 256LL) {
+        const int c = (int)((i / HW) % C);
+        const float pt = sums[c * 3], S = sums[c * 3 + 1] + sums[c * 3 + 2] + 1e-7f;
+        const float zz = z[i], tt = t[i];
+        const float p = 1.f / (1.f + expf(-zz));
+        const float dD = -2.f * (tt * S - pt) / (S * S);
+        dz[i] = scale * (dw / (float)C * dD * p * (1.f - p) + bw / (float)n * (p - tt));
+    }
+}
+
+int bce_ppp(int HW, int* per) {
+    int ppp = cdiv(HW, 4096);
+    if (ppp > 16) ppp = 16;
+    if (ppp < 1) ppp = 1;
+    const int pp = cdiv(HW, ppp);
+    if (per) *per = pp;
+    return cdiv(HW, pp);
+}
+
+// ---------------------------------------------------------------- Adam (+L2), flat buffer
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
+                            const float* __restrict__ hyper) {
+    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], bc1 = hyper[5], bc2 = hyper[6], gs = hyper[7];
+    const float step_size = lr / bc1, rs = 1.f / sqrtf(bc2);
+    const int64_t n4 = n >> 2;
+    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < n4; i += gridDim.x * 256LL) {
+        float4 pp = reinterpret_cast<float4*>(p)[i], gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+#define SALT_ADAM1(X) { const float gr = gg.X * gs + wd * pp.X; mm.X = b1 * mm.X + (1.f - b1) * gr; vv.X = b2 * vv.X + (1.f - b2) * gr * gr; \
+                        pp.X -= step_size * mm.X / (sqrtf(vv.X) * rs + eps); }
+        SALT_ADAM1(x) SALT_ADAM1(y) SALT_ADAM1(z) SALT_ADAM1(w)
+        reinterpret_cast<float4*>(p)[i] = pp; reinterpret_cast<float4*>(m)[i] = mm; reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    for (int64_t i = (n4 << 2) + blockIdx.x * 256LL + threadIdx.x; i < n; i += gridDim.x * 256LL) {
+        const float gr = g[i] * gs + wd * p[i];
+        const float m1 = b1 * m[i] + (1.f - b1) * gr, v1 = b2 * v[i] + (1.f - b2) * gr * gr;
+        m[i] = m1; v[i] = v1;
+        p[i] -= step_size * m1 / (sqrtf(v1) * rs + eps);
+    }
+}
+
+__global__ void adam_tick_kernel(float* hyper, int64_t* step) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const int64_t t = step[0] + 1;
+        step[0] = t;
+        hyper[5] = (float)(1.0 - pow((double)hyper[1], (double)t));
+        hyper[6] = (float)(1.0 - pow((double)hyper[2], (double)t));
+    }
+}
+
+// ---------------------------------------------------------------- TTA: sigmoid -> inverse flip -> mean
+struct TtaKP { const float* logits; float* prob; int V, B, C, H, W; int ud[16], lr[16]; };
+__global__ void tta_mean_kernel(TtaKP p) {
+    const int64_t hw = (int64_t)p.H * p.W, n = (int64_t)p.B * p.C * hw;
+    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < n; i += gridDim.x * 256LL) {
+        const int x = (int)(i % p.W); int64_t r = i / p.W; const int y = (int)(r % p.H); const int64_t plane = r / p.H;
+        float s = 0.f;
+        for (int v = 0; v < p.V; ++v) {
+            const int yy = p.ud[v] ? p.H - 1 - y : y, xx = p.lr[v] ? p.W - 1 - x : x;
+            const float zz = p.logits[((int64_t)v * p.B * p.C + plane) * hw + (int64_t)yy * p.W + xx];
+            s += 1.f / (1.f + expf(-zz));
+        }
+        p.prob[i] = s / (float)p.V;
+    }
+}
+__global__ void flip_kernel(salt_flip_args a) {
+    const int64_t hw = (int64_t)a.H * a.W, n = (int64_t)a.B * a.C * hw;
+    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < n; i += gridDim.x * 256LL) {
+        const int x = (int)(i % a.W); int64_t r = i / a.W; const int y = (int)(r % a.H); const int64_t plane = r / a.H;
+        const int yy = a.flip_ud ? a.H - 1 - y : y, xx = a.flip_lr ? a.W - 1 - x : x;
+        a.y[i] = a.x[plane * hw + (int64_t)yy * a.W + xx];
+    }
+}
+
+}  // namespace
+
+extern "C" int salt_lovasz_hinge(const salt_lovasz_args* a, void* stream) {
+    if (!a || !a->logits || !a->target || a->B < 1 || a->P < 0 || !a->ws_keys || !a->ws_vals || !a->loss_per_image || !a->loss)
+        SALT_FAIL(SALT_E_BADARG, "lovasz: bad args");
+    hipLaunchKernelGGL(lovasz_kernel, dim3(a->B), dim3(LT), 0, (hipStream_t)stream, *a);
+    SALT_CHECK_LAUNCH();
+    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a->loss_per_image, a->B, a->loss_scale, a->loss);
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}
+
+extern "C" int salt_bce_dice_parts(const salt_bce_dice_args* a) {
+    if (!a || a->B < 1 || a->C < 1 || a->HW < 1) return -1;
+    return a->B * a->C * bce_ppp(a->HW, nullptr);
+}
+
+extern "C" int salt_bce_dice(const salt_bce_dice_args* a, void* stream) {
+    if (!a || !a->logits || !a->target || a->B < 1 || a->C < 1 || a->HW < 1 || !a->partials || !a->sums || !a->loss) SALT_FAIL(SALT_E_BADARG, "bce_dice: bad args");
+    int per = 0;
+    const int ppp = bce_ppp(a->HW, &per);
+    if (a->nparts != a->B * a->C * ppp) SALT_FAIL(SALT_E_BADARG, "bce_dice: nparts %d, expected %d", a->nparts, a->B * a->C * ppp);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bce_dice_partial_kernel, dim3(a->nparts), dim3(256), 0, st, a->logits, a->target, a->HW, ppp, per, a->partials);
+    SALT_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bce_dice_finalize_kernel, dim3(1), dim3(64), 0, st, a->partials, a->B, a->C, ppp, a->HW, a->dice_weight, a->bce_weight, a->loss_scale, a->sums, a->loss);
+    SALT_CHECK_LAUNCH();
+    if (a->dlogits) {
+        const int64_t n = (int64_t)a->B * a->C * a->HW;
+        const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+        hipLaunchKernelGGL(bce_dice_grad_kernel, dim3(blocks), dim3(256), 0, st, a->logits, a->target, a->B, a->C, a->HW, a->sums, a->dice_weight, a->bce_weight, a->loss_scale, a->dlogits);
+        SALT_CHECK_LAUNCH();
+    }
+    return SALT_OK;
+}
+
+extern "C" int salt_adam(const salt_adam_args* a, void* stream) {
+    if (!a || !a->param || !a->grad || !a->exp_avg || !a->exp_avg_sq || !a->hyper || a->n < 0) SALT_FAIL(SALT_E_BADARG, "adam: bad args");
+    if (a->n == 0) return SALT_OK;
+    if ((reinterpret_cast<uintptr_t>(a->param) | reinterpret_cast<uintptr_t>(a->grad) | reinterpret_cast<uintptr_t>(a->exp_avg) | reinterpret_cast<uintptr_t>(a->exp_avg_sq)) & 15)
+        SALT_FAIL(SALT_E_BADARG, "adam: buffers must be 16-byte aligned");
+    const int64_t n4 = (a->n + 3) / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a->param, a->grad, a->exp_avg, a->exp_avg_sq, a->n, a->hyper);
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}
+
+extern "C" int salt_adam_tick(const salt_adam_tick_args* a, void* stream) {
+    if (!a || !a->hyper || !a->step) SALT_FAIL(SALT_E_BADARG, "adam_tick: bad args");
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a->hyper, a->step);
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}
+
+extern "C" int salt_tta_mean(const salt_tta_mean_args* a, void* stream) {
+    if (!a || !a->logits || !a->prob || a->V < 1 || a->V > 16 || !a->flip_ud || !a->flip_lr) SALT_FAIL(SALT_E_BADARG, "tta_mean: bad args");
+    TtaKP p;
+    p.logits = a->logits; p.prob = a->prob; p.V = a->V; p.B = a->B; p.C = a->C; p.H = a->H; p.W = a->W;
+    for (int v = 0; v < a->V; ++v) { p.ud[v] = a->flip_ud[v]; p.lr[v] = a->flip_lr[v]; }
+    const int64_t n = (int64_t)a->B * a->C * a->H * a->W;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(tta_mean_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}
+
+extern "C" int salt_flip(const salt_flip_args* a, void* stream) {
+    if (!a || !a->x || !a->y) SALT_FAIL(SALT_E_BADARG, "flip: bad args");
+    const int64_t n = (int64_t)a->B * a->C * a->H * a->W;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(flip_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *a);
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}

@@ -1,0 +1,136 @@
+// runtime.hip — error text, device info, the static-program executor and hipGraph capture/replay.
+//
+// The reference drives its network through Python autograd, one torch operator at a time
+// (models.py:105-136).  Here a step is a flat, static list of operator descriptors built once by the
+// host; running it is ONE call that enqueues every kernel on a HIP stream, and the same list can be
+// captured into a hipGraph so that a launch-bound step costs one graph launch.
+#include <stdarg.h>
+#include <string.h>
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void salt_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* salt_last_error(void) { return g_err; }
+
+extern "C" int salt_abi_version(void) { return 3; }
+
+extern "C" int salt_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name_len) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) SALT_FAIL((int)e, "hipGetDevice: %s", hipGetErrorString(e));
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) SALT_FAIL((int)e, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (cu_count) *cu_count = prop.multiProcessorCount;
+    if (lds_bytes) *lds_bytes = (int)prop.sharedMemPerBlock;
+    if (arch_name && arch_name_len > 0) { strncpy(arch_name, prop.gcnArchName, arch_name_len - 1); arch_name[arch_name_len - 1] = 0; }
+    return SALT_OK;
+}
+
+extern "C" int salt_program_run_range(const salt_program_entry* e, int begin, int end, void* stream) {
+    if (!e || begin < 0 || end < begin) SALT_FAIL(SALT_E_BADARG, "program: bad range");
+    for (int i = begin; i < end; ++i) {
+        const int rc = e[i].fn(e[i].args, stream);
+        if (rc) {
+            char prev[400];
+            strncpy(prev, g_err, sizeof(prev) - 1); prev[sizeof(prev) - 1] = 0;
+            salt_set_error("program entry %d failed (%d): %s", i, rc, prev);
+            return rc;
+        }
+    }
+    return SALT_OK;
+}
+
+extern "C" int salt_program_run(const salt_program_entry* e, int n, void* stream) {
+    return salt_program_run_range(e, 0, n, stream);
+}
+
+extern "C" int salt_graph_capture(const salt_program_entry* e, int n, void* stream, void** out) {
+    if (!out || !stream) SALT_FAIL(SALT_E_BADARG, "graph capture needs a non-default stream");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t err = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+    if (err != hipSuccess) SALT_FAIL((int)err, "hipStreamBeginCapture: %s", hipGetErrorString(err));
+    const int rc = salt_program_run(e, n, stream);
+    hipGraph_t graph = nullptr;
+    err = hipStreamEndCapture(st, &graph);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (err != hipSuccess) SALT_FAIL((int)err, "hipStreamEndCapture: %s", hipGetErrorString(err));
+    hipGraphExec_t exec = nullptr;
+    err = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (err != hipSuccess) SALT_FAIL((int)err, "hipGraphInstantiate: %s", hipGetErrorString(err));
+    *out = (void*)exec;
+    return SALT_OK;
+}
+
+extern "C" int salt_graph_launch(void* exec, void* stream) {
+    hipError_t err = hipGraphLaunch((hipGraphExec_t)exec, (hipStream_t)stream);
+    if (err != hipSuccess) SALT_FAIL((int)err, "hipGraphLaunch: %s", hipGetErrorString(err));
+    return SALT_OK;
+}
+
+extern "C" int salt_graph_destroy(void* exec) {
+    if (exec) (void)hipGraphExecDestroy((hipGraphExec_t)exec);
+    return SALT_OK;
+}
+
+__global__ void zero_kernel(uint32_t* p, int64_t n4) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+
+extern "C" int salt_zero(const salt_zero_args* a, void* stream) {
+    if (!a || !a->p || a->bytes < 0 || (a->bytes & 3)) SALT_FAIL(SALT_E_BADARG, "zero: bad args");
+    if (a->bytes == 0) return SALT_OK;
+    const int64_t n4 = a->bytes / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(zero_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (uint32_t*)a->p, n4);
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}
+
+// sizeof() of every struct of saltnet.h in declaration order: the Python host compares them with its
+// ctypes mirror at import so that a layout mismatch can never go unnoticed.
+extern "C" int salt_abi_struct_sizes(int* out, int n) {
+    static const int sizes[] = {
+    (int)sizeof(salt_view),
+    (int)sizeof(salt_conv_args),
+    (int)sizeof(salt_conv_wgrad_args),
+    (int)sizeof(salt_wgrad_reduce_args),
+    (int)sizeof(salt_pack_conv_weight_args),
+    (int)sizeof(salt_conv_first_args),
+    (int)sizeof(salt_conv_first_wgrad_args),
+    (int)sizeof(salt_head1x1_args),
+    (int)sizeof(salt_head1x1_bwd_args),
+    (int)sizeof(salt_bn_finalize_args),
+    (int)sizeof(salt_bn_fold_args),
+    (int)sizeof(salt_affine_act_args),
+    (int)sizeof(salt_bn_bwd_args),
+    (int)sizeof(salt_relu_bwd_args),
+    (int)sizeof(salt_maxpool2_args),
+    (int)sizeof(salt_maxpool2_bwd_args),
+    (int)sizeof(salt_avgpool2_args),
+    (int)sizeof(salt_bilinear_args),
+    (int)sizeof(salt_pad_fold_args),
+    (int)sizeof(salt_add_args),
+    (int)sizeof(salt_layout_args),
+    (int)sizeof(salt_scse_args),
+    (int)sizeof(salt_scse_bwd_args),
+    (int)sizeof(salt_lovasz_args),
+    (int)sizeof(salt_bce_dice_args),
+    (int)sizeof(salt_adam_args),
+    (int)sizeof(salt_adam_tick_args),
+    (int)sizeof(salt_zero_args),
+    (int)sizeof(salt_tta_mean_args),
+    (int)sizeof(salt_flip_args),
+    (int)sizeof(salt_program_entry)};
+    const int m = (int)(sizeof(sizes) / sizeof(sizes[0]));
+    for (int i = 0; i < n && i < m; ++i) out[i] = sizes[i];
+    return m;
+}

@@ -1,0 +1,319 @@
+// se.hip — concurrent spatial + channel squeeze-excitation of the reference decoder
+// (architectures/base.py:82-117): out = relu(x*cSE(x) + x*sSE(x)).
+// The reference makes 3 extra full-tensor passes per SE branch; here forward is: one reduction pass
+// (global average pool partials), a tiny per-image FC kernel, one fused apply pass.  Backward is one fused
+// pass (dx direct terms + per-image partial sums), the FC backward, and one broadcast-add pass.
+// Channel count must be a power of two (64 / 256 in the reference's U-Nets); C/VE lanes share a pixel.
+#include "common.h"
+
+namespace {
+
+template <typename T> struct P16 {
+    static constexpr int N = Elem<T>::VE;
+    static __device__ __forceinline__ void ld(const T* p, float* f) { unpack16<T>(*reinterpret_cast<const u32x4*>(p), f); }
+    static __device__ __forceinline__ void st(T* p, const float* f) { *reinterpret_cast<u32x4*>(p) = pack16<T>(f); }
+};
+
+// per-image partial channel sums: partials[b][part][C]
+template <typename T>
+__global__ __launch_bounds__(256) void gap_partial_kernel(salt_view x, float* partials, int nparts, int pix_per_part) {
+    constexpr int N = P16<T>::N;
+    extern __shared__ float sm[];
+    const int C = x.C, cpv = C / N, R = 256 / cpv;
+    const int b = blockIdx.x / nparts, part = blockIdx.x % nparts;
+    const int hw = x.H * x.W;
+    const int p0 = part * pix_per_part, p1 = min(p0 + pix_per_part, hw);
+    const int row = threadIdx.x / cpv, cv = threadIdx.x % cpv;
+    float s[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) s[j] = 0.f;
+    for (int pix = p0 + row; pix < p1; pix += R) {
+        float f[N];
+        P16<T>::ld((const T*)x.p + ((int64_t)b * hw + pix) * x.cs + cv * N, f);
+#pragma unroll
+        for (int j = 0; j < N; ++j) s[j] += f[j];
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) sm[(row * cpv + cv) * N + j] = s[j];
+    __syncthreads();
+    if (row == 0) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            float t = 0.f;
+            for (int r = 0; r < R; ++r) t += sm[(r * cpv + cv) * N + j];
+            partials[((int64_t)b * nparts + part) * C + cv * N + j] = t;
+        }
+    }
+}
+
+// one block per image: gap -> hidden -> gate_c
+__global__ void se_fc_kernel(const float* partials, int nparts, int C, int R, float inv_hw, const float* w1, const float* b1,
+                             const float* w2, const float* b2, float* gap, float* hidden, float* gate_c) {
+    extern __shared__ float sm[];       // [C] gap, [R] hidden
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float t = 0.f;
+        for (int k = 0; k < nparts; ++k) t += partials[((int64_t)b * nparts + k) * C + c];
+        t *= inv_hw;
+        sm[c] = t; gap[b * C + c] = t;
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < R; r += blockDim.x) {
+        float t = b1[r];
+        for (int c = 0; c < C; ++c) t += w1[r * C + c] * sm[c];
+        t = fmaxf(t, 0.f);
+        sm[C + r] = t; hidden[b * R + r] = t;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float t = b2[c];
+        for (int r = 0; r < R; ++r) t += w2[c * R + r] * sm[C + r];
+        gate_c[b * C + c] = 1.f / (1.f + __expf(-t));
+    }
+}
+
+template <typename T>
+__global__ void scse_apply_kernel(salt_view x, const float* gate_c, const float* ws, const float* bs, float* gate_s, salt_view y, int cpv_log2) {
+    constexpr int N = P16<T>::N;
+    const int cpv = 1 << cpv_log2;
+    const int hw = x.H * x.W;
+    const int64_t npix = (int64_t)x.B * hw;
+    const int64_t units_pad = ((npix << cpv_log2) + 255) & ~255LL;
+    const float bsv = bs[0];
+    for (int64_t u = blockIdx.x * 256LL + threadIdx.x; u < units_pad; u += gridDim.x * 256LL) {
+        const int64_t pix = u >> cpv_log2; const int cv = (int)(u & (cpv - 1));
+        float f[N];
+        float dot = 0.f;
+        const bool ok = pix < npix;
+        if (ok) {
+            P16<T>::ld((const T*)x.p + pix * x.cs + cv * N, f);
+#pragma unroll
+            for (int j = 0; j < N; ++j) dot += f[j] * ws[cv * N + j];
+        }
+        for (int s = 1; s < cpv; s <<= 1) dot += __shfl_xor(dot, s);
+        if (ok) {
+            const float gs = 1.f / (1.f + __expf(-(dot + bsv)));
+            const int b = (int)(pix / hw);
+#pragma unroll
+            for (int j = 0; j < N; ++j) f[j] = fmaxf(f[j] * (gate_c[b * x.C + cv * N + j] + gs), 0.f);
+            P16<T>::st((T*)y.p + pix * y.cs + cv * N, f);
+            if (cv == 0) gate_s[pix] = gs;
+        }
+    }
+}
+
+// backward pass 1: dx = g*(gc+gs) + ds*ws ; per-(image,part) partial sums of g*x (-> d gate_c), ds*x (-> g_ws), ds (-> g_bs)
+template <typename T>
+__global__ __launch_bounds__(256) void scse_bwd1_kernel(salt_view x, salt_view y, salt_view dy, const float* gate_c, const float* gate_s,
+                                                        const float* ws, salt_view dx, int accumulate, float* partials, int nparts,
+                                                        int pix_per_part, int cpv_log2) {
+    constexpr int N = P16<T>::N;
+    extern __shared__ float sm[];
+    const int C = x.C, cpv = 1 << cpv_log2, R = 256 >> cpv_log2;
+    const int b = blockIdx.x / nparts, part = blockIdx.x % nparts;
+    const int hw = x.H * x.W;
+    const int p0 = part * pix_per_part, p1 = min(p0 + pix_per_part, hw);
+    const int row = threadIdx.x >> cpv_log2, cv = threadIdx.x & (cpv - 1);
+    float s_gc[N], s_ws[N], s_bs = 0.f, gc[N], wsv[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) { s_gc[j] = 0.f; s_ws[j] = 0.f; gc[j] = gate_c[b * C + cv * N + j]; wsv[j] = ws[cv * N + j]; }
+    const int iters = (p1 - p0 + R - 1) / R;
+    for (int it = 0; it < iters; ++it) {
+        const int pix = p0 + it * R + row;
+        const bool ok = pix < p1;
+        float xv[N], g[N];
+        float dgs = 0.f, gs = 0.f;
+        const int64_t gp = (int64_t)b * hw + pix;
+        if (ok) {
+            float yv[N];
+            P16<T>::ld((const T*)x.p + gp * x.cs + cv * N, xv);
+            P16<T>::ld((const T*)y.p + gp * y.cs + cv * N, yv);
+            P16<T>::ld((const T*)dy.p + gp * dy.cs + cv * N, g);
+            gs = gate_s[gp];
+#pragma unroll
+            for (int j = 0; j < N; ++j) { g[j] = yv[j] > 0.f ? g[j] : 0.f; dgs += g[j] * xv[j]; }
+        }
+        for (int s = 1; s < cpv; s <<= 1) dgs += __shfl_xor(dgs, s);
+        if (ok) {
+            const float ds = dgs * gs * (1.f - gs);
+            float o[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                o[j] = g[j] * (gc[j] + gs) + ds * wsv[j];
+                s_gc[j] += g[j] * xv[j];
+                s_ws[j] += ds * xv[j];
+            }
+            if (cv == 0) s_bs += ds;
+            T* dst = (T*)dx.p + gp * dx.cs + cv * N;
+            if (accumulate) { float old[N]; P16<T>::ld(dst, old);
+#pragma unroll
+                for (int j = 0; j < N; ++j) o[j] += old[j]; }
+            P16<T>::st(dst, o);
+        }
+    }
+    // block combine (fixed order)
+    float* sg = sm; float* sw = sm + 256 * N; float* sb = sm + 512 * N;
+#pragma unroll
+    for (int j = 0; j < N; ++j) { sg[(row * cpv + cv) * N + j] = s_gc[j]; sw[(row * cpv + cv) * N + j] = s_ws[j]; }
+    if (cv == 0) sb[row] = s_bs;
+    __syncthreads();
+    float* out = partials + ((int64_t)b * nparts + part) * (2 * C + 1);
+    if (row == 0) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            float t1 = 0.f, t2 = 0.f;
+            for (int r = 0; r < R; ++r) { t1 += sg[(r * cpv + cv) * N + j]; t2 += sw[(r * cpv + cv) * N + j]; }
+            out[cv * N + j] = t1; out[C + cv * N + j] = t2;
+        }
+        if (cv == 0) { float t = 0.f; for (int r = 0; r < R; ++r) t += sb[r]; out[2 * C] = t; }
+    }
+}
+
+// FC backward: single block.  dgap[b][c] out; parameter grads written (not accumulated).
+__global__ void se_fc_bwd_kernel(const float* partials, int nparts, int B, int C, int R, const float* w1, const float* w2,
+                                 const float* gap, const float* hidden, const float* gate_c,
+                                 float* g_w1, float* g_b1, float* g_w2, float* g_b2, float* g_ws, float* g_bs, float* dgap, float inv_hw) {
+    extern __shared__ float sm[];       // du [B][C], dh [B][R]
+    float* du = sm; float* dh = sm + B * C;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    for (int i = tid; i < B * C; i += nt) {
+        const int b = i / C, c = i - b * C;
+        float t = 0.f;
+        for (int k = 0; k < nparts; ++k) t += partials[((int64_t)b * nparts + k) * (2 * C + 1) + c];
+        const float g = gate_c[i];
+        du[i] = t * g * (1.f - g);
+    }
+    for (int c = tid; c < C; c += nt) {
+        float t = 0.f;
+        for (int b = 0; b < B; ++b) for (int k = 0; k < nparts; ++k) t += partials[((int64_t)b * nparts + k) * (2 * C + 1) + C + c];
+        g_ws[c] = t;
+    }
+    if (tid == 0) {
+        float t = 0.f;
+        for (int b = 0; b < B; ++b) for (int k = 0; k < nparts; ++k) t += partials[((int64_t)b * nparts + k) * (2 * C + 1) + 2 * C];
+        g_bs[0] = t;
+    }
+    __syncthreads();
+    for (int i = tid; i < B * R; i += nt) {
+        const int b = i / R, r = i - b * R;
+        float t = 0.f;
+        for (int c = 0; c < C; ++c) t += du[b * C + c] * w2[c * R + r];
+        dh[i] = hidden[i] > 0.f ? t : 0.f;
+    }
+    for (int i = tid; i < C * R; i += nt) {
+        const int c = i / R, r = i - c * R;
+        float t = 0.f;
+        for (int b = 0; b < B; ++b) t += du[b * C + c] * hidden[b * R + r];
+        g_w2[i] = t;
+    }
+    for (int c = tid; c < C; c += nt) { float t = 0.f; for (int b = 0; b < B; ++b) t += du[b * C + c]; g_b2[c] = t; }
+    __syncthreads();
+    for (int i = tid; i < R * C; i += nt) {
+        const int r = i / C, c = i - r * C;
+        float t = 0.f;
+        for (int b = 0; b < B; ++b) t += dh[b * R + r] * gap[b * C + c];
+        g_w1[i] = t;
+    }
+    for (int r = tid; r < R; r += nt) { float t = 0.f; for (int b = 0; b < B; ++b) t += dh[b * R + r]; g_b1[r] = t; }
+    for (int i = tid; i < B * C; i += nt) {
+        const int b = i / C, c = i - b * C;
+        float t = 0.f;
+        for (int r = 0; r < R; ++r) t += dh[b * R + r] * w1[r * C + c];
+        dgap[i] = t * inv_hw;
+    }
+}
+
+template <typename T>
+__global__ void bcast_add_kernel(salt_view dx, const float* dgap) {
+    constexpr int N = P16<T>::N;
+    const int cpv = dx.C / N;
+    const int hw = dx.H * dx.W;
+    const int64_t units = (int64_t)dx.B * hw * cpv;
+    for (int64_t u = blockIdx.x * 256LL + threadIdx.x; u < units; u += gridDim.x * 256LL) {
+        const int64_t pix = u / cpv; const int cv = (int)(u - pix * cpv);
+        const int b = (int)(pix / hw);
+        float f[N];
+        T* p = (T*)dx.p + pix * dx.cs + cv * N;
+        P16<T>::ld(p, f);
+#pragma unroll
+        for (int j = 0; j < N; ++j) f[j] += dgap[b * dx.C + cv * N + j];
+        P16<T>::st(p, f);
+    }
+}
+
+int scse_nparts(const salt_view& x, int* per) {
+    const int hw = x.H * x.W;
+    int parts = cdiv(hw, 256);
+    if (parts > 64) parts = 64;
+    if (parts < 1) parts = 1;
+    const int pp = cdiv(hw, parts);
+    if (per) *per = pp;
+    return cdiv(hw, pp);
+}
+
+template <typename T> bool se_ok(const salt_view& v) {
+    constexpr int VE = Elem<T>::VE;
+    const int cpv = v.C / VE;
+    return (v.C % VE) == 0 && (v.cs % VE) == 0 && ((reinterpret_cast<uintptr_t>(v.p) & 15) == 0) && cpv >= 1 && cpv <= 64 && (cpv & (cpv - 1)) == 0;
+}
+
+}  // namespace
+
+extern "C" int salt_scse_parts(const salt_scse_args* a) {
+    if (!a || !view_ok(a->x)) return -1;
+    return scse_nparts(a->x, nullptr);
+}
+
+extern "C" int salt_scse(const salt_scse_args* a, void* stream) {
+    if (!a || !view_ok(a->x) || !view_ok(a->y) || a->x.C != a->y.C || a->R < 1 || !a->w1 || !a->b1 || !a->w2 || !a->b2 || !a->ws || !a->bs ||
+        !a->gap_partials || !a->gap || !a->hidden || !a->gate_c || !a->gate_s) SALT_FAIL(SALT_E_BADARG, "scse: bad args");
+    int per = 0;
+    const int nparts = scse_nparts(a->x, &per);
+    if (a->nparts != nparts) SALT_FAIL(SALT_E_BADARG, "scse: nparts %d, expected %d", a->nparts, nparts);
+    hipStream_t st = (hipStream_t)stream;
+    const int C = a->x.C;
+    SALT_DISPATCH_DTYPE(a->dtype, T, {
+        if (!se_ok<T>(a->x) || !se_ok<T>(a->y)) SALT_FAIL(SALT_E_UNSUPPORTED, "scse: C=%d must be a power of two with 16-byte aligned rows", C);
+        constexpr int VE = Elem<T>::VE;
+        hipLaunchKernelGGL(gap_partial_kernel<T>, dim3(a->x.B * nparts), dim3(256), 256 * VE * sizeof(float), st, a->x, a->gap_partials, nparts, per);
+        SALT_CHECK_LAUNCH();
+        hipLaunchKernelGGL(se_fc_kernel, dim3(a->x.B), dim3(256), (C + a->R) * sizeof(float), st, a->gap_partials, nparts, C, a->R,
+                           1.0f / (float)(a->x.H * a->x.W), a->w1, a->b1, a->w2, a->b2, a->gap, a->hidden, a->gate_c);
+        SALT_CHECK_LAUNCH();
+        const int cpv_log2 = ilog2_ceil(C / VE);
+        const int64_t units = view_pixels(a->x) << cpv_log2;
+        const int blocks = (int)((units + 255) / 256 < 4096 ? (units + 255) / 256 : 4096);
+        hipLaunchKernelGGL(scse_apply_kernel<T>, dim3(blocks), dim3(256), 0, st, a->x, a->gate_c, a->ws, a->bs, a->gate_s, a->y, cpv_log2);
+    })
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}
+
+extern "C" int salt_scse_bwd(const salt_scse_bwd_args* a, void* stream) {
+    if (!a || !view_ok(a->x) || !view_ok(a->y) || !view_ok(a->dy) || !view_ok(a->dx) || !a->w1 || !a->w2 || !a->ws || !a->gap || !a->hidden ||
+        !a->gate_c || !a->gate_s || !a->partials || !a->g_w1 || !a->g_b1 || !a->g_w2 || !a->g_b2 || !a->g_ws || !a->g_bs || !a->dgap)
+        SALT_FAIL(SALT_E_BADARG, "scse_bwd: bad args");
+    int per = 0;
+    const int nparts = scse_nparts(a->x, &per);
+    if (a->nparts != nparts) SALT_FAIL(SALT_E_BADARG, "scse_bwd: nparts %d, expected %d", a->nparts, nparts);
+    hipStream_t st = (hipStream_t)stream;
+    const int C = a->x.C, B = a->x.B;
+    const size_t fc_lds = (size_t)B * (C + a->R) * sizeof(float);
+    if (fc_lds > 64 * 1024) SALT_FAIL(SALT_E_LDS, "scse_bwd: batch*channels too large for the FC backward (%zu B)", fc_lds);
+    SALT_DISPATCH_DTYPE(a->dtype, T, {
+        if (!se_ok<T>(a->x) || !se_ok<T>(a->y) || !se_ok<T>(a->dy) || !se_ok<T>(a->dx)) SALT_FAIL(SALT_E_UNSUPPORTED, "scse_bwd: layout");
+        constexpr int VE = Elem<T>::VE;
+        const int cpv_log2 = ilog2_ceil(C / VE);
+        hipLaunchKernelGGL(scse_bwd1_kernel<T>, dim3(B * nparts), dim3(256), (512 * VE + 256) * sizeof(float), st, a->x, a->y, a->dy, a->gate_c,
+                           a->gate_s, a->ws, a->dx, a->accumulate, a->partials, nparts, per, cpv_log2);
+        SALT_CHECK_LAUNCH();
+        hipLaunchKernelGGL(se_fc_bwd_kernel, dim3(1), dim3(256), fc_lds, st, a->partials, nparts, B, C, a->R, a->w1, a->w2, a->gap, a->hidden,
+                           a->gate_c, a->g_w1, a->g_b1, a->g_w2, a->g_b2, a->g_ws, a->g_bs, a->dgap, 1.0f / (float)(a->x.H * a->x.W));
+        SALT_CHECK_LAUNCH();
+        const int64_t units = view_pixels(a->dx) * (C / VE);
+        const int blocks = (int)((units + 255) / 256 < 4096 ? (units + 255) / 256 : 4096);
+        hipLaunchKernelGGL(bcast_add_kernel<T>, dim3(blocks), dim3(256), 0, st, a->dx, a->dgap);
+    })
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}

@@ -1,0 +1,667 @@
+"""Static-program engine: builds the forward and backward operator lists of a network ONCE per
+(batch shape, mode) and runs each as a single call into libsaltnet_hip.so.
+
+The reference executes its U-Nets through PyTorch autograd, one operator at a time from Python
+(common_blocks/models.py:105-136).  Here the module tree (architectures.py) "emits" its operators into
+a :class:`Graph`; every emitter also pushes a closure that later emits the matching backward operators,
+so the backward program is derived mechanically in reverse order with static gradient-accumulation
+flags.  Activations are NHWC buffers that live for the lifetime of the graph (288 GB of HBM makes
+re-materialisation pointless); skip connections and the hypercolumn are channel SLICES of wider
+buffers that their producers write in place, so ``torch.cat`` never copies anything.
+
+PyTorch is used for device memory (tensors), streams and nothing else on this path.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _abi
+from ._abi import OP_FUNCS, STRUCTS, SaltError, check, fill, lib
+
+DT_CODE = {'f32': 0, 'bf16': 1}
+TORCH_DT = {'f32': torch.float32, 'bf16': torch.bfloat16}
+VEC = {'f32': 4, 'bf16': 8}
+
+
+def _round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+class Scratch:
+    """Named shared workspace request; resolved to one allocation (max size) when the graph is finalized."""
+
+    def __init__(self, name, nbytes):
+        self.name, self.nbytes = name, int(nbytes)
+
+
+class Program:
+    """A flat list of (operator, argument struct) pairs executed by salt_program_run."""
+
+    def __init__(self, name=''):
+        self.name = name
+        self.ops = []          # (opname, fn, struct)
+        self.patches = []      # (struct, path, Scratch)
+        self._entries = None
+        self.marks = {}
+
+    def add(self, opname, **fields):
+        fn, S = OP_FUNCS['salt_' + opname]
+        s = S()
+        plain = {}
+        for k, v in fields.items():
+            if isinstance(v, Scratch):
+                self.patches.append((s, (k,), v))
+            elif isinstance(v, tuple) and len(v) == 2 and isinstance(v[1], Scratch):   # (view, scratch) -> view.p patched
+                plain[k] = v[0]
+                self.patches.append((s, (k, 'p'), v[1]))
+            else:
+                plain[k] = v
+        fill(s, **plain)
+        self.ops.append((opname, fn, s))
+        return s
+
+    def mark(self, label):
+        self.marks[label] = len(self.ops)
+
+    def extend(self, other):
+        self.ops.extend(other.ops)
+        self.patches.extend(other.patches)
+        self._entries = None
+
+    def finalize(self):
+        n = len(self.ops)
+        Entry = STRUCTS['salt_program_entry']
+        arr = (Entry * max(n, 1))()
+        for i, (_, fn, s) in enumerate(self.ops):
+            arr[i].fn = ctypes.cast(fn, ctypes.c_void_p).value
+            arr[i].args = ctypes.addressof(s)
+        self._entries = arr
+        return self
+
+    def __len__(self):
+        return len(self.ops)
+
+    def run(self, stream=None, begin=0, end=None):
+        if self._entries is None:
+            self.finalize()
+        end = len(self.ops) if end is None else end
+        st = _stream_ptr(stream)
+        rc = lib.salt_program_run_range(ctypes.cast(self._entries, ctypes.c_void_p), begin, end, st)
+        if rc != 0:
+            msg = lib.salt_last_error().decode(errors='replace')
+            m = None
+            try:
+                m = int(msg.split('program entry')[1].split()[0])
+            except Exception:
+                pass
+            where = (' [%s]' % self.ops[m][0]) if m is not None and m < len(self.ops) else ''
+            raise SaltError('program %s failed (%d)%s: %s' % (self.name, rc, where, msg))
+
+    def run_debug(self, stream=None):
+        """Run op by op with a device sync after each (pinpoints a faulting kernel)."""
+        st = _stream_ptr(stream)
+        for i, (name, fn, s) in enumerate(self.ops):
+            check(fn(ctypes.byref(s), st), '%s[%d] %s' % (self.name, i, name))
+            torch.cuda.synchronize()
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        stream = torch.cuda.current_stream()
+    return ctypes.c_void_p(stream.cuda_stream)
+
+
+class Buffer:
+    """NHWC storage [B,H,W,Ct] (+ lazily allocated gradient storage of the same geometry)."""
+
+    def __init__(self, graph, B, H, W, C, name=''):
+        self.g, self.B, self.H, self.W, self.C = graph, B, H, W, C
+        self.Ct = _round_up(C, graph.ve)
+        self.name = name
+        self.t = graph.alloc((B, H, W, self.Ct), graph.tdtype)
+        self.grad_t = None
+        self.grad_init = np.zeros(self.Ct, dtype=bool)
+
+    def grad(self):
+        if self.grad_t is None:
+            self.grad_t = self.g.alloc((self.B, self.H, self.W, self.Ct), self.g.tdtype)
+        return self.grad_t
+
+
+class Act:
+    """A channel slice [c0, c0+C) of a Buffer."""
+
+    def __init__(self, buf, c0=0, C=None):
+        self.buf, self.c0 = buf, c0
+        self.C = buf.C if C is None else C
+
+    B = property(lambda s: s.buf.B)
+    H = property(lambda s: s.buf.H)
+    W = property(lambda s: s.buf.W)
+
+    def slice(self, c0, C):
+        return Act(self.buf, self.c0 + c0, C)
+
+    def _view(self, t):
+        v = STRUCTS['salt_view']()
+        v.p = t.data_ptr() + self.c0 * t.element_size()
+        v.B, v.H, v.W, v.C, v.cs = self.buf.B, self.buf.H, self.buf.W, self.C, self.buf.Ct
+        return v
+
+    def view(self):
+        return self._view(self.buf.t)
+
+    def gview(self):
+        return self._view(self.buf.grad())
+
+    def grad_state(self):
+        """-> accumulate flag for the next writer of this slice's gradient; marks it initialised."""
+        st = self.buf.grad_init[self.c0:self.c0 + self.C]
+        if st.all():
+            return 1
+        if st.any():
+            raise SaltError('gradient of %s partially initialised' % self.buf.name)
+        self.buf.grad_init[self.c0:self.c0 + self.C] = True
+        return 0
+
+    def grad_ready(self):
+        return bool(self.buf.grad_init[self.c0:self.c0 + self.C].all())
+
+    def tensor(self):
+        """NHWC torch view [B,H,W,C] of the activation (tests / debugging)."""
+        return self.buf.t[..., self.c0:self.c0 + self.C]
+
+    def grad_tensor(self):
+        return self.buf.grad()[..., self.c0:self.c0 + self.C]
+
+
+def null_view():
+    return STRUCTS['salt_view']()
+
+
+def shaped_view(ptr, B, H, W, C, cs=None):
+    v = STRUCTS['salt_view']()
+    v.p, v.B, v.H, v.W, v.C, v.cs = ptr, B, H, W, C, (C if cs is None else cs)
+    return v
+
+
+def conv_taps(KH, KW, pad_y, pad_x):
+    """[(kh, kw, dy, dx)] for a cross-correlation with the given top/left padding."""
+    return [(kh, kw, kh - pad_y, kw - pad_x) for kh in range(KH) for kw in range(KW)]
+
+
+class Graph:
+    """Forward + backward programs of one network instance for fixed (B, H, W), dtype and BN mode."""
+
+    def __init__(self, engine, train):
+        self.engine = engine
+        self.device = engine.device
+        self.dtype = engine.dtype
+        self.dt = DT_CODE[self.dtype]
+        self.tdtype = TORCH_DT[self.dtype]
+        self.ve = VEC[self.dtype]
+        self.train = train
+        self.fwd = Program('forward')
+        self.bwd = Program('backward')
+        self.tape = []
+        self.keep = []
+        self.scratch = {}
+        self.bytes = 0
+        self._touched = []
+        self.grad_ready = []
+
+    # ------------------------------------------------------------------ memory
+    def alloc(self, shape, dtype, zero=True):
+        t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+        self.keep.append(t)
+        self.bytes += t.numel() * t.element_size()
+        return t
+
+    def new_act(self, B, H, W, C, name=''):
+        return Act(Buffer(self, B, H, W, C, name))
+
+    def f32(self, n):
+        return self.alloc((max(int(n), 1),), torch.float32)
+
+    def finalize(self):
+        sizes = {}
+        for prog in (self.fwd, self.bwd):
+            for _, _, sc in prog.patches:
+                sizes[sc.name] = max(sizes.get(sc.name, 0), sc.nbytes)
+        for name, nb in sizes.items():
+            self.scratch[name] = self.alloc((_round_up(max(nb, 16), 16),), torch.uint8, zero=False)
+        for prog in (self.fwd, self.bwd):
+            for s, path, sc in prog.patches:
+                obj = s
+                for a in path[:-1]:
+                    obj = getattr(obj, a)
+                setattr(obj, path[-1], self.scratch[sc.name].data_ptr())
+            prog.finalize()
+        return self
+
+    def _gp(self, param):
+        """Gradient pointer of a parameter; remembers that the current backward closure finalises it."""
+        self._touched.append(param)
+        return self.engine.grad_ptr(param)
+
+    def build_backward(self):
+        """Emit the backward program (reverse tape order).  Also records, per parameter, the program position
+        after which its gradient is final (parallel.plan_buckets turns that into all-reduce buckets)."""
+        self.grad_ready = []
+        for fn in reversed(self.tape):
+            self._touched = []
+            fn()
+            for p in self._touched:
+                off, n = self.engine.grad_range(p)
+                self.grad_ready.append((off, n, len(self.bwd.ops)))
+        self.tape = []
+
+    # ------------------------------------------------------------------ helpers
+    def _es(self):
+        return 4 if self.dtype == 'f32' else 2
+
+    def _conv_launch(self, prog, x_view, wp, taps_dydx, in_step, pad_mode, y_view, OH, OW, out_step=1, out_oy=0, out_ox=0,
+                     bias=None, scale=None, shift=None, relu=0, accumulate=0, stats=None, stats_cnt=None, part0=0, cfg=0):
+        kw = dict(dtype=self.dt, x=x_view, w=wp, ntaps=len(taps_dydx), tap_dy=[t[0] for t in taps_dydx], tap_dx=[t[1] for t in taps_dydx],
+                  in_step=in_step, pad_mode=pad_mode, y=y_view, OH=OH, OW=OW, out_step=out_step, out_oy=out_oy, out_ox=out_ox,
+                  bias=bias, scale=scale, shift=shift, relu=relu, accumulate=accumulate, stats=stats, stats_cnt=stats_cnt,
+                  stats_part0=part0, cfg=cfg)
+        return prog.add('conv', **kw)
+
+    def _conv_parts(self, x_view, taps_dydx, in_step, y_view, OH, OW, cfg=0):
+        S = STRUCTS['salt_conv_args']()
+        fill(S, dtype=self.dt, x=x_view, w=1, ntaps=len(taps_dydx), tap_dy=[t[0] for t in taps_dydx], tap_dx=[t[1] for t in taps_dydx],
+             in_step=in_step, pad_mode=0, y=y_view, OH=OH, OW=OW, out_step=1, cfg=cfg)
+        n = lib.salt_conv_stats_parts(ctypes.byref(S))
+        if n < 0:
+            raise SaltError('conv plan failed: ' + lib.salt_last_error().decode())
+        return n
+
+    # ------------------------------------------------------------------ BatchNorm plumbing
+    def _bn_train_fwd(self, y, bn, relu, res, out, nparts, stats, cnt):
+        w = self.engine.bn_work(bn)
+        nbt = bn.num_batches_tracked.data_ptr() if bn.num_batches_tracked is not None else None
+        self.fwd.add('bn_finalize', stats=stats, stats_cnt=cnt, nparts=nparts, C=bn.num_features, gamma=bn.weight.data_ptr(),
+                     beta=bn.bias.data_ptr(), running_mean=bn.running_mean.data_ptr(), running_var=bn.running_var.data_ptr(),
+                     num_batches_tracked=nbt, momentum=bn.momentum, eps=bn.eps, mean=w['mean'].data_ptr(), invstd=w['invstd'].data_ptr(),
+                     scale=w['scale'].data_ptr(), shift=w['shift'].data_ptr())
+        self.fwd.add('affine_act', dtype=self.dt, y=y.view(), scale=w['scale'].data_ptr(), shift=w['shift'].data_ptr(),
+                     res=res.view() if res is not None else null_view(), relu=int(relu), a=out.view())
+        return w
+
+    def _bn_train_bwd(self, y, bn, relu, res, out, w):
+        """emit backward of out = relu?(bn(y) (+res)); returns nothing, leaves grad in y.grad (and res.grad)."""
+        S = STRUCTS['salt_bn_bwd_args']()
+        fill(S, y=y.view())
+        nparts = lib.salt_bn_bwd_parts(ctypes.byref(S))
+        C = bn.num_features
+        gw, gb = self._gp(bn.weight), self._gp(bn.bias)
+        coef = self.f32(3 * C)
+        dres = null_view()
+        acc_res = 0
+        if res is not None:
+            acc_res = res.grad_state()
+            dres = res.gview()
+        acc_y = y.grad_state()
+        assert acc_y == 0, 'conv output gradient has a single producer'
+        self.bwd.add('bn_bwd', dtype=self.dt, da=out.gview(), a=out.view() if relu else null_view(), y=y.view(), relu=int(relu),
+                     mean=w['mean'].data_ptr(), invstd=w['invstd'].data_ptr(), gamma=bn.weight.data_ptr(),
+                     partials=Scratch('bn_bwd', nparts * 2 * C * 4), nparts=nparts, dgamma=gw, dbeta=gb, accumulate_param_grads=0,
+                     coef=coef.data_ptr(), dy=y.gview(), dres=dres, accumulate_dres=acc_res)
+
+    # ------------------------------------------------------------------ dense convolution (+BN +ReLU +residual)
+    def conv(self, x, conv, bn=None, relu=False, res=None, out=None, replicate=False, name=''):
+        """nn.Conv2d (k in {1,3} or (k,1)/(1,k); stride 1|2; zero pad or the reference's replicate top/right pad)
+        optionally followed by BatchNorm2d, residual add and ReLU."""
+        eng = self.engine
+        Cout, Cin, KH, KW = conv.weight.shape
+        assert Cin == x.C, (name, Cin, x.C)
+        stride = conv.stride[0]
+        if replicate:
+            assert stride == 1
+            taps = [(kh, kw, kh - (KH - 1), kw) for kh in range(KH) for kw in range(KW)]
+            pad_mode = 1
+            OH, OW = x.H, x.W
+        else:
+            py, px = conv.padding
+            taps = conv_taps(KH, KW, py, px)
+            pad_mode = 0
+            OH = (x.H + 2 * py - KH) // stride + 1
+            OW = (x.W + 2 * px - KW) // stride + 1
+        tk = [(t[0], t[1]) for t in taps]
+        td = [(t[2], t[3]) for t in taps]
+        pk = eng.packed(conv, tk, transposed=False)
+        bias = conv.bias.data_ptr() if conv.bias is not None else None
+        if out is None:
+            out = self.new_act(x.B, OH, OW, Cout, name)
+        assert (out.B, out.H, out.W, out.C) == (x.B, OH, OW, Cout), name
+        y = None
+        w = None
+        if bn is not None and self.train:
+            y = self.new_act(x.B, OH, OW, Cout, name + '.y')
+            nparts = self._conv_parts(x.view(), td, stride, y.view(), OH, OW)
+            stats, cnt = Scratch('stats', nparts * 2 * Cout * 4), Scratch('stats_cnt', nparts * 4)
+            self._conv_launch(self.fwd, x.view(), pk.data_ptr(), td, stride, pad_mode, y.view(), OH, OW, bias=bias, stats=stats, stats_cnt=cnt)
+            w = self._bn_train_fwd(y, bn, relu, res, out, nparts, stats, cnt)
+        elif bn is not None:
+            w = eng.bn_work(bn)
+            if res is None:
+                self._conv_launch(self.fwd, x.view(), pk.data_ptr(), td, stride, pad_mode, out.view(), OH, OW, bias=bias,
+                                  scale=w['scale'].data_ptr(), shift=w['shift'].data_ptr(), relu=int(relu))
+            else:
+                self._conv_launch(self.fwd, x.view(), pk.data_ptr(), td, stride, pad_mode, out.view(), OH, OW, bias=bias,
+                                  scale=w['scale'].data_ptr(), shift=w['shift'].data_ptr(), relu=0)
+                self.fwd.add('affine_act', dtype=self.dt, y=out.view(), scale=None, shift=None, res=res.view(), relu=int(relu), a=out.view())
+        else:
+            assert res is None
+            self._conv_launch(self.fwd, x.view(), pk.data_ptr(), td, stride, pad_mode, out.view(), OH, OW, bias=bias, relu=int(relu))
+
+        if self.train:
+            def backward():
+                if bn is not None:
+                    self._bn_train_bwd(y, bn, relu, res, out, w)
+                    dy = y
+                else:
+                    if conv.bias is not None:
+                        raise NotImplementedError('bias gradient of a dense conv without BatchNorm (not on the reference path)')
+                    dy = out
+                    if relu:
+                        self.bwd.add('relu_bwd', dtype=self.dt, da=out.gview(), a=out.view(), dy=out.gview(), accumulate=0)
+                # weight gradient: P = dY (a = cout), Q = X (b = cin)
+                self._wgrad(dy.gview(), x.view(), td, tk, stride, pad_mode, conv.weight, KH, KW)
+                # data gradient
+                if x.buf.name != '__input__':
+                    self._dgrad(conv, x, dy, taps, stride, replicate, KH, KW)
+            self.tape.append(backward)
+        return out
+
+    def _wgrad(self, p_view, q_view, taps_dydx, taps_khkw, q_step, pad_mode, weight, KH, KW):
+        """dW = sum_p P[p,:]^T Q[p*q_step + tap, :] -> weight.grad (reference layout [Ca][Cb][KH][KW])."""
+        gw = self._gp(weight)
+        Ca, Cb = p_view.C, q_view.C
+        first = True
+        for i in range(0, len(taps_dydx), 9 if len(taps_dydx) != 16 else 4):
+            chunk = list(range(i, min(i + (9 if len(taps_dydx) != 16 else 4), len(taps_dydx))))
+            S = STRUCTS['salt_conv_wgrad_args']()
+            fill(S, dtype=self.dt, p=p_view, q=q_view, ntaps=len(chunk), tap_dy=[taps_dydx[j][0] for j in chunk],
+                 tap_dx=[taps_dydx[j][1] for j in chunk], q_step=q_step, pad_mode=pad_mode)
+            ns = lib.salt_conv_wgrad_nsplit(ctypes.byref(S))
+            if ns < 0:
+                raise SaltError('wgrad plan failed: ' + lib.salt_last_error().decode())
+            nbytes = ns * len(chunk) * Ca * Cb * 4
+            self.bwd.add('conv_wgrad', dtype=self.dt, p=p_view, q=q_view, ntaps=len(chunk), tap_dy=[taps_dydx[j][0] for j in chunk],
+                         tap_dx=[taps_dydx[j][1] for j in chunk], q_step=q_step, pad_mode=pad_mode, partials=Scratch('wgrad', nbytes), nsplit=ns)
+            self.bwd.add('wgrad_reduce', partials=Scratch('wgrad', nbytes), nsplit=ns, ntaps=len(chunk), Ca=Ca, Cb=Cb, KH=KH, KW=KW,
+                         tap_kh=[taps_khkw[j][0] for j in chunk], tap_kw=[taps_khkw[j][1] for j in chunk], grad=gw, accumulate=0)
+            first = False
+
+    def _dgrad(self, conv, x, dy, taps, stride, replicate, KH, KW):
+        eng = self.engine
+        tk = [(t[0], t[1]) for t in taps]
+        pk = eng.packed(conv, tk, transposed=True)       # n = cin, c = cout
+        if replicate:
+            # gradient w.r.t. the replicate-padded input on the extended domain, then fold the pad back
+            top, right = KH - 1, KW - 1
+            Hp, Wp = x.H + top, x.W + right
+            ext = shaped_view(0, x.B, Hp, Wp, x.C, _round_up(x.C, self.ve))
+            nbytes = x.B * Hp * Wp * ext.cs * self._es()
+            td = [(-(t[2]) - top, -(t[3])) for t in taps]
+            self._conv_launch(self.bwd, dy.gview(), pk.data_ptr(), td, 1, 0, (ext, Scratch('dgrad_ext', nbytes)), Hp, Wp)
+            acc = x.grad_state()
+            self.bwd.add('pad_fold', dtype=self.dt, xp=(ext, Scratch('dgrad_ext', nbytes)), top=top, bottom=0, left=0, right=right,
+                         x=x.gview(), accumulate=acc)
+            return
+        acc = x.grad_state()
+        if stride == 1:
+            td = [(-t[2], -t[3]) for t in taps]
+            self._conv_launch(self.bwd, dy.gview(), pk.data_ptr(), td, 1, 0, x.gview(), x.H, x.W, accumulate=acc)
+            return
+        # stride 2: one launch per output parity phase (a transposed convolution)
+        phases = []
+        for ay in range(2):
+            for ax in range(2):
+                sel = [i for i, t in enumerate(taps) if (t[2] - ay) % 2 == 0 and (t[3] - ax) % 2 == 0]
+                phases.append((ay, ax, sel))
+        if any(not sel for _, _, sel in phases) and not acc:
+            self.fill(x, 0.0, grad=True)
+            acc = 1
+        for ay, ax, sel in phases:
+            oh, ow = (x.H - ay + 1) // 2, (x.W - ax + 1) // 2
+            if not sel or oh <= 0 or ow <= 0:
+                continue
+            pk_s = eng.packed(conv, [tk[i] for i in sel], transposed=True)
+            td = [((ay - taps[i][2]) // 2, (ax - taps[i][3]) // 2) for i in sel]
+            self._conv_launch(self.bwd, dy.gview(), pk_s.data_ptr(), td, 1, 0, x.gview(), oh, ow, out_step=2, out_oy=ay, out_ox=ax, accumulate=acc)
+
+    def fill(self, act, value, grad=False):
+        assert value == 0.0
+        t = act.buf.grad() if grad else act.buf.t
+        if act.c0 == 0 and act.C == act.buf.C:
+            (self.bwd if grad else self.fwd).add('zero', p=t.data_ptr(), bytes=t.numel() * t.element_size())
+        else:   # channel slice: y = a - a via affine (scale 0) keeps it one pass
+            z = self.f32(2 * act.C)
+            v = act.gview() if grad else act.view()
+            (self.bwd if grad else self.fwd).add('affine_act', dtype=self.dt, y=v, scale=z.data_ptr(), shift=z.data_ptr() + 4 * act.C,
+                                                 res=null_view(), relu=0, a=v)
+
+    # ------------------------------------------------------------------ transposed convolution (k3 op1 / k4, stride 2, pad 1)
+    def conv_transpose(self, x, deconv, bn=None, relu=False, out=None, name=''):
+        eng = self.engine
+        Cin, Cout, KH, KW = deconv.weight.shape
+        assert Cin == x.C and deconv.stride[0] == 2 and deconv.padding[0] == 1 and KH == KW and KH in (3, 4)
+        p = 1
+        OH, OW = 2 * x.H, 2 * x.W
+        bias = deconv.bias.data_ptr() if deconv.bias is not None else None
+        if out is None:
+            out = self.new_act(x.B, OH, OW, Cout, name)
+        train_bn = bn is not None and self.train
+        tgt = self.new_act(x.B, OH, OW, Cout, name + '.y') if train_bn else out
+        w = eng.bn_work(bn) if bn is not None else None
+        phases = []
+        for fy in range(2):
+            for fx in range(2):
+                sel = [(u, v, (fy + p - u) // 2, (fx + p - v) // 2) for u in range(KH) for v in range(KW)
+                       if (fy + p - u) % 2 == 0 and (fx + p - v) % 2 == 0]
+                phases.append((fy, fx, sel))
+        part0 = 0
+        total_parts = 0
+        plans = []
+        for fy, fx, sel in phases:
+            td = [(s[2], s[3]) for s in sel]
+            n = self._conv_parts(x.view(), td, 1, shaped_view(1, x.B, x.H, x.W, Cout), x.H, x.W) if train_bn else 0
+            plans.append(n)
+            total_parts += n
+        stats = Scratch('stats', total_parts * 2 * Cout * 4) if train_bn else None
+        cnt = Scratch('stats_cnt', total_parts * 4) if train_bn else None
+        for (fy, fx, sel), n in zip(phases, plans):
+            pk = eng.packed(deconv, [(s[0], s[1]) for s in sel], transposed=True)       # n = cout (D1), c = cin (D0)
+            td = [(s[2], s[3]) for s in sel]
+            if train_bn:
+                self._conv_launch(self.fwd, x.view(), pk.data_ptr(), td, 1, 0, tgt.view(), x.H, x.W, out_step=2, out_oy=fy, out_ox=fx,
+                                  bias=bias, stats=stats, stats_cnt=cnt, part0=part0)
+            elif bn is not None:
+                self._conv_launch(self.fwd, x.view(), pk.data_ptr(), td, 1, 0, tgt.view(), x.H, x.W, out_step=2, out_oy=fy, out_ox=fx,
+                                  bias=bias, scale=w['scale'].data_ptr(), shift=w['shift'].data_ptr(), relu=int(relu))
+            else:
+                self._conv_launch(self.fwd, x.view(), pk.data_ptr(), td, 1, 0, tgt.view(), x.H, x.W, out_step=2, out_oy=fy, out_ox=fx,
+                                  bias=bias, relu=int(relu))
+            part0 += n
+        if train_bn:
+            self._bn_train_fwd(tgt, bn, relu, None, out, total_parts, stats, cnt)
+        if self.train:
+            def backward():
+                if bn is None:
+                    raise NotImplementedError('ConvTranspose2d without BatchNorm in training')
+                self._bn_train_bwd(tgt, bn, relu, None, out, w)
+                taps_all = [(u, v, u - p, v - p) for u in range(KH) for v in range(KW)]
+                # weight gradient: P = X (a = cin), Q = dY (b = cout), dY sampled at 2i - p + u
+                self._wgrad(x.view(), tgt.gview(), [(t[2], t[3]) for t in taps_all], [(t[0], t[1]) for t in taps_all], 2, 0,
+                            deconv.weight, KH, KW)
+                # data gradient: stride-2 convolution of dY with W[cin][cout] (n = cin, c = cout)
+                pk = eng.packed(deconv, [(t[0], t[1]) for t in taps_all], transposed=False)
+                acc = x.grad_state()
+                self._conv_launch(self.bwd, tgt.gview(), pk.data_ptr(), [(t[2], t[3]) for t in taps_all], 2, 0, x.gview(), x.H, x.W, accumulate=acc)
+            self.tape.append(backward)
+        return out
+
+    # ------------------------------------------------------------------ first layer (fp32 NCHW input image)
+    def conv_first(self, x_nchw, conv, bn, relu=True, name=''):
+        eng = self.engine
+        B, Cin, H, W = x_nchw.shape
+        Cout, _, K, _ = conv.weight.shape
+        stride, pad = conv.stride[0], conv.padding[0]
+        OH = (H + 2 * pad - K) // stride + 1
+        OW = (W + 2 * pad - K) // stride + 1
+        out = self.new_act(B, OH, OW, Cout, name)
+        bias = conv.bias.data_ptr() if conv.bias is not None else None
+        common = dict(dtype=self.dt, x=x_nchw.data_ptr(), B=B, Cin=Cin, H=H, W=W, w=conv.weight.data_ptr(), K=K, stride=stride, pad=pad, bias=bias)
+        if self.train:
+            y = self.new_act(B, OH, OW, Cout, name + '.y')
+            S = STRUCTS['salt_conv_first_args']()
+            fill(S, B=B, Cin=Cin, H=H, W=W, K=K, stride=stride, pad=pad)
+            nparts = lib.salt_conv_first_stats_parts(ctypes.byref(S))
+            stats, cnt = Scratch('stats', nparts * 2 * Cout * 4), Scratch('stats_cnt', nparts * 4)
+            self.fwd.add('conv_first', y=y.view(), relu=0, stats=stats, stats_cnt=cnt, **common)
+            w = self._bn_train_fwd(y, bn, relu, None, out, nparts, stats, cnt)
+
+            def backward():
+                self._bn_train_bwd(y, bn, relu, None, out, w)
+                S2 = STRUCTS['salt_conv_first_wgrad_args']()
+                fill(S2, B=B, Cin=Cin, H=H, W=W, K=K, stride=stride, pad=pad)
+                np_ = lib.salt_conv_first_wgrad_parts(ctypes.byref(S2))
+                self.bwd.add('conv_first_wgrad', dtype=self.dt, x=x_nchw.data_ptr(), B=B, Cin=Cin, H=H, W=W, K=K, stride=stride, pad=pad,
+                             dy=y.gview(), partials=Scratch('wgrad', np_ * Cout * Cin * K * K * 4), nparts=np_,
+                             grad=self._gp(conv.weight), accumulate=0)
+            self.tape.append(backward)
+        else:
+            w = eng.bn_work(bn)
+            self.fwd.add('conv_first', y=out.view(), scale=w['scale'].data_ptr(), shift=w['shift'].data_ptr(), relu=int(relu), **common)
+        return out
+
+    # ------------------------------------------------------------------ logit head: 1x1 conv to <= 4 channels, fp32 NCHW out
+    def head(self, x, conv, logits_nchw):
+        Cout = conv.weight.shape[0]
+        self.fwd.add('head1x1', dtype=self.dt, x=x.view(), w=conv.weight.data_ptr(), bias=conv.bias.data_ptr() if conv.bias is not None else None,
+                     Cout=Cout, y_nchw=logits_nchw.data_ptr(), y=null_view())
+        if self.train:
+            self.dlogits = self.alloc(tuple(logits_nchw.shape), torch.float32)
+
+            def backward():
+                S = STRUCTS['salt_head1x1_bwd_args']()
+                fill(S, x=x.view())
+                nparts = lib.salt_head1x1_bwd_parts(ctypes.byref(S))
+                acc = x.grad_state()
+                self.bwd.add('head1x1_bwd', dtype=self.dt, x=x.view(), w=conv.weight.data_ptr(), Cout=Cout, dy_nchw=self.dlogits.data_ptr(),
+                             dx=x.gview(), accumulate=acc, partials=Scratch('head', nparts * Cout * (x.C + 1) * 4), nparts=nparts,
+                             gw=self._gp(conv.weight), gb=self._gp(conv.bias) if conv.bias is not None else None)
+            self.tape.append(backward)
+
+    # ------------------------------------------------------------------ layout boundary (fp32 NCHW <-> NHWC activations)
+    def from_nchw(self, x_nchw, name='input'):
+        B, C, H, W = x_nchw.shape
+        a = self.new_act(B, H, W, C, name)
+        self.fwd.add('layout', dtype=self.dt, nchw=x_nchw.data_ptr(), nhwc=a.view(), to_nhwc=1)
+        if self.train:
+            dx = self.alloc((B, C, H, W), torch.float32)
+            self.input_grads = getattr(self, 'input_grads', []) + [dx]
+
+            def backward():
+                if a.grad_ready():
+                    self.bwd.add('layout', dtype=self.dt, nchw=dx.data_ptr(), nhwc=a.gview(), to_nhwc=0)
+            self.tape.append(backward)
+        return a
+
+    def to_nchw(self, a, out_nchw):
+        self.fwd.add('layout', dtype=self.dt, nchw=out_nchw.data_ptr(), nhwc=a.view(), to_nhwc=0)
+        if self.train:
+            self.dlogits = self.alloc(tuple(out_nchw.shape), torch.float32)
+
+            def backward():
+                assert a.grad_state() == 0
+                self.bwd.add('layout', dtype=self.dt, nchw=self.dlogits.data_ptr(), nhwc=a.gview(), to_nhwc=1)
+            self.tape.append(backward)
+
+    # ------------------------------------------------------------------ pooling / resize
+    def maxpool2(self, x, out=None, name=''):
+        if out is None:
+            out = self.new_act(x.B, x.H // 2, x.W // 2, x.C, name)
+        self.fwd.add('maxpool2', dtype=self.dt, x=x.view(), y=out.view())
+        if self.train:
+            def backward():
+                acc = x.grad_state()
+                self.bwd.add('maxpool2_bwd', dtype=self.dt, x=x.view(), dy=out.gview(), dx=x.gview(), accumulate=acc)
+            self.tape.append(backward)
+        return out
+
+    def avgpool2(self, x, out=None, name=''):
+        if out is None:
+            out = self.new_act(x.B, x.H // 2, x.W // 2, x.C, name)
+        self.fwd.add('avgpool2', dtype=self.dt, x=x.view(), y=out.view(), backward=0, accumulate=0)
+        if self.train:
+            def backward():
+                acc = x.grad_state()
+                self.bwd.add('avgpool2', dtype=self.dt, x=x.gview(), y=out.gview(), backward=1, accumulate=acc)
+            self.tape.append(backward)
+        return out
+
+    def upsample(self, x, R, out=None, name=''):
+        if out is None:
+            out = self.new_act(x.B, x.H * R, x.W * R, x.C, name)
+        self.fwd.add('bilinear', dtype=self.dt, x=x.view(), y=out.view(), R=R, backward=0, accumulate=0)
+        if self.train:
+            def backward():
+                acc = x.grad_state()
+                self.bwd.add('bilinear', dtype=self.dt, x=x.gview(), y=out.gview(), R=R, backward=1, accumulate=acc)
+            self.tape.append(backward)
+        return out
+
+    def add(self, a, b, out=None, name=''):
+        if out is None:
+            out = self.new_act(a.B, a.H, a.W, a.C, name)
+        self.fwd.add('add', dtype=self.dt, a=a.view(), b=b.view(), y=out.view(), accumulate=0)
+        if self.train:
+            def backward():
+                for t in (a, b):
+                    acc = t.grad_state()
+                    self.bwd.add('add', dtype=self.dt, a=out.gview(), b=null_view(), y=t.gview(), accumulate=acc)
+            self.tape.append(backward)
+        return out
+
+    def copy(self, a, out):
+        self.fwd.add('add', dtype=self.dt, a=a.view(), b=null_view(), y=out.view(), accumulate=0)
+        if self.train:
+            def backward():
+                acc = a.grad_state()
+                self.bwd.add('add', dtype=self.dt, a=out.gview(), b=null_view(), y=a.gview(), accumulate=acc)
+            self.tape.append(backward)
+        return out
+
+    # ------------------------------------------------------------------ scSE
+    def scse(self, x, cse, sse, out=None, name=''):
+        """relu(x*cSE(x) + x*sSE(x)); cse.fc = Sequential(Linear, ReLU, Linear, Sigmoid), sse.fc = Conv2d(C,1,1)."""
+        eng = self.engine
+        if out is None:
+            out = self.new_act(x.B, x.H, x.W, x.C, name)
+        l1, l2, cs = cse.fc[0], cse.fc[2], sse.fc
+        R, C, B = l1.weight.shape[0], x.C, x.B
+        S = STRUCTS['salt_scse_args']()
+        fill(S, x=x.view())
+        nparts = lib.salt_scse_parts(ctypes.byref(S))
+        gap, hid, gc, gs = self.f32(B * C), self.f32(B * R), self.f32(B * C), self.f32(B * x.H * x.W)
+        self.fwd.add('scse', dtype=self.dt, x=x.view(), w1=l1.weight.data_ptr(), b1=l1.bias.data_ptr(), w2=l2.weight.data_ptr(),
+                     b2=l2.bias.data_ptr(), R=R, ws=cs.weight.data_ptr(), bs=cs.bias.data_ptr(), gap_partials=Scratch('se', B * nparts * (2 * C + 1) * 4),
+                     nparts=nparts, gap=gap.data_ptr(), hidden=hid.data_ptr(), gate_c=gc.data_ptr(), gate_s=gs.data_ptr(), y=out.view())
+        if self.train:
+            def backward():
+                acc = x.grad_state()
+                dgap = self.f32(B * C)
+                gp = self._gp
+                self.bwd.add('scse_bwd', dtype=self.dt, x=x.view(), y=out.view(), dy=out.gview(), w1=l1.weight.data_ptr(), w2=l2.weight.data_ptr(),
+                             R=R, ws=cs.weight.data_ptr(), gap=gap.data_ptr(), hidden=hid.data_ptr(), gate_c=gc.data_ptr(), gate_s=gs.data_ptr(),
+                             partials=Scratch('se', B * nparts * (2 * C + 1) * 4), nparts=nparts, g_w1=gp(l1.weight), g_b1=gp(l1.bias),
+                             g_w2=gp(l2.weight), g_b2=gp(l2.bias), g_ws=gp(cs.weight), g_bs=gp(cs.bias), dgap=dgap.data_ptr(),
+                             dx=x.gview(), accumulate=acc)
+            self.tape.append(backward)
+        return out

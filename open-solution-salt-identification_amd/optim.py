@@ -1,0 +1,98 @@
+"""Fused Adam with L2-in-gradient weight decay over the engine's flat parameter buffer.
+
+Mirrors ``optim.Adam(weight_regularization(model, regularize, weight_decay_conv2d), lr=...)`` of the reference
+(models.py:74-75,289-297): one parameter group over every parameter that receives a gradient (BN affine and
+biases included), classic Adam (not AdamW), torch defaults beta=(0.9,0.999), eps=1e-8.  The surface the
+reference's callbacks touch is kept: ``param_groups`` (lr is read AND written by the schedulers,
+callbacks.py:262-275), ``state_dict()``, ``zero_grad()``, ``step()``."""
+import ctypes
+
+import torch
+
+from ._abi import SaltError
+from .engine import Program
+
+
+def weight_regularization(model, regularize, weight_decay_conv2d):
+    """models.py:289-297 — returns the param-group list in the reference's format."""
+    params = [p for p in model.parameters() if p.requires_grad]
+    if regularize:
+        return [{'params': params, 'weight_decay': weight_decay_conv2d}]
+    return [params]
+
+
+class FusedAdam:
+    def __init__(self, param_groups, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, model=None):
+        if isinstance(param_groups, (list, tuple)) and param_groups and isinstance(param_groups[0], dict):
+            g = dict(param_groups[0])
+        else:
+            g = {'params': list(param_groups[0] if param_groups and isinstance(param_groups[0], (list, tuple)) else param_groups)}
+        g.setdefault('lr', lr)
+        g.setdefault('betas', betas)
+        g.setdefault('eps', eps)
+        g.setdefault('weight_decay', weight_decay)
+        g['initial_lr'] = g['lr']
+        self.param_groups = [g]
+        self.model = model
+        self._eng = None
+        self._host_hyper = None
+        self.steps = 0
+        self.grad_scale = 1.0
+
+    # -- lazily bound to the engine's flat buffers
+    def _bind(self):
+        eng = self.model.engine()
+        if self._eng is eng:
+            return
+        self._eng = eng
+        dev = eng.device
+        self.exp_avg = torch.zeros_like(eng.flat)
+        self.exp_avg_sq = torch.zeros_like(eng.flat)
+        self.hyper = torch.zeros(8, dtype=torch.float32, device=dev)
+        self.step_t = torch.full((1,), self.steps, dtype=torch.int64, device=dev)
+        self._host_hyper = None
+        self.prog = Program('adam')
+        self.prog.add('adam_tick', hyper=self.hyper.data_ptr(), step=self.step_t.data_ptr())
+        self.prog.add('adam', param=eng.flat.data_ptr(), grad=eng.grads.data_ptr(), exp_avg=self.exp_avg.data_ptr(),
+                      exp_avg_sq=self.exp_avg_sq.data_ptr(), n=eng.n_live, hyper=self.hyper.data_ptr())
+        self.prog.finalize()
+
+    def _sync_hyper(self):
+        g = self.param_groups[0]
+        cur = (float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']), float(g['weight_decay']), float(self.grad_scale))
+        if cur != self._host_hyper:
+            self.hyper[:5].copy_(torch.tensor(cur[:5], dtype=torch.float32))
+            self.hyper[7:8].fill_(cur[5])
+            self._host_hyper = cur
+
+    def zero_grad(self, set_to_none=False):
+        pass        # the backward program overwrites every gradient each step
+
+    def step(self, closure=None):
+        if self.model is None:
+            raise SaltError('FusedAdam needs the HipNetwork it optimises (model=...)')
+        self._bind()
+        self._sync_hyper()
+        self.prog.run()
+        self.steps += 1
+        self._eng.touch(weights=True, stats=False)
+
+    def state_dict(self):
+        g = {k: v for k, v in self.param_groups[0].items() if k != 'params'}
+        g['params'] = list(range(len(self.param_groups[0]['params'])))
+        st = {}
+        if self._eng is not None:
+            st = {'step': self.steps, 'exp_avg': self.exp_avg.detach().cpu(), 'exp_avg_sq': self.exp_avg_sq.detach().cpu()}
+        return {'state': st, 'param_groups': [g]}
+
+    def load_state_dict(self, sd):
+        for k, v in sd['param_groups'][0].items():
+            if k != 'params':
+                self.param_groups[0][k] = v
+        st = sd.get('state', {})
+        if st:
+            self._bind()
+            self.steps = int(st['step'])
+            self.step_t.fill_(self.steps)
+            self.exp_avg.copy_(st['exp_avg'])
+            self.exp_avg_sq.copy_(st['exp_avg_sq'])

@@ -1,0 +1,201 @@
+"""Engine: owns the flat parameter/gradient/optimizer buffers of one model, the packed compute copies of
+its convolution weights, the BatchNorm work vectors, and the compiled (static) programs per batch shape.
+
+Design notes (MI355X-first):
+  * fp32 master parameters live in ONE flat buffer in the reference's own tensor layouts, so
+    ``state_dict()`` is the reference's; gradients live in a second flat buffer of the same layout, so
+    the optimizer is one fused kernel over 30 M floats and data-parallel all-reduce works on contiguous
+    byte ranges (buckets) without gather/scatter copies.
+  * convolution kernels read PACKED copies ([chunk][tap][n][64 B], bf16 or f32; plus the transposed copy
+    the data-gradient needs) that a tiny pack program refreshes after every optimizer step.
+  * a training step = pack -> forward -> loss -> backward (in bucket segments, all-reduce on a side
+    stream) -> fused Adam; each is one call into the native executor.
+"""
+import ctypes
+
+import torch
+from torch import nn
+
+from . import _abi
+from ._abi import SaltError, lib
+from .engine import Graph, Program, Scratch, DT_CODE, TORCH_DT
+
+
+def _require_gpu(device):
+    if device.type != 'cuda':
+        raise SaltError('the HIP path needs a GPU tensor/device (got %s); there is no CPU fallback' % device)
+
+
+class CompiledNet:
+    """One static instance: input/target/logits buffers + forward/backward programs for fixed (B,C,H,W)."""
+
+    def __init__(self, engine, shape, train, num_classes):
+        B, C, H, W = shape
+        self.engine, self.shape, self.train = engine, shape, train
+        g = Graph(engine, train)
+        self.g = g
+        self.x = g.alloc((B, C, H, W), torch.float32)
+        oshape = engine.module.output_shape(shape) if hasattr(engine.module, 'output_shape') else (B, num_classes, H, W)
+        self.logits = g.alloc(tuple(oshape), torch.float32)
+        engine.module.emit(g, self.x, self.logits)
+        self.dlogits = getattr(g, 'dlogits', None)
+        if train:
+            self.target = g.alloc(tuple(oshape), torch.float32)
+            self.loss = g.alloc((1,), torch.float32)
+            self.loss_per_image = g.alloc((B,), torch.float32)
+            g.build_backward()
+        g.finalize()
+        self.fwd, self.bwd = g.fwd, g.bwd
+        self._loss_progs = {}
+
+    def loss_program(self, kind, loss_scale):
+        key = (kind, float(loss_scale))
+        if key in self._loss_progs:
+            return self._loss_progs[key]
+        g = self.g
+        B, K, H, W = self.logits.shape
+        p = Program('loss:' + kind)
+        if kind == 'lovasz':
+            P = K * H * W
+            wk = g.alloc((2, B, P), torch.int32, zero=False)
+            wv = g.alloc((2, B, P), torch.int32, zero=False)
+            p.add('lovasz_hinge', logits=self.logits.data_ptr(), target=self.target.data_ptr(), B=B, P=P, ws_keys=wk.data_ptr(),
+                  ws_vals=wv.data_ptr(), loss_per_image=self.loss_per_image.data_ptr(), loss=self.loss.data_ptr(),
+                  dlogits=self.dlogits.data_ptr(), loss_scale=loss_scale)
+        elif kind == 'bce_dice':
+            S = _abi.STRUCTS['salt_bce_dice_args']()
+            _abi.fill(S, B=B, C=K, HW=H * W)
+            nparts = lib.salt_bce_dice_parts(ctypes.byref(S))
+            parts = g.alloc((nparts * 4,), torch.float32)
+            sums = g.alloc((3 * K + 1,), torch.float32)
+            p.add('bce_dice', logits=self.logits.data_ptr(), target=self.target.data_ptr(), B=B, C=K, HW=H * W, dice_weight=0.2, bce_weight=0.9,
+                  partials=parts.data_ptr(), nparts=nparts, sums=sums.data_ptr(), loss=self.loss.data_ptr(), dlogits=self.dlogits.data_ptr(),
+                  loss_scale=loss_scale)
+        else:
+            raise SaltError('unknown native loss %r' % kind)
+        p.finalize()
+        self._loss_progs[key] = p
+        return p
+
+
+class Engine:
+    def __init__(self, module, device, dtype='f32'):
+        _require_gpu(device)
+        if dtype not in DT_CODE:
+            raise SaltError('dtype must be f32 or bf16')
+        self.module, self.device, self.dtype = module, device, dtype
+        self._flatten()
+        self._packed = {}
+        self._pack_ops = Program('pack')
+        self._bn = {}
+        self._fold_ops = Program('bn_fold')
+        self.nets = {}
+        self.wver = 0                   # bumped whenever master weights change
+        self.sver = 0                   # bumped whenever BN running statistics change
+        self._packed_version = -1
+        self._folded_version = None
+        self.world = 1
+
+    # ------------------------------------------------------------------ flat parameter storage
+    def _flatten(self):
+        m = self.module
+        dead = set(m.dead_parameter_names()) if hasattr(m, 'dead_parameter_names') else set()
+        seen = {}
+        live = []
+        for name, p in m.named_parameters():
+            if id(p) in seen:
+                continue
+            seen[id(p)] = name
+            if p.requires_grad and name not in dead:
+                live.append((name, p))
+        total = sum(((p.numel() + 3) // 4) * 4 for _, p in live)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self.grads = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self._off = {}
+        self.live_names = []
+        off = 0
+        for name, p in live:
+            n = p.numel()
+            view = self.flat[off:off + n].view(p.shape)
+            view.copy_(p.data.to(self.device, torch.float32))
+            p.data = view
+            p.grad = self.grads[off:off + n].view(p.shape)
+            self._off[id(p)] = (off, n)
+            self.live_names.append(name)
+            off += ((n + 3) // 4) * 4
+        self.n_live = total
+        self.live_params = [p for _, p in live]
+        for name, p in m.named_parameters():              # dead parameters just move to the device
+            if id(p) not in self._off and p.device != self.device:
+                p.data = p.data.to(self.device)
+        for name, b in m.named_buffers():
+            if b.device != self.device:
+                b.data = b.data.to(self.device)
+
+    def grad_ptr(self, param):
+        off, _ = self._off[id(param)]
+        return self.grads.data_ptr() + 4 * off
+
+    def grad_range(self, param):
+        return self._off[id(param)]
+
+    # ------------------------------------------------------------------ packed conv weights
+    def packed(self, conv, taps_khkw, transposed):
+        key = (id(conv), tuple(taps_khkw), bool(transposed))
+        if key in self._packed:
+            return self._packed[key]
+        D0, D1, KH, KW = conv.weight.shape
+        n, c = (D1, D0) if transposed else (D0, D1)
+        elems = lib.salt_packed_weight_elems(DT_CODE[self.dtype], len(taps_khkw), n, c)
+        t = torch.zeros(elems, dtype=TORCH_DT[self.dtype], device=self.device)
+        self._pack_ops.add('pack_conv_weight', dtype=DT_CODE[self.dtype], w=conv.weight.data_ptr(), D0=D0, D1=D1, KH=KH, KW=KW,
+                           ntaps=len(taps_khkw), tap_kh=[a for a, _ in taps_khkw], tap_kw=[b for _, b in taps_khkw],
+                           transpose=int(transposed), wp=t.data_ptr())
+        self._pack_ops._entries = None
+        self._packed[key] = t
+        self._packed_version = -1
+        return t
+
+    def bn_work(self, bn):
+        if id(bn) in self._bn:
+            return self._bn[id(bn)]
+        C = bn.num_features
+        w = {k: torch.zeros(C, dtype=torch.float32, device=self.device) for k in ('mean', 'invstd', 'scale', 'shift')}
+        self._fold_ops.add('bn_fold', C=C, gamma=bn.weight.data_ptr(), beta=bn.bias.data_ptr(), running_mean=bn.running_mean.data_ptr(),
+                           running_var=bn.running_var.data_ptr(), eps=bn.eps, scale=w['scale'].data_ptr(), shift=w['shift'].data_ptr())
+        self._fold_ops._entries = None
+        self._bn[id(bn)] = w
+        self._folded_version = None
+        return w
+
+    def touch(self, weights=True, stats=True):
+        """Master weights / BN statistics changed: packed copies / folded BN are stale."""
+        if weights:
+            self.wver += 1
+        if stats:
+            self.sver += 1
+
+    def refresh(self, train):
+        if self._packed_version != self.wver:
+            self._pack_ops.run()
+            self._packed_version = self.wver
+        if not train and self._folded_version != (self.wver, self.sver):
+            self._fold_ops.run()
+            self._folded_version = (self.wver, self.sver)
+
+    # ------------------------------------------------------------------ compiled instances
+    def net(self, shape, train):
+        key = (tuple(shape), bool(train))
+        if key not in self.nets:
+            self.nets[key] = CompiledNet(self, tuple(shape), train, self.module.num_classes)
+        return self.nets[key]
+
+    def forward(self, x, train):
+        _require_gpu(x.device)
+        net = self.net(x.shape, train)
+        net.x.copy_(x)
+        self.refresh(train)
+        net.fwd.run()
+        if train:
+            self.touch(weights=False, stats=True)            # BN running statistics moved
+        return net

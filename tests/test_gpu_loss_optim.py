@@ -1,0 +1,90 @@
+"""GPU parity: Lovasz hinge / BCE+Dice kernels and the fused Adam step vs reference goldens and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden, T, assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.mark.parametrize('case', ['random', 'all0', 'all1', 'p1', 'ties', 'big'])
+def test_lovasz_vs_reference_golden(case):
+    from salt_amd import losses
+    fx = golden('F6_lovasz')
+    z = T(fx[case + '_z']).to(DEV).requires_grad_(True)
+    t = T(fx[case + '_t']).to(DEV)
+    loss = losses.lovasz_loss(z, t)
+    loss.backward()
+    ref = float(fx[case + '_loss'])
+    assert abs(float(loss) - ref) <= 1e-5 * max(1.0, abs(ref)), (float(loss), ref)
+    g = z.grad.cpu().numpy()
+    if case != 'ties':
+        assert_close(g, fx[case + '_gz'], 1e-4, 'dlogits')
+    else:   # gradients inside a tie group depend on the (arbitrary) order the reference's sort produced
+        e = (1 - fx[case + '_z'] * (2 * fx[case + '_t'] - 1)).reshape(3, -1)
+        g1, g2 = g.reshape(3, -1), fx[case + '_gz'].reshape(3, -1)
+        for b in range(3):
+            for v in np.unique(e[b]):
+                m = e[b] == v
+                assert abs(g1[b][m].sum() - g2[b][m].sum()) < 1e-5
+
+
+def test_lovasz_full_size_vs_oracle_and_properties():
+    """BASELINE C3 size (B=64, P=2*128*128): loss vs the oracle's closed form, sum(g_k)=1 => sum|grad| bound, determinism."""
+    from salt_amd import losses
+    from oracle import losses as OL
+    g = torch.Generator().manual_seed(3)
+    B, H, W = 64, 128, 128
+    z = torch.randn(B, 2, H, W, generator=g) * 2
+    m = (torch.rand(B, 1, H, W, generator=g) < 0.3).float()
+    m[:8] = 0                                        # empty masks (dataset trait)
+    t = torch.cat([1 - m, m], 1)
+    l1, g1 = losses.native_loss(z.to(DEV), t.to(DEV), 'lovasz')
+    l2, g2 = losses.native_loss(z.to(DEV), t.to(DEV), 'lovasz')
+    assert float(l1) == float(l2) and torch.equal(g1, g2)          # deterministic
+    ref, gref = OL.lovasz_hinge_grad_closed_form(z[:4], t[:4])
+    l4, g4 = losses.native_loss(z[:4].to(DEV), t[:4].to(DEV), 'lovasz')
+    assert abs(float(l4) - ref) < 2e-5 * max(1, abs(ref))
+    assert_close(g4.cpu(), gref.float(), 2e-4, 'grad vs closed form')
+    # |d loss/d z_i| = elu'(e_i) g_k / B <= g_k / B and sum_k g_k = 1 per image
+    per_image = g1.abs().reshape(B, -1).sum(1).cpu()
+    assert float(per_image.max()) <= 1.0 / B + 1e-6
+
+
+def test_bce_dice_vs_reference_golden():
+    from salt_amd import losses
+    fx = golden('F7_bce_dice')
+    z = T(fx['z']).to(DEV).requires_grad_(True)
+    loss = losses.mixed_dice_bce_loss(z, T(fx['t']).to(DEV))
+    loss.backward()
+    assert abs(float(loss) - float(fx['loss'])) < 1e-5
+    assert_close(z.grad.cpu(), fx['gz'], 1e-4, 'dlogits')
+
+
+def test_fused_adam_matches_torch_semantics():
+    from salt_amd import architectures as A
+    from salt_amd.optim import FusedAdam, weight_regularization
+    from oracle import losses as OL
+    torch.manual_seed(0)
+    net = A.VanillaUNet(2, 1, 16, 2).to(DEV)
+    eng = net.engine(torch.device(DEV))
+    opt = FusedAdam(weight_regularization(net, True, 1e-4), lr=1e-3, model=net)
+    ps = [p.detach().cpu().clone() for p in eng.live_params]
+    ms = [torch.zeros_like(p) for p in ps]
+    vs = [torch.zeros_like(p) for p in ps]
+    gen = torch.Generator().manual_seed(1)
+    for step in range(1, 4):
+        gs = [torch.randn(p.shape, generator=gen) * 0.1 for p in ps]
+        for p, g in zip(eng.live_params, gs):
+            off, n = eng.grad_range(p)
+            eng.grads[off:off + n].copy_(g.reshape(-1))
+        opt.step()
+        OL.adam_l2_step(ps, gs, ms, vs, step, lr=1e-3, weight_decay=1e-4)
+    for p, r in zip(eng.live_params, ps):
+        assert_close(p.detach().cpu(), r, 1e-5, 'adam param')
+    assert opt.state_dict()['param_groups'][0]['lr'] == 1e-3
+    opt.param_groups[0]['lr'] = 5e-4                                   # scheduler writes lr (callbacks.py:273-275)
+    opt.step()
+    assert abs(float(opt.hyper[0]) - 5e-4) < 1e-12

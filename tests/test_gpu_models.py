@@ -1,0 +1,181 @@
+"""GPU parity of whole networks (through the nn.Module / SegmentationModel surface) against the goldens the
+reference produced (64x64, B=2) and against the oracle on seeded inputs at BASELINE sizes."""
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden, T, assert_close
+import closed_form as CF
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _fill_closed_form(net):
+    first = {}
+    sd = net.state_dict()
+    for k, v in sd.items():
+        first.setdefault(v.data_ptr() if v.numel() else ('e', k), k)
+    new = OrderedDict()
+    for k, v in sd.items():
+        ck = first[v.data_ptr() if v.numel() else ('e', k)]
+        new[k] = CF.tensor_for(ck, v.shape).to(v.dtype)
+    net.load_state_dict(new)
+    return net
+
+
+def _nets():
+    from salt_amd import architectures as A
+    return {'unet_resnet34_hyper': lambda: A.UNetResNet(34, 2, dropout_2d=0.0, pretrained=False, use_hypercolumn=True),
+            'ternaus_resnet34_deconv': lambda: A.TernausUNetResNet(34, 2, dropout_2d=0.0, pretrained=False, is_deconv=True),
+            'ternaus_resnet34_upsample': lambda: A.TernausUNetResNet(34, 2, dropout_2d=0.0, pretrained=False, is_deconv=False)}
+
+
+@pytest.mark.parametrize('tag', ['unet_resnet34_hyper', 'ternaus_resnet34_deconv', 'ternaus_resnet34_upsample'])
+def test_eval_logits_and_masks_match_reference(tag):
+    fx = golden('F8_' + tag)
+    net = _fill_closed_form(_nets()[tag]()).to(DEV)
+    net.eval()
+    with torch.no_grad():
+        logits = net(T(fx['x']).to(DEV)).cpu()
+    assert_close(logits, fx['eval_logits'], 1e-3, 'eval logits')              # north_star: <= 1e-3 relative, fp32
+    # per-pixel class decision sigmoid(logit[1]) > 0.5 <=> logit[1] > 0 must be bit-exact (postprocessing.py:41-43)
+    assert np.array_equal((logits[:, 1] > 0).numpy().astype(np.uint8), fx['eval_mask'])
+
+
+@pytest.mark.parametrize('tag', ['unet_resnet34_hyper', 'ternaus_resnet34_deconv'])
+def test_one_training_step_matches_reference(tag):
+    """zero_grad -> forward -> lovasz -> backward -> Adam(lr 1e-4, L2 1e-4) exactly as models.py:105-136."""
+    from salt_amd.optim import FusedAdam, weight_regularization
+    from salt_amd import losses
+    fx = golden('F8_' + tag)
+    net = _fill_closed_form(_nets()[tag]()).to(DEV)
+    net.train()
+    opt = FusedAdam(weight_regularization(net, True, 1e-4), lr=1e-4, model=net)
+    out = net(T(fx['x']).to(DEV))
+    assert_close(out.detach().cpu(), fx['train_logits'], 2e-3, 'train logits')
+    loss = losses.lovasz_loss(out, T(fx['t']).to(DEV)) * 1.0
+    loss.backward()
+    ref = float(fx['train_loss'])
+    assert abs(float(loss) - ref) < 2e-3 * max(1.0, abs(ref)), (float(loss), ref)
+    names = fx['param_names'].tolist()
+    idx = {n: i for i, n in enumerate(names)}
+    eng = net.engine()
+    dead = set(net.dead_parameter_names())
+    checked = 0
+    worst = (0.0, '')
+    own = dict(net.named_parameters())
+    for k, p in own.items():
+        i = idx[k]
+        has = bool(fx['param_has_grad'][i])
+        assert has == (k not in dead), k
+        if has and fx['grad_norm'][i] > 1e-4:
+            off, n = eng.grad_range(p)
+            gn = float(eng.grads[off:off + n].double().norm())
+            rel = abs(gn - fx['grad_norm'][i]) / fx['grad_norm'][i]
+            worst = max(worst, (rel, k))
+            checked += 1
+    assert checked > 100 and worst[0] < 1e-2, worst
+    for k in fx:
+        if k.startswith('fullgrad:'):
+            p = own[k[9:]]
+            off, n = eng.grad_range(p)
+            assert_close(eng.grads[off:off + n].view(p.shape).cpu(), fx[k], 5e-3, k)
+    opt.step()
+    torch.cuda.synchronize()
+    for k, p in own.items():
+        i = idx[k]
+        if fx['param_has_grad'][i] and fx['grad_norm'][i] > 1e-4:
+            pn = float(p.detach().double().norm())
+            assert abs(pn - fx['post_norm'][i]) <= 2e-5 * max(fx['post_norm'][i], 1e-3), (k, pn, fx['post_norm'][i])
+    sd = net.state_dict()
+    for k, s in zip(fx['bn_keys'].tolist(), fx['bn_sum'].tolist()):
+        assert abs(float(sd[k].double().sum()) - s) <= 1e-3 * max(1.0, abs(s)), k
+
+
+def test_vanilla_unet_matches_oracle_c1_shape():
+    """BASELINE C1: vanilla 4-level U-Net, [32,1,128,128] fp32 — eval logits/masks and one train step vs the oracle."""
+    from salt_amd import architectures as A
+    from oracle import nets as ON, specs as OS, losses as OL
+    net = _fill_closed_form(A.VanillaUNet(2, 1, 16, 4)).to(DEV)
+    spec = OS.spec_vanilla_unet()
+    assert list(spec.keys()) == list(net.state_dict().keys())
+    sd = CF.state_for((k, s) for k, (s, _) in spec.items())
+    x = CF.input_for('c1', (32, 1, 128, 128))
+    t = CF.mask_for('c1', (32, 128, 128))
+    net.eval()
+    with torch.no_grad():
+        y = net(x.to(DEV)).cpu()
+        yr = ON.vanilla_unet(sd, x, False)
+    assert_close(y, yr, 1e-3, 'eval logits')
+    near = yr[:, 1].abs() > 1e-4 * float(yr.abs().max())
+    assert torch.equal((y[:, 1] > 0)[near], (yr[:, 1] > 0)[near])
+    net.train()
+    xs, ts = x[:8], t[:8]
+    for k in OS.trainable_keys(spec):
+        sd[k].requires_grad_(True)
+    out_r = ON.vanilla_unet(sd, xs, True)
+    loss_r = OL.lovasz_loss(out_r, ts)
+    loss_r.backward()
+    from salt_amd import losses
+    out = net(xs.to(DEV))
+    loss = losses.lovasz_loss(out, ts.to(DEV))
+    loss.backward()
+    assert abs(float(loss) - float(loss_r)) < 1e-3 * max(1.0, abs(float(loss_r)))
+    eng = net.engine()
+    for k, p in net.named_parameters():
+        gr = sd[k].grad
+        if gr is None or float(gr.norm()) < 1e-4:
+            continue
+        off, n = eng.grad_range(p)
+        assert_close(eng.grads[off:off + n].view(p.shape).cpu(), gr, 1e-2, 'grad ' + k)
+
+
+def test_segmentation_model_surface_fit_and_transform(tmp_path):
+    """The drop-in boundary: SegmentationModel(architecture_config, training_config, callbacks_config) with
+    fit / transform / persist / load as main.py uses them (main.py:365-366,389; utils.py:444-467)."""
+    from salt_amd.models import SegmentationModel
+    arch = {'model_params': {'architecture': 'VanillaUNet', 'out_channels': 2, 'activation': 'sigmoid'},
+            'optimizer_params': {'lr': 1e-3}, 'regularizer_params': {'regularize': True, 'weight_decay_conv2d': 1e-4}}
+    torch.manual_seed(0)
+    m = SegmentationModel(arch, {'epochs': 2}, {})
+    X = CF.input_for('seg', (8, 1, 64, 64))
+    M = CF.mask_for('seg', (8, 64, 64))
+    batches = [[X[:4], M[:4]], [X[4:], M[4:]]]
+    losses = []
+
+    class Rec:
+        def set_params(self, *a, **k): pass
+        def on_train_begin(self): pass
+        def on_train_end(self): pass
+        def on_epoch_begin(self): pass
+        def on_epoch_end(self): pass
+        def on_batch_begin(self): pass
+        def on_batch_end(self, metrics): losses.append(float(metrics['sum']))
+        def training_break(self): return False
+    m.callbacks.callbacks.append(Rec())
+    m.fit((batches, len(batches)))
+    assert len(losses) == 4 and all(np.isfinite(losses))
+    out = m.transform(([X[:4], X[4:]], 2))
+    preds = out['mask_prediction']
+    assert len(preds) == 8 and preds[0].shape == (2, 64, 64) and preds[0].dtype == np.float32
+    assert float(np.min(preds[0])) >= 0 and float(np.max(preds[0])) <= 1
+    path = str(tmp_path / 'best.torch')
+    m.persist(path)
+    sd = torch.load(path)
+    assert all(k.startswith('module.') for k in sd)
+    m2 = SegmentationModel(arch, {'epochs': 1}, {})
+    m2.load(path)
+    out2 = m2.transform(([X[:4], X[4:]], 2))
+    np.testing.assert_allclose(out2['mask_prediction'][3], preds[3], rtol=1e-5, atol=1e-6)
+    assert m.optimizer.state_dict()['param_groups'][0]['lr'] == 1e-3
+    assert m.output_names == ['mask'] and m.loss_function[0][2] == 1.0
+
+
+def test_cpu_tensor_is_rejected_loudly():
+    from salt_amd import architectures as A, SaltError
+    net = A.VanillaUNet(2, 1, 16, 2)
+    with pytest.raises(SaltError):
+        net(torch.zeros(1, 1, 16, 16))
