@@ -395,6 +395,7 @@ struct WgradKP {
     int th_log2, tw_log2, nb, hh, hw;
     int tiles_y, tiles_x, ntiles, nsplit;
     int a_blocks, b_blocks;
+    int bmp;                        // pixels per K tile (64 | 128)
 };
 
 template <typename T> struct WRow { static constexpr int BYTES = 64 * (int)sizeof(T); };   // 64 channels per pixel row
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradKP p) {
     constexpr int VE = Elem<T>::VE;
     constexpr int PPR = 64 / VE;                                // 16-byte pieces per pixel row
     constexpr int ROWB = (sizeof(T) == 2) ? 192 : 256;           // bf16 rows padded to 192 B: conflict-free tr reads
-    constexpr int BMP = 128;                                     // pixels per tile
+    const int BMP = p.bmp;                                       // pixels per K tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sP = smem;
     unsigned char* sQ = smem + BMP * ROWB;
@@ -548,14 +549,19 @@ int wgrad_plan(const salt_conv_wgrad_args* a, WgradKP* k, int* nsplit_out) {
         min_dy = a->tap_dy[t] < min_dy ? a->tap_dy[t] : min_dy; max_dy = a->tap_dy[t] > max_dy ? a->tap_dy[t] : max_dy;
         min_dx = a->tap_dx[t] < min_dx ? a->tap_dx[t] : min_dx; max_dx = a->tap_dx[t] > max_dx ? a->tap_dx[t] : max_dx;
     }
-    const int BM = 128;
-    k->tw_log2 = ilog2_ceil(a->p.W) < 4 ? ilog2_ceil(a->p.W) : 4;
-    int rem = 7 - k->tw_log2;
-    k->th_log2 = ilog2_ceil(a->p.H) < rem ? ilog2_ceil(a->p.H) : rem;
-    k->nb = BM >> (k->tw_log2 + k->th_log2);
-    const int th = 1 << k->th_log2, tw = 1 << k->tw_log2;
-    k->hh = (th - 1) * a->q_step + (max_dy - min_dy) + 1;
-    k->hw = (tw - 1) * a->q_step + (max_dx - min_dx) + 1;
+    const int rowb = a->dtype == SALT_F32 ? 256 : 192;
+    int th = 1, tw = 1;
+    for (int bmp = 128; bmp >= 32; bmp >>= 1) {
+        k->bmp = bmp;
+        k->tw_log2 = ilog2_ceil(a->p.W) < 4 ? ilog2_ceil(a->p.W) : 4;
+        int rem = ilog2_ceil(bmp) - k->tw_log2;
+        k->th_log2 = ilog2_ceil(a->p.H) < rem ? ilog2_ceil(a->p.H) : rem;
+        k->nb = bmp >> (k->tw_log2 + k->th_log2);
+        th = 1 << k->th_log2; tw = 1 << k->tw_log2;
+        k->hh = (th - 1) * a->q_step + (max_dy - min_dy) + 1;
+        k->hw = (tw - 1) * a->q_step + (max_dx - min_dx) + 1;
+        if ((size_t)(bmp + k->nb * k->hh * k->hw) * rowb <= 80 * 1024) break;     // keep >= 2 workgroups per CU
+    }
     k->P = a->p.p; k->Q = a->q.p; k->partials = a->partials;
     k->B = a->p.B; k->PH = a->p.H; k->PW = a->p.W; k->Ca = a->p.C; k->p_cs = a->p.cs;
     k->QH = a->q.H; k->QW = a->q.W; k->Cb = a->q.C; k->q_cs = a->q.cs;
@@ -642,7 +648,7 @@ extern "C" int salt_conv_wgrad_nsplit(const salt_conv_wgrad_args* a) {
 template <typename T>
 static int launch_wgrad(const WgradKP& k, hipStream_t st) {
     constexpr int ROWB = (sizeof(T) == 2) ? 192 : 256;
-    const size_t lds = (size_t)(128 + k.nb * k.hh * k.hw) * ROWB;
+    const size_t lds = (size_t)(k.bmp + k.nb * k.hh * k.hw) * ROWB;
     if (lds > 160 * 1024) SALT_FAIL(SALT_E_LDS, "wgrad: needs %zu bytes of LDS", lds);
     const dim3 grid((unsigned)(k.a_blocks * k.b_blocks * k.nsplit));
 #define SALT_WG(NT) { auto kern = conv_wgrad_kernel<T, NT>; \

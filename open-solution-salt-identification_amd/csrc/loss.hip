@@ -134,10 +134,12 @@ __global__ __launch_bounds__(LT) void lovasz_kernel(salt_lovasz_args a) {
         if (ok) {
             const float e = key_to_float(k0[i]);
             const float kf = (float)(i + 1), ck = (float)c_k, ckm = (float)(c_k - lab);
-            const float jk = 1.f - (G - ck) / (G + (kf - ck));
+            // exactly the reference's fp32 sequence (lovasz_losses.py:27-32): one correctly rounded division, one
+            // subtraction from 1, one first difference; no fma contraction (the difference cancels ~3 digits)
+            const float jk = __fsub_rn(1.f, __fdiv_rn(G - ck, G + (kf - ck)));
             float jm = 0.f;
-            if (i > 0) jm = 1.f - (G - ckm) / (G + ((kf - 1.f) - ckm));
-            const float g = (i > 0) ? jk - jm : jk;
+            if (i > 0) jm = __fsub_rn(1.f, __fdiv_rn(G - ckm, G + ((kf - 1.f) - ckm)));
+            const float g = (i > 0) ? __fsub_rn(jk, jm) : jk;
             const float el = e > 0.f ? e : expm1f(e);
             lsum += el * g;
             if (dz) {

@@ -52,24 +52,35 @@ def lovasz_loss(output, target):
     return lovasz_hinge(output, target.long())
 
 
-def lovasz_hinge_grad_closed_form(logits, labels):
-    """(loss, dloss/dlogits) for per_image=True, computed without autograd in float64.
+def lovasz_hinge_grad_closed_form(logits, labels, dtype=torch.float64):
+    """(loss, dloss/dlogits) for per_image=True, computed without autograd.
 
-    d/dz_{pi(k)} = -s_{pi(k)} * elu'(e_{pi(k)}) * g_k / B ; ties are ordered by torch.sort(stable=True)."""
+    d/dz_{pi(k)} = -s_{pi(k)} * elu'(e_{pi(k)}) * g_k / B ; ties are ordered by torch.sort(stable=True) (flat-index
+    order, the rule the HIP kernel's stable radix sort follows).  ``dtype=torch.float32`` reproduces the reference's
+    fp32 operation sequence for g_k (its first difference cancels ~3 digits), float64 is the well-conditioned truth."""
     B = logits.shape[0]
-    z = logits.detach().double().reshape(B, -1)
-    y = labels.detach().double().reshape(B, -1)
+    z = logits.detach().to(dtype).reshape(B, -1)
+    y = labels.detach().to(dtype).reshape(B, -1)
     s = 2 * y - 1
     e = 1 - z * s
     grad = torch.zeros_like(z)
     total = 0.0
     for b in range(B):
         es, perm = torch.sort(e[b], descending=True, stable=True)
-        g = lovasz_grad(y[b][perm]).double()
-        total += float((F.elu(es) * g).sum())
+        g = lovasz_grad(y[b][perm]).to(dtype) if dtype == torch.float32 else _lovasz_grad64(y[b][perm])
+        total += float((F.elu(es) * g).double().sum())
         d = torch.where(es > 0, torch.ones_like(es), torch.exp(es))
         grad[b, perm] = -s[b][perm] * d * g / B
     return total / B, grad.reshape(logits.shape)
+
+
+def _lovasz_grad64(gt_sorted):
+    gt = gt_sorted.double()
+    total = gt.sum()
+    jac = 1.0 - (total - gt.cumsum(0)) / (total + (1.0 - gt).cumsum(0))
+    if gt.numel() > 1:
+        jac = torch.cat([jac[:1], jac[1:] - jac[:-1]])
+    return jac
 
 
 def dice_loss(output, target, smooth=0.0, eps=1e-7):

@@ -146,8 +146,8 @@ def spec_vanilla_unet(num_classes=2, in_ch=1, base=16, levels=4):
     c = f
     for i in range(levels, 0, -1):
         f = base * 2 ** (i - 1)
+        _bn(s, 'up%d.batch_norm.' % i, f)                 # base.DeconvConv2dBnRelu registers batch_norm first
         s['up%d.deconv.weight' % i] = ((c, f, 3, 3), 'convT_w'); s['up%d.deconv.bias' % i] = ((f,), 'convT_b')
-        _bn(s, 'up%d.batch_norm.' % i, f)
         _conv_bn_relu(s, 'dec%d.0.' % i, 2 * f, f)
         _conv_bn_relu(s, 'dec%d.1.' % i, f, f)
         c = f

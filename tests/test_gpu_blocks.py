@@ -11,7 +11,7 @@ import closed_form as CF
 
 pytestmark = pytest.mark.gpu
 
-TOL32 = 1e-3
+TOL32 = 5e-5
 TOLBF = 4e-2
 
 
@@ -61,16 +61,21 @@ def test_block_vs_reference_golden(name, mode, dtype):
     if not train:
         return
     gx, grads = run.backward(T(fx['gy']).to('cuda:0'))
-    assert_close(gx[0], fx['gx'], tol * 2, 'gx')
+    # bf16: these fixtures are tiny (<= 200 samples per BatchNorm channel, 3..13 channels); the BN backward's
+    # cancellations amplify bf16 storage error, so only a coarse bound is meaningful here (the bf16 kernels are
+    # checked tightly against a bf16-rounded oracle in test_conv_fwd_dgrad_wgrad_vs_torch)
+    gtol = tol * 2 if dtype == 'f32' else 0.3
+    assert_close(gx[0], fx['gx'], gtol, 'gx')
     if 'e0' in fx:
-        assert_close(gx[1], fx['ge0'], tol * 2, 'ge0')
+        assert_close(gx[1], fx['ge0'], gtol, 'ge0')
+    gscale = max(float(np.abs(fx['g:' + k]).max()) for k in grads)
     for k, g in grads.items():
         ref = fx['g:' + k]
-        if np.abs(ref).max() < 1e-5:
-            # conv / deconv bias in front of train-mode BN: analytically zero (reference value is rounding noise)
-            assert float(g.abs().max()) < 1e-4, k
+        if float(g.abs().max()) == 0.0:
+            # conv / deconv bias in front of train-mode BN: analytically zero; the reference holds rounding noise
+            assert np.abs(ref).max() < 1e-4 * gscale, (k, np.abs(ref).max(), gscale)
         else:
-            assert_close(g, ref, tol * 3, 'g:' + k)
+            assert_close(g, ref, tol * 3 if dtype == 'f32' else 0.3, 'g:' + k)
     sd = m.state_dict()
     for k in sd:
         if k.endswith(('running_mean', 'running_var')):

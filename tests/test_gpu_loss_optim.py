@@ -22,13 +22,14 @@ def test_lovasz_vs_reference_golden(case):
     g = z.grad.cpu().numpy()
     if case != 'ties':
         assert_close(g, fx[case + '_gz'], 1e-4, 'dlogits')
-    else:   # gradients inside a tie group depend on the (arbitrary) order the reference's sort produced
-        e = (1 - fx[case + '_z'] * (2 * fx[case + '_t'] - 1)).reshape(3, -1)
-        g1, g2 = g.reshape(3, -1), fx[case + '_gz'].reshape(3, -1)
-        for b in range(3):
-            for v in np.unique(e[b]):
-                m = e[b] == v
-                assert abs(g1[b][m].sum() - g2[b][m].sum()) < 1e-5
+    else:
+        # Inside a group of tied errors the per-element gradient depends on the order the sort happens to produce
+        # (only the loss value is order-invariant).  The HIP sort is stable (flat-index order), so compare with
+        # the oracle's closed form evaluated with a stable sort.
+        from oracle import losses as OL
+        lv, gref = OL.lovasz_hinge_grad_closed_form(T(fx[case + '_z']), T(fx[case + '_t']))
+        assert abs(lv - float(loss)) < 1e-5
+        assert_close(g, gref.float().numpy(), 2e-4, 'dlogits (stable tie order)')
 
 
 def test_lovasz_full_size_vs_oracle_and_properties():
@@ -44,10 +45,23 @@ def test_lovasz_full_size_vs_oracle_and_properties():
     l1, g1 = losses.native_loss(z.to(DEV), t.to(DEV), 'lovasz')
     l2, g2 = losses.native_loss(z.to(DEV), t.to(DEV), 'lovasz')
     assert float(l1) == float(l2) and torch.equal(g1, g2)          # deterministic
-    ref, gref = OL.lovasz_hinge_grad_closed_form(z[:4], t[:4])
     l4, g4 = losses.native_loss(z[:4].to(DEV), t[:4].to(DEV), 'lovasz')
+    zr = z[:4].clone().requires_grad_(True)
+    lr_ = OL.lovasz_loss(zr, t[:4])                      # the reference's arithmetic through autograd
+    lr_.backward()
+    assert abs(float(l4) - float(lr_)) < 2e-5 * max(1, abs(float(lr_)))
+    # With 32768 fp32 keys per image a few exact ties occur; per-element gradients inside a tie group depend on the
+    # sort's tie order (torch.sort is unstable, the HIP radix sort is stable), so the element-wise check uses the
+    # oracle's closed form with a STABLE sort and the reference's fp32 operation sequence ...
+    ref32, gref32 = OL.lovasz_hinge_grad_closed_form(z[:4], t[:4], dtype=torch.float32)
+    assert abs(float(l4) - ref32) < 2e-5 * max(1, abs(ref32))
+    assert_close(g4.cpu(), gref32, 2e-5, 'grad vs fp32 closed form (stable ties)')
+    # ... while vs torch's own (unstable) order only tie-group members may differ, and vs float64 the bar is the
+    # fp32 cancellation of g_k = J_k - J_(k-1) (~1e-3, present in the reference itself)
+    assert float((g4.cpu() - zr.grad).abs().max()) <= 4e-3 * float(zr.grad.abs().max())
+    ref, gref = OL.lovasz_hinge_grad_closed_form(z[:4], t[:4])
     assert abs(float(l4) - ref) < 2e-5 * max(1, abs(ref))
-    assert_close(g4.cpu(), gref.float(), 2e-4, 'grad vs closed form')
+    assert_close(g4.cpu(), gref.float(), 5e-3, 'grad vs float64 closed form')
     # |d loss/d z_i| = elu'(e_i) g_k / B <= g_k / B and sum_k g_k = 1 per image
     per_image = g1.abs().reshape(B, -1).sum(1).cpu()
     assert float(per_image.max()) <= 1.0 / B + 1e-6
@@ -87,4 +101,4 @@ def test_fused_adam_matches_torch_semantics():
     assert opt.state_dict()['param_groups'][0]['lr'] == 1e-3
     opt.param_groups[0]['lr'] = 5e-4                                   # scheduler writes lr (callbacks.py:273-275)
     opt.step()
-    assert abs(float(opt.hyper[0]) - 5e-4) < 1e-12
+    assert abs(float(opt.hyper[0]) - 5e-4) < 1e-9

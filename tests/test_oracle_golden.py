@@ -102,9 +102,12 @@ def test_lovasz_matches_reference(case):
     assert abs(float(lb) - float(fx[case + '_loss_batch'])) <= 3e-6 * max(1, abs(float(lb)))
     # closed-form gradient agrees with autograd (no ties)
     if case in ('random', 'big', 'all0', 'all1'):
+        lv, g = OL.lovasz_hinge_grad_closed_form(T(fx[case + '_z']), T(fx[case + '_t']), dtype=torch.float32)
+        assert abs(lv - float(fx[case + '_loss'])) < 1e-5
+        assert_close(g, fx[case + '_gz'], 1e-5, 'closed form grad (fp32 op sequence)')
         lv, g = OL.lovasz_hinge_grad_closed_form(T(fx[case + '_z']), T(fx[case + '_t']))
         assert abs(lv - float(fx[case + '_loss'])) < 1e-5
-        assert_close(g.float(), fx[case + '_gz'], 1e-5, 'closed form grad')
+        assert_close(g.float(), fx[case + '_gz'], 1e-3, 'closed form grad (float64: g_k cancellation bound)')
 
 
 def test_bce_dice_matches_reference():
