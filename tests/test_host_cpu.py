@@ -115,20 +115,20 @@ class M(torch.nn.Module):
         super().__init__(); s.p = torch.nn.Parameter(w.clone())
 m = M(); dp.broadcast_parameters(m)
 assert float(m.p[0]) == 1.0
-dist.barrier(); print('rank', dp.rank, 'ok')
+dist.barrier(); open(os.path.join(%(out)r, 'rank%%d.ok' %% dp.rank), 'w').write('ok')
 '''
 
 
 def test_two_rank_gloo_gradient_average(tmp_path):
     script = tmp_path / 'worker.py'
-    script.write_text(_WORKER % {'root': ROOT})
+    script.write_text(_WORKER % {'root': ROOT, 'out': str(tmp_path)})
     port = 29500 + (os.getpid() % 500)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
            '--master-port', str(port), str(script)]
     env = dict(os.environ, OMP_NUM_THREADS='1')
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    assert 'rank 0 ok' in r.stdout and 'rank 1 ok' in r.stdout
+    assert (tmp_path / 'rank0.ok').exists() and (tmp_path / 'rank1.ok').exists()
 
 
 def test_product_never_imports_the_oracle_or_reads_the_reference():
