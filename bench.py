@@ -1,0 +1,273 @@
+#!/usr/bin/env python
+"""bench.py — training images/s (+ val IoU) of the ResNet34 hypercolumn U-Net on synthetic 101x101 salt tiles.
+
+    python bench.py --gpus N --steps K --warmup W [--dtype bf16|f32] [--workload r34_hyper|ternaus34|vanilla] [--batch 32]
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)
+
+A "step" is one `_fit_loop`-equivalent pass of the hot path (reference models.py:105-136) over one resident minibatch:
+pack weights -> forward -> Lovasz hinge -> backward (bucketed RCCL all-reduce on a side stream when N > 1) -> fused Adam.
+W untimed warm-up steps, then EXACTLY K timed steps bracketed by barrier + torch.cuda.synchronize(), MAX over ranks.
+Rank 0 prints ONE JSON line.  Inputs are resident in HBM before the timed region (no PCIe inside it).
+
+Extra objects in the line:
+  roofline     the kernel that takes the most time in a step, measured live with HIP event pairs on the launch stream
+               (salt_program_run_timed): achieved = algorithmic FLOPs of its launches / their summed duration.
+  cpu_baseline the oracle (plain-PyTorch CPU restatement, kind "port") timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f32': 157.3}      # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+# ----------------------------------------------------------------------------- synthetic data
+def synth_tiles(n, seed, size=101):
+    """Seismic-like 101x101 gray tiles + salt masks: smoothed noise texture, ellipse/half-plane bodies, ~38 % empty."""
+    r = np.random.RandomState(seed)
+    img = r.randn(n, size + 8, size + 8).astype(np.float32)
+    k = np.array([1, 4, 6, 4, 1], np.float32) / 16
+    for _ in range(2):
+        img = sum(k[i] * np.roll(img, i - 2, axis=1) for i in range(5))
+        img = sum(k[i] * np.roll(img, i - 2, axis=2) for i in range(5))
+    img = img[:, 4:-4, 4:-4]
+    img = (img - img.mean()) / (img.std() + 1e-6)
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float32)
+    mask = np.zeros((n, size, size), np.float32)
+    for i in range(n):
+        u = r.rand()
+        if u < 0.38:
+            continue
+        if u < 0.7:
+            cy, cx = r.uniform(0, size, 2)
+            ry, rx = r.uniform(12, 70, 2)
+            mask[i] = (((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1).astype(np.float32)
+        else:
+            a = r.uniform(0, 2 * np.pi)
+            off = r.uniform(20, 80)
+            mask[i] = ((yy * np.sin(a) + xx * np.cos(a)) > off).astype(np.float32)
+    img = img * 0.18 + 0.45 + 0.22 * mask * (0.6 + 0.4 * r.rand(n, 1, 1).astype(np.float32))     # intensity shift inside salt
+    return np.clip(img, 0, 1), mask
+
+
+def preprocess(img, mask, train, channels):
+    """Reference loader geometry: train = resize 101->102 + edge-pad 13 -> 128 (neptune.yaml:22-26, augmentation.py:79-85);
+    inference = edge-pad to 128 with the (13,14,14,13) split (augmentation.py:247-284).  Normalise with the ImageNet
+    statistics; 3-channel mode applies AddDepthChannels (loaders.py:607-612, utils.py:494-500)."""
+    x = torch.from_numpy(img)[:, None]
+    m = torch.from_numpy(mask)[:, None]
+    if train:
+        x = torch.nn.functional.interpolate(x, size=(102, 102), mode='bilinear', align_corners=False)
+        m = (torch.nn.functional.interpolate(m, size=(102, 102), mode='nearest') > 0.5).float()
+        pad = (13, 13, 13, 13)
+    else:
+        pad = (14, 13, 13, 14)                      # (left, right, top, bottom)
+    x = torch.nn.functional.pad(x, pad, mode='replicate')
+    m = torch.nn.functional.pad(m, pad, mode='replicate')
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    if channels == 1:
+        x = (x - mean[0]) / std[0]
+    else:
+        x = torch.cat([(x - mean[c]) / std[c] for c in range(3)], 1)
+        h = x.shape[2]
+        x[:, 1] = torch.linspace(0, 1, h)[None, :, None]
+        x[:, 2] = x[:, 0] * x[:, 1]
+    t = torch.cat([1 - m, m], 1)
+    return x.contiguous(), t.contiguous()
+
+
+def iou_metric(pred, gt):
+    """mean IoU with the reference's empty-mask conventions (metrics.py:21-34,53-59) on 101x101 crops."""
+    vals = []
+    for p, g in zip(pred, gt):
+        if not g.any() and not p.any():
+            vals.append(1.0)
+        elif g.any() != p.any():
+            vals.append(0.0)
+        else:
+            vals.append(float((p & g).sum()) / float((p | g).sum()))
+    return float(np.mean(vals))
+
+
+# ----------------------------------------------------------------------------- conv FLOP accounting (algorithmic)
+def op_flops(name, s):
+    """Algorithmic FLOPs (2*MAC) of one native operator launch, from its argument struct; 0 for bandwidth ops."""
+    if name == 'conv':
+        return 2.0 * s.x.B * s.OH * s.OW * s.y.C * s.x.C * s.ntaps
+    if name == 'conv_wgrad':
+        return 2.0 * s.p.B * s.p.H * s.p.W * s.p.C * s.q.C * s.ntaps
+    if name == 'conv_first':
+        return 2.0 * s.B * s.y.H * s.y.W * s.y.C * s.Cin * s.K * s.K
+    if name == 'conv_first_wgrad':
+        return 2.0 * s.B * s.dy.H * s.dy.W * s.dy.C * s.Cin * s.K * s.K
+    return 0.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=40)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--dtype', default=os.environ.get('SALT_BENCH_DTYPE', 'bf16'), choices=['bf16', 'f32'])
+    ap.add_argument('--workload', default='r34_hyper', choices=['r34_hyper', 'ternaus34', 'vanilla'])
+    ap.add_argument('--batch', type=int, default=32, help='images per GPU per step')
+    ap.add_argument('--loss', default='lovasz', choices=['lovasz', 'bce_dice'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-iou', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs a GPU'
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl')
+    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    dev = torch.device('cuda', local)
+
+    import salt_amd
+    from salt_amd.models import SegmentationModel
+
+    arch_name = {'r34_hyper': 'UNetResNet', 'ternaus34': 'TernausUNetResNet', 'vanilla': 'VanillaUNet'}[args.workload]
+    channels = 1 if args.workload == 'vanilla' else 3
+    arch = {'model_params': {'architecture': arch_name, 'out_channels': 2, 'activation': 'sigmoid', 'loss': args.loss,
+                             'compute_dtype': args.dtype},
+            'optimizer_params': {'lr': 1e-4}, 'regularizer_params': {'regularize': True, 'weight_decay_conv2d': 1e-4}}
+    torch.manual_seed(1234)
+    model = SegmentationModel(arch, {'epochs': 1}, {})
+    model._to_device()
+    model.model.train()
+    model.dp.broadcast_parameters(model.model)
+
+    # resident synthetic data: a pool of minibatches per rank (different tiles on every rank)
+    B = args.batch
+    pool_batches = 8
+    img, msk = synth_tiles(B * pool_batches, seed=1234 + 17 * rank)
+    X, T = preprocess(img, msk, True, channels)
+    X, T = X.to(dev), T.to(dev)
+    batches = [(X[i * B:(i + 1) * B], T[i * B:(i + 1) * B]) for i in range(pool_batches)]
+
+    def step(i):
+        return model._fit_loop(list(batches[i % pool_batches]))
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te[0])
+    value = world * B * args.steps / elapsed
+    final_loss = float(loss['sum'])
+
+    out = {'metric': 'training images/sec, U-Net ResNet34 101x101 (pad->128) bs32/GPU', 'value': round(value, 2), 'unit': 'images/s',
+           'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),
+           'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+           'config': {'workload': '%s 128x128 (101 resized+edge-padded) batch %d/GPU, %s loss, Adam lr1e-4 L2 1e-4, train-mode BN'
+                                  % ({'r34_hyper': 'architectures.unet.UNetResNet(34, hypercolumn)', 'ternaus34': 'unet_models.UNetResNet(34, deconv)',
+                                      'vanilla': 'vanilla 4-level U-Net (16 filters, 1 channel)'}[args.workload], B, args.loss),
+                      'global_batch': B * world, 'image': [128, 128], 'parallelism': 'dp%d' % world},
+           'final_loss': round(final_loss, 5)}
+
+    # ------------------------------------------------------------------ live roofline (rank 0): event pair around every operator
+    if rank == 0:
+        eng = model.model.engine()
+        net = eng.net((B, channels, 128, 128), True)
+        net.x.copy_(batches[0][0]); net.target.copy_(batches[0][1])
+        groups = {}
+        reps = 3
+        for _ in range(reps):
+            eng.refresh(True)
+            for prog in (net.fwd, net.loss_program(args.loss, 1.0), net.bwd):
+                for name, s, ms in prog.run_timed():
+                    kname = name
+                    g = groups.setdefault(kname, [0.0, 0.0, 0])
+                    g[0] += ms; g[1] += op_flops(name, s); g[2] += 1
+        total_ms = sum(g[0] for g in groups.values()) / reps
+        dom = max(groups.items(), key=lambda kv: kv[1][0])
+        dn, (dms, dfl, dcnt) = dom
+        peak = MFMA_PEAK_TFLOPS[args.dtype]
+        ach = dfl / (dms * 1e-3) / 1e12 if dms > 0 else 0.0
+        kern = {'conv': 'conv_mfma_kernel (fwd + dgrad launches)', 'conv_wgrad': 'conv_wgrad_kernel'}.get(dn, dn)
+        out['roofline'] = {'kernel': kern, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                           'frac': round(ach / peak, 4), 'traffic': None, 'launches_per_step': dcnt // reps,
+                           'avg_launch_us': round(1e3 * dms / dcnt, 2), 'share_of_step': round(dms / reps / total_ms, 3),
+                           'algorithmic_gflop_per_step': round(dfl / reps / 1e9, 2)}
+        out['op_time_ms'] = {k: round(v[0] / reps, 3) for k, v in sorted(groups.items(), key=lambda kv: -kv[1][0])[:8]}
+        all_fl = sum(g[1] for g in groups.values()) / reps
+        out['step_tflops'] = round(all_fl * world / (elapsed / args.steps) / 1e12 / world, 2)
+
+    # ------------------------------------------------------------------ val IoU on held-out synthetic tiles (after the K steps)
+    if not args.no_iou and rank == 0:
+        vi, vm = synth_tiles(128, seed=999)
+        Xv, _ = preprocess(vi, vm, False, channels)
+        model.model.eval()
+        preds = []
+        with torch.no_grad():
+            for i in range(0, 128, B):
+                lg = model.model(Xv[i:i + B].to(dev))
+                preds.append((lg[:, 1, 13:114, 14:115] > 0).cpu().numpy())      # crop 128->101 (postprocessing.py:24-38), sigmoid>0.5
+        model.model.train()
+        out['val_iou'] = round(iou_metric(np.concatenate(preds), vm > 0.5), 4)
+        out['val_iou_note'] = 'mean IoU on 128 held-out synthetic tiles after %d training steps from random init' % (args.warmup + args.steps)
+
+    # ------------------------------------------------------------------ CPU baseline: the oracle on the host cores (bounded sample)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import nets as ON, specs as OS, losses as OL
+        torch.set_num_threads(os.cpu_count())
+        spec = OS.SPECS[arch_name]() if arch_name != 'VanillaUNet' else OS.spec_vanilla_unet()
+        sd = OS.init_state(spec, seed=0)
+        keys = OS.trainable_keys(spec)
+        for k in keys:
+            sd[k].requires_grad_(True)
+        params = [sd[k] for k in keys]
+        m_ = [torch.zeros_like(p) for p in params]
+        v_ = [torch.zeros_like(p) for p in params]
+        cb = 8
+        xc, tc = batches[0][0][:cb].cpu().float(), batches[0][1][:cb].cpu().float()
+        times = []
+        for it in range(4):
+            t1 = time.perf_counter()
+            for p in params:
+                p.grad = None
+            o = ON.FORWARDS[arch_name](sd, xc, True)
+            l = OL.LOSSES[args.loss](o, tc)
+            l.backward()
+            with torch.no_grad():
+                OL.adam_l2_step([p.data for p in params], [p.grad for p in params], m_, v_, it + 1)
+            times.append(time.perf_counter() - t1)
+        med = float(np.median(times[1:]))
+        out['cpu_baseline'] = {'value': round(cb / med, 2), 'unit': 'images/s', 'cores': os.cpu_count(), 'kind': 'port',
+                               'sample': 'oracle (plain PyTorch CPU fp32, %d threads) same network/loss/optimizer, batch %d, median of 3 steps after 1 warm-up'
+                                         % (torch.get_num_threads(), cb)}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

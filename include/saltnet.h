@@ -508,6 +508,8 @@ typedef struct {
 } salt_program_entry;
 int salt_program_run(const salt_program_entry* entries, int n, void* stream);
 int salt_program_run_range(const salt_program_entry* entries, int begin, int end, void* stream);
+/* as run_range, with a HIP event pair around every entry on `stream`; ms_out[i] = elapsed ms of entry begin+i */
+int salt_program_run_timed(const salt_program_entry* entries, int begin, int end, void* stream, float* ms_out);
 int salt_graph_capture(const salt_program_entry* entries, int n, void* stream, void** graph_exec_out);
 int salt_graph_launch(void* graph_exec, void* stream);
 int salt_graph_destroy(void* graph_exec);

@@ -53,19 +53,53 @@ __global__ void affine_act_kernel(salt_view y, const float* scale, const float* 
 }
 
 // ---------------------------------------------------------------- BN finalize (Chan combine, fp64, fixed order)
+// Two stages so that no thread walks thousands of partials serially:
+//   stage 1: one block per chunk of BN_CHUNK partials, threads over channels (coalesced rows); the chunk's merged
+//            (sum, M2) overwrites the chunk's FIRST partial row in place (each thread owns its channel column);
+//   stage 2: per channel, merge the <= nparts/BN_CHUNK chunk heads (chunk counts come from an LDS pre-pass).
+constexpr int BN_CHUNK = 64;
+
+__global__ void bn_chunk_kernel(float* stats, const float* cnt, int nparts, int C) {
+    const int k0 = blockIdx.x * BN_CHUNK;
+    const int k1 = min(k0 + BN_CHUNK, nparts);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double n = 0.0, mean = 0.0, m2 = 0.0;
+        for (int k = k0; k < k1; ++k) {
+            const double nk = (double)cnt[k];
+            if (nk <= 0.0) continue;
+            const double mk = (double)stats[((int64_t)k * 2 + 0) * C + c] / nk;
+            const double m2k = (double)stats[((int64_t)k * 2 + 1) * C + c];
+            const double d = mk - mean, nn = n + nk;
+            mean += d * nk / nn;
+            m2 += m2k + d * d * n * nk / nn;
+            n = nn;
+        }
+        stats[((int64_t)k0 * 2 + 0) * C + c] = (float)(mean * n);
+        stats[((int64_t)k0 * 2 + 1) * C + c] = (float)m2;
+    }
+}
+
 __global__ void bn_finalize_kernel(salt_bn_finalize_args a) {
+    extern __shared__ float chunk_cnt[];
+    const int nchunks = (a.nparts + BN_CHUNK - 1) / BN_CHUNK;
+    for (int j = threadIdx.x; j < nchunks; j += blockDim.x) {
+        float s = 0.f;
+        const int k1 = min((j + 1) * BN_CHUNK, a.nparts);
+        for (int k = j * BN_CHUNK; k < k1; ++k) s += a.stats_cnt[k];
+        chunk_cnt[j] = s;
+    }
+    __syncthreads();
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c == 0 && a.num_batches_tracked) *a.num_batches_tracked += 1;
     if (c >= a.C) return;
     double n = 0.0, mean = 0.0, m2 = 0.0;
-    for (int k = 0; k < a.nparts; ++k) {
-        const double nk = (double)a.stats_cnt[k];
+    for (int j = 0; j < nchunks; ++j) {
+        const double nk = (double)chunk_cnt[j];
         if (nk <= 0.0) continue;
-        const double sk = (double)a.stats[((int64_t)k * 2 + 0) * a.C + c];
-        const double m2k = (double)a.stats[((int64_t)k * 2 + 1) * a.C + c];
-        const double mk = sk / nk;
-        const double d = mk - mean;
-        const double nn = n + nk;
+        const int64_t k = (int64_t)j * BN_CHUNK;
+        const double mk = (double)a.stats[(k * 2 + 0) * a.C + c] / nk;
+        const double m2k = (double)a.stats[(k * 2 + 1) * a.C + c];
+        const double d = mk - mean, nn = n + nk;
         mean += d * nk / nn;
         m2 += m2k + d * d * n * nk / nn;
         n = nn;
@@ -141,12 +175,20 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(salt_view da, salt_v
     }
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* partials, int nparts, int C, double M, const float* gamma, const float* invstd,
+// 256 threads = 4 part-rows x 64 channels; rows take parts k = row, row+4, ... (fixed order), then combine.
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* partials, int nparts, int C, double M, const float* gamma, const float* invstd,
                                        float* dgamma, float* dbeta, int accumulate, float* coef) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double sm[2][4][64];
+    const int cl = threadIdx.x & 63, row = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     double s1 = 0.0, s2 = 0.0;
-    for (int k = 0; k < nparts; ++k) { s1 += (double)partials[((int64_t)k * 2) * C + c]; s2 += (double)partials[((int64_t)k * 2 + 1) * C + c]; }
+    if (c < C)
+        for (int k = row; k < nparts; k += 4) { s1 += (double)partials[((int64_t)k * 2) * C + c]; s2 += (double)partials[((int64_t)k * 2 + 1) * C + c]; }
+    sm[0][row][cl] = s1; sm[1][row][cl] = s2;
+    __syncthreads();
+    if (row != 0 || c >= C) return;
+    s1 = sm[0][0][cl] + sm[0][1][cl] + sm[0][2][cl] + sm[0][3][cl];
+    s2 = sm[1][0][cl] + sm[1][1][cl] + sm[1][2][cl] + sm[1][3][cl];
     if (dgamma) { dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2; dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1; }
     coef[c] = gamma[c] * invstd[c];
     coef[C + c] = (float)(s1 / M);
@@ -468,7 +510,11 @@ extern "C" int salt_affine_act(const salt_affine_act_args* a, void* stream) {
 extern "C" int salt_bn_finalize(const salt_bn_finalize_args* a, void* stream) {
     if (!a || !a->stats || !a->stats_cnt || a->C < 1 || a->nparts < 1 || !a->gamma || !a->beta || !a->mean || !a->invstd || !a->scale || !a->shift)
         SALT_FAIL(SALT_E_BADARG, "bn_finalize: bad args");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(a->C, 64)), dim3(64), 0, (hipStream_t)stream, *a);
+    const int nchunks = cdiv(a->nparts, BN_CHUNK);
+    hipLaunchKernelGGL(bn_chunk_kernel, dim3(nchunks), dim3(a->C < 256 ? ((a->C + 63) / 64) * 64 : 256), 0, (hipStream_t)stream,
+                       const_cast<float*>(a->stats), a->stats_cnt, a->nparts, a->C);
+    SALT_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(a->C, 64)), dim3(64), nchunks * sizeof(float), (hipStream_t)stream, *a);
     SALT_CHECK_LAUNCH();
     return SALT_OK;
 }
@@ -482,8 +528,8 @@ extern "C" int salt_bn_fold(const salt_bn_fold_args* a, void* stream) {
 
 static int bn_bwd_nparts(const salt_bn_bwd_args* a, int64_t* ppb) {
     const int64_t npix = view_pixels(a->y);
-    int64_t parts = (npix + 127) / 128;
-    if (parts > 1024) parts = 1024;
+    int64_t parts = (npix + 255) / 256;
+    if (parts > 512) parts = 512;
     if (parts < 1) parts = 1;
     const int64_t per = (npix + parts - 1) / parts;
     if (ppb) *ppb = per;
@@ -516,7 +562,7 @@ extern "C" int salt_bn_bwd(const salt_bn_bwd_args* a, void* stream) {
         if (v) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), dim3(nparts), dim3(256), lds, st, a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->partials, per);
         else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), dim3(nparts), dim3(256), lds, st, a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->partials, per);
         SALT_CHECK_LAUNCH();
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, st, a->partials, nparts, C, (double)view_pixels(a->y),
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(256), 0, st, a->partials, nparts, C, (double)view_pixels(a->y),
                            a->gamma, a->invstd, a->dgamma, a->dbeta, a->accumulate_param_grads, a->coef);
         SALT_CHECK_LAUNCH();
         const int64_t units = view_pixels(a->y) * cpv;

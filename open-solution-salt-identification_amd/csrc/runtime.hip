@@ -48,6 +48,27 @@ extern "C" int salt_program_run_range(const salt_program_entry* e, int begin, in
     return SALT_OK;
 }
 
+// Same as salt_program_run_range but brackets every entry with HIP events recorded on `stream` (the stream the
+// kernels are launched on) and returns the elapsed milliseconds per entry.  Used by bench.py for the live roofline.
+extern "C" int salt_program_run_timed(const salt_program_entry* e, int begin, int end, void* stream, float* ms_out) {
+    if (!e || begin < 0 || end < begin || !ms_out) SALT_FAIL(SALT_E_BADARG, "program: bad range");
+    const int n = end - begin;
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t* ev = new hipEvent_t[n + 1];
+    for (int i = 0; i <= n; ++i) if (hipEventCreate(&ev[i]) != hipSuccess) { delete[] ev; SALT_FAIL(SALT_E_BADARG, "hipEventCreate failed"); }
+    int rc = SALT_OK;
+    (void)hipEventRecord(ev[0], st);
+    for (int i = 0; i < n && rc == SALT_OK; ++i) {
+        rc = e[begin + i].fn(e[begin + i].args, stream);
+        (void)hipEventRecord(ev[i + 1], st);
+    }
+    (void)hipStreamSynchronize(st);
+    if (rc == SALT_OK) for (int i = 0; i < n; ++i) { float ms = 0.f; (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]); ms_out[i] = ms; }
+    for (int i = 0; i <= n; ++i) (void)hipEventDestroy(ev[i]);
+    delete[] ev;
+    return rc;
+}
+
 extern "C" int salt_program_run(const salt_program_entry* e, int n, void* stream) {
     return salt_program_run_range(e, 0, n, stream);
 }

@@ -99,6 +99,15 @@ class Program:
             where = (' [%s]' % self.ops[m][0]) if m is not None and m < len(self.ops) else ''
             raise SaltError('program %s failed (%d)%s: %s' % (self.name, rc, where, msg))
 
+    def run_timed(self, stream=None):
+        """Run with a HIP event pair around every entry (on the launch stream); returns [(opname, struct, ms)]."""
+        if self._entries is None:
+            self.finalize()
+        n = len(self.ops)
+        ms = (ctypes.c_float * max(n, 1))()
+        check(lib.salt_program_run_timed(ctypes.cast(self._entries, ctypes.c_void_p), 0, n, _stream_ptr(stream), ms), 'run_timed')
+        return [(self.ops[i][0], self.ops[i][2], float(ms[i])) for i in range(n)]
+
     def run_debug(self, stream=None):
         """Run op by op with a device sync after each (pinpoints a faulting kernel)."""
         st = _stream_ptr(stream)

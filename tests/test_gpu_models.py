@@ -35,6 +35,7 @@ def _grad_report(net, ref_grads):
     tests cannot hold here; L2 / cosine measures are the meaningful whole-net statistics."""
     eng = net.engine()
     worst, dots, n1, n2, n = (0.0, ''), 0.0, 0.0, 0.0, 0
+    gmax = max(float(g.abs().max()) for g in ref_grads.values() if g is not None)
     for k, p in net.named_parameters():
         gr = ref_grads.get(k)
         if gr is None or float(gr.abs().max()) < 1e-7:
@@ -42,6 +43,11 @@ def _grad_report(net, ref_grads):
         off, cnt = eng.grad_range(p)
         mine = eng.grads[off:off + cnt].view(p.shape).cpu().double()
         gr = gr.double()
+        if float(mine.abs().max()) == 0.0:
+            # conv / deconv bias in front of train-mode BatchNorm: analytically zero (sum of the BN input gradient);
+            # the HIP path writes exact zeros, the reference holds rounding noise
+            assert float(gr.abs().max()) < 1e-3 * gmax, (k, float(gr.abs().max()), gmax)
+            continue
         e = float((mine - gr).norm() / gr.norm())
         worst = max(worst, (e, k))
         dots += float((mine * gr).sum()); n1 += float((mine * mine).sum()); n2 += float((gr * gr).sum())
