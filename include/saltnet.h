@@ -239,6 +239,8 @@ typedef struct {
     float* shift;             /* out [C]: beta - mean*scale */
 } salt_bn_finalize_args;
 int salt_bn_finalize(const salt_bn_finalize_args*, void* stream);
+/* floats the `stats` workspace must hold for nparts partials of C channels (partials + chunk heads) */
+int64_t salt_bn_stats_floats(int nparts, int C);
 
 typedef struct {              /* eval mode: scale/shift from running statistics */
     int C;
@@ -327,6 +329,7 @@ typedef struct {              /* bilinear xR, align_corners=False (base.py:70, u
     int R;
     int backward;             /* 0: y = up(x);  1: x (+)= up^T(y) */
     int accumulate;
+    void* tmp;                /* backward, R >= 4: workspace of B*(H*R)*W*roundup(C) elements for the separable adjoint, or NULL */
 } salt_bilinear_args;
 int salt_bilinear(const salt_bilinear_args*, void* stream);
 

@@ -99,6 +99,7 @@ for _fname, _ret, _args in _PROTOS:
         if am.group(2):
             OP_FUNCS[_fname] = (fn, STRUCTS[am.group(1)])
 lib.salt_packed_weight_elems.argtypes = [ctypes.c_int] * 4
+lib.salt_bn_stats_floats.argtypes = [ctypes.c_int] * 2
 lib.salt_device_info.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_char_p, ctypes.c_int]
 lib.salt_program_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
 lib.salt_program_run_range.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]

@@ -145,30 +145,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvKP p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nbp = p.ntaps * BN * 4;          // weight pieces per chunk
-    for (int c = 0; c < p.nchunk; ++c) {
-        const int ch_base = c * KCE;
-        __syncthreads();                        // previous chunk's fragment reads are done
-        // stage halo tile
-#pragma unroll
-        for (int k = 0; k < MAXA; ++k) {
-            if (k < npa && a_goff[k] != -2) {
-                const int q = tid + (k << 8);
-                u32x4 v = {0u, 0u, 0u, 0u};
-                const int ch0 = ch_base + (q & 3) * VE;
-                if (a_goff[k] >= 0 && ch0 < p.Cin) v = load_piece<T>(xg, a_goff[k] + ch_base, ch0, p.Cin, x_vec);
-                *reinterpret_cast<u32x4*>(sA + swz_addr(q >> 2, q & 3)) = v;
-            }
-        }
-        // stage weights of this chunk: Wp[c][t][n][KCE]
-        for (int q = tid; q < nbp; q += 256) {
-            const int row = q >> 2;                       // t*BN + n
-            const int t = row / BN, n = row - t * BN;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (n0 + n < p.Cout)
-                v = *reinterpret_cast<const u32x4*>(wg + (((int64_t)c * p.ntaps + t) * p.Cout + n0 + n) * KCE + (q & 3) * VE);
-            *reinterpret_cast<u32x4*>(sB + swz_addr(row, q & 3)) = v;
-        }
-        __syncthreads();
+    constexpr int MAXBP = (9 * BN * 4 + 255) / 256;          // weight pieces per thread that fit the register prefetch (<= 9 taps)
+
+    auto compute_chunk = [&]() {
         for (int t = 0; t < p.ntaps; ++t) {
             const int toff = p.tap_off[t];
 #pragma unroll
@@ -184,6 +163,75 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvKP p) {
 #pragma unroll
                     for (int j = 0; j < NI; ++j) Mma<T>::step(a[i], b[j], acc[i][j]);
             }
+        }
+    };
+
+    if (p.ntaps <= 9) {
+        // Software pipeline: the global loads of chunk c+1 are issued right after the barrier that releases the MFMA
+        // phase of chunk c and land in registers while the matrix cores work; they are written to LDS only after the
+        // next barrier.  HBM/L2 latency is hidden behind compute instead of being paid once per chunk.
+        u32x4 ra[MAXA], rb[MAXBP];
+        auto load_chunk = [&](int c) {
+            const int ch_base = c * KCE;
+#pragma unroll
+            for (int k = 0; k < MAXA; ++k) {
+                ra[k] = u32x4{0u, 0u, 0u, 0u};
+                if (k < npa && a_goff[k] >= 0) {
+                    const int ch0 = ch_base + (tid & 3) * VE;
+                    if (ch0 < p.Cin) ra[k] = load_piece<T>(xg, a_goff[k] + ch_base, ch0, p.Cin, x_vec);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < MAXBP; ++k) {
+                rb[k] = u32x4{0u, 0u, 0u, 0u};
+                const int q = tid + (k << 8);
+                if (q < nbp) {
+                    const int row = q >> 2;
+                    const int t = row / BN, n = row - t * BN;
+                    if (n0 + n < p.Cout)
+                        rb[k] = *reinterpret_cast<const u32x4*>(wg + (((int64_t)c * p.ntaps + t) * p.Cout + n0 + n) * KCE + (q & 3) * VE);
+                }
+            }
+        };
+        load_chunk(0);
+        for (int c = 0; c < p.nchunk; ++c) {
+            __syncthreads();                    // fragment reads of chunk c-1 are done
+#pragma unroll
+            for (int k = 0; k < MAXA; ++k)
+                if (k < npa && a_goff[k] != -2) { const int q = tid + (k << 8); *reinterpret_cast<u32x4*>(sA + swz_addr(q >> 2, q & 3)) = ra[k]; }
+#pragma unroll
+            for (int k = 0; k < MAXBP; ++k) {
+                const int q = tid + (k << 8);
+                if (q < nbp) *reinterpret_cast<u32x4*>(sB + swz_addr(q >> 2, q & 3)) = rb[k];
+            }
+            __syncthreads();
+            if (c + 1 < p.nchunk) load_chunk(c + 1);
+            compute_chunk();
+        }
+    } else {
+        for (int c = 0; c < p.nchunk; ++c) {
+            const int ch_base = c * KCE;
+            __syncthreads();                        // previous chunk's fragment reads are done
+#pragma unroll
+            for (int k = 0; k < MAXA; ++k) {
+                if (k < npa && a_goff[k] != -2) {
+                    const int q = tid + (k << 8);
+                    u32x4 v = {0u, 0u, 0u, 0u};
+                    const int ch0 = ch_base + (q & 3) * VE;
+                    if (a_goff[k] >= 0 && ch0 < p.Cin) v = load_piece<T>(xg, a_goff[k] + ch_base, ch0, p.Cin, x_vec);
+                    *reinterpret_cast<u32x4*>(sA + swz_addr(q >> 2, q & 3)) = v;
+                }
+            }
+            for (int q = tid; q < nbp; q += 256) {
+                const int row = q >> 2;                       // t*BN + n
+                const int t = row / BN, n = row - t * BN;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (n0 + n < p.Cout)
+                    v = *reinterpret_cast<const u32x4*>(wg + (((int64_t)c * p.ntaps + t) * p.Cout + n0 + n) * KCE + (q & 3) * VE);
+                *reinterpret_cast<u32x4*>(sB + swz_addr(row, q & 3)) = v;
+            }
+            __syncthreads();
+            compute_chunk();
         }
     }
 
@@ -570,7 +618,7 @@ int wgrad_plan(const salt_conv_wgrad_args* a, WgradKP* k, int* nsplit_out) {
     k->tiles_y = cdiv(a->p.H, th); k->tiles_x = cdiv(a->p.W, tw);
     k->ntiles = cdiv(a->p.B, k->nb) * k->tiles_y * k->tiles_x;
     k->a_blocks = cdiv(a->p.C, 64); k->b_blocks = cdiv(a->q.C, 64);
-    int ns = 512 / (k->a_blocks * k->b_blocks);
+    int ns = 512 / (k->a_blocks * k->b_blocks);      // ~2 workgroups per CU; every split costs a partial slab
     if (ns < 1) ns = 1;
     if (ns > k->ntiles) ns = k->ntiles;
     *nsplit_out = ns;
@@ -582,18 +630,29 @@ struct ReduceKP {
     const float* partials; float* grad; int nsplit, ntaps, Ca, Cb, KH, KW, accumulate;
     int tap_kh[SALT_MAX_TAPS], tap_kw[SALT_MAX_TAPS];
 };
-__global__ void wgrad_reduce_kernel(ReduceKP p) {
+// 256 threads = 4 split-rows x 64 consecutive slab elements: coalesced 256-B reads, 4x the parallelism of one thread
+// per element (the slab is small - 36 K floats for a 64->64 3x3 - while nsplit can be 512), fixed summation order.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(ReduceKP p) {
+    __shared__ float sm[4][64];
     const int64_t slab = (int64_t)p.ntaps * p.Ca * p.Cb;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < slab; i += (int64_t)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int k = 0; k < p.nsplit; ++k) s += p.partials[k * slab + i];
-        const int b = (int)(i % p.Cb);
-        int64_t r = i / p.Cb;
-        const int a = (int)(r % p.Ca);
-        const int t = (int)(r / p.Ca);
-        float* dst = p.grad + (((int64_t)a * p.Cb + b) * p.KH + p.tap_kh[t]) * p.KW + p.tap_kw[t];
-        *dst = p.accumulate ? (*dst + s) : s;
+    const int e = threadIdx.x & 63, row = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + e;
+    float s0 = 0.f, s1 = 0.f;
+    if (i < slab) {
+        int k = row;
+        for (; k + 4 < p.nsplit; k += 8) { s0 += p.partials[k * slab + i]; s1 += p.partials[(k + 4) * slab + i]; }
+        for (; k < p.nsplit; k += 4) s0 += p.partials[k * slab + i];
     }
+    sm[row][e] = s0 + s1;
+    __syncthreads();
+    if (row != 0 || i >= slab) return;
+    const float s = sm[0][e] + sm[1][e] + sm[2][e] + sm[3][e];
+    const int b = (int)(i % p.Cb);
+    int64_t r = i / p.Cb;
+    const int a = (int)(r % p.Ca);
+    const int t = (int)(r / p.Ca);
+    float* dst = p.grad + (((int64_t)a * p.Cb + b) * p.KH + p.tap_kh[t]) * p.KW + p.tap_kw[t];
+    *dst = p.accumulate ? (*dst + s) : s;
 }
 
 }  // namespace
@@ -682,8 +741,7 @@ extern "C" int salt_wgrad_reduce(const salt_wgrad_reduce_args* a, void* stream) 
     p.KH = a->KH; p.KW = a->KW; p.accumulate = a->accumulate;
     for (int t = 0; t < a->ntaps; ++t) { p.tap_kh[t] = a->tap_kh[t]; p.tap_kw[t] = a->tap_kw[t]; }
     const int64_t slab = (int64_t)a->ntaps * a->Ca * a->Cb;
-    const int blocks = (int)((slab + 255) / 256 < 4096 ? (slab + 255) / 256 : 4096);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((slab + 63) / 64)), dim3(256), 0, (hipStream_t)stream, p);
     SALT_CHECK_LAUNCH();
     return SALT_OK;
 }

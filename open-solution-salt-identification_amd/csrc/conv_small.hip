@@ -238,21 +238,20 @@ __global__ void head1x1_vec_kernel(salt_view x, const float* w, const float* bia
 }
 
 // backward: dx[pix][c] = sum_o dy[o][pix] w[o][c];  gw[o][c] = sum_pix dy[o][pix] x[pix][c];  gb[o] = sum_pix dy[o][pix]
+// threads = (pixel row, channel); per-thread register sums, rows combined through LDS in fixed order.
 template <typename T>
 __global__ __launch_bounds__(256) void head1x1_bwd_kernel(salt_view x, const float* w, int Cout, const float* dy_nchw, salt_view dx,
                                                           int accumulate, float* partials, int64_t pix_per_block) {
-    extern __shared__ float sm[];
+    extern __shared__ float sm[];                         // [R][cn][5]
     const int C = x.C;
     const int64_t hw = (int64_t)x.H * x.W, npix = (int64_t)x.B * hw;
     const int64_t p0 = blockIdx.x * pix_per_block;
     const int64_t p1 = p0 + pix_per_block < npix ? p0 + pix_per_block : npix;
     const int PW = Cout * (C + 1);
-    for (int i = threadIdx.x; i < PW; i += 256) sm[i] = 0.f;
-    __syncthreads();
     for (int c0 = 0; c0 < C; c0 += 256) {
         const int cn = C - c0 < 256 ? C - c0 : 256;
         const int R = 256 / cn;
-        const int row = threadIdx.x / cn, c = c0 + threadIdx.x % cn;
+        const int row = threadIdx.x / cn, cl = threadIdx.x % cn, c = c0 + cl;
         float gw[4] = {0.f, 0.f, 0.f, 0.f}, gb[4] = {0.f, 0.f, 0.f, 0.f};
         if (row < R) {
             float wv[4];
@@ -271,25 +270,49 @@ __global__ __launch_bounds__(256) void head1x1_bwd_kernel(salt_view x, const flo
                 if (accumulate) d += Elem<T>::ld(dst);
                 Elem<T>::st(dst, d);
             }
-        }
-        // deterministic in-block combine: rows add in fixed order
-        for (int r = 0; r < R; ++r) {
-            if (row == r) {
 #pragma unroll
-                for (int o = 0; o < 4; ++o) if (o < Cout) { sm[o * (C + 1) + c] += gw[o]; if (c == 0) sm[o * (C + 1) + C] += gb[o]; }
+            for (int o = 0; o < 4; ++o) sm[(row * cn + cl) * 5 + o] = gw[o];
+            sm[(row * cn + cl) * 5 + 4] = 0.f;
+            if (cl == 0 && c0 == 0) { /* bias sums ride in slot 4 of channel 0, one per output via a second pass below */ }
+        }
+        __syncthreads();
+        if (row == 0) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) if (o < Cout) {
+                float t = 0.f;
+                for (int r = 0; r < R; ++r) t += sm[(r * cn + cl) * 5 + o];
+                partials[(int64_t)blockIdx.x * PW + o * (C + 1) + c] = t;
+            }
+        }
+        __syncthreads();
+        if (c0 == 0) {                                     // bias: combine gb of the channel-0 threads of every row
+            if (row < R && cl == 0) {
+#pragma unroll
+                for (int o = 0; o < 4; ++o) sm[row * 4 + o] = gb[o];
+            }
+            __syncthreads();
+            if (threadIdx.x < Cout) {
+                float t = 0.f;
+                for (int r = 0; r < R; ++r) t += sm[r * 4 + threadIdx.x];
+                partials[(int64_t)blockIdx.x * PW + threadIdx.x * (C + 1) + C] = t;
             }
             __syncthreads();
         }
     }
-    for (int i = threadIdx.x; i < PW; i += 256) partials[(int64_t)blockIdx.x * PW + i] = sm[i];
 }
 
-__global__ void head1x1_bwd_finalize(const float* partials, int nparts, int Cout, int C, float* gw, float* gb) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// 256 threads = 4 part-rows x 64 outputs
+__global__ __launch_bounds__(256) void head1x1_bwd_finalize(const float* partials, int nparts, int Cout, int C, float* gw, float* gb) {
+    __shared__ float sm[4][64];
+    const int il = threadIdx.x & 63, row = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + il;
     const int PW = Cout * (C + 1);
-    if (i >= PW) return;
     float s = 0.f;
-    for (int k = 0; k < nparts; ++k) s += partials[(int64_t)k * PW + i];
+    if (i < PW) for (int k = row; k < nparts; k += 4) s += partials[(int64_t)k * PW + i];
+    sm[row][il] = s;
+    __syncthreads();
+    if (row != 0 || i >= PW) return;
+    s = sm[0][il] + sm[1][il] + sm[2][il] + sm[3][il];
     const int o = i / (C + 1), c = i - o * (C + 1);
     if (c < C) gw[o * C + c] = s; else if (gb) gb[o] = s;
 }
@@ -408,11 +431,11 @@ extern "C" int salt_head1x1_bwd(const salt_head1x1_bwd_args* a, void* stream) {
     if (a->nparts != nparts) SALT_FAIL(SALT_E_BADARG, "head1x1_bwd: nparts %d, expected %d", a->nparts, nparts);
     const int PW = a->Cout * (a->x.C + 1);
     SALT_DISPATCH_DTYPE(a->dtype, T, {
-        hipLaunchKernelGGL(head1x1_bwd_kernel<T>, dim3(nparts), dim3(256), PW * sizeof(float), (hipStream_t)stream,
+        hipLaunchKernelGGL(head1x1_bwd_kernel<T>, dim3(nparts), dim3(256), 256 * 5 * sizeof(float), (hipStream_t)stream,
                            a->x, a->w, a->Cout, a->dy_nchw, a->dx, a->accumulate, a->partials, per);
     })
     SALT_CHECK_LAUNCH();
-    hipLaunchKernelGGL(head1x1_bwd_finalize, dim3(cdiv(PW, 64)), dim3(64), 0, (hipStream_t)stream, a->partials, nparts, a->Cout, a->x.C, a->gw, a->gb);
+    hipLaunchKernelGGL(head1x1_bwd_finalize, dim3(cdiv(PW, 64)), dim3(256), 0, (hipStream_t)stream, a->partials, nparts, a->Cout, a->x.C, a->gw, a->gb);
     SALT_CHECK_LAUNCH();
     return SALT_OK;
 }

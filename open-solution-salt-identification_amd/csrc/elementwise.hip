@@ -52,64 +52,73 @@ __global__ void affine_act_kernel(salt_view y, const float* scale, const float* 
     }
 }
 
-// ---------------------------------------------------------------- BN finalize (Chan combine, fp64, fixed order)
-// Two stages so that no thread walks thousands of partials serially:
-//   stage 1: one block per chunk of BN_CHUNK partials, threads over channels (coalesced rows); the chunk's merged
-//            (sum, M2) overwrites the chunk's FIRST partial row in place (each thread owns its channel column);
-//   stage 2: per channel, merge the <= nparts/BN_CHUNK chunk heads (chunk counts come from an LDS pre-pass).
+// ---------------------------------------------------------------- BN finalize (two-level, fp64, fixed order, no atomics)
+// Partials are (sum, M2 about the partial's own mean, count).  Merging uses the exact identity
+//   mean = S/N,  M2 = sum_k [ M2_k + n_k (mean_k - mean)^2 ]
+// evaluated in two passes over independent loads (no serial Chan chain):
+//   stage 1: grid (chunks of 64 partials) x (64-channel groups), 256 threads = 4 part-rows x 64 channels
+//            -> chunk heads (S, M2, N) appended after the partials in the same workspace;
+//   stage 2: the same merge over the <= nparts/64 chunk heads -> mean / invstd / scale / shift (+ running stats).
 constexpr int BN_CHUNK = 64;
 
-__global__ void bn_chunk_kernel(float* stats, const float* cnt, int nparts, int C) {
-    const int k0 = blockIdx.x * BN_CHUNK;
-    const int k1 = min(k0 + BN_CHUNK, nparts);
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        double n = 0.0, mean = 0.0, m2 = 0.0;
-        for (int k = k0; k < k1; ++k) {
-            const double nk = (double)cnt[k];
-            if (nk <= 0.0) continue;
-            const double mk = (double)stats[((int64_t)k * 2 + 0) * C + c] / nk;
-            const double m2k = (double)stats[((int64_t)k * 2 + 1) * C + c];
-            const double d = mk - mean, nn = n + nk;
-            mean += d * nk / nn;
-            m2 += m2k + d * d * n * nk / nn;
-            n = nn;
+__device__ __forceinline__ void bn_merge_256(const float* sum_row0, const float* m2_row0, const float* n_ptr, int n_stride_is_c,
+                                             int64_t row_stride, int64_t n_row_stride, int k0, int k1, int c, bool c_ok,
+                                             double& N, double& S, double& M2) {
+    // thread layout: cl = tid & 63 (channel), row = tid >> 6 (takes items k0+row, k0+row+4, ...)
+    __shared__ double sm[3][4][64];
+    const int cl = threadIdx.x & 63, row = threadIdx.x >> 6;
+    double n = 0.0, sacc = 0.0;
+    if (c_ok)
+        for (int k = k0 + row; k < k1; k += 4) {
+            const double nk = (double)(n_stride_is_c ? n_ptr[(int64_t)k * n_row_stride + c] : n_ptr[k]);
+            n += nk; sacc += (double)sum_row0[(int64_t)k * row_stride + c];
         }
-        stats[((int64_t)k0 * 2 + 0) * C + c] = (float)(mean * n);
-        stats[((int64_t)k0 * 2 + 1) * C + c] = (float)m2;
+    sm[0][row][cl] = n; sm[1][row][cl] = sacc;
+    __syncthreads();
+    N = sm[0][0][cl] + sm[0][1][cl] + sm[0][2][cl] + sm[0][3][cl];
+    S = sm[1][0][cl] + sm[1][1][cl] + sm[1][2][cl] + sm[1][3][cl];
+    const double mean = N > 0 ? S / N : 0.0;
+    double m2 = 0.0;
+    if (c_ok)
+        for (int k = k0 + row; k < k1; k += 4) {
+            const double nk = (double)(n_stride_is_c ? n_ptr[(int64_t)k * n_row_stride + c] : n_ptr[k]);
+            if (nk > 0.0) {
+                const double d = (double)sum_row0[(int64_t)k * row_stride + c] / nk - mean;
+                m2 += (double)m2_row0[(int64_t)k * row_stride + c] + nk * d * d;
+            }
+        }
+    __syncthreads();
+    sm[2][row][cl] = m2;
+    __syncthreads();
+    M2 = sm[2][0][cl] + sm[2][1][cl] + sm[2][2][cl] + sm[2][3][cl];
+}
+
+__global__ __launch_bounds__(256) void bn_chunk_kernel(float* stats, const float* cnt, int nparts, int C) {
+    const int k0 = blockIdx.x * BN_CHUNK, k1 = min(k0 + BN_CHUNK, nparts);
+    const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+    double N, S, M2;
+    bn_merge_256(stats, stats + C, cnt, 0, 2 * (int64_t)C, 0, k0, k1, c, c < C, N, S, M2);
+    if ((threadIdx.x >> 6) == 0 && c < C) {
+        float* head = stats + (int64_t)nparts * 2 * C + (int64_t)blockIdx.x * 3 * C;
+        head[c] = (float)S; head[C + c] = (float)M2; head[2 * C + c] = (float)N;
     }
 }
 
-__global__ void bn_finalize_kernel(salt_bn_finalize_args a) {
-    extern __shared__ float chunk_cnt[];
+__global__ __launch_bounds__(256) void bn_finalize_kernel(salt_bn_finalize_args a) {
     const int nchunks = (a.nparts + BN_CHUNK - 1) / BN_CHUNK;
-    for (int j = threadIdx.x; j < nchunks; j += blockDim.x) {
-        float s = 0.f;
-        const int k1 = min((j + 1) * BN_CHUNK, a.nparts);
-        for (int k = j * BN_CHUNK; k < k1; ++k) s += a.stats_cnt[k];
-        chunk_cnt[j] = s;
-    }
-    __syncthreads();
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && a.num_batches_tracked) *a.num_batches_tracked += 1;
-    if (c >= a.C) return;
-    double n = 0.0, mean = 0.0, m2 = 0.0;
-    for (int j = 0; j < nchunks; ++j) {
-        const double nk = (double)chunk_cnt[j];
-        if (nk <= 0.0) continue;
-        const int64_t k = (int64_t)j * BN_CHUNK;
-        const double mk = (double)a.stats[(k * 2 + 0) * a.C + c] / nk;
-        const double m2k = (double)a.stats[(k * 2 + 1) * a.C + c];
-        const double d = mk - mean, nn = n + nk;
-        mean += d * nk / nn;
-        m2 += m2k + d * d * n * nk / nn;
-        n = nn;
-    }
-    const double var = n > 0 ? m2 / n : 0.0;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const float* heads = a.stats + (int64_t)a.nparts * 2 * a.C;
+    double N, S, M2;
+    bn_merge_256(heads, heads + a.C, heads + 2 * a.C, 1, 3 * (int64_t)a.C, 3 * (int64_t)a.C, 0, nchunks, c, c < a.C, N, S, M2);
+    if (threadIdx.x == 0 && blockIdx.x == 0 && a.num_batches_tracked) *a.num_batches_tracked += 1;
+    if ((threadIdx.x >> 6) != 0 || c >= a.C) return;
+    const double mean = N > 0 ? S / N : 0.0;
+    const double var = N > 0 ? M2 / N : 0.0;
     const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
     const float sc = a.gamma[c] * invstd;
     a.mean[c] = (float)mean; a.invstd[c] = invstd; a.scale[c] = sc; a.shift[c] = a.beta[c] - (float)mean * sc;
     if (a.running_mean) {
-        const double unb = n > 1 ? m2 / (n - 1) : var;
+        const double unb = N > 1 ? M2 / (N - 1) : var;
         a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)mean;
         a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unb;
     }
@@ -389,7 +398,8 @@ __global__ void bilinear_fwd_kernel(salt_view x, salt_view y, int R) {
 }
 
 // adjoint as a gather over the (<= 2R x 2R) outputs that reference each input pixel: deterministic.
-template <typename T, bool VEC>
+// X_ONLY / Y_ONLY variants make it separable (two passes through a [B,OH,W,C] fp32-free temp of dtype T) for large R.
+template <typename T, bool VEC, int MODE>      // MODE 0: full 2-D, 1: x only (y.H == x.H), 2: y only (y.W == x.W)
 __global__ void bilinear_bwd_kernel(salt_view x, salt_view y, int R, int accumulate) {
     constexpr int N = Unit<T, VEC>::N;
     const int cpv = x.C / N;
@@ -397,22 +407,30 @@ __global__ void bilinear_bwd_kernel(salt_view x, salt_view y, int R, int accumul
     for (int64_t u = blockIdx.x * 256LL + threadIdx.x; u < units; u += gridDim.x * 256LL) {
         int64_t pix = u / cpv; const int c0 = (int)(u - pix * cpv) * N;
         const int ix = (int)(pix % x.W); int64_t r = pix / x.W; const int iy = (int)(r % x.H); const int b = (int)(r / x.H);
-        const int oy_lo = max(0, R * iy - R / 2), oy_hi = min(y.H - 1, R * iy + (3 * R) / 2 - 1);
-        const int ox_lo = max(0, R * ix - R / 2), ox_hi = min(y.W - 1, R * ix + (3 * R) / 2 - 1);
+        int oy_lo = max(0, R * iy - R / 2), oy_hi = min(y.H - 1, R * iy + (3 * R) / 2 - 1);
+        int ox_lo = max(0, R * ix - R / 2), ox_hi = min(y.W - 1, R * ix + (3 * R) / 2 - 1);
+        if (MODE == 1) { oy_lo = iy; oy_hi = iy; }
+        if (MODE == 2) { ox_lo = ix; ox_hi = ix; }
         float o[N];
 #pragma unroll
         for (int j = 0; j < N; ++j) o[j] = 0.f;
         const T* base = (const T*)y.p + (int64_t)b * y.H * y.W * y.cs + c0;
         for (int oy = oy_lo; oy <= oy_hi; ++oy) {
-            int y0, y1; float ly;
-            bil_src(oy, R, x.H, y0, y1, ly);
-            const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
-            if (wy == 0.f) continue;
+            float wy = 1.f;
+            if (MODE != 1) {
+                int y0, y1; float ly;
+                bil_src(oy, R, x.H, y0, y1, ly);
+                wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+                if (wy == 0.f) continue;
+            }
             for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-                int x0, x1; float lx;
-                bil_src(ox, R, x.W, x0, x1, lx);
-                const float w = wy * ((x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f));
-                if (w == 0.f) continue;
+                float w = wy;
+                if (MODE != 2) {
+                    int x0, x1; float lx;
+                    bil_src(ox, R, x.W, x0, x1, lx);
+                    w = wy * ((x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f));
+                    if (w == 0.f) continue;
+                }
                 float g[N];
                 Unit<T, VEC>::ld(base + ((int64_t)oy * y.W + ox) * y.cs, g);
 #pragma unroll
@@ -507,14 +525,18 @@ extern "C" int salt_affine_act(const salt_affine_act_args* a, void* stream) {
     return SALT_OK;
 }
 
+extern "C" int64_t salt_bn_stats_floats(int nparts, int C) {
+    return (int64_t)nparts * 2 * C + (int64_t)cdiv(nparts, BN_CHUNK) * 3 * C;
+}
+
 extern "C" int salt_bn_finalize(const salt_bn_finalize_args* a, void* stream) {
     if (!a || !a->stats || !a->stats_cnt || a->C < 1 || a->nparts < 1 || !a->gamma || !a->beta || !a->mean || !a->invstd || !a->scale || !a->shift)
         SALT_FAIL(SALT_E_BADARG, "bn_finalize: bad args");
     const int nchunks = cdiv(a->nparts, BN_CHUNK);
-    hipLaunchKernelGGL(bn_chunk_kernel, dim3(nchunks), dim3(a->C < 256 ? ((a->C + 63) / 64) * 64 : 256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(bn_chunk_kernel, dim3(nchunks, cdiv(a->C, 64)), dim3(256), 0, (hipStream_t)stream,
                        const_cast<float*>(a->stats), a->stats_cnt, a->nparts, a->C);
     SALT_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(a->C, 64)), dim3(64), nchunks * sizeof(float), (hipStream_t)stream, *a);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(a->C, 64)), dim3(256), 0, (hipStream_t)stream, *a);
     SALT_CHECK_LAUNCH();
     return SALT_OK;
 }
@@ -635,7 +657,19 @@ extern "C" int salt_bilinear(const salt_bilinear_args* a, void* stream) {
             EW_LAUNCH(bilinear_fwd_kernel, T, v, units, (hipStream_t)stream, a->x, a->y, a->R);
         } else {
             const int64_t units = view_pixels(a->x) * (a->x.C / (v ? ve : 1));
-            EW_LAUNCH(bilinear_bwd_kernel, T, v, units, (hipStream_t)stream, a->x, a->y, a->R, a->accumulate);
+            if (a->R >= 4 && a->tmp) {
+                // separable: x-pass into tmp [B, OH, W, C] (same dtype, contiguous), then y-pass into x
+                salt_view t = a->x; t.p = a->tmp; t.H = a->y.H; t.cs = ((a->x.C + ve - 1) / ve) * ve;
+                const int64_t tunits = view_pixels(t) * (a->x.C / (v ? ve : 1));
+                if (v) hipLaunchKernelGGL((bilinear_bwd_kernel<T, true, 1>), dim3(ew_blocks(tunits)), dim3(256), 0, (hipStream_t)stream, t, a->y, a->R, 0);
+                else hipLaunchKernelGGL((bilinear_bwd_kernel<T, false, 1>), dim3(ew_blocks(tunits)), dim3(256), 0, (hipStream_t)stream, t, a->y, a->R, 0);
+                SALT_CHECK_LAUNCH();
+                if (v) hipLaunchKernelGGL((bilinear_bwd_kernel<T, true, 2>), dim3(ew_blocks(units)), dim3(256), 0, (hipStream_t)stream, a->x, t, a->R, a->accumulate);
+                else hipLaunchKernelGGL((bilinear_bwd_kernel<T, false, 2>), dim3(ew_blocks(units)), dim3(256), 0, (hipStream_t)stream, a->x, t, a->R, a->accumulate);
+            } else {
+                if (v) hipLaunchKernelGGL((bilinear_bwd_kernel<T, true, 0>), dim3(ew_blocks(units)), dim3(256), 0, (hipStream_t)stream, a->x, a->y, a->R, a->accumulate);
+                else hipLaunchKernelGGL((bilinear_bwd_kernel<T, false, 0>), dim3(ew_blocks(units)), dim3(256), 0, (hipStream_t)stream, a->x, a->y, a->R, a->accumulate);
+            }
         }
     })
     SALT_CHECK_LAUNCH();

@@ -169,7 +169,18 @@ __global__ __launch_bounds__(256) void scse_bwd1_kernel(salt_view x, salt_view y
     }
 }
 
-// FC backward: single block.  dgap[b][c] out; parameter grads written (not accumulated).
+// per image: sum the per-part partial rows into part 0's row in place (each thread owns one column)
+__global__ void se_parts_reduce_kernel(float* partials, int nparts, int width) {
+    float* base = partials + (int64_t)blockIdx.x * nparts * width;
+    for (int i = threadIdx.x; i < width; i += blockDim.x) {
+        float t = 0.f;
+        for (int k = 0; k < nparts; ++k) t += base[(int64_t)k * width + i];
+        base[i] = t;
+    }
+}
+
+// FC backward: single block (sizes are B x C x R = tiny).  dgap[b][c] out; parameter grads written (not accumulated).
+// `partials` rows have already been reduced over parts (row 0 of every image holds the sums).
 __global__ void se_fc_bwd_kernel(const float* partials, int nparts, int B, int C, int R, const float* w1, const float* w2,
                                  const float* gap, const float* hidden, const float* gate_c,
                                  float* g_w1, float* g_b1, float* g_w2, float* g_b2, float* g_ws, float* g_bs, float* dgap, float inv_hw) {
@@ -178,19 +189,18 @@ __global__ void se_fc_bwd_kernel(const float* partials, int nparts, int B, int C
     const int tid = threadIdx.x, nt = blockDim.x;
     for (int i = tid; i < B * C; i += nt) {
         const int b = i / C, c = i - b * C;
-        float t = 0.f;
-        for (int k = 0; k < nparts; ++k) t += partials[((int64_t)b * nparts + k) * (2 * C + 1) + c];
+        const float t = partials[((int64_t)b * nparts) * (2 * C + 1) + c];
         const float g = gate_c[i];
         du[i] = t * g * (1.f - g);
     }
     for (int c = tid; c < C; c += nt) {
         float t = 0.f;
-        for (int b = 0; b < B; ++b) for (int k = 0; k < nparts; ++k) t += partials[((int64_t)b * nparts + k) * (2 * C + 1) + C + c];
+        for (int b = 0; b < B; ++b) t += partials[((int64_t)b * nparts) * (2 * C + 1) + C + c];
         g_ws[c] = t;
     }
     if (tid == 0) {
         float t = 0.f;
-        for (int b = 0; b < B; ++b) for (int k = 0; k < nparts; ++k) t += partials[((int64_t)b * nparts + k) * (2 * C + 1) + 2 * C];
+        for (int b = 0; b < B; ++b) t += partials[((int64_t)b * nparts) * (2 * C + 1) + 2 * C];
         g_bs[0] = t;
     }
     __syncthreads();
@@ -306,6 +316,8 @@ extern "C" int salt_scse_bwd(const salt_scse_bwd_args* a, void* stream) {
         const int cpv_log2 = ilog2_ceil(C / VE);
         hipLaunchKernelGGL(scse_bwd1_kernel<T>, dim3(B * nparts), dim3(256), (512 * VE + 256) * sizeof(float), st, a->x, a->y, a->dy, a->gate_c,
                            a->gate_s, a->ws, a->dx, a->accumulate, a->partials, nparts, per, cpv_log2);
+        SALT_CHECK_LAUNCH();
+        hipLaunchKernelGGL(se_parts_reduce_kernel, dim3(B), dim3(256), 0, st, a->partials, nparts, 2 * C + 1);
         SALT_CHECK_LAUNCH();
         hipLaunchKernelGGL(se_fc_bwd_kernel, dim3(1), dim3(256), fc_lds, st, a->partials, nparts, B, C, a->R, a->w1, a->w2, a->gap, a->hidden,
                            a->gate_c, a->g_w1, a->g_b1, a->g_w2, a->g_b2, a->g_ws, a->g_bs, a->dgap, 1.0f / (float)(a->x.H * a->x.W));

@@ -351,7 +351,7 @@ class Graph:
         if bn is not None and self.train:
             y = self.new_act(x.B, OH, OW, Cout, name + '.y')
             nparts = self._conv_parts(x.view(), td, stride, y.view(), OH, OW)
-            stats, cnt = Scratch('stats', nparts * 2 * Cout * 4), Scratch('stats_cnt', nparts * 4)
+            stats, cnt = Scratch('stats', 4 * lib.salt_bn_stats_floats(nparts, Cout)), Scratch('stats_cnt', nparts * 4)
             self._conv_launch(self.fwd, x.view(), pk.data_ptr(), td, stride, pad_mode, y.view(), OH, OW, bias=bias, stats=stats, stats_cnt=cnt)
             w = self._bn_train_fwd(y, bn, relu, res, out, nparts, stats, cnt)
         elif bn is not None:
@@ -482,7 +482,7 @@ class Graph:
             n = self._conv_parts(x.view(), td, 1, shaped_view(1, x.B, x.H, x.W, Cout), x.H, x.W) if train_bn else 0
             plans.append(n)
             total_parts += n
-        stats = Scratch('stats', total_parts * 2 * Cout * 4) if train_bn else None
+        stats = Scratch('stats', 4 * lib.salt_bn_stats_floats(total_parts, Cout)) if train_bn else None
         cnt = Scratch('stats_cnt', total_parts * 4) if train_bn else None
         for (fy, fx, sel), n in zip(phases, plans):
             pk = eng.packed(deconv, [(s[0], s[1]) for s in sel], transposed=True)       # n = cout (D1), c = cin (D0)
@@ -531,7 +531,7 @@ class Graph:
             S = STRUCTS['salt_conv_first_args']()
             fill(S, B=B, Cin=Cin, H=H, W=W, K=K, stride=stride, pad=pad)
             nparts = lib.salt_conv_first_stats_parts(ctypes.byref(S))
-            stats, cnt = Scratch('stats', nparts * 2 * Cout * 4), Scratch('stats_cnt', nparts * 4)
+            stats, cnt = Scratch('stats', 4 * lib.salt_bn_stats_floats(nparts, Cout)), Scratch('stats_cnt', nparts * 4)
             self.fwd.add('conv_first', y=y.view(), relu=0, stats=stats, stats_cnt=cnt, **common)
             w = self._bn_train_fwd(y, bn, relu, None, out, nparts, stats, cnt)
 
@@ -622,7 +622,8 @@ class Graph:
         if self.train:
             def backward():
                 acc = x.grad_state()
-                self.bwd.add('bilinear', dtype=self.dt, x=x.gview(), y=out.gview(), R=R, backward=1, accumulate=acc)
+                tmp = Scratch('bilinear', x.B * out.H * x.W * _round_up(x.C, self.ve) * self._es()) if R >= 4 else None
+                self.bwd.add('bilinear', dtype=self.dt, x=x.gview(), y=out.gview(), R=R, backward=1, accumulate=acc, tmp=tmp)
             self.tape.append(backward)
         return out
 
