@@ -191,6 +191,41 @@ typedef struct {
 int salt_conv_first_wgrad(const salt_conv_first_wgrad_args*, void* stream);
 int salt_conv_first_wgrad_parts(const salt_conv_first_wgrad_args*);
 
+/* ResNet stem on the matrix cores: conv KxK stride 2 (K odd, pad K/2; 7x7 s2 p3 in torchvision) over Cin <= 4 channels
+ * == a ((K+1)/2)^2-tap stride-1 convolution over the 2x2 space-to-depth image z[b,Y,X,(ph*2+pw)*Cin+c] = x[b,c,2Y+ph,2X+pw]
+ * (4*Cin channels zero-padded to 16).  These three helpers move data / weights / weight-gradients between the two forms;
+ * the convolution itself and its weight gradient are salt_conv / salt_conv_wgrad on z. */
+typedef struct {
+    int dtype;
+    const float* x;           /* fp32 NCHW [B,Cin,H,W], H and W even */
+    int B;
+    int Cin;
+    int H;
+    int W;
+    salt_view z;              /* [B,H/2,W/2,16] */
+} salt_s2d_args;
+int salt_s2d(const salt_s2d_args*, void* stream);
+
+typedef struct {
+    int dtype;                /* of the packed copy */
+    const float* w;           /* [Cout][Cin][K][K] fp32 master */
+    int Cout;
+    int Cin;
+    int K;
+    void* wp;                 /* packed [1][T*T][Cout][KC], T = (K+1)/2, tap t = (dh+T/2)*T + (dw+T/2) */
+} salt_pack_stem_weight_args;
+int salt_pack_stem_weight(const salt_pack_stem_weight_args*, void* stream);
+
+typedef struct {
+    const float* g16;         /* [Cout][16][T][T] fp32: weight gradient in the space-to-depth form */
+    int Cout;
+    int Cin;
+    int K;
+    float* grad;              /* [Cout][Cin][K][K] */
+    int accumulate;
+} salt_stem_grad_unfold_args;
+int salt_stem_grad_unfold(const salt_stem_grad_unfold_args*, void* stream);
+
 typedef struct {
     int dtype;
     salt_view x;

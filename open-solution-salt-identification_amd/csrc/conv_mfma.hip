@@ -453,6 +453,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradKP p) {
     constexpr int VE = Elem<T>::VE;
     constexpr int PPR = 64 / VE;                                // 16-byte pieces per pixel row
     constexpr int ROWB = (sizeof(T) == 2) ? 192 : 256;           // bf16 rows padded to 192 B: conflict-free tr reads
+    constexpr bool PIPE = sizeof(T) == 2;                        // register-prefetch pipeline (fits the VGPR budget for bf16)
+    constexpr int MAXP = 128 * PPR / 256, MAXQ = 10;
     const int BMP = p.bmp;                                       // pixels per K tile
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sP = smem;
@@ -476,45 +478,48 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradKP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    for (int tile = split; tile < p.ntiles; tile += p.nsplit) {
+    // piece q of the P tile / Q halo tile of `tile` (zero outside the grid / channel range)
+    auto fetchP = [&](int tile, int q) -> u32x4 {
         int tt = tile;
         const int txi = tt % p.tiles_x; tt /= p.tiles_x;
         const int tyi = tt % p.tiles_y;
         const int tbi = tt / p.tiles_y;
-        const int oy0 = tyi << p.th_log2, ox0 = txi << p.tw_log2, b0 = tbi * p.nb;
-        const int iy0 = oy0 * p.q_step + p.min_dy, ix0 = ox0 * p.q_step + p.min_dx;
-        __syncthreads();
-        // stage P tile: BMP pixels x 64 channels (zero outside the grid / channel range)
-        for (int q = tid; q < BMP * PPR; q += 256) {
-            const int m = q / PPR, pc = q - m * PPR;
-            const int tx = m & ((1 << p.tw_log2) - 1);
-            const int ty = (m >> p.tw_log2) & ((1 << p.th_log2) - 1);
-            const int bl = m >> (p.tw_log2 + p.th_log2);
-            const int oy = oy0 + ty, ox = ox0 + tx, b = b0 + bl;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            const int ch0 = a0 + pc * VE;
-            if (b < p.B && oy < p.PH && ox < p.PW && ch0 < p.Ca)
-                v = load_piece<T>(Pg, (((int64_t)b * p.PH + oy) * p.PW + ox) * p.p_cs + ch0, ch0, p.Ca, p_vec);
-            *reinterpret_cast<u32x4*>(sP + m * ROWB + pc * 16) = v;
-        }
-        // stage Q halo tile
-        for (int q = tid; q < phalo * PPR; q += 256) {
-            const int pix = q / PPR, pc = q - pix * PPR;
-            const int bl = pix / hhw;
-            const int r = pix - bl * hhw;
-            const int hy = r / p.hw, hx = r - hy * p.hw;
-            int iy = iy0 + hy, ix = ix0 + hx;
-            const int b = b0 + bl;
-            bool valid = b < p.B;
-            if (p.pad_mode) { iy = min(max(iy, 0), p.QH - 1); ix = min(max(ix, 0), p.QW - 1); }
-            else valid = valid && iy >= 0 && iy < p.QH && ix >= 0 && ix < p.QW;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            const int ch0 = c0 + pc * VE;
-            if (valid && ch0 < p.Cb)
-                v = load_piece<T>(Qg, (((int64_t)b * p.QH + iy) * p.QW + ix) * p.q_cs + ch0, ch0, p.Cb, q_vec);
-            *reinterpret_cast<u32x4*>(sQ + pix * ROWB + pc * 16) = v;
-        }
-        __syncthreads();
+        const int m = q / PPR, pc = q - m * PPR;
+        const int tx = m & ((1 << p.tw_log2) - 1);
+        const int ty = (m >> p.tw_log2) & ((1 << p.th_log2) - 1);
+        const int bl = m >> (p.tw_log2 + p.th_log2);
+        const int oy = (tyi << p.th_log2) + ty, ox = (txi << p.tw_log2) + tx, b = tbi * p.nb + bl;
+        const int ch0 = a0 + pc * VE;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (b < p.B && oy < p.PH && ox < p.PW && ch0 < p.Ca)
+            v = load_piece<T>(Pg, (((int64_t)b * p.PH + oy) * p.PW + ox) * p.p_cs + ch0, ch0, p.Ca, p_vec);
+        return v;
+    };
+    auto fetchQ = [&](int tile, int q) -> u32x4 {
+        int tt = tile;
+        const int txi = tt % p.tiles_x; tt /= p.tiles_x;
+        const int tyi = tt % p.tiles_y;
+        const int tbi = tt / p.tiles_y;
+        const int iy0 = (tyi << p.th_log2) * p.q_step + p.min_dy, ix0 = (txi << p.tw_log2) * p.q_step + p.min_dx;
+        const int pix = q / PPR, pc = q - pix * PPR;
+        const int bl = pix / hhw;
+        const int r = pix - bl * hhw;
+        const int hy = r / p.hw, hx = r - hy * p.hw;
+        int iy = iy0 + hy, ix = ix0 + hx;
+        const int b = tbi * p.nb + bl;
+        bool valid = b < p.B;
+        if (p.pad_mode) { iy = min(max(iy, 0), p.QH - 1); ix = min(max(ix, 0), p.QW - 1); }
+        else valid = valid && iy >= 0 && iy < p.QH && ix >= 0 && ix < p.QW;
+        const int ch0 = c0 + pc * VE;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (valid && ch0 < p.Cb)
+            v = load_piece<T>(Qg, (((int64_t)b * p.QH + iy) * p.QW + ix) * p.q_cs + ch0, ch0, p.Cb, q_vec);
+        return v;
+    };
+    auto lds_p = [&](int q) -> u32x4* { const int m = q / PPR; return reinterpret_cast<u32x4*>(sP + m * ROWB + (q - m * PPR) * 16); };
+    auto lds_q = [&](int q) -> u32x4* { const int m = q / PPR; return reinterpret_cast<u32x4*>(sQ + m * ROWB + (q - m * PPR) * 16); };
+
+    auto compute_tile = [&]() {
         if constexpr (sizeof(T) == 4) {
             // f32: v_mfma_f32_32x32x2_f32, A[i=a][k=pixel], B[k=pixel][j=b]; one dword per lane per operand.
             const int khalf = lane >> 5, l31 = lane & 31;
@@ -537,12 +542,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradKP p) {
             // bf16: v_mfma_f32_32x32x16_bf16 needs 8 k(=pixel)-consecutive values per lane while LDS rows are
             // channel-contiguous: ds_read_b64_tr_b16 transposes a [4 pixel][16 channel] block per 16-lane group.
             typedef short s16x4 __attribute__((ext_vector_type(4)));
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
             typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
             const int khalf = lane >> 5;
             const int g16 = (lane >> 4) & 1;                     // which 16-row half of the 32-row operand
             const int i16 = lane & 15;
             const int prow = i16 >> 2;                           // pixel within the k-quad this lane fetches
             const int pcol = (i16 & 3) * 4;                      // channel offset of its 4 contiguous elements
+            const int acol = (wa * 32 + g16 * 16 + pcol) * 2;
+            const int bcol = (wb * 32 + g16 * 16 + pcol) * 2;
             for (int k0 = 0; k0 < BMP; k0 += 16) {
                 int mq[2], qpix[2];
 #pragma unroll
@@ -554,11 +562,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradKP p) {
                     const int bl = m >> (p.tw_log2 + p.th_log2);
                     qpix[h] = bl * hhw + ty * p.q_step * p.hw + tx * p.q_step;
                 }
-                const int acol = (wa * 32 + g16 * 16 + pcol) * 2;
-                const int bcol = (wb * 32 + g16 * 16 + pcol) * 2;
                 s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sP + mq[0] * ROWB + acol));
                 s16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sP + mq[1] * ROWB + acol));
-                typedef short s16x8 __attribute__((ext_vector_type(8)));
                 s16x8 av = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
@@ -570,6 +575,37 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradKP p) {
                     }
                 }
             }
+        }
+    };
+
+    const int np = BMP * PPR, nq = phalo * PPR;
+    if (PIPE && nq <= MAXQ * 256) {
+        // software pipeline: next tile's global loads fly while the matrix cores work on the current one
+        u32x4 rp[MAXP], rq[MAXQ];
+        auto load_tile = [&](int tile) {
+#pragma unroll
+            for (int k = 0; k < MAXP; ++k) { const int q = tid + (k << 8); rp[k] = q < np ? fetchP(tile, q) : u32x4{0u, 0u, 0u, 0u}; }
+#pragma unroll
+            for (int k = 0; k < MAXQ; ++k) { const int q = tid + (k << 8); rq[k] = q < nq ? fetchQ(tile, q) : u32x4{0u, 0u, 0u, 0u}; }
+        };
+        if (split < p.ntiles) load_tile(split);
+        for (int tile = split; tile < p.ntiles; tile += p.nsplit) {
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < MAXP; ++k) { const int q = tid + (k << 8); if (q < np) *lds_p(q) = rp[k]; }
+#pragma unroll
+            for (int k = 0; k < MAXQ; ++k) { const int q = tid + (k << 8); if (q < nq) *lds_q(q) = rq[k]; }
+            __syncthreads();
+            if (tile + p.nsplit < p.ntiles) load_tile(tile + p.nsplit);
+            compute_tile();
+        }
+    } else {
+        for (int tile = split; tile < p.ntiles; tile += p.nsplit) {
+            __syncthreads();
+            for (int q = tid; q < np; q += 256) *lds_p(q) = fetchP(tile, q);
+            for (int q = tid; q < nq; q += 256) *lds_q(q) = fetchQ(tile, q);
+            __syncthreads();
+            compute_tile();
         }
     }
     // write the partial slab: partials[split][t][a][b]

@@ -317,6 +317,61 @@ __global__ __launch_bounds__(256) void head1x1_bwd_finalize(const float* partial
     if (c < C) gw[o * C + c] = s; else if (gb) gb[o] = s;
 }
 
+// ---------------------------------------------------------------- stem via space-to-depth (see saltnet.h)
+template <typename T>
+__global__ void s2d_kernel(const float* x, int B, int Cin, int H, int W, salt_view z) {
+    const int64_t npix = (int64_t)z.B * z.H * z.W;
+    for (int64_t pix = blockIdx.x * 256LL + threadIdx.x; pix < npix; pix += gridDim.x * 256LL) {
+        const int X = (int)(pix % z.W); int64_t r = pix / z.W; const int Y = (int)(r % z.H); const int b = (int)(r / z.H);
+        float f[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) f[j] = 0.f;
+        for (int c = 0; c < Cin; ++c) {
+            const float* src = x + (((int64_t)b * Cin + c) * H + 2 * Y) * W + 2 * X;
+            const float2 r0 = *reinterpret_cast<const float2*>(src), r1 = *reinterpret_cast<const float2*>(src + W);
+            f[0 * Cin + c] = r0.x; f[1 * Cin + c] = r0.y; f[2 * Cin + c] = r1.x; f[3 * Cin + c] = r1.y;
+        }
+        T* dst = (T*)z.p + pix * z.cs;
+        if (sizeof(T) == 2) { *reinterpret_cast<u32x4*>(dst) = pack16<T>(f); *reinterpret_cast<u32x4*>(dst + 8) = pack16<T>(f + 8); }
+        else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x4*>(dst + 4 * q) = pack16<T>(f + 4 * q);
+        }
+    }
+}
+
+template <typename T>
+__global__ void pack_stem_weight_kernel(const float* w, int Cout, int Cin, int K, T* wp) {
+    constexpr int KCE = 64 / (int)sizeof(T);
+    const int TT = (K + 1) / 2, half = TT / 2, pad = K / 2;
+    const int total = TT * TT * Cout * KCE;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int kc = i % KCE; int r = i / KCE; const int n = r % Cout; const int t = r / Cout;
+        const int dh = t / TT - half, dw = t % TT - half;
+        float v = 0.f;
+        if (kc < 4 * Cin) {
+            const int pp = kc / Cin, c = kc - pp * Cin, ph = pp >> 1, pw = pp & 1;
+            const int kh = 2 * dh + ph + pad, kw = 2 * dw + pw + pad;
+            if (kh >= 0 && kh < K && kw >= 0 && kw < K) v = w[(((int64_t)n * Cin + c) * K + kh) * K + kw];
+        }
+        Elem<T>::st(wp + i, v);
+    }
+}
+
+__global__ void stem_grad_unfold_kernel(const float* g16, int Cout, int Cin, int K, float* grad, int accumulate) {
+    const int TT = (K + 1) / 2, half = TT / 2, pad = K / 2;
+    const int total = Cout * Cin * K * K;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int kw = i % K; int r = i / K; const int kh = r % K; r /= K; const int c = r % Cin; const int n = r / Cin;
+        // kh - pad = 2*dh + ph with ph in {0,1}
+        const int eh = kh - pad, ew = kw - pad;
+        const int ph = eh & 1, pw = ew & 1;
+        const int dh = (eh - ph) / 2, dw = (ew - pw) / 2;
+        const float v = g16[(((int64_t)n * 16 + (ph * 2 + pw) * Cin + c) * TT + dh + half) * TT + dw + half];
+        grad[i] = accumulate ? grad[i] + v : v;
+    }
+}
+
 int head_parts(const salt_view& x, int64_t* per) {
     const int64_t npix = view_pixels(x);
     int64_t parts = (npix + 255) / 256;
@@ -393,6 +448,34 @@ extern "C" int salt_conv_first_wgrad(const salt_conv_first_wgrad_args* a, void* 
     SALT_CHECK_LAUNCH();
     const int64_t n = (int64_t)Cout * KKC;
     hipLaunchKernelGGL(partial_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a->partials, nparts, n, a->grad, a->accumulate);
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}
+
+extern "C" int salt_s2d(const salt_s2d_args* a, void* stream) {
+    if (!a || !a->x || !view_ok(a->z) || a->Cin < 1 || a->Cin > 4 || (a->H & 1) || (a->W & 1) || a->z.H != a->H / 2 || a->z.W != a->W / 2 ||
+        a->z.C != 16 || a->z.B != a->B || (a->z.cs % 16) != 0 || (reinterpret_cast<uintptr_t>(a->z.p) & 15) || (reinterpret_cast<uintptr_t>(a->x) & 7))
+        SALT_FAIL(SALT_E_BADARG, "s2d: bad args");
+    const int64_t npix = view_pixels(a->z);
+    const int blocks = (int)((npix + 255) / 256 < 4096 ? (npix + 255) / 256 : 4096);
+    SALT_DISPATCH_DTYPE(a->dtype, T, { hipLaunchKernelGGL(s2d_kernel<T>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a->x, a->B, a->Cin, a->H, a->W, a->z); })
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}
+
+extern "C" int salt_pack_stem_weight(const salt_pack_stem_weight_args* a, void* stream) {
+    if (!a || !a->w || !a->wp || a->Cin < 1 || a->Cin > 4 || !(a->K & 1) || a->K < 3 || a->K > 7) SALT_FAIL(SALT_E_BADARG, "pack_stem_weight: bad args");
+    const int TT = (a->K + 1) / 2;
+    const int total = TT * TT * a->Cout * (a->dtype == SALT_F32 ? 16 : 32);
+    SALT_DISPATCH_DTYPE(a->dtype, T, { hipLaunchKernelGGL(pack_stem_weight_kernel<T>, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, a->w, a->Cout, a->Cin, a->K, (T*)a->wp); })
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}
+
+extern "C" int salt_stem_grad_unfold(const salt_stem_grad_unfold_args* a, void* stream) {
+    if (!a || !a->g16 || !a->grad || a->Cin < 1 || a->Cin > 4 || !(a->K & 1) || a->K < 3 || a->K > 7) SALT_FAIL(SALT_E_BADARG, "stem_grad_unfold: bad args");
+    const int total = a->Cout * a->Cin * a->K * a->K;
+    hipLaunchKernelGGL(stem_grad_unfold_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, a->g16, a->Cout, a->Cin, a->K, a->grad, a->accumulate);
     SALT_CHECK_LAUNCH();
     return SALT_OK;
 }

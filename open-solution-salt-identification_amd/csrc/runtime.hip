@@ -19,7 +19,7 @@ void salt_set_error(const char* fmt, ...) {
 
 extern "C" const char* salt_last_error(void) { return g_err; }
 
-extern "C" int salt_abi_version(void) { return 3; }
+extern "C" int salt_abi_version(void) { return 4; }
 
 extern "C" int salt_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name_len) {
     int dev = 0;
@@ -127,6 +127,9 @@ extern "C" int salt_abi_struct_sizes(int* out, int n) {
     (int)sizeof(salt_pack_conv_weight_args),
     (int)sizeof(salt_conv_first_args),
     (int)sizeof(salt_conv_first_wgrad_args),
+    (int)sizeof(salt_s2d_args),
+    (int)sizeof(salt_pack_stem_weight_args),
+    (int)sizeof(salt_stem_grad_unfold_args),
     (int)sizeof(salt_head1x1_args),
     (int)sizeof(salt_head1x1_bwd_args),
     (int)sizeof(salt_bn_finalize_args),

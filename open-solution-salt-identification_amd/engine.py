@@ -521,6 +521,8 @@ class Graph:
         B, Cin, H, W = x_nchw.shape
         Cout, _, K, _ = conv.weight.shape
         stride, pad = conv.stride[0], conv.padding[0]
+        if stride == 2 and K % 2 == 1 and pad == K // 2 and H % 2 == 0 and W % 2 == 0 and conv.bias is None and bn is not None:
+            return self._stem_s2d(x_nchw, conv, bn, relu, name)
         OH = (H + 2 * pad - K) // stride + 1
         OW = (W + 2 * pad - K) // stride + 1
         out = self.new_act(B, OH, OW, Cout, name)
@@ -547,6 +549,52 @@ class Graph:
         else:
             w = eng.bn_work(bn)
             self.fwd.add('conv_first', y=out.view(), scale=w['scale'].data_ptr(), shift=w['shift'].data_ptr(), relu=int(relu), **common)
+        return out
+
+    def _stem_s2d(self, x_nchw, conv, bn, relu, name):
+        """ResNet stem (KxK stride 2 over <= 4 channels) on the matrix cores: 2x2 space-to-depth turns it into a
+        ((K+1)/2)^2-tap stride-1 convolution over 16 channels, which the dense MFMA kernels run ~15x faster than the
+        vector-ALU direct kernel; weights / weight-gradients are folded between the two forms by tiny kernels."""
+        eng = self.engine
+        B, Cin, H, W = x_nchw.shape
+        Cout, _, K, _ = conv.weight.shape
+        TT, half = (K + 1) // 2, (K + 1) // 4
+        z = self.new_act(B, H // 2, W // 2, 16, name + '.s2d')
+        self.fwd.add('s2d', dtype=self.dt, x=x_nchw.data_ptr(), B=B, Cin=Cin, H=H, W=W, z=z.view())
+        wp = eng.packed_stem(conv)
+        taps = [(dh - half, dw - half) for dh in range(TT) for dw in range(TT)]
+        OH, OW = H // 2, W // 2
+        out = self.new_act(B, OH, OW, Cout, name)
+        if self.train:
+            y = self.new_act(B, OH, OW, Cout, name + '.y')
+            nparts = self._conv_parts(z.view(), taps, 1, y.view(), OH, OW)
+            stats, cnt = Scratch('stats', 4 * lib.salt_bn_stats_floats(nparts, Cout)), Scratch('stats_cnt', nparts * 4)
+            self._conv_launch(self.fwd, z.view(), wp.data_ptr(), taps, 1, 0, y.view(), OH, OW, stats=stats, stats_cnt=cnt)
+            w = self._bn_train_fwd(y, bn, relu, None, out, nparts, stats, cnt)
+
+            def backward():
+                self._bn_train_bwd(y, bn, relu, None, out, w)
+                g16 = self.f32(Cout * 16 * TT * TT)
+                # dW'[t][n][c'] : P = dY (a = cout), Q = z (b = 16 s2d channels); reduce into [Cout][16][T][T], then unfold
+                gw_tmp = g16.data_ptr()
+                per = 8 if len(taps) > 9 else 9
+                for i in range(0, len(taps), per):
+                    chunk = list(range(i, min(i + per, len(taps))))
+                    S = STRUCTS['salt_conv_wgrad_args']()
+                    fill(S, dtype=self.dt, p=y.gview(), q=z.view(), ntaps=len(chunk), tap_dy=[taps[j][0] for j in chunk],
+                         tap_dx=[taps[j][1] for j in chunk], q_step=1, pad_mode=0)
+                    ns = lib.salt_conv_wgrad_nsplit(ctypes.byref(S))
+                    nbytes = ns * len(chunk) * Cout * 16 * 4
+                    self.bwd.add('conv_wgrad', dtype=self.dt, p=y.gview(), q=z.view(), ntaps=len(chunk), tap_dy=[taps[j][0] for j in chunk],
+                                 tap_dx=[taps[j][1] for j in chunk], q_step=1, pad_mode=0, partials=Scratch('wgrad', nbytes), nsplit=ns)
+                    self.bwd.add('wgrad_reduce', partials=Scratch('wgrad', nbytes), nsplit=ns, ntaps=len(chunk), Ca=Cout, Cb=16, KH=TT, KW=TT,
+                                 tap_kh=[j // TT for j in chunk], tap_kw=[j % TT for j in chunk], grad=gw_tmp, accumulate=0)
+                self.bwd.add('stem_grad_unfold', g16=gw_tmp, Cout=Cout, Cin=Cin, K=K, grad=self._gp(conv.weight), accumulate=0)
+            self.tape.append(backward)
+        else:
+            w = eng.bn_work(bn)
+            self._conv_launch(self.fwd, z.view(), wp.data_ptr(), taps, 1, 0, out.view(), OH, OW,
+                              scale=w['scale'].data_ptr(), shift=w['shift'].data_ptr(), relu=int(relu))
         return out
 
     # ------------------------------------------------------------------ logit head: 1x1 conv to <= 4 channels, fp32 NCHW out

@@ -156,6 +156,20 @@ class Engine:
         self._packed_version = -1
         return t
 
+    def packed_stem(self, conv):
+        key = (id(conv), 'stem')
+        if key in self._packed:
+            return self._packed[key]
+        Cout, Cin, K, _ = conv.weight.shape
+        TT = (K + 1) // 2
+        elems = lib.salt_packed_weight_elems(DT_CODE[self.dtype], TT * TT, Cout, 16)
+        t = torch.zeros(elems, dtype=TORCH_DT[self.dtype], device=self.device)
+        self._pack_ops.add('pack_stem_weight', dtype=DT_CODE[self.dtype], w=conv.weight.data_ptr(), Cout=Cout, Cin=Cin, K=K, wp=t.data_ptr())
+        self._pack_ops._entries = None
+        self._packed[key] = t
+        self._packed_version = -1
+        return t
+
     def bn_work(self, bn):
         if id(bn) in self._bn:
             return self._bn[id(bn)]
