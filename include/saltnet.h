@@ -303,12 +303,13 @@ int salt_affine_act(const salt_affine_act_args*, void* stream);
 typedef struct {              /* backward of a = relu?(bn(y) (+res)) in train mode */
     int dtype;
     salt_view da;             /* grad wrt a */
-    salt_view a;              /* forward output (ReLU mask); a.p == NULL when relu == 0 */
+    salt_view a;              /* forward output (ReLU mask).  a.p == NULL: relu == 0, or (no residual) recompute the mask from y */
     salt_view y;              /* conv output (pre-BN) */
     int relu;
     const float* mean;
     const float* invstd;
     const float* gamma;
+    const float* beta;        /* needed when the mask is recomputed from y */
     float* partials;          /* [nparts][2][C] workspace */
     int nparts;               /* as returned by salt_bn_bwd_parts */
     float* dgamma;            /* [C] */

@@ -331,8 +331,9 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
     // ---- tile config heuristic (overridable for tests/tuning)
     int id = a->cfg;
     if (id == 0) {
+        const bool big = a->in_step == 1 && a->OH >= 16 && a->OW >= 16 && pixels >= 256 * 256 * 2;
         if (Cout <= 32) id = 4;
-        else if (Cout <= 64) id = (a->in_step == 1 && a->OH >= 16 && a->OW >= 16 && pixels >= 256 * 256 * 2) ? 2 : 1;
+        else if (big) id = 2;                 // 256-pixel tiles: the chunk's weights are staged once per 256 pixels
         else id = 1;
         const int64_t wgs = ((pixels + 127) / 128) * cdiv(Cout, 64);
         if (id == 1 && wgs < 256) id = 5;

@@ -135,7 +135,8 @@ __global__ void bn_fold_kernel(salt_bn_fold_args a) {
 // pass 1: per-block partial sums of dyh = da*mask and dyh*xhat per channel.
 template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(salt_view da, salt_view a, salt_view y, int relu,
-                                                            const float* mean, const float* invstd, float* partials, int64_t pix_per_block) {
+                                                            const float* mean, const float* invstd, const float* gamma, const float* beta,
+                                                            float* partials, int64_t pix_per_block) {
     constexpr int N = Unit<T, VEC>::N;
     extern __shared__ float sm[];
     const int C = y.C, cpv = C / N;
@@ -146,21 +147,37 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(salt_view da, salt_v
         const int cvn = cpv - cv0 < 256 ? cpv - cv0 : 256;
         const int R = 256 / cvn;
         const int row = threadIdx.x / cvn, cv = cv0 + threadIdx.x % cvn;
-        float s1[N], s2[N], mu[N], is[N];
+        float s1[N], s2[N], mu[N], is[N], sc[N], sh[N];
 #pragma unroll
         for (int j = 0; j < N; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+        const bool mask_from_y = relu && a.p == nullptr;      // a = relu(y*scale + shift): the mask is recomputed, `a` is not read
         if (row < R) {
             const int c0 = cv * N;
 #pragma unroll
-            for (int j = 0; j < N; ++j) { mu[j] = mean[c0 + j]; is[j] = invstd[c0 + j]; }
+            for (int j = 0; j < N; ++j) {
+                mu[j] = mean[c0 + j]; is[j] = invstd[c0 + j];
+                sc[j] = gamma[c0 + j] * is[j]; sh[j] = beta[c0 + j] - mu[j] * sc[j];
+            }
             for (int64_t pix = p0 + row; pix < p1; pix += R) {
-                float g[N], yy[N], aa[N];
+                float g[N], yy[N], msk[N];
                 Unit<T, VEC>::ld((const T*)da.p + pix * da.cs + c0, g);
                 Unit<T, VEC>::ld((const T*)y.p + pix * y.cs + c0, yy);
-                if (relu) Unit<T, VEC>::ld((const T*)a.p + pix * a.cs + c0, aa);
+#pragma unroll
+                for (int j = 0; j < N; ++j) msk[j] = 1.f;
+                if (relu) {
+                    if (mask_from_y) {
+#pragma unroll
+                        for (int j = 0; j < N; ++j) msk[j] = (yy[j] * sc[j] + sh[j] > 0.f) ? 1.f : 0.f;
+                    } else {
+                        float aa[N];
+                        Unit<T, VEC>::ld((const T*)a.p + pix * a.cs + c0, aa);
+#pragma unroll
+                        for (int j = 0; j < N; ++j) msk[j] = aa[j] > 0.f ? 1.f : 0.f;
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
-                    const float gg = (relu && !(aa[j] > 0.f)) ? 0.f : g[j];
+                    const float gg = g[j] * msk[j];
                     s1[j] += gg; s2[j] += gg * (yy[j] - mu[j]) * is[j];
                 }
             }
@@ -206,19 +223,34 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* parti
 
 template <typename T, bool VEC>
 __global__ void bn_bwd_apply_kernel(salt_view da, salt_view a, salt_view y, int relu, const float* mean, const float* invstd,
-                                    const float* coef, salt_view dy, salt_view dres, int acc_dres) {
+                                    const float* gamma, const float* beta, const float* coef, salt_view dy, salt_view dres, int acc_dres) {
     constexpr int N = Unit<T, VEC>::N;
     const int C = y.C, cpv = C / N;
     const int64_t units = (int64_t)y.B * y.H * y.W * cpv;
     for (int64_t u = blockIdx.x * 256LL + threadIdx.x; u < units; u += gridDim.x * 256LL) {
         const int64_t pix = u / cpv; const int c0 = (int)(u - pix * cpv) * N;
-        float g[N], yy[N], aa[N], o[N];
+        float g[N], yy[N], o[N], msk[N];
         Unit<T, VEC>::ld((const T*)da.p + pix * da.cs + c0, g);
         Unit<T, VEC>::ld((const T*)y.p + pix * y.cs + c0, yy);
-        if (relu) Unit<T, VEC>::ld((const T*)a.p + pix * a.cs + c0, aa);
+#pragma unroll
+        for (int j = 0; j < N; ++j) msk[j] = 1.f;
+        if (relu) {
+            if (a.p == nullptr) {                 // a = relu(y*scale + shift): recompute the mask, never read `a`
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const float sc = gamma[c0 + j] * invstd[c0 + j];
+                    msk[j] = (yy[j] * sc + (beta[c0 + j] - mean[c0 + j] * sc) > 0.f) ? 1.f : 0.f;
+                }
+            } else {
+                float aa[N];
+                Unit<T, VEC>::ld((const T*)a.p + pix * a.cs + c0, aa);
+#pragma unroll
+                for (int j = 0; j < N; ++j) msk[j] = aa[j] > 0.f ? 1.f : 0.f;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < N; ++j) {
-            const float gg = (relu && !(aa[j] > 0.f)) ? 0.f : g[j];
+            const float gg = g[j] * msk[j];
             g[j] = gg;
             const float xh = (yy[j] - mean[c0 + j]) * invstd[c0 + j];
             o[j] = coef[c0 + j] * (gg - coef[C + c0 + j] - xh * coef[2 * C + c0 + j]);
@@ -566,7 +598,8 @@ extern "C" int salt_bn_bwd_parts(const salt_bn_bwd_args* a) {
 extern "C" int salt_bn_bwd(const salt_bn_bwd_args* a, void* stream) {
     if (!a || !view_ok(a->da) || !view_ok(a->y) || !view_ok(a->dy) || !same_shape(a->da, a->y) || !same_shape(a->dy, a->y))
         SALT_FAIL(SALT_E_BADARG, "bn_bwd: bad views");
-    if (a->relu && (!view_ok(a->a) || !same_shape(a->a, a->y))) SALT_FAIL(SALT_E_BADARG, "bn_bwd: relu needs the forward output");
+    if (a->relu && a->a.p && (!view_ok(a->a) || !same_shape(a->a, a->y))) SALT_FAIL(SALT_E_BADARG, "bn_bwd: forward output shape");
+    if (a->relu && !a->a.p && (a->dres.p || !a->beta)) SALT_FAIL(SALT_E_BADARG, "bn_bwd: the ReLU mask can be recomputed from y only without a residual (and needs beta)");
     if (a->dres.p && !same_shape(a->dres, a->y)) SALT_FAIL(SALT_E_BADARG, "bn_bwd: dres shape");
     if (!a->mean || !a->invstd || !a->gamma || !a->partials || !a->coef) SALT_FAIL(SALT_E_BADARG, "bn_bwd: missing buffers");
     int64_t per = 0;
@@ -576,19 +609,19 @@ extern "C" int salt_bn_bwd(const salt_bn_bwd_args* a, void* stream) {
     const int C = a->y.C;
     SALT_DISPATCH_DTYPE(a->dtype, T, {
         const int ve = Elem<T>::VE;
-        const bool v = vec_ok(a->da, ve) && vec_ok(a->y, ve) && vec_ok(a->dy, ve) && vec_ok(a->dres, ve) && (!a->relu || vec_ok(a->a, ve));
+        const bool v = vec_ok(a->da, ve) && vec_ok(a->y, ve) && vec_ok(a->dy, ve) && vec_ok(a->dres, ve) && vec_ok(a->a, ve);
         const int N = v ? ve : 1;
         const int cpv = C / N;
         const int cvn = cpv < 256 ? cpv : 256;
         const size_t lds = (size_t)(256 / cvn) * cvn * N * 2 * sizeof(float);
-        if (v) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), dim3(nparts), dim3(256), lds, st, a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->partials, per);
-        else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), dim3(nparts), dim3(256), lds, st, a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->partials, per);
+        if (v) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), dim3(nparts), dim3(256), lds, st, a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->gamma, a->beta, a->partials, per);
+        else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), dim3(nparts), dim3(256), lds, st, a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->gamma, a->beta, a->partials, per);
         SALT_CHECK_LAUNCH();
         hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(256), 0, st, a->partials, nparts, C, (double)view_pixels(a->y),
                            a->gamma, a->invstd, a->dgamma, a->dbeta, a->accumulate_param_grads, a->coef);
         SALT_CHECK_LAUNCH();
         const int64_t units = view_pixels(a->y) * cpv;
-        EW_LAUNCH(bn_bwd_apply_kernel, T, v, units, st, a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->coef, a->dy, a->dres, a->accumulate_dres);
+        EW_LAUNCH(bn_bwd_apply_kernel, T, v, units, st, a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->gamma, a->beta, a->coef, a->dy, a->dres, a->accumulate_dres);
     })
     SALT_CHECK_LAUNCH();
     return SALT_OK;

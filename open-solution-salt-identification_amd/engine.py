@@ -315,8 +315,9 @@ class Graph:
             dres = res.gview()
         acc_y = y.grad_state()
         assert acc_y == 0, 'conv output gradient has a single producer'
-        self.bwd.add('bn_bwd', dtype=self.dt, da=out.gview(), a=out.view() if relu else null_view(), y=y.view(), relu=int(relu),
-                     mean=w['mean'].data_ptr(), invstd=w['invstd'].data_ptr(), gamma=bn.weight.data_ptr(),
+        # without a residual a = relu(y*scale + shift): the kernel recomputes the mask from y and never reads `a`
+        self.bwd.add('bn_bwd', dtype=self.dt, da=out.gview(), a=out.view() if (relu and res is not None) else null_view(), y=y.view(), relu=int(relu),
+                     mean=w['mean'].data_ptr(), invstd=w['invstd'].data_ptr(), gamma=bn.weight.data_ptr(), beta=bn.bias.data_ptr(),
                      partials=Scratch('bn_bwd', nparts * 2 * C * 4), nparts=nparts, dgamma=gw, dbeta=gb, accumulate_param_grads=0,
                      coef=coef.data_ptr(), dy=y.gview(), dres=dres, accumulate_dres=acc_res)
 
