@@ -104,6 +104,7 @@ lib.salt_device_info.argtypes = [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ct
 lib.salt_program_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
 lib.salt_program_run_range.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 lib.salt_program_run_timed.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
+lib.salt_program_run_streams.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
 lib.salt_graph_capture.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
 lib.salt_graph_launch.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 lib.salt_graph_destroy.argtypes = [ctypes.c_void_p]

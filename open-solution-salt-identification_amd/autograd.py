@@ -20,7 +20,7 @@ class HipNetFunction(torch.autograd.Function):
         if net.dlogits is None:
             raise SaltError('network was compiled without a backward program')
         net.dlogits.copy_(dlogits)
-        net.bwd.run()
+        net.bwd.run(side=eng.side_stream)
         grads = []
         for p in eng.live_params:
             off, n = eng.grad_range(p)

@@ -19,7 +19,7 @@ void salt_set_error(const char* fmt, ...) {
 
 extern "C" const char* salt_last_error(void) { return g_err; }
 
-extern "C" int salt_abi_version(void) { return 4; }
+extern "C" int salt_abi_version(void) { return 5; }
 
 extern "C" int salt_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name_len) {
     int dev = 0;
@@ -67,6 +67,47 @@ extern "C" int salt_program_run_timed(const salt_program_entry* e, int begin, in
     for (int i = 0; i <= n; ++i) (void)hipEventDestroy(ev[i]);
     delete[] ev;
     return rc;
+}
+
+namespace {
+struct EventPool {
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    int ensure() {
+        for (int i = 0; i < 2; ++i)
+            if (!ev[i] && hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return -1;
+        return 0;
+    }
+};
+thread_local EventPool g_events;
+}  // namespace
+
+extern "C" int salt_program_run_streams(const salt_program_entry* e, int begin, int end, void* main_stream, void* side_stream) {
+    if (!side_stream || side_stream == main_stream) return salt_program_run_range(e, begin, end, main_stream);
+    if (!e || begin < 0 || end < begin) SALT_FAIL(SALT_E_BADARG, "program: bad range");
+    if (g_events.ensure()) SALT_FAIL(SALT_E_BADARG, "hipEventCreate failed");
+    hipStream_t ms = (hipStream_t)main_stream, ss = (hipStream_t)side_stream;
+    bool main_dirty = true, side_used = false;       // main_dirty: main has work the side stream has not been ordered after
+    for (int i = begin; i < end; ++i) {
+        const bool side = e[i].stream == 1;
+        if (side && main_dirty) {
+            (void)hipEventRecord(g_events.ev[0], ms);
+            (void)hipStreamWaitEvent(ss, g_events.ev[0], 0);
+            main_dirty = false;
+        }
+        const int rc = e[i].fn(e[i].args, side ? side_stream : main_stream);
+        if (rc) {
+            char prev[400];
+            strncpy(prev, g_err, sizeof(prev) - 1); prev[sizeof(prev) - 1] = 0;
+            salt_set_error("program entry %d failed (%d): %s", i, rc, prev);
+            return rc;
+        }
+        if (side) side_used = true; else main_dirty = true;
+    }
+    if (side_used) {
+        (void)hipEventRecord(g_events.ev[1], ss);
+        (void)hipStreamWaitEvent(ms, g_events.ev[1], 0);
+    }
+    return SALT_OK;
 }
 
 extern "C" int salt_program_run(const salt_program_entry* e, int n, void* stream) {

@@ -42,13 +42,15 @@ class Program:
     def __init__(self, name=''):
         self.name = name
         self.ops = []          # (opname, fn, struct)
+        self.streams = []      # 0 main / 1 side, per op
         self.patches = []      # (struct, path, Scratch)
         self._entries = None
         self.marks = {}
 
-    def add(self, opname, **fields):
+    def add(self, opname, stream=0, **fields):
         fn, S = OP_FUNCS['salt_' + opname]
         s = S()
+        self.streams.append(stream)
         plain = {}
         for k, v in fields.items():
             if isinstance(v, Scratch):
@@ -67,6 +69,7 @@ class Program:
 
     def extend(self, other):
         self.ops.extend(other.ops)
+        self.streams.extend(other.streams)
         self.patches.extend(other.patches)
         self._entries = None
 
@@ -77,18 +80,23 @@ class Program:
         for i, (_, fn, s) in enumerate(self.ops):
             arr[i].fn = ctypes.cast(fn, ctypes.c_void_p).value
             arr[i].args = ctypes.addressof(s)
+            arr[i].stream = self.streams[i]
         self._entries = arr
         return self
 
     def __len__(self):
         return len(self.ops)
 
-    def run(self, stream=None, begin=0, end=None):
+    def run(self, stream=None, begin=0, end=None, side=None):
+        """Enqueue ops [begin, end).  With ``side`` (a torch.cuda.Stream) ops tagged stream=1 run on it concurrently."""
         if self._entries is None:
             self.finalize()
         end = len(self.ops) if end is None else end
         st = _stream_ptr(stream)
-        rc = lib.salt_program_run_range(ctypes.cast(self._entries, ctypes.c_void_p), begin, end, st)
+        if side is not None:
+            rc = lib.salt_program_run_streams(ctypes.cast(self._entries, ctypes.c_void_p), begin, end, st, ctypes.c_void_p(side.cuda_stream))
+        else:
+            rc = lib.salt_program_run_range(ctypes.cast(self._entries, ctypes.c_void_p), begin, end, st)
         if rc != 0:
             msg = lib.salt_last_error().decode(errors='replace')
             m = None
@@ -401,9 +409,9 @@ class Graph:
             if ns < 0:
                 raise SaltError('wgrad plan failed: ' + lib.salt_last_error().decode())
             nbytes = ns * len(chunk) * Ca * Cb * 4
-            self.bwd.add('conv_wgrad', dtype=self.dt, p=p_view, q=q_view, ntaps=len(chunk), tap_dy=[taps_dydx[j][0] for j in chunk],
+            self.bwd.add('conv_wgrad', stream=1, dtype=self.dt, p=p_view, q=q_view, ntaps=len(chunk), tap_dy=[taps_dydx[j][0] for j in chunk],
                          tap_dx=[taps_dydx[j][1] for j in chunk], q_step=q_step, pad_mode=pad_mode, partials=Scratch('wgrad', nbytes), nsplit=ns)
-            self.bwd.add('wgrad_reduce', partials=Scratch('wgrad', nbytes), nsplit=ns, ntaps=len(chunk), Ca=Ca, Cb=Cb, KH=KH, KW=KW,
+            self.bwd.add('wgrad_reduce', stream=1, partials=Scratch('wgrad', nbytes), nsplit=ns, ntaps=len(chunk), Ca=Ca, Cb=Cb, KH=KH, KW=KW,
                          tap_kh=[taps_khkw[j][0] for j in chunk], tap_kw=[taps_khkw[j][1] for j in chunk], grad=gw, accumulate=0)
             first = False
 
@@ -543,7 +551,7 @@ class Graph:
                 S2 = STRUCTS['salt_conv_first_wgrad_args']()
                 fill(S2, B=B, Cin=Cin, H=H, W=W, K=K, stride=stride, pad=pad)
                 np_ = lib.salt_conv_first_wgrad_parts(ctypes.byref(S2))
-                self.bwd.add('conv_first_wgrad', dtype=self.dt, x=x_nchw.data_ptr(), B=B, Cin=Cin, H=H, W=W, K=K, stride=stride, pad=pad,
+                self.bwd.add('conv_first_wgrad', stream=1, dtype=self.dt, x=x_nchw.data_ptr(), B=B, Cin=Cin, H=H, W=W, K=K, stride=stride, pad=pad,
                              dy=y.gview(), partials=Scratch('wgrad', np_ * Cout * Cin * K * K * 4), nparts=np_,
                              grad=self._gp(conv.weight), accumulate=0)
             self.tape.append(backward)
@@ -586,11 +594,11 @@ class Graph:
                          tap_dx=[taps[j][1] for j in chunk], q_step=1, pad_mode=0)
                     ns = lib.salt_conv_wgrad_nsplit(ctypes.byref(S))
                     nbytes = ns * len(chunk) * Cout * 16 * 4
-                    self.bwd.add('conv_wgrad', dtype=self.dt, p=y.gview(), q=z.view(), ntaps=len(chunk), tap_dy=[taps[j][0] for j in chunk],
+                    self.bwd.add('conv_wgrad', stream=1, dtype=self.dt, p=y.gview(), q=z.view(), ntaps=len(chunk), tap_dy=[taps[j][0] for j in chunk],
                                  tap_dx=[taps[j][1] for j in chunk], q_step=1, pad_mode=0, partials=Scratch('wgrad', nbytes), nsplit=ns)
-                    self.bwd.add('wgrad_reduce', partials=Scratch('wgrad', nbytes), nsplit=ns, ntaps=len(chunk), Ca=Cout, Cb=16, KH=TT, KW=TT,
+                    self.bwd.add('wgrad_reduce', stream=1, partials=Scratch('wgrad', nbytes), nsplit=ns, ntaps=len(chunk), Ca=Cout, Cb=16, KH=TT, KW=TT,
                                  tap_kh=[j // TT for j in chunk], tap_kw=[j % TT for j in chunk], grad=gw_tmp, accumulate=0)
-                self.bwd.add('stem_grad_unfold', g16=gw_tmp, Cout=Cout, Cin=Cin, K=K, grad=self._gp(conv.weight), accumulate=0)
+                self.bwd.add('stem_grad_unfold', stream=1, g16=gw_tmp, Cout=Cout, Cin=Cin, K=K, grad=self._gp(conv.weight), accumulate=0)
             self.tape.append(backward)
         else:
             w = eng.bn_work(bn)

@@ -108,7 +108,7 @@ class DataParallel:
         if optimizer is not None:
             optimizer.grad_scale = 1.0 / self.world
         if self.world == 1:
-            net.bwd.run()
+            net.bwd.run(side=eng.side_stream)
             return
         key = id(net)
         if key not in self._plans:
@@ -122,7 +122,7 @@ class DataParallel:
         for lo, hi, ridx in self._plans[key]:
             ridx = min(max(ridx, pos), n_ops)
             if ridx > pos:
-                net.bwd.run(begin=pos, end=ridx)
+                net.bwd.run(begin=pos, end=ridx, side=eng.side_stream)
                 pos = ridx
             ev = torch.cuda.Event()
             ev.record(cur)
@@ -130,6 +130,6 @@ class DataParallel:
                 comm.wait_event(ev)
                 works.append(dist.all_reduce(eng.grads[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
         if pos < n_ops:
-            net.bwd.run(begin=pos, end=n_ops)
+            net.bwd.run(begin=pos, end=n_ops, side=eng.side_stream)
         for w in works:
             w.wait()            # the compute stream waits for RCCL before Adam reads the gradients

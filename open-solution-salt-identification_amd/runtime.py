@@ -95,6 +95,7 @@ class Engine:
         self._packed_version = -1
         self._folded_version = None
         self.world = 1
+        self.side_stream = torch.cuda.Stream(device=device)     # weight-gradient kernels overlap the data-gradient chain
 
     # ------------------------------------------------------------------ flat parameter storage
     def _flatten(self):

@@ -37,7 +37,7 @@ class BlockRun:
 
     def backward(self, gy):
         self.g.dlogits.copy_(gy)
-        self.g.bwd.run()
+        self.g.bwd.run(side=self.eng.side_stream)
         torch.cuda.synchronize()
         gx = [t.cpu() for t in getattr(self.g, 'input_grads', [])]
         grads = OrderedDict()
