@@ -70,8 +70,11 @@ __device__ __forceinline__ int swz_addr(int row, int slot) {        // 64-byte r
 
 constexpr int MAXA = 9;     // halo pieces per thread: P_halo*4 <= 9*256
 
-template <typename T, int MI, int NI, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvKP p) {
+// NT > 0: tap count known at compile time (9 for every 3x3): the tap loop is fully unrolled so the compiler keeps the tap
+// offsets in SGPRs, folds the weight-row offsets into ds_read immediates and hoists the next taps' fragment reads above the
+// current MFMAs (the runtime-loop form serialised s_load -> address VALU -> ds_read -> MFMA per tap).
+template <typename T, int MI, int NI, int WM, int WN, int NT>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
     constexpr int BN = 32 * NI * WN;
     constexpr int KCE = 64 / (int)sizeof(T);
     constexpr int VE = Elem<T>::VE;
@@ -147,26 +150,44 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvKP p) {
     const int nbp = p.ntaps * BN * 4;          // weight pieces per chunk
     constexpr int MAXBP = (9 * BN * 4 + 255) / 256;          // weight pieces per thread that fit the register prefetch (<= 9 taps)
 
+    // per-lane fragment base addresses.  A: row r = pbase + tap offset, byte = r*64 + (((slot ^ (r>>2)) & 3) << 4); the
+    // second k-step (slot | 2) is the same address XOR 32.  B: rows t*BN + n with BN % 16 == 0, so the swizzle term does
+    // not depend on the tap: byte = t*BN*64 + const.
+    int b_addr[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) b_addr[j] = swz_addr(nrow[j], khalf);
+    auto tap_mma = [&](int t, int toff) {
+        u32x4 a0[MI], a1[MI], b0[NI], b1[NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int ad = swz_addr(pbase[i] + toff, khalf);
+            a0[i] = *reinterpret_cast<const u32x4*>(sA + ad);
+            a1[i] = *reinterpret_cast<const u32x4*>(sA + (ad ^ 32));
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            b0[j] = *reinterpret_cast<const u32x4*>(sB + t * (BN * 64) + b_addr[j]);
+            b1[j] = *reinterpret_cast<const u32x4*>(sB + t * (BN * 64) + (b_addr[j] ^ 32));
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) Mma<T>::step(a0[i], b0[j], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) Mma<T>::step(a1[i], b1[j], acc[i][j]);
+    };
     auto compute_chunk = [&]() {
-        for (int t = 0; t < p.ntaps; ++t) {
-            const int toff = p.tap_off[t];
+        if constexpr (NT > 0) {
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int slot = (s << 1) | khalf;
-                u32x4 a[MI], b[NI];
-#pragma unroll
-                for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const u32x4*>(sA + swz_addr(pbase[i] + toff, slot));
-#pragma unroll
-                for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const u32x4*>(sB + swz_addr(t * BN + nrow[j], slot));
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) Mma<T>::step(a[i], b[j], acc[i][j]);
-            }
+            for (int t = 0; t < NT; ++t) tap_mma(t, p.tap_off[t]);
+        } else {
+            for (int t = 0; t < p.ntaps; ++t) tap_mma(t, p.tap_off[t]);
         }
     };
 
-    if (p.ntaps <= 9) {
+    if (NT > 0 || p.ntaps <= 9) {
         // Software pipeline: the global loads of chunk c+1 are issued right after the barrier that releases the MFMA
         // phase of chunk c and land in registers while the matrix cores work; they are written to LDS only after the
         // next barrier.  HBM/L2 latency is hidden behind compute instead of being paid once per chunk.
@@ -235,26 +256,31 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvKP p) {
         }
     }
 
-    // ---- epilogue.  C layout (32x32): col n = lane&31, row m = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    T* yg = reinterpret_cast<T*>(p.y);
+    // ---- epilogue.  C layout (32x32): col n = lane&31, row m = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // The accumulator tile goes through LDS (free after the main loop) so that the global stores are whole 16-byte
+    // pieces of NHWC pixel rows (a wave writes full 128-B lines) instead of 2/4-byte scattered stores.
+    constexpr int BM = 32 * MI * WM;
+    constexpr int PITCH = BN + 16 / (int)sizeof(T);               // elements per LDS row (16-byte pad: no bank aliasing of rows)
+    constexpr int PPO = BN / VE;                                   // 16-byte pieces per output pixel row
+    T* sO = reinterpret_cast<T*>(smem);
     float ssum[NI], cntf = 0.f;
 #pragma unroll
     for (int j = 0; j < NI; ++j) ssum[j] = 0.f;
-    int64_t yoff[MI][16];
+    unsigned vmask[MI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
+        vmask[i] = 0u;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
             const int tx = m & ((1 << p.tw_log2) - 1);
             const int ty = (m >> p.tw_log2) & ((1 << p.th_log2) - 1);
             const int bl = m >> (p.tw_log2 + p.th_log2);
-            const int oy = oy0 + ty, ox = ox0 + tx, b = b0 + bl;
-            const bool valid = (b < p.B) && (oy < p.OH) && (ox < p.OW) && (bl < p.nb);
-            yoff[i][r] = valid ? (((int64_t)b * p.OHf + oy * p.out_step + p.out_oy) * p.OWf + ox * p.out_step + p.out_ox) * p.y_cs : -1;
-            if (valid) cntf += 1.f;
+            const bool valid = (b0 + bl < p.B) && (oy0 + ty < p.OH) && (ox0 + tx < p.OW);
+            if (valid) { vmask[i] |= 1u << r; cntf += 1.f; }
         }
     }
+    __syncthreads();                                               // every wave is done reading sA / sB
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int n = n0 + nrow[j];
@@ -269,14 +295,43 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvKP p) {
                 float v = (acc[i][j][r] + bias) * sc + sh;
                 if (p.relu) v = fmaxf(v, 0.f);
                 acc[i][j][r] = v;
-                if (yoff[i][r] >= 0) {
-                    ssum[j] += v;
-                    if (nok) {
-                        T* dst = yg + yoff[i][r] + n;
-                        if (p.accumulate) v += Elem<T>::ld(dst);
-                        Elem<T>::st(dst, v);
-                    }
+                if ((vmask[i] >> r) & 1u) ssum[j] += v;
+                const int ml = (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                Elem<T>::st(sO + ml * PITCH + nrow[j], v);
+            }
+        }
+    }
+    __syncthreads();
+    {
+        T* yg = reinterpret_cast<T*>(p.y);
+        const bool y_vec = ((p.y_cs % VE) == 0) && ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0);
+        for (int q = tid; q < BM * PPO; q += 256) {
+            const int m = q / PPO, pc = q - m * PPO;
+            const int tx = m & ((1 << p.tw_log2) - 1);
+            const int ty = (m >> p.tw_log2) & ((1 << p.th_log2) - 1);
+            const int bl = m >> (p.tw_log2 + p.th_log2);
+            const int oy = oy0 + ty, ox = ox0 + tx, b = b0 + bl;
+            const int n = n0 + pc * VE;
+            if (b >= p.B || oy >= p.OH || ox >= p.OW || n >= p.Cout) continue;
+            T* dst = yg + (((int64_t)b * p.OHf + oy * p.out_step + p.out_oy) * p.OWf + ox * p.out_step + p.out_ox) * p.y_cs + n;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(sO + m * PITCH + pc * VE);
+            if (y_vec && n + VE <= p.Cout) {
+                if (p.accumulate) {
+                    float f[VE], o[VE];
+                    unpack16<T>(v, f);
+                    unpack16<T>(*reinterpret_cast<const u32x4*>(dst), o);
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) f[e] += o[e];
+                    *reinterpret_cast<u32x4*>(dst) = pack16<T>(f);
+                } else {
+                    *reinterpret_cast<u32x4*>(dst) = v;
                 }
+            } else {
+                float f[VE];
+                unpack16<T>(v, f);
+#pragma unroll
+                for (int e = 0; e < VE; ++e)
+                    if (n + e < p.Cout) Elem<T>::st(dst + e, p.accumulate ? f[e] + Elem<T>::ld(dst + e) : f[e]);
             }
         }
     }
@@ -292,7 +347,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvKP p) {
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    if (yoff[i][r] >= 0) { const float d = acc[i][j][r] - mean; m2 += d * d; }
+                    if ((vmask[i] >> r) & 1u) { const float d = acc[i][j][r] - mean; m2 += d * d; }
             m2 += __shfl_xor(m2, 32);
             const int n = n0 + nrow[j];
             if (khalf == 0 && n < p.Cout) {
@@ -376,23 +431,34 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
     k.relu = a->relu; k.accumulate = a->accumulate; k.stats_part0 = a->stats_part0;
     pl->grid = dim3((unsigned)(tiles_b * k.tiles_y * k.tiles_x), (unsigned)cdiv(Cout, BN), 1);
     pl->lds = (size_t)k.a_bytes + (size_t)a->ntaps * BN * 64;
+    {   // the epilogue stages the BM x BN output tile through the same LDS
+        const size_t es = a->dtype == SALT_F32 ? 4 : 2;
+        const size_t out_bytes = (size_t)(32 * cfg->MI * cfg->WM) * (BN * es + 16);
+        if (out_bytes > pl->lds) pl->lds = out_bytes;
+    }
     pl->parts = tiles_b * k.tiles_y * k.tiles_x * cfg->WM;
     if (pl->lds > 160 * 1024) SALT_FAIL(SALT_E_LDS, "conv: needs %zu bytes of LDS", pl->lds);
     return SALT_OK;
 }
 
-template <typename T, int MI, int NI, int WM, int WN>
-int launch_cfg(const Plan& pl, hipStream_t st) {
-    auto kern = conv_mfma_kernel<T, MI, NI, WM, WN>;
-    static size_t attr_set = 0;
-    if (pl.lds > 64 * 1024 && pl.lds > attr_set) {
+template <typename T, int MI, int NI, int WM, int WN, int NT>
+int launch_cfg_nt(const Plan& pl, hipStream_t st) {
+    auto kern = conv_mfma_kernel<T, MI, NI, WM, WN, NT>;
+    static bool attr_set = false;
+    if (pl.lds > 64 * 1024 && !attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) SALT_FAIL((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = 160 * 1024;
+        attr_set = true;
     }
     hipLaunchKernelGGL(kern, pl.grid, dim3(256), pl.lds, st, pl.kp);
     SALT_CHECK_LAUNCH();
     return SALT_OK;
+}
+
+template <typename T, int MI, int NI, int WM, int WN>
+int launch_cfg(const Plan& pl, hipStream_t st) {
+    if (pl.kp.ntaps == 9) return launch_cfg_nt<T, MI, NI, WM, WN, 9>(pl, st);
+    return launch_cfg_nt<T, MI, NI, WM, WN, 0>(pl, st);
 }
 
 template <typename T>
