@@ -131,9 +131,24 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
     torch.cuda.set_device(local)
-    if world > 1:
+    if world > 1 or os.environ.get('SALT_FORCE_DP_PATH'):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
+        # RCCL prints a version banner on stdout when the first communicator is created; the contract is ONE JSON line
+        # on stdout, so stdout is pointed at stderr while the process group and its communicator come up
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group('nccl')
+            warm = torch.zeros(1, device='cuda')
+            dist.all_reduce(warm)
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
     dev = torch.device('cuda', local)
 
@@ -265,7 +280,7 @@ def main():
                                          % (torch.get_num_threads(), cb)}
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -91,14 +91,14 @@ class DataParallel:
     # ------------------------------------------------------------------ flat-buffer reducer (device agnostic)
     def allreduce_flat(self, flat, buckets):
         """Sum-reduce contiguous ranges of ``flat`` in place (the 1/world factor is applied by the optimizer)."""
-        if self.world == 1:
+        if self.world == 1 and not (os.environ.get('SALT_FORCE_DP_PATH') and dist.is_initialized()):
             return
         works = [dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True) for lo, hi, _ in buckets]
         for w in works:
             w.wait()
 
     def allreduce_gradients(self, eng):
-        if self.world == 1:
+        if self.world == 1 and not (os.environ.get('SALT_FORCE_DP_PATH') and dist.is_initialized()):
             return
         self.allreduce_flat(eng.grads, [(0, eng.n_live, 0)])
 
@@ -107,7 +107,7 @@ class DataParallel:
         """Run net.bwd; with world > 1 run it in bucket segments with the all-reduce on a side stream."""
         if optimizer is not None:
             optimizer.grad_scale = 1.0 / self.world
-        if self.world == 1:
+        if self.world == 1 and not (os.environ.get('SALT_FORCE_DP_PATH') and dist.is_initialized()):
             net.bwd.run(side=eng.side_stream)
             return
         key = id(net)
