@@ -146,6 +146,19 @@ typedef struct {
 int salt_pack_conv_weight(const salt_pack_conv_weight_args*, void* stream);
 int64_t salt_packed_weight_elems(int dtype, int ntaps, int n, int c);
 
+/* All pack jobs of a network in ONE launch: `jobs` is a DEVICE array of salt_pack_conv_weight_args (same dtype),
+ * `job_block0` a DEVICE array [njobs+1] of prefix block counts (256 elements of the packed copy per block... see
+ * salt_pack_job_blocks).  Replaces ~100 tiny launches per optimizer step by one. */
+typedef struct {
+    const void* jobs;
+    const int* job_block0;
+    int njobs;
+    int total_blocks;
+    int dtype;
+} salt_pack_batched_args;
+int salt_pack_batched(const salt_pack_batched_args*, void* stream);
+int salt_pack_job_blocks(const salt_pack_conv_weight_args*);
+
 /* ------------------------------------------------------------------ thin-channel direct convolutions
  * First layer (Cin <= 4: ResNet stem conv7x7 s2 p3, encoders.py:23-31 / torchvision; vanilla U-Net's
  * first 3x3) and heads with Cout <= 4 (final 1x1 unet.py:84-87, unet_models.py:138; sSE base.py:110).
@@ -272,6 +285,8 @@ typedef struct {
     float* invstd;            /* out [C] */
     float* scale;             /* out [C]: gamma*invstd */
     float* shift;             /* out [C]: beta - mean*scale */
+    int* counter;             /* device int, zero on entry (restored to zero on exit): the last chunk block finalizes in the
+                                 same launch (one kernel instead of two); NULL = two launches */
 } salt_bn_finalize_args;
 int salt_bn_finalize(const salt_bn_finalize_args*, void* stream);
 /* floats the `stats` workspace must hold for nparts partials of C channels (partials + chunk heads) */
@@ -319,6 +334,7 @@ typedef struct {              /* backward of a = relu?(bn(y) (+res)) in train mo
     salt_view dy;             /* out: grad wrt y */
     salt_view dres;           /* out: grad wrt residual (masked da); dres.p == NULL: none */
     int accumulate_dres;
+    int* counter;             /* device int, zero on entry/exit: last reduce block computes the coefficients (2 launches instead of 3) */
 } salt_bn_bwd_args;
 int salt_bn_bwd(const salt_bn_bwd_args*, void* stream);
 int salt_bn_bwd_parts(const salt_bn_bwd_args*);

@@ -498,6 +498,36 @@ __global__ void pack_weight_kernel(PackKP p) {
     }
 }
 
+constexpr int PACK_EPB = 2048;          // packed elements per block in the batched pack kernel
+template <typename T>
+__global__ __launch_bounds__(256) void pack_batched_kernel(const salt_pack_conv_weight_args* jobs, const int* job_block0, int njobs) {
+    constexpr int KCE = 64 / (int)sizeof(T);
+    // binary search: job j with job_block0[j] <= blockIdx.x < job_block0[j+1]
+    int lo = 0, hi = njobs - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (job_block0[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+    const salt_pack_conv_weight_args& a = jobs[lo];
+    const int N = a.transpose ? a.D1 : a.D0, C = a.transpose ? a.D0 : a.D1;
+    const int nchunk = (C + KCE - 1) / KCE;
+    const int64_t total = (int64_t)nchunk * a.ntaps * N * KCE;
+    const int64_t base = (int64_t)(blockIdx.x - job_block0[lo]) * PACK_EPB;
+    T* out = reinterpret_cast<T*>(a.wp);
+    for (int e = threadIdx.x; e < PACK_EPB; e += 256) {
+        const int64_t i = base + e;
+        if (i >= total) break;
+        const int kc = (int)(i % KCE);
+        int64_t r = i / KCE;
+        const int n = (int)(r % N); r /= N;
+        const int t = (int)(r % a.ntaps);
+        const int ch = (int)(r / a.ntaps) * KCE + kc;
+        float v = 0.f;
+        if (ch < C) {
+            const int d0 = a.transpose ? ch : n, d1 = a.transpose ? n : ch;
+            v = a.w[(((int64_t)d0 * a.D1 + d1) * a.KH + a.tap_kh[t]) * a.KW + a.tap_kw[t]];
+        }
+        Elem<T>::st(out + i, v);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ weight gradient
 // dW[t][a][b] = sum_p P[p,a] * Q[pad(p*q_step + tap_t), b].  Workgroup = 64(a) x 64(b) block for all taps of
 // the launch over a slice of the pixel tiles (split-K); 4 waves as 2(a) x 2(b), each 32x32 per tap.
@@ -797,6 +827,24 @@ extern "C" int salt_pack_conv_weight(const salt_pack_conv_weight_args* a, void* 
     if (a->dtype == SALT_F32) hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
     else if (a->dtype == SALT_BF16) hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
     else SALT_FAIL(SALT_E_BADARG, "pack: dtype");
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}
+
+extern "C" int salt_pack_job_blocks(const salt_pack_conv_weight_args* a) {
+    if (!a) return -1;
+    const int KCE = a->dtype == SALT_F32 ? 16 : 32;
+    const int N = a->transpose ? a->D1 : a->D0, C = a->transpose ? a->D0 : a->D1;
+    const int64_t total = (int64_t)cdiv(C, KCE) * a->ntaps * N * KCE;
+    return (int)((total + PACK_EPB - 1) / PACK_EPB);
+}
+
+extern "C" int salt_pack_batched(const salt_pack_batched_args* a, void* stream) {
+    if (!a || !a->jobs || !a->job_block0 || a->njobs < 1 || a->total_blocks < 1) SALT_FAIL(SALT_E_BADARG, "pack_batched: bad args");
+    const auto* jobs = reinterpret_cast<const salt_pack_conv_weight_args*>(a->jobs);
+    if (a->dtype == SALT_F32) hipLaunchKernelGGL(pack_batched_kernel<float>, dim3(a->total_blocks), dim3(256), 0, (hipStream_t)stream, jobs, a->job_block0, a->njobs);
+    else if (a->dtype == SALT_BF16) hipLaunchKernelGGL(pack_batched_kernel<bf16_t>, dim3(a->total_blocks), dim3(256), 0, (hipStream_t)stream, jobs, a->job_block0, a->njobs);
+    else SALT_FAIL(SALT_E_BADARG, "pack_batched: dtype");
     SALT_CHECK_LAUNCH();
     return SALT_OK;
 }

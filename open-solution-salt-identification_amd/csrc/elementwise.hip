@@ -93,24 +93,33 @@ __device__ __forceinline__ void bn_merge_256(const float* sum_row0, const float*
     M2 = sm[2][0][cl] + sm[2][1][cl] + sm[2][2][cl] + sm[2][3][cl];
 }
 
-__global__ __launch_bounds__(256) void bn_chunk_kernel(float* stats, const float* cnt, int nparts, int C) {
-    const int k0 = blockIdx.x * BN_CHUNK, k1 = min(k0 + BN_CHUNK, nparts);
-    const int c = blockIdx.y * 64 + (threadIdx.x & 63);
-    double N, S, M2;
-    bn_merge_256(stats, stats + C, cnt, 0, 2 * (int64_t)C, 0, k0, k1, c, c < C, N, S, M2);
-    if ((threadIdx.x >> 6) == 0 && c < C) {
-        float* head = stats + (int64_t)nparts * 2 * C + (int64_t)blockIdx.x * 3 * C;
-        head[c] = (float)S; head[C + c] = (float)M2; head[2 * C + c] = (float)N;
+// Inter-workgroup hand-off (cdna guide G16): every wave drains its stores, the block barriers, ONE lane issues an
+// agent-scope release fence + vmcnt(0) and then the relaxed device-scope ticket; the block that draws the last ticket
+// issues an agent-scope acquire (L1 invalidate) before re-reading the other blocks' data.  Placement independent.
+__device__ __forceinline__ bool last_block_ticket(int* counter, int total_blocks) {
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int prev = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (prev == total_blocks - 1) ? 1 : 0;
+        if (s_last) {
+            __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
     }
+    __syncthreads();
+    return s_last != 0;
 }
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(salt_bn_finalize_args a) {
+__device__ __forceinline__ void bn_finalize_group(const salt_bn_finalize_args& a, int cgroup) {
     const int nchunks = (a.nparts + BN_CHUNK - 1) / BN_CHUNK;
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int c = cgroup * 64 + (threadIdx.x & 63);
     const float* heads = a.stats + (int64_t)a.nparts * 2 * a.C;
     double N, S, M2;
     bn_merge_256(heads, heads + a.C, heads + 2 * a.C, 1, 3 * (int64_t)a.C, 3 * (int64_t)a.C, 0, nchunks, c, c < a.C, N, S, M2);
-    if (threadIdx.x == 0 && blockIdx.x == 0 && a.num_batches_tracked) *a.num_batches_tracked += 1;
     if ((threadIdx.x >> 6) != 0 || c >= a.C) return;
     const double mean = N > 0 ? S / N : 0.0;
     const double var = N > 0 ? M2 / N : 0.0;
@@ -124,6 +133,28 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(salt_bn_finalize_args 
     }
 }
 
+__global__ __launch_bounds__(256) void bn_chunk_kernel(salt_bn_finalize_args a) {
+    float* stats = const_cast<float*>(a.stats);
+    const int nparts = a.nparts, C = a.C;
+    const int k0 = blockIdx.x * BN_CHUNK, k1 = min(k0 + BN_CHUNK, nparts);
+    const int c = blockIdx.y * 64 + (threadIdx.x & 63);
+    double N, S, M2;
+    bn_merge_256(stats, stats + C, a.stats_cnt, 0, 2 * (int64_t)C, 0, k0, k1, c, c < C, N, S, M2);
+    if ((threadIdx.x >> 6) == 0 && c < C) {
+        float* head = stats + (int64_t)nparts * 2 * C + (int64_t)blockIdx.x * 3 * C;
+        head[c] = (float)S; head[C + c] = (float)M2; head[2 * C + c] = (float)N;
+    }
+    if (!a.counter) return;
+    if (!last_block_ticket(a.counter, gridDim.x * gridDim.y)) return;
+    if (threadIdx.x == 0 && a.num_batches_tracked) *a.num_batches_tracked += 1;
+    for (int g = 0; g < (C + 63) / 64; ++g) { bn_finalize_group(a, g); __syncthreads(); }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(salt_bn_finalize_args a) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && a.num_batches_tracked) *a.num_batches_tracked += 1;
+    bn_finalize_group(a, blockIdx.x);
+}
+
 __global__ void bn_fold_kernel(salt_bn_fold_args a) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= a.C) return;
@@ -133,10 +164,33 @@ __global__ void bn_fold_kernel(salt_bn_fold_args a) {
 
 // ---------------------------------------------------------------- BN backward
 // pass 1: per-block partial sums of dyh = da*mask and dyh*xhat per channel.
+struct BnBwdFin { int* counter; double M; float* dgamma; float* dbeta; int accumulate; float* coef; };
+
+__device__ __forceinline__ void bn_bwd_finalize_group(const float* partials, int nparts, int C, const BnBwdFin& f, const float* gamma,
+                                                      const float* invstd, int cgroup) {
+    __shared__ double smf[2][4][64];
+    const int cl = threadIdx.x & 63, row = threadIdx.x >> 6;
+    const int c = cgroup * 64 + cl;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+        for (int k = row; k < nparts; k += 4) { s1 += (double)partials[((int64_t)k * 2) * C + c]; s2 += (double)partials[((int64_t)k * 2 + 1) * C + c]; }
+    smf[0][row][cl] = s1; smf[1][row][cl] = s2;
+    __syncthreads();
+    if (row == 0 && c < C) {
+        s1 = smf[0][0][cl] + smf[0][1][cl] + smf[0][2][cl] + smf[0][3][cl];
+        s2 = smf[1][0][cl] + smf[1][1][cl] + smf[1][2][cl] + smf[1][3][cl];
+        if (f.dgamma) { f.dgamma[c] = f.accumulate ? f.dgamma[c] + (float)s2 : (float)s2; f.dbeta[c] = f.accumulate ? f.dbeta[c] + (float)s1 : (float)s1; }
+        f.coef[c] = gamma[c] * invstd[c];
+        f.coef[C + c] = (float)(s1 / f.M);
+        f.coef[2 * C + c] = (float)(s2 / f.M);
+    }
+    __syncthreads();
+}
+
 template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(salt_view da, salt_view a, salt_view y, int relu,
                                                             const float* mean, const float* invstd, const float* gamma, const float* beta,
-                                                            float* partials, int64_t pix_per_block) {
+                                                            float* partials, int64_t pix_per_block, BnBwdFin fin) {
     constexpr int N = Unit<T, VEC>::N;
     extern __shared__ float sm[];
     const int C = y.C, cpv = C / N;
@@ -199,6 +253,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(salt_view da, salt_v
         }
         __syncthreads();
     }
+    if (!fin.counter) return;
+    if (!last_block_ticket(fin.counter, gridDim.x)) return;
+    for (int g = 0; g < (C + 63) / 64; ++g) bn_bwd_finalize_group(partials, gridDim.x, C, fin, gamma, invstd, g);
 }
 
 // 256 threads = 4 part-rows x 64 channels; rows take parts k = row, row+4, ... (fixed order), then combine.
@@ -565,10 +622,9 @@ extern "C" int salt_bn_finalize(const salt_bn_finalize_args* a, void* stream) {
     if (!a || !a->stats || !a->stats_cnt || a->C < 1 || a->nparts < 1 || !a->gamma || !a->beta || !a->mean || !a->invstd || !a->scale || !a->shift)
         SALT_FAIL(SALT_E_BADARG, "bn_finalize: bad args");
     const int nchunks = cdiv(a->nparts, BN_CHUNK);
-    hipLaunchKernelGGL(bn_chunk_kernel, dim3(nchunks, cdiv(a->C, 64)), dim3(256), 0, (hipStream_t)stream,
-                       const_cast<float*>(a->stats), a->stats_cnt, a->nparts, a->C);
+    hipLaunchKernelGGL(bn_chunk_kernel, dim3(nchunks, cdiv(a->C, 64)), dim3(256), 0, (hipStream_t)stream, *a);
     SALT_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(a->C, 64)), dim3(256), 0, (hipStream_t)stream, *a);
+    if (!a->counter) hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(a->C, 64)), dim3(256), 0, (hipStream_t)stream, *a);
     SALT_CHECK_LAUNCH();
     return SALT_OK;
 }
@@ -614,12 +670,15 @@ extern "C" int salt_bn_bwd(const salt_bn_bwd_args* a, void* stream) {
         const int cpv = C / N;
         const int cvn = cpv < 256 ? cpv : 256;
         const size_t lds = (size_t)(256 / cvn) * cvn * N * 2 * sizeof(float);
-        if (v) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), dim3(nparts), dim3(256), lds, st, a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->gamma, a->beta, a->partials, per);
-        else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), dim3(nparts), dim3(256), lds, st, a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->gamma, a->beta, a->partials, per);
+        BnBwdFin fin{a->counter, (double)view_pixels(a->y), a->dgamma, a->dbeta, a->accumulate_param_grads, a->coef};
+        if (v) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), dim3(nparts), dim3(256), lds, st, a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->gamma, a->beta, a->partials, per, fin);
+        else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), dim3(nparts), dim3(256), lds, st, a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->gamma, a->beta, a->partials, per, fin);
         SALT_CHECK_LAUNCH();
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(256), 0, st, a->partials, nparts, C, (double)view_pixels(a->y),
-                           a->gamma, a->invstd, a->dgamma, a->dbeta, a->accumulate_param_grads, a->coef);
-        SALT_CHECK_LAUNCH();
+        if (!a->counter) {
+            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(256), 0, st, a->partials, nparts, C, (double)view_pixels(a->y),
+                               a->gamma, a->invstd, a->dgamma, a->dbeta, a->accumulate_param_grads, a->coef);
+            SALT_CHECK_LAUNCH();
+        }
         const int64_t units = view_pixels(a->y) * cpv;
         EW_LAUNCH(bn_bwd_apply_kernel, T, v, units, st, a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->gamma, a->beta, a->coef, a->dy, a->dres, a->accumulate_dres);
     })

@@ -19,7 +19,7 @@ void salt_set_error(const char* fmt, ...) {
 
 extern "C" const char* salt_last_error(void) { return g_err; }
 
-extern "C" int salt_abi_version(void) { return 5; }
+extern "C" int salt_abi_version(void) { return 6; }
 
 extern "C" int salt_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name_len) {
     int dev = 0;
@@ -166,6 +166,7 @@ extern "C" int salt_abi_struct_sizes(int* out, int n) {
     (int)sizeof(salt_conv_wgrad_args),
     (int)sizeof(salt_wgrad_reduce_args),
     (int)sizeof(salt_pack_conv_weight_args),
+    (int)sizeof(salt_pack_batched_args),
     (int)sizeof(salt_conv_first_args),
     (int)sizeof(salt_conv_first_wgrad_args),
     (int)sizeof(salt_s2d_args),

@@ -190,9 +190,34 @@ class Engine:
         if stats:
             self.sver += 1
 
+    def _build_pack_batch(self):
+        """One launch packs every convolution weight: the per-job argument structs are copied to a device table."""
+        import numpy as np
+        S = _abi.STRUCTS['salt_pack_conv_weight_args']
+        jobs = [(name, s) for (name, fn, s) in self._pack_ops.ops if name == 'pack_conv_weight']
+        others = Program('pack_misc')
+        for (name, fn, s), st in zip(self._pack_ops.ops, self._pack_ops.streams):
+            if name != 'pack_conv_weight':
+                others.ops.append((name, fn, s)); others.streams.append(st)
+        batched = Program('pack')
+        if jobs:
+            raw = b''.join(bytes(s) for _, s in jobs)
+            blocks = [lib.salt_pack_job_blocks(ctypes.byref(s)) for _, s in jobs]
+            pref = np.concatenate([[0], np.cumsum(blocks)]).astype(np.int32)
+            self._pack_table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+            self._pack_pref = torch.from_numpy(pref).to(self.device)
+            batched.add('pack_batched', jobs=self._pack_table.data_ptr(), job_block0=self._pack_pref.data_ptr(), njobs=len(jobs),
+                        total_blocks=int(pref[-1]), dtype=DT_CODE[self.dtype])
+        batched.extend(others)
+        batched.finalize()
+        self._pack_batched = batched
+        self._pack_batched_n = len(self._pack_ops)
+
     def refresh(self, train):
         if self._packed_version != self.wver:
-            self._pack_ops.run()
+            if getattr(self, '_pack_batched_n', -1) != len(self._pack_ops):
+                self._build_pack_batch()
+            self._pack_batched.run()
             self._packed_version = self.wver
         if not train and self._folded_version != (self.wver, self.sver):
             self._fold_ops.run()
