@@ -285,8 +285,6 @@ typedef struct {
     float* invstd;            /* out [C] */
     float* scale;             /* out [C]: gamma*invstd */
     float* shift;             /* out [C]: beta - mean*scale */
-    int* counter;             /* device int, zero on entry (restored to zero on exit): the last chunk block finalizes in the
-                                 same launch (one kernel instead of two); NULL = two launches */
 } salt_bn_finalize_args;
 int salt_bn_finalize(const salt_bn_finalize_args*, void* stream);
 /* floats the `stats` workspace must hold for nparts partials of C channels (partials + chunk heads) */
@@ -334,7 +332,6 @@ typedef struct {              /* backward of a = relu?(bn(y) (+res)) in train mo
     salt_view dy;             /* out: grad wrt y */
     salt_view dres;           /* out: grad wrt residual (masked da); dres.p == NULL: none */
     int accumulate_dres;
-    int* counter;             /* device int, zero on entry/exit: last reduce block computes the coefficients (2 launches instead of 3) */
 } salt_bn_bwd_args;
 int salt_bn_bwd(const salt_bn_bwd_args*, void* stream);
 int salt_bn_bwd_parts(const salt_bn_bwd_args*);

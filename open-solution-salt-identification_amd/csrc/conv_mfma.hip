@@ -336,8 +336,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
         }
     }
     if (p.stats) {
+        // BatchNorm partial of this workgroup: per-wave (sum, M2 about the wave's mean, count) from the registers, then the WM
+        // wave rows are merged in fixed order (Chan) through LDS so that one (sum, M2, count) row per workgroup reaches HBM.
         cntf += __shfl_xor(cntf, 32);
-        const int part = p.stats_part0 + blockIdx.x * WM + wm;
+        float* sS = reinterpret_cast<float*>(smem);                // [WM][BN][2] then [WM] counts
+        float* sC = sS + WM * BN * 2;
+        __syncthreads();                                           // the output tile in LDS has been stored
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
             float s = ssum[j] + __shfl_xor(ssum[j], 32);
@@ -349,13 +353,33 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
                 for (int r = 0; r < 16; ++r)
                     if ((vmask[i] >> r) & 1u) { const float d = acc[i][j][r] - mean; m2 += d * d; }
             m2 += __shfl_xor(m2, 32);
-            const int n = n0 + nrow[j];
-            if (khalf == 0 && n < p.Cout) {
-                p.stats[((int64_t)part * 2 + 0) * p.Cout + n] = s;
-                p.stats[((int64_t)part * 2 + 1) * p.Cout + n] = m2;
-            }
+            if (khalf == 0) { sS[(wm * BN + nrow[j]) * 2 + 0] = s; sS[(wm * BN + nrow[j]) * 2 + 1] = m2; }
         }
-        if (lane == 0 && wn == 0 && blockIdx.y == 0) p.stats_cnt[part] = cntf;
+        if (lane == 0 && wn == 0) sC[wm] = cntf;
+        __syncthreads();
+        const int part = p.stats_part0 + blockIdx.x;
+        if (tid < BN) {
+            float N = 0.f, S = 0.f, M2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) {
+                const float nk = sC[w];
+                if (nk > 0.f) {
+                    const float sk = sS[(w * BN + tid) * 2 + 0], mk = sS[(w * BN + tid) * 2 + 1];
+                    if (N == 0.f) { N = nk; S = sk; M2 = mk; }
+                    else {
+                        const float d = sk / nk - S / N;
+                        M2 += mk + d * d * (N * nk / (N + nk));
+                        S += sk; N += nk;
+                    }
+                }
+            }
+            const int n = n0 + tid;
+            if (n < p.Cout) {
+                p.stats[((int64_t)part * 2 + 0) * p.Cout + n] = S;
+                p.stats[((int64_t)part * 2 + 1) * p.Cout + n] = M2;
+            }
+            if (tid == 0 && blockIdx.y == 0) p.stats_cnt[part] = N;
+        }
     }
 }
 
@@ -436,7 +460,7 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
         const size_t out_bytes = (size_t)(32 * cfg->MI * cfg->WM) * (BN * es + 16);
         if (out_bytes > pl->lds) pl->lds = out_bytes;
     }
-    pl->parts = tiles_b * k.tiles_y * k.tiles_x * cfg->WM;
+    pl->parts = tiles_b * k.tiles_y * k.tiles_x;
     if (pl->lds > 160 * 1024) SALT_FAIL(SALT_E_LDS, "conv: needs %zu bytes of LDS", pl->lds);
     return SALT_OK;
 }

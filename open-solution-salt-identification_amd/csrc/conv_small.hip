@@ -301,18 +301,114 @@ __global__ __launch_bounds__(256) void head1x1_bwd_kernel(salt_view x, const flo
     }
 }
 
-// 256 threads = 4 part-rows x 64 outputs
+// 16-byte variant: thread = (pixel row, 16-byte channel group); U pixels in flight per thread.
+template <typename T>
+__global__ __launch_bounds__(256) void head1x1_bwd_vec_kernel(salt_view x, const float* w, int Cout, const float* dy_nchw, salt_view dx,
+                                                              int accumulate, float* partials, int64_t pix_per_block) {
+    constexpr int N = Elem<T>::VE;
+    constexpr int U = 4;
+    extern __shared__ float sm[];                         // [R][cpv][N][4]
+    const int C = x.C, cpv = C / N;                       // host guarantees cpv <= 256
+    const int64_t hw = (int64_t)x.H * x.W, npix = (int64_t)x.B * hw;
+    const int64_t p0 = blockIdx.x * pix_per_block;
+    const int64_t p1 = p0 + pix_per_block < npix ? p0 + pix_per_block : npix;
+    const int PW = Cout * (C + 1);
+    const int R = 256 / cpv;
+    const int row = threadIdx.x / cpv, cv = threadIdx.x % cpv, c0 = cv * N;
+    float gw[4][N], gb[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int j = 0; j < N; ++j) gw[o][j] = 0.f;
+    if (row < R) {
+        float wv[4][N];
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+            for (int j = 0; j < N; ++j) wv[o][j] = o < Cout ? w[o * C + c0 + j] : 0.f;
+        for (int64_t pixb = p0 + row; pixb < p1; pixb += (int64_t)U * R) {
+            float xv[U][N], old[U][N], g[U][4];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t pix = pixb + (int64_t)u * R;
+#pragma unroll
+                for (int j = 0; j < N; ++j) { xv[u][j] = 0.f; old[u][j] = 0.f; }
+#pragma unroll
+                for (int o = 0; o < 4; ++o) g[u][o] = 0.f;
+                if (pix < p1) {
+                    const int64_t b = pix / hw, sp = pix - b * hw;
+                    unpack16<T>(*reinterpret_cast<const u32x4*>((const T*)x.p + pix * x.cs + c0), xv[u]);
+                    if (accumulate) unpack16<T>(*reinterpret_cast<const u32x4*>((const T*)dx.p + pix * dx.cs + c0), old[u]);
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) if (o < Cout) g[u][o] = dy_nchw[(b * Cout + o) * hw + sp];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t pix = pixb + (int64_t)u * R;
+                float d[N];
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) { t += g[u][o] * wv[o][j]; gw[o][j] += g[u][o] * xv[u][j]; }
+                    d[j] = t + old[u][j];
+                }
+#pragma unroll
+                for (int o = 0; o < 4; ++o) gb[o] += g[u][o];
+                if (pix < p1) *reinterpret_cast<u32x4*>((T*)dx.p + pix * dx.cs + c0) = pack16<T>(d);
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+            for (int j = 0; j < N; ++j) sm[((row * cpv + cv) * N + j) * 4 + o] = gw[o][j];
+    }
+    __syncthreads();
+    if (row == 0) {
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) if (o < Cout) {
+                float t = 0.f;
+                for (int r = 0; r < R; ++r) t += sm[((r * cpv + cv) * N + j) * 4 + o];
+                partials[(int64_t)blockIdx.x * PW + o * (C + 1) + c0 + j] = t;
+            }
+    }
+    __syncthreads();
+    if (row < R && cv == 0) {
+#pragma unroll
+        for (int o = 0; o < 4; ++o) sm[row * 4 + o] = gb[o];
+    }
+    __syncthreads();
+    if (threadIdx.x < Cout) {
+        float t = 0.f;
+        for (int r = 0; r < R; ++r) t += sm[r * 4 + threadIdx.x];
+        partials[(int64_t)blockIdx.x * PW + threadIdx.x * (C + 1) + C] = t;
+    }
+}
+
+// 256 threads = 16 part-rows x 16 outputs, 8 loads in flight
 __global__ __launch_bounds__(256) void head1x1_bwd_finalize(const float* partials, int nparts, int Cout, int C, float* gw, float* gb) {
-    __shared__ float sm[4][64];
-    const int il = threadIdx.x & 63, row = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + il;
+    __shared__ float sm[16][16];
+    const int il = threadIdx.x & 15, row = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + il;
     const int PW = Cout * (C + 1);
     float s = 0.f;
-    if (i < PW) for (int k = row; k < nparts; k += 4) s += partials[(int64_t)k * PW + i];
+    if (i < PW)
+        for (int k = row; k < nparts; k += 16 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int kk = k + 16 * u; v[u] = kk < nparts ? partials[(int64_t)kk * PW + i] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
     sm[row][il] = s;
     __syncthreads();
     if (row != 0 || i >= PW) return;
-    s = sm[0][il] + sm[1][il] + sm[2][il] + sm[3][il];
+    s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += sm[r][il];
     const int o = i / (C + 1), c = i - o * (C + 1);
     if (c < C) gw[o * C + c] = s; else if (gb) gb[o] = s;
 }
@@ -374,8 +470,8 @@ __global__ void stem_grad_unfold_kernel(const float* g16, int Cout, int Cin, int
 
 int head_parts(const salt_view& x, int64_t* per) {
     const int64_t npix = view_pixels(x);
-    int64_t parts = (npix + 255) / 256;
-    if (parts > 512) parts = 512;
+    int64_t parts = (npix + 63) / 64;
+    if (parts > 1024) parts = 1024;
     if (parts < 1) parts = 1;
     const int64_t pp = (npix + parts - 1) / parts;
     if (per) *per = pp;
@@ -514,11 +610,16 @@ extern "C" int salt_head1x1_bwd(const salt_head1x1_bwd_args* a, void* stream) {
     if (a->nparts != nparts) SALT_FAIL(SALT_E_BADARG, "head1x1_bwd: nparts %d, expected %d", a->nparts, nparts);
     const int PW = a->Cout * (a->x.C + 1);
     SALT_DISPATCH_DTYPE(a->dtype, T, {
-        hipLaunchKernelGGL(head1x1_bwd_kernel<T>, dim3(nparts), dim3(256), 256 * 5 * sizeof(float), (hipStream_t)stream,
-                           a->x, a->w, a->Cout, a->dy_nchw, a->dx, a->accumulate, a->partials, per);
+        constexpr int VE = Elem<T>::VE;
+        const bool v = a->x.C % VE == 0 && a->x.cs % VE == 0 && a->dx.cs % VE == 0 && a->x.C / VE <= 256 &&
+                       ((reinterpret_cast<uintptr_t>(a->x.p) | reinterpret_cast<uintptr_t>(a->dx.p)) & 15) == 0;
+        if (v) hipLaunchKernelGGL(head1x1_bwd_vec_kernel<T>, dim3(nparts), dim3(256), 256 * VE * 4 * sizeof(float), (hipStream_t)stream,
+                                  a->x, a->w, a->Cout, a->dy_nchw, a->dx, a->accumulate, a->partials, per);
+        else hipLaunchKernelGGL(head1x1_bwd_kernel<T>, dim3(nparts), dim3(256), 256 * 5 * sizeof(float), (hipStream_t)stream,
+                                a->x, a->w, a->Cout, a->dy_nchw, a->dx, a->accumulate, a->partials, per);
     })
     SALT_CHECK_LAUNCH();
-    hipLaunchKernelGGL(head1x1_bwd_finalize, dim3(cdiv(PW, 64)), dim3(256), 0, (hipStream_t)stream, a->partials, nparts, a->Cout, a->x.C, a->gw, a->gb);
+    hipLaunchKernelGGL(head1x1_bwd_finalize, dim3(cdiv(PW, 16)), dim3(256), 0, (hipStream_t)stream, a->partials, nparts, a->Cout, a->x.C, a->gw, a->gb);
     SALT_CHECK_LAUNCH();
     return SALT_OK;
 }

@@ -52,76 +52,64 @@ __global__ void affine_act_kernel(salt_view y, const float* scale, const float* 
     }
 }
 
-// ---------------------------------------------------------------- BN finalize (two-level, fp64, fixed order, no atomics)
-// Partials are (sum, M2 about the partial's own mean, count).  Merging uses the exact identity
+// ---------------------------------------------------------------- BN finalize (one launch, fp64, fixed order, no atomics)
+// Partials are (sum, M2 about the partial's own mean, count), one per convolution workgroup.  Merging uses the exact identity
 //   mean = S/N,  M2 = sum_k [ M2_k + n_k (mean_k - mean)^2 ]
-// evaluated in two passes over independent loads (no serial Chan chain):
-//   stage 1: grid (chunks of 64 partials) x (64-channel groups), 256 threads = 4 part-rows x 64 channels
-//            -> chunk heads (S, M2, N) appended after the partials in the same workspace;
-//   stage 2: the same merge over the <= nparts/64 chunk heads -> mean / invstd / scale / shift (+ running stats).
-constexpr int BN_CHUNK = 64;
-
-__device__ __forceinline__ void bn_merge_256(const float* sum_row0, const float* m2_row0, const float* n_ptr, int n_stride_is_c,
-                                             int64_t row_stride, int64_t n_row_stride, int k0, int k1, int c, bool c_ok,
-                                             double& N, double& S, double& M2) {
-    // thread layout: cl = tid & 63 (channel), row = tid >> 6 (takes items k0+row, k0+row+4, ...)
-    __shared__ double sm[3][4][64];
-    const int cl = threadIdx.x & 63, row = threadIdx.x >> 6;
-    double n = 0.0, sacc = 0.0;
-    if (c_ok)
-        for (int k = k0 + row; k < k1; k += 4) {
-            const double nk = (double)(n_stride_is_c ? n_ptr[(int64_t)k * n_row_stride + c] : n_ptr[k]);
-            n += nk; sacc += (double)sum_row0[(int64_t)k * row_stride + c];
+// The kernel is latency-bound (a few hundred KB at most), so the layout maximises loads in flight: 256 threads = ROWS part-rows x
+// (256/ROWS) channels, ROWS in {4, 16, 64} picked so that a thread holds <= 16 partials in registers (one batch, no re-read in the
+// second pass) for every layer of the networks here; more partials loop over batches and re-read in pass two.
+template <int ROWS>
+__global__ __launch_bounds__(256) void bn_finalize_kernel(salt_bn_finalize_args a) {
+    constexpr int CPB = 256 / ROWS, U = 16;
+    __shared__ double sm[2][ROWS][CPB];
+    const int cl = threadIdx.x % CPB, row = threadIdx.x / CPB;
+    const int c = blockIdx.x * CPB + cl;
+    const bool c_ok = c < a.C;
+    const int nparts = a.nparts, C = a.C;
+    const int nb = (nparts + ROWS * U - 1) / (ROWS * U);
+    float sv[U], mv[U], nv[U];
+    auto load_batch = [&](int b) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = (b * U + u) * ROWS + row;
+            const bool ok = c_ok && k < nparts;
+            sv[u] = ok ? a.stats[((int64_t)k * 2 + 0) * C + c] : 0.f;
+            mv[u] = ok ? a.stats[((int64_t)k * 2 + 1) * C + c] : 0.f;
+            nv[u] = ok ? a.stats_cnt[k] : 0.f;
         }
+    };
+    double n = 0.0, sacc = 0.0;
+    for (int b = 0; b < nb; ++b) {
+        load_batch(b);
+#pragma unroll
+        for (int u = 0; u < U; ++u) { n += (double)nv[u]; sacc += (double)sv[u]; }
+    }
     sm[0][row][cl] = n; sm[1][row][cl] = sacc;
     __syncthreads();
-    N = sm[0][0][cl] + sm[0][1][cl] + sm[0][2][cl] + sm[0][3][cl];
-    S = sm[1][0][cl] + sm[1][1][cl] + sm[1][2][cl] + sm[1][3][cl];
+    double N = 0.0, S = 0.0;
+#pragma unroll 8
+    for (int r = 0; r < ROWS; ++r) { N += sm[0][r][cl]; S += sm[1][r][cl]; }
     const double mean = N > 0 ? S / N : 0.0;
     double m2 = 0.0;
-    if (c_ok)
-        for (int k = k0 + row; k < k1; k += 4) {
-            const double nk = (double)(n_stride_is_c ? n_ptr[(int64_t)k * n_row_stride + c] : n_ptr[k]);
-            if (nk > 0.0) {
-                const double d = (double)sum_row0[(int64_t)k * row_stride + c] / nk - mean;
-                m2 += (double)m2_row0[(int64_t)k * row_stride + c] + nk * d * d;
+    for (int b = 0; b < nb; ++b) {
+        if (nb > 1) load_batch(b);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (nv[u] > 0.f) {
+                const double nk = (double)nv[u];
+                const double d = (double)sv[u] / nk - mean;
+                m2 += (double)mv[u] + nk * d * d;
             }
-        }
-    __syncthreads();
-    sm[2][row][cl] = m2;
-    __syncthreads();
-    M2 = sm[2][0][cl] + sm[2][1][cl] + sm[2][2][cl] + sm[2][3][cl];
-}
-
-// Inter-workgroup hand-off (cdna guide G16): every wave drains its stores, the block barriers, ONE lane issues an
-// agent-scope release fence + vmcnt(0) and then the relaxed device-scope ticket; the block that draws the last ticket
-// issues an agent-scope acquire (L1 invalidate) before re-reading the other blocks' data.  Placement independent.
-__device__ __forceinline__ bool last_block_ticket(int* counter, int total_blocks) {
-    __shared__ int s_last;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int prev = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (prev == total_blocks - 1) ? 1 : 0;
-        if (s_last) {
-            __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
     }
     __syncthreads();
-    return s_last != 0;
-}
-
-__device__ __forceinline__ void bn_finalize_group(const salt_bn_finalize_args& a, int cgroup) {
-    const int nchunks = (a.nparts + BN_CHUNK - 1) / BN_CHUNK;
-    const int c = cgroup * 64 + (threadIdx.x & 63);
-    const float* heads = a.stats + (int64_t)a.nparts * 2 * a.C;
-    double N, S, M2;
-    bn_merge_256(heads, heads + a.C, heads + 2 * a.C, 1, 3 * (int64_t)a.C, 3 * (int64_t)a.C, 0, nchunks, c, c < a.C, N, S, M2);
-    if ((threadIdx.x >> 6) != 0 || c >= a.C) return;
-    const double mean = N > 0 ? S / N : 0.0;
+    sm[0][row][cl] = m2;
+    __syncthreads();
+    if (threadIdx.x == 0 && blockIdx.x == 0 && a.num_batches_tracked) *a.num_batches_tracked += 1;
+    if (row != 0 || !c_ok) return;
+    double M2 = 0.0;
+#pragma unroll 8
+    for (int r = 0; r < ROWS; ++r) M2 += sm[0][r][cl];
     const double var = N > 0 ? M2 / N : 0.0;
     const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
     const float sc = a.gamma[c] * invstd;
@@ -133,27 +121,7 @@ __device__ __forceinline__ void bn_finalize_group(const salt_bn_finalize_args& a
     }
 }
 
-__global__ __launch_bounds__(256) void bn_chunk_kernel(salt_bn_finalize_args a) {
-    float* stats = const_cast<float*>(a.stats);
-    const int nparts = a.nparts, C = a.C;
-    const int k0 = blockIdx.x * BN_CHUNK, k1 = min(k0 + BN_CHUNK, nparts);
-    const int c = blockIdx.y * 64 + (threadIdx.x & 63);
-    double N, S, M2;
-    bn_merge_256(stats, stats + C, a.stats_cnt, 0, 2 * (int64_t)C, 0, k0, k1, c, c < C, N, S, M2);
-    if ((threadIdx.x >> 6) == 0 && c < C) {
-        float* head = stats + (int64_t)nparts * 2 * C + (int64_t)blockIdx.x * 3 * C;
-        head[c] = (float)S; head[C + c] = (float)M2; head[2 * C + c] = (float)N;
-    }
-    if (!a.counter) return;
-    if (!last_block_ticket(a.counter, gridDim.x * gridDim.y)) return;
-    if (threadIdx.x == 0 && a.num_batches_tracked) *a.num_batches_tracked += 1;
-    for (int g = 0; g < (C + 63) / 64; ++g) { bn_finalize_group(a, g); __syncthreads(); }
-}
-
-__global__ __launch_bounds__(256) void bn_finalize_kernel(salt_bn_finalize_args a) {
-    if (threadIdx.x == 0 && blockIdx.x == 0 && a.num_batches_tracked) *a.num_batches_tracked += 1;
-    bn_finalize_group(a, blockIdx.x);
-}
+inline int bn_rows_for(int nparts) { return nparts <= 64 ? 4 : (nparts <= 256 ? 16 : 64); }
 
 __global__ void bn_fold_kernel(salt_bn_fold_args a) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -164,33 +132,10 @@ __global__ void bn_fold_kernel(salt_bn_fold_args a) {
 
 // ---------------------------------------------------------------- BN backward
 // pass 1: per-block partial sums of dyh = da*mask and dyh*xhat per channel.
-struct BnBwdFin { int* counter; double M; float* dgamma; float* dbeta; int accumulate; float* coef; };
-
-__device__ __forceinline__ void bn_bwd_finalize_group(const float* partials, int nparts, int C, const BnBwdFin& f, const float* gamma,
-                                                      const float* invstd, int cgroup) {
-    __shared__ double smf[2][4][64];
-    const int cl = threadIdx.x & 63, row = threadIdx.x >> 6;
-    const int c = cgroup * 64 + cl;
-    double s1 = 0.0, s2 = 0.0;
-    if (c < C)
-        for (int k = row; k < nparts; k += 4) { s1 += (double)partials[((int64_t)k * 2) * C + c]; s2 += (double)partials[((int64_t)k * 2 + 1) * C + c]; }
-    smf[0][row][cl] = s1; smf[1][row][cl] = s2;
-    __syncthreads();
-    if (row == 0 && c < C) {
-        s1 = smf[0][0][cl] + smf[0][1][cl] + smf[0][2][cl] + smf[0][3][cl];
-        s2 = smf[1][0][cl] + smf[1][1][cl] + smf[1][2][cl] + smf[1][3][cl];
-        if (f.dgamma) { f.dgamma[c] = f.accumulate ? f.dgamma[c] + (float)s2 : (float)s2; f.dbeta[c] = f.accumulate ? f.dbeta[c] + (float)s1 : (float)s1; }
-        f.coef[c] = gamma[c] * invstd[c];
-        f.coef[C + c] = (float)(s1 / f.M);
-        f.coef[2 * C + c] = (float)(s2 / f.M);
-    }
-    __syncthreads();
-}
-
 template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(salt_view da, salt_view a, salt_view y, int relu,
                                                             const float* mean, const float* invstd, const float* gamma, const float* beta,
-                                                            float* partials, int64_t pix_per_block, BnBwdFin fin) {
+                                                            float* partials, int64_t pix_per_block) {
     constexpr int N = Unit<T, VEC>::N;
     extern __shared__ float sm[];
     const int C = y.C, cpv = C / N;
@@ -212,27 +157,32 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(salt_view da, salt_v
                 mu[j] = mean[c0 + j]; is[j] = invstd[c0 + j];
                 sc[j] = gamma[c0 + j] * is[j]; sh[j] = beta[c0 + j] - mu[j] * sc[j];
             }
-            for (int64_t pix = p0 + row; pix < p1; pix += R) {
-                float g[N], yy[N], msk[N];
-                Unit<T, VEC>::ld((const T*)da.p + pix * da.cs + c0, g);
-                Unit<T, VEC>::ld((const T*)y.p + pix * y.cs + c0, yy);
+            constexpr int U = 4;                               // U pixels in flight per thread: the loop is load-latency bound
+            for (int64_t pixb = p0 + row; pixb < p1; pixb += (int64_t)U * R) {
+                float g[U][N], yy[U][N], aa[U][N];
 #pragma unroll
-                for (int j = 0; j < N; ++j) msk[j] = 1.f;
-                if (relu) {
-                    if (mask_from_y) {
+                for (int u = 0; u < U; ++u) {
+                    const int64_t pix = pixb + (int64_t)u * R;
 #pragma unroll
-                        for (int j = 0; j < N; ++j) msk[j] = (yy[j] * sc[j] + sh[j] > 0.f) ? 1.f : 0.f;
+                    for (int j = 0; j < N; ++j) aa[u][j] = 0.f;
+                    if (pix < p1) {
+                        Unit<T, VEC>::ld((const T*)da.p + pix * da.cs + c0, g[u]);
+                        Unit<T, VEC>::ld((const T*)y.p + pix * y.cs + c0, yy[u]);
+                        if (relu && !mask_from_y) Unit<T, VEC>::ld((const T*)a.p + pix * a.cs + c0, aa[u]);
                     } else {
-                        float aa[N];
-                        Unit<T, VEC>::ld((const T*)a.p + pix * a.cs + c0, aa);
 #pragma unroll
-                        for (int j = 0; j < N; ++j) msk[j] = aa[j] > 0.f ? 1.f : 0.f;
+                        for (int j = 0; j < N; ++j) { g[u][j] = 0.f; yy[u][j] = mu[j]; }
                     }
                 }
 #pragma unroll
-                for (int j = 0; j < N; ++j) {
-                    const float gg = g[j] * msk[j];
-                    s1[j] += gg; s2[j] += gg * (yy[j] - mu[j]) * is[j];
+                for (int u = 0; u < U; ++u) {
+#pragma unroll
+                    for (int j = 0; j < N; ++j) {
+                        float m = 1.f;
+                        if (relu) m = mask_from_y ? ((yy[u][j] * sc[j] + sh[j] > 0.f) ? 1.f : 0.f) : (aa[u][j] > 0.f ? 1.f : 0.f);
+                        const float gg = g[u][j] * m;
+                        s1[j] += gg; s2[j] += gg * (yy[u][j] - mu[j]) * is[j];
+                    }
                 }
             }
         }
@@ -253,25 +203,35 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(salt_view da, salt_v
         }
         __syncthreads();
     }
-    if (!fin.counter) return;
-    if (!last_block_ticket(fin.counter, gridDim.x)) return;
-    for (int g = 0; g < (C + 63) / 64; ++g) bn_bwd_finalize_group(partials, gridDim.x, C, fin, gamma, invstd, g);
 }
 
-// 256 threads = 4 part-rows x 64 channels; rows take parts k = row, row+4, ... (fixed order), then combine.
+// 256 threads = ROWS part-rows x (256/ROWS) channels (see bn_finalize_kernel); rows take parts k = row, row+ROWS, ... in fixed order.
+template <int ROWS>
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* partials, int nparts, int C, double M, const float* gamma, const float* invstd,
                                        float* dgamma, float* dbeta, int accumulate, float* coef) {
-    __shared__ double sm[2][4][64];
-    const int cl = threadIdx.x & 63, row = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    constexpr int CPB = 256 / ROWS, U = 16;
+    __shared__ double sm[2][ROWS][CPB];
+    const int cl = threadIdx.x % CPB, row = threadIdx.x / CPB;
+    const int c = blockIdx.x * CPB + cl;
     double s1 = 0.0, s2 = 0.0;
-    if (c < C)
-        for (int k = row; k < nparts; k += 4) { s1 += (double)partials[((int64_t)k * 2) * C + c]; s2 += (double)partials[((int64_t)k * 2 + 1) * C + c]; }
+    for (int k0 = row; k0 < nparts; k0 += ROWS * U) {
+        float v1[U], v2[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = k0 + u * ROWS;
+            const bool ok = c < C && k < nparts;
+            v1[u] = ok ? partials[((int64_t)k * 2) * C + c] : 0.f;
+            v2[u] = ok ? partials[((int64_t)k * 2 + 1) * C + c] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { s1 += (double)v1[u]; s2 += (double)v2[u]; }
+    }
     sm[0][row][cl] = s1; sm[1][row][cl] = s2;
     __syncthreads();
     if (row != 0 || c >= C) return;
-    s1 = sm[0][0][cl] + sm[0][1][cl] + sm[0][2][cl] + sm[0][3][cl];
-    s2 = sm[1][0][cl] + sm[1][1][cl] + sm[1][2][cl] + sm[1][3][cl];
+    s1 = 0.0; s2 = 0.0;
+#pragma unroll 8
+    for (int r = 0; r < ROWS; ++r) { s1 += sm[0][r][cl]; s2 += sm[1][r][cl]; }
     if (dgamma) { dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2; dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1; }
     coef[c] = gamma[c] * invstd[c];
     coef[C + c] = (float)(s1 / M);
@@ -615,16 +575,17 @@ extern "C" int salt_affine_act(const salt_affine_act_args* a, void* stream) {
 }
 
 extern "C" int64_t salt_bn_stats_floats(int nparts, int C) {
-    return (int64_t)nparts * 2 * C + (int64_t)cdiv(nparts, BN_CHUNK) * 3 * C;
+    return (int64_t)nparts * 2 * C;
 }
 
 extern "C" int salt_bn_finalize(const salt_bn_finalize_args* a, void* stream) {
     if (!a || !a->stats || !a->stats_cnt || a->C < 1 || a->nparts < 1 || !a->gamma || !a->beta || !a->mean || !a->invstd || !a->scale || !a->shift)
         SALT_FAIL(SALT_E_BADARG, "bn_finalize: bad args");
-    const int nchunks = cdiv(a->nparts, BN_CHUNK);
-    hipLaunchKernelGGL(bn_chunk_kernel, dim3(nchunks, cdiv(a->C, 64)), dim3(256), 0, (hipStream_t)stream, *a);
-    SALT_CHECK_LAUNCH();
-    if (!a->counter) hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(a->C, 64)), dim3(256), 0, (hipStream_t)stream, *a);
+    const int rows = bn_rows_for(a->nparts);
+    hipStream_t st = (hipStream_t)stream;
+    if (rows == 4) hipLaunchKernelGGL(bn_finalize_kernel<4>, dim3(cdiv(a->C, 64)), dim3(256), 0, st, *a);
+    else if (rows == 16) hipLaunchKernelGGL(bn_finalize_kernel<16>, dim3(cdiv(a->C, 16)), dim3(256), 0, st, *a);
+    else hipLaunchKernelGGL(bn_finalize_kernel<64>, dim3(cdiv(a->C, 4)), dim3(256), 0, st, *a);
     SALT_CHECK_LAUNCH();
     return SALT_OK;
 }
@@ -638,7 +599,7 @@ extern "C" int salt_bn_fold(const salt_bn_fold_args* a, void* stream) {
 
 static int bn_bwd_nparts(const salt_bn_bwd_args* a, int64_t* ppb) {
     const int64_t npix = view_pixels(a->y);
-    int64_t parts = (npix + 255) / 256;
+    int64_t parts = (npix + 31) / 32;                       // >= 32 pixels per block (small maps need the blocks), <= 512 blocks
     if (parts > 512) parts = 512;
     if (parts < 1) parts = 1;
     const int64_t per = (npix + parts - 1) / parts;
@@ -670,13 +631,15 @@ extern "C" int salt_bn_bwd(const salt_bn_bwd_args* a, void* stream) {
         const int cpv = C / N;
         const int cvn = cpv < 256 ? cpv : 256;
         const size_t lds = (size_t)(256 / cvn) * cvn * N * 2 * sizeof(float);
-        BnBwdFin fin{a->counter, (double)view_pixels(a->y), a->dgamma, a->dbeta, a->accumulate_param_grads, a->coef};
-        if (v) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), dim3(nparts), dim3(256), lds, st, a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->gamma, a->beta, a->partials, per, fin);
-        else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), dim3(nparts), dim3(256), lds, st, a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->gamma, a->beta, a->partials, per, fin);
+        if (v) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), dim3(nparts), dim3(256), lds, st, a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->gamma, a->beta, a->partials, per);
+        else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), dim3(nparts), dim3(256), lds, st, a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->gamma, a->beta, a->partials, per);
         SALT_CHECK_LAUNCH();
-        if (!a->counter) {
-            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(256), 0, st, a->partials, nparts, C, (double)view_pixels(a->y),
-                               a->gamma, a->invstd, a->dgamma, a->dbeta, a->accumulate_param_grads, a->coef);
+        {
+            const int rows = bn_rows_for(nparts);
+            const double M = (double)view_pixels(a->y);
+            if (rows == 4) hipLaunchKernelGGL(bn_bwd_finalize_kernel<4>, dim3(cdiv(C, 64)), dim3(256), 0, st, a->partials, nparts, C, M, a->gamma, a->invstd, a->dgamma, a->dbeta, a->accumulate_param_grads, a->coef);
+            else if (rows == 16) hipLaunchKernelGGL(bn_bwd_finalize_kernel<16>, dim3(cdiv(C, 16)), dim3(256), 0, st, a->partials, nparts, C, M, a->gamma, a->invstd, a->dgamma, a->dbeta, a->accumulate_param_grads, a->coef);
+            else hipLaunchKernelGGL(bn_bwd_finalize_kernel<64>, dim3(cdiv(C, 4)), dim3(256), 0, st, a->partials, nparts, C, M, a->gamma, a->invstd, a->dgamma, a->dbeta, a->accumulate_param_grads, a->coef);
             SALT_CHECK_LAUNCH();
         }
         const int64_t units = view_pixels(a->y) * cpv;

@@ -228,8 +228,6 @@ class Graph:
         self.bytes = 0
         self._touched = []
         self.grad_ready = []
-        # last-block tickets of the fused BN finalize kernels: [0] forward, [1] backward (each program is serial on its stream)
-        self.tickets = self.alloc((4,), torch.int32)
 
     # ------------------------------------------------------------------ memory
     def alloc(self, shape, dtype, zero=True):
@@ -305,7 +303,7 @@ class Graph:
         self.fwd.add('bn_finalize', stats=stats, stats_cnt=cnt, nparts=nparts, C=bn.num_features, gamma=bn.weight.data_ptr(),
                      beta=bn.bias.data_ptr(), running_mean=bn.running_mean.data_ptr(), running_var=bn.running_var.data_ptr(),
                      num_batches_tracked=nbt, momentum=bn.momentum, eps=bn.eps, mean=w['mean'].data_ptr(), invstd=w['invstd'].data_ptr(),
-                     scale=w['scale'].data_ptr(), shift=w['shift'].data_ptr(), counter=self.tickets[0:].data_ptr())
+                     scale=w['scale'].data_ptr(), shift=w['shift'].data_ptr())
         self.fwd.add('affine_act', dtype=self.dt, y=y.view(), scale=w['scale'].data_ptr(), shift=w['shift'].data_ptr(),
                      res=res.view() if res is not None else null_view(), relu=int(relu), a=out.view())
         return w
@@ -329,7 +327,7 @@ class Graph:
         self.bwd.add('bn_bwd', dtype=self.dt, da=out.gview(), a=out.view() if (relu and res is not None) else null_view(), y=y.view(), relu=int(relu),
                      mean=w['mean'].data_ptr(), invstd=w['invstd'].data_ptr(), gamma=bn.weight.data_ptr(), beta=bn.bias.data_ptr(),
                      partials=Scratch('bn_bwd', nparts * 2 * C * 4), nparts=nparts, dgamma=gw, dbeta=gb, accumulate_param_grads=0,
-                     coef=coef.data_ptr(), dy=y.gview(), dres=dres, accumulate_dres=acc_res, counter=self.tickets[1:].data_ptr())
+                     coef=coef.data_ptr(), dy=y.gview(), dres=dres, accumulate_dres=acc_res)
 
     # ------------------------------------------------------------------ dense convolution (+BN +ReLU +residual)
     def conv(self, x, conv, bn=None, relu=False, res=None, out=None, replicate=False, name=''):
