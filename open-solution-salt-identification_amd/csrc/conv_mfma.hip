@@ -17,6 +17,7 @@
 //   (exact f32, bitwise an fmaf chain) with the k-slots permuted so both operands are 16-byte LDS reads.
 // Epilogue: bias, optional folded-BN affine + ReLU (eval), optional accumulate, and deterministic
 // per-wave BatchNorm partial statistics (sum, M2) for train mode.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -775,7 +776,12 @@ int wgrad_plan(const salt_conv_wgrad_args* a, WgradKP* k, int* nsplit_out) {
     k->tiles_y = cdiv(a->p.H, th); k->tiles_x = cdiv(a->p.W, tw);
     k->ntiles = cdiv(a->p.B, k->nb) * k->tiles_y * k->tiles_x;
     k->a_blocks = cdiv(a->p.C, 64); k->b_blocks = cdiv(a->q.C, 64);
-    int ns = 512 / (k->a_blocks * k->b_blocks);      // ~2 workgroups per CU; every split costs a partial slab
+    // every split costs a partial slab (written here, read again by the reduce): bound the workgroup count and give each
+    // workgroup enough pixel tiles to amortise its slab
+    static const int target_wgs = getenv("SALT_WGRAD_WGS") ? atoi(getenv("SALT_WGRAD_WGS")) : 512;
+    static const int min_tiles = getenv("SALT_WGRAD_TPW") ? atoi(getenv("SALT_WGRAD_TPW")) : 8;
+    int ns = target_wgs / (k->a_blocks * k->b_blocks);
+    if (ns > k->ntiles / min_tiles) ns = k->ntiles / min_tiles;
     if (ns < 1) ns = 1;
     if (ns > k->ntiles) ns = k->ntiles;
     *nsplit_out = ns;

@@ -95,7 +95,9 @@ class Engine:
         self._packed_version = -1
         self._folded_version = None
         self.world = 1
-        self.side_stream = torch.cuda.Stream(device=device)     # weight-gradient kernels overlap the data-gradient chain
+        import os
+        # weight-gradient kernels overlap the data-gradient chain
+        self.side_stream = torch.cuda.Stream(device=device, priority=int(os.environ.get('SALT_SIDE_PRIO', '0')))
 
     # ------------------------------------------------------------------ flat parameter storage
     def _flatten(self):
