@@ -600,69 +600,85 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradKP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    // piece q of the P tile / Q halo tile of `tile` (zero outside the grid / channel range)
-    auto fetchP = [&](int tile, int q) -> u32x4 {
-        int tt = tile;
-        const int txi = tt % p.tiles_x; tt /= p.tiles_x;
-        const int tyi = tt % p.tiles_y;
-        const int tbi = tt / p.tiles_y;
-        const int m = q / PPR, pc = q - m * PPR;
+    // ---- tile walk without divisions: tile = (tbi, tyi, txi), advanced by nsplit with carries
+    struct TileC { int tbi, tyi, txi; };
+    auto decode = [&](int tile) { TileC c; c.txi = tile % p.tiles_x; const int tt = tile / p.tiles_x; c.tyi = tt % p.tiles_y; c.tbi = tt / p.tiles_y; return c; };
+    const TileC tstep = decode(p.nsplit);
+    auto advance = [&](TileC& c) {
+        c.txi += tstep.txi; if (c.txi >= p.tiles_x) { c.txi -= p.tiles_x; ++c.tyi; }
+        c.tyi += tstep.tyi; if (c.tyi >= p.tiles_y) { c.tyi -= p.tiles_y; ++c.tbi; }
+        c.tbi += tstep.tbi;
+    };
+    // ---- tile-invariant piece descriptors.  Piece q = tid + 256 k covers 16 bytes of pixel row q / PPR; 256 % PPR == 0, so the
+    // channel piece (tid % PPR) is the same for every k and only the pixel coordinates (packed bl:ty:tx / bl:hy:hx) differ.
+    const int pcx = tid % PPR;
+    const int chP = a0 + pcx * VE, chQ = c0 + pcx * VE;
+    const int np = BMP * PPR, nq = phalo * PPR;
+    auto descP = [&](int q) -> unsigned {
+        if (q >= np || chP >= p.Ca) return 0xffffffffu;
+        const int m = q / PPR;
         const int tx = m & ((1 << p.tw_log2) - 1);
         const int ty = (m >> p.tw_log2) & ((1 << p.th_log2) - 1);
         const int bl = m >> (p.tw_log2 + p.th_log2);
-        const int oy = (tyi << p.th_log2) + ty, ox = (txi << p.tw_log2) + tx, b = tbi * p.nb + bl;
-        const int ch0 = a0 + pc * VE;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (b < p.B && oy < p.PH && ox < p.PW && ch0 < p.Ca)
-            v = load_piece<T>(Pg, (((int64_t)b * p.PH + oy) * p.PW + ox) * p.p_cs + ch0, ch0, p.Ca, p_vec);
-        return v;
+        return (unsigned)((bl << 16) | (ty << 8) | tx);
     };
-    auto fetchQ = [&](int tile, int q) -> u32x4 {
-        int tt = tile;
-        const int txi = tt % p.tiles_x; tt /= p.tiles_x;
-        const int tyi = tt % p.tiles_y;
-        const int tbi = tt / p.tiles_y;
-        const int iy0 = (tyi << p.th_log2) * p.q_step + p.min_dy, ix0 = (txi << p.tw_log2) * p.q_step + p.min_dx;
-        const int pix = q / PPR, pc = q - pix * PPR;
+    auto descQ = [&](int q) -> unsigned {
+        if (q >= nq || chQ >= p.Cb) return 0xffffffffu;
+        const int pix = q / PPR;
         const int bl = pix / hhw;
         const int r = pix - bl * hhw;
         const int hy = r / p.hw, hx = r - hy * p.hw;
-        int iy = iy0 + hy, ix = ix0 + hx;
-        const int b = tbi * p.nb + bl;
+        return (unsigned)((bl << 16) | (hy << 8) | hx);
+    };
+    auto fetchP = [&](const TileC& c, unsigned d) -> u32x4 {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (d == 0xffffffffu) return v;
+        const int oy = (c.tyi << p.th_log2) + (int)((d >> 8) & 255u), ox = (c.txi << p.tw_log2) + (int)(d & 255u), b = c.tbi * p.nb + (int)(d >> 16);
+        if (b < p.B && oy < p.PH && ox < p.PW)
+            v = load_piece<T>(Pg, (((int64_t)b * p.PH + oy) * p.PW + ox) * p.p_cs + chP, chP, p.Ca, p_vec);
+        return v;
+    };
+    auto fetchQ = [&](const TileC& c, unsigned d) -> u32x4 {
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (d == 0xffffffffu) return v;
+        int iy = (c.tyi << p.th_log2) * p.q_step + p.min_dy + (int)((d >> 8) & 255u);
+        int ix = (c.txi << p.tw_log2) * p.q_step + p.min_dx + (int)(d & 255u);
+        const int b = c.tbi * p.nb + (int)(d >> 16);
         bool valid = b < p.B;
         if (p.pad_mode) { iy = min(max(iy, 0), p.QH - 1); ix = min(max(ix, 0), p.QW - 1); }
         else valid = valid && iy >= 0 && iy < p.QH && ix >= 0 && ix < p.QW;
-        const int ch0 = c0 + pc * VE;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (valid && ch0 < p.Cb)
-            v = load_piece<T>(Qg, (((int64_t)b * p.QH + iy) * p.QW + ix) * p.q_cs + ch0, ch0, p.Cb, q_vec);
+        if (valid) v = load_piece<T>(Qg, (((int64_t)b * p.QH + iy) * p.QW + ix) * p.q_cs + chQ, chQ, p.Cb, q_vec);
         return v;
     };
-    auto lds_p = [&](int q) -> u32x4* { const int m = q / PPR; return reinterpret_cast<u32x4*>(sP + m * ROWB + (q - m * PPR) * 16); };
-    auto lds_q = [&](int q) -> u32x4* { const int m = q / PPR; return reinterpret_cast<u32x4*>(sQ + m * ROWB + (q - m * PPR) * 16); };
+    auto lds_p = [&](int q) -> u32x4* { return reinterpret_cast<u32x4*>(sP + (q / PPR) * ROWB + pcx * 16); };
+    auto lds_q = [&](int q) -> u32x4* { return reinterpret_cast<u32x4*>(sQ + (q / PPR) * ROWB + pcx * 16); };
+
+    int tob[NT];                                                // tap offsets in LDS bytes (uniform)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) tob[t] = p.tap_off[t] * ROWB;  // the plan repeats tap 0 in the slots ntaps..NT-1 (never stored)
 
     auto compute_tile = [&]() {
         if constexpr (sizeof(T) == 4) {
             // f32: v_mfma_f32_32x32x2_f32, A[i=a][k=pixel], B[k=pixel][j=b]; one dword per lane per operand.
             const int khalf = lane >> 5, l31 = lane & 31;
+            const int aoff = (wa * 32 + l31) * 4, boff = (wb * 32 + l31) * 4;
             for (int k0 = 0; k0 < BMP; k0 += 2) {
                 const int m = k0 + khalf;
                 const int tx = m & ((1 << p.tw_log2) - 1);
                 const int ty = (m >> p.tw_log2) & ((1 << p.th_log2) - 1);
                 const int bl = m >> (p.tw_log2 + p.th_log2);
-                const int qpix = bl * hhw + ty * p.q_step * p.hw + tx * p.q_step;
-                const float av = *reinterpret_cast<const float*>(sP + m * ROWB + (wa * 32 + l31) * 4);
+                const int qb = (bl * hhw + ty * p.q_step * p.hw + tx * p.q_step) * ROWB + boff;
+                const float av = *reinterpret_cast<const float*>(sP + m * ROWB + aoff);
+                float bv[NT];
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    if (t < p.ntaps) {
-                        const float bv = *reinterpret_cast<const float*>(sQ + (qpix + p.tap_off[t]) * ROWB + (wb * 32 + l31) * 4);
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
-                    }
-                }
+                for (int t = 0; t < NT; ++t) bv[t] = *reinterpret_cast<const float*>(sQ + qb + tob[t]);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[t], 0, 0, 0);
             }
         } else {
             // bf16: v_mfma_f32_32x32x16_bf16 needs 8 k(=pixel)-consecutive values per lane while LDS rows are
             // channel-contiguous: ds_read_b64_tr_b16 transposes a [4 pixel][16 channel] block per 16-lane group.
+            // All 2 + 2 NT transposed reads of a k-step are issued before the first MFMA (no control flow in between).
             typedef short s16x4 __attribute__((ext_vector_type(4)));
             typedef short s16x8 __attribute__((ext_vector_type(8)));
             typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
@@ -674,43 +690,50 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradKP p) {
             const int acol = (wa * 32 + g16 * 16 + pcol) * 2;
             const int bcol = (wb * 32 + g16 * 16 + pcol) * 2;
             for (int k0 = 0; k0 < BMP; k0 += 16) {
-                int mq[2], qpix[2];
+                int pa[2], qb[2];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const int m = k0 + khalf * 8 + h * 4 + prow;
-                    mq[h] = m;
                     const int tx = m & ((1 << p.tw_log2) - 1);
                     const int ty = (m >> p.tw_log2) & ((1 << p.th_log2) - 1);
                     const int bl = m >> (p.tw_log2 + p.th_log2);
-                    qpix[h] = bl * hhw + ty * p.q_step * p.hw + tx * p.q_step;
+                    pa[h] = m * ROWB + acol;
+                    qb[h] = (bl * hhw + ty * p.q_step * p.hw + tx * p.q_step) * ROWB + bcol;
                 }
-                s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sP + mq[0] * ROWB + acol));
-                s16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sP + mq[1] * ROWB + acol));
-                s16x8 av = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+                const s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sP + pa[0]));
+                const s16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sP + pa[1]));
+                s16x4 blo[NT], bhi[NT];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    if (t < p.ntaps) {
-                        s16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sQ + (qpix[0] + p.tap_off[t]) * ROWB + bcol));
-                        s16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sQ + (qpix[1] + p.tap_off[t]) * ROWB + bcol));
-                        s16x8 bv = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc[t], 0, 0, 0);
-                    }
+                    blo[t] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sQ + qb[0] + tob[t]));
+                    bhi[t] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sQ + qb[1] + tob[t]));
+                }
+                const s16x8 av = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const s16x8 bv = {blo[t][0], blo[t][1], blo[t][2], blo[t][3], bhi[t][0], bhi[t][1], bhi[t][2], bhi[t][3]};
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), acc[t], 0, 0, 0);
                 }
             }
         }
     };
 
-    const int np = BMP * PPR, nq = phalo * PPR;
     if (PIPE && nq <= MAXQ * 256) {
         // software pipeline: next tile's global loads fly while the matrix cores work on the current one
+        unsigned dp[MAXP], dq[MAXQ];
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) dp[k] = descP(tid + (k << 8));
+#pragma unroll
+        for (int k = 0; k < MAXQ; ++k) dq[k] = descQ(tid + (k << 8));
         u32x4 rp[MAXP], rq[MAXQ];
-        auto load_tile = [&](int tile) {
+        auto load_tile = [&](const TileC& c) {
 #pragma unroll
-            for (int k = 0; k < MAXP; ++k) { const int q = tid + (k << 8); rp[k] = q < np ? fetchP(tile, q) : u32x4{0u, 0u, 0u, 0u}; }
+            for (int k = 0; k < MAXP; ++k) rp[k] = fetchP(c, dp[k]);
 #pragma unroll
-            for (int k = 0; k < MAXQ; ++k) { const int q = tid + (k << 8); rq[k] = q < nq ? fetchQ(tile, q) : u32x4{0u, 0u, 0u, 0u}; }
+            for (int k = 0; k < MAXQ; ++k) rq[k] = fetchQ(c, dq[k]);
         };
-        if (split < p.ntiles) load_tile(split);
+        TileC cur = decode(split);
+        if (split < p.ntiles) load_tile(cur);
         for (int tile = split; tile < p.ntiles; tile += p.nsplit) {
             __syncthreads();
 #pragma unroll
@@ -718,16 +741,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradKP p) {
 #pragma unroll
             for (int k = 0; k < MAXQ; ++k) { const int q = tid + (k << 8); if (q < nq) *lds_q(q) = rq[k]; }
             __syncthreads();
-            if (tile + p.nsplit < p.ntiles) load_tile(tile + p.nsplit);
+            advance(cur);
+            if (tile + p.nsplit < p.ntiles) load_tile(cur);
             compute_tile();
         }
     } else {
+        TileC cur = decode(split);
         for (int tile = split; tile < p.ntiles; tile += p.nsplit) {
             __syncthreads();
-            for (int q = tid; q < np; q += 256) *lds_p(q) = fetchP(tile, q);
-            for (int q = tid; q < nq; q += 256) *lds_q(q) = fetchQ(tile, q);
+            for (int q = tid; q < np; q += 256) *lds_p(q) = fetchP(cur, descP(q));
+            for (int q = tid; q < nq; q += 256) *lds_q(q) = fetchQ(cur, descQ(q));
             __syncthreads();
             compute_tile();
+            advance(cur);
         }
     }
     // write the partial slab: partials[split][t][a][b]
@@ -773,6 +799,7 @@ int wgrad_plan(const salt_conv_wgrad_args* a, WgradKP* k, int* nsplit_out) {
     k->QH = a->q.H; k->QW = a->q.W; k->Cb = a->q.C; k->q_cs = a->q.cs;
     k->ntaps = a->ntaps; k->q_step = a->q_step; k->pad_mode = a->pad_mode; k->min_dy = min_dy; k->min_dx = min_dx;
     for (int t = 0; t < a->ntaps; ++t) k->tap_off[t] = (a->tap_dy[t] - min_dy) * k->hw + (a->tap_dx[t] - min_dx);
+    for (int t = a->ntaps; t < SALT_MAX_TAPS; ++t) k->tap_off[t] = k->tap_off[0];      // padding slots of the NT-tap kernel instance
     k->tiles_y = cdiv(a->p.H, th); k->tiles_x = cdiv(a->p.W, tw);
     k->ntiles = cdiv(a->p.B, k->nb) * k->tiles_y * k->tiles_x;
     k->a_blocks = cdiv(a->p.C, 64); k->b_blocks = cdiv(a->q.C, 64);
