@@ -69,7 +69,8 @@ __device__ __forceinline__ int swz_addr(int row, int slot) {        // 64-byte r
     return row * 64 + (((slot ^ (row >> 2)) & 3) << 4);
 }
 
-constexpr int MAXA = 9;     // halo pieces per thread: P_halo*4 <= 9*256
+constexpr int MAXA = 9;     // halo pieces per thread: P_halo*4 <= 9*256 (6*256 for the 256-pixel tile: keeps its prefetch registers in budget)
+constexpr int maxa_for(int bm) { return bm >= 256 ? 6 : MAXA; }
 
 // NT > 0: tap count known at compile time (9 for every 3x3): the tap loop is fully unrolled so the compiler keeps the tap
 // offsets in SGPRs, folds the weight-row offsets into ds_read immediates and hoists the next taps' fragment reads above the
@@ -99,8 +100,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
     const T* wg = reinterpret_cast<const T*>(p.w);
     const bool x_vec = ((p.x_cs % VE) == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
 
-    // ---- per-thread halo staging pieces (fixed for the whole chunk loop)
-    int64_t a_goff[MAXA];
+    // ---- per-thread halo staging pieces (fixed for the whole chunk loop); offsets are relative to image b0 (fit 32 bits)
+    constexpr int MAXA = maxa_for(32 * MI * WM);
+    const T* xg0 = xg + (int64_t)b0 * p.H * p.W * p.x_cs;
+    int a_goff[MAXA];
     const int npa = (phalo * 4 + 255) >> 8;
 #pragma unroll
     for (int k = 0; k < MAXA; ++k) {
@@ -114,15 +117,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
                 const int hy = r / p.hw;
                 const int hx = r - hy * p.hw;
                 int iy = iy0 + hy, ix = ix0 + hx;
-                const int b = b0 + bl;
-                bool valid = b < p.B;
+                bool valid = b0 + bl < p.B;
                 if (p.pad_mode) {
                     iy = min(max(iy, 0), p.H - 1);
                     ix = min(max(ix, 0), p.W - 1);
                 } else {
                     valid = valid && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
                 }
-                a_goff[k] = valid ? (((int64_t)b * p.H + iy) * p.W + ix) * p.x_cs + (q & 3) * VE : -1;
+                a_goff[k] = valid ? ((bl * p.H + iy) * p.W + ix) * p.x_cs + (q & 3) * VE : -1;
             }
         }
     }
@@ -179,10 +181,39 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
 #pragma unroll
             for (int j = 0; j < NI; ++j) Mma<T>::step(a1[i], b1[j], acc[i][j]);
     };
+    // NT > 0: fragment software pipeline over the 2 NT (tap, k-step) stages - the LDS reads of stage s+1 are issued before the
+    // MFMAs of stage s, and sched_group_barrier pins that interleave (the default schedule sinks every read to its first use,
+    // which exposes the full LDS latency to a wave that has only one partner on its SIMD).
+    struct Frag { u32x4 a[MI], b[NI]; };
+    auto load_frag = [&](int s, Frag& f) {
+        const int t = s >> 1, hx = (s & 1) << 5;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) f.a[i] = *reinterpret_cast<const u32x4*>(sA + (swz_addr(pbase[i] + p.tap_off[t], khalf) ^ hx));
+#pragma unroll
+        for (int j = 0; j < NI; ++j) f.b[j] = *reinterpret_cast<const u32x4*>(sB + t * (BN * 64) + (b_addr[j] ^ hx));
+    };
+    auto mma_frag = [&](const Frag& f) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) Mma<T>::step(f.a[i], f.b[j], acc[i][j]);
+    };
     auto compute_chunk = [&]() {
         if constexpr (NT > 0) {
+            Frag f0, f1;
+            load_frag(0, f0);
+            __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);         // stage 0 reads (prologue)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) tap_mma(t, p.tap_off[t]);
+            for (int s = 0; s < 2 * NT; s += 2) {
+                load_frag(s + 1, f1);
+                mma_frag(f0);
+                __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);     // DS reads of stage s+1 ...
+                __builtin_amdgcn_sched_group_barrier(0x008, MI * NI, 0);     // ... then the MFMAs of stage s
+                if (s + 2 < 2 * NT) load_frag(s + 2, f0);
+                mma_frag(f1);
+                if (s + 2 < 2 * NT) __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, MI * NI, 0);
+            }
         } else {
             for (int t = 0; t < p.ntaps; ++t) tap_mma(t, p.tap_off[t]);
         }
@@ -200,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
                 ra[k] = u32x4{0u, 0u, 0u, 0u};
                 if (k < npa && a_goff[k] >= 0) {
                     const int ch0 = ch_base + (tid & 3) * VE;
-                    if (ch0 < p.Cin) ra[k] = load_piece<T>(xg, a_goff[k] + ch_base, ch0, p.Cin, x_vec);
+                    if (ch0 < p.Cin) ra[k] = load_piece<T>(xg0, a_goff[k] + ch_base, ch0, p.Cin, x_vec);
                 }
             }
 #pragma unroll
@@ -240,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
                     const int q = tid + (k << 8);
                     u32x4 v = {0u, 0u, 0u, 0u};
                     const int ch0 = ch_base + (q & 3) * VE;
-                    if (a_goff[k] >= 0 && ch0 < p.Cin) v = load_piece<T>(xg, a_goff[k] + ch_base, ch0, p.Cin, x_vec);
+                    if (a_goff[k] >= 0 && ch0 < p.Cin) v = load_piece<T>(xg0, a_goff[k] + ch_base, ch0, p.Cin, x_vec);
                     *reinterpret_cast<u32x4*>(sA + swz_addr(q >> 2, q & 3)) = v;
                 }
             }
@@ -432,7 +463,7 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
         k.hh = (th - 1) * a->in_step + (max_dy - min_dy) + 1;
         k.hw = (tw - 1) * a->in_step + (max_dx - min_dx) + 1;
         const int phalo = k.nb * k.hh * k.hw;
-        if (phalo * 4 > MAXA * 256) {
+        if (phalo * 4 > maxa_for(BM) * 256) {
             if (attempt == 0 && cfg->id != 5) { for (const auto& c : kCfgs) if (c.id == 5) cfg = &c; continue; }
             SALT_FAIL(SALT_E_UNSUPPORTED, "conv: halo tile of %d pixels too large", phalo);
         }
