@@ -113,6 +113,63 @@ def op_flops(name, s):
     return 0.0
 
 
+CPU_LEG_THREADS = 16        # a fixed, modest thread count: GPU boxes advertise 256 logical CPUs but oversubscribing them makes
+CPU_LEG_BATCH = 8           # the torch CPU kernels orders of magnitude slower; the sample is 1 warm-up + 3 timed steps of batch 8
+CPU_LEG_TIMEOUT_S = 150
+
+
+def cpu_baseline_leg(arch_name, loss_name, channels):
+    """Child process: time the oracle (oracle/, plain PyTorch CPU fp32) on a bounded sample of the same workload."""
+    torch.set_num_threads(CPU_LEG_THREADS)
+    from oracle import nets as ON, specs as OS, losses as OL
+    spec = OS.SPECS[arch_name]() if arch_name != 'VanillaUNet' else OS.spec_vanilla_unet()
+    sd = OS.init_state(spec, seed=0)
+    keys = OS.trainable_keys(spec)
+    for k in keys:
+        sd[k].requires_grad_(True)
+    params = [sd[k] for k in keys]
+    m_ = [torch.zeros_like(p) for p in params]
+    v_ = [torch.zeros_like(p) for p in params]
+    cb = CPU_LEG_BATCH
+    img, msk = synth_tiles(cb, seed=1234)
+    xc, tc = preprocess(img, msk, True, channels)
+    times = []
+    t_start = time.perf_counter()
+    for it in range(4):
+        t1 = time.perf_counter()
+        for p in params:
+            p.grad = None
+        o = ON.FORWARDS[arch_name](sd, xc, True)
+        l = OL.LOSSES[loss_name](o, tc)
+        l.backward()
+        with torch.no_grad():
+            OL.adam_l2_step([p.data for p in params], [p.grad for p in params], m_, v_, it + 1)
+        times.append(time.perf_counter() - t1)
+        if time.perf_counter() - t_start > 60 and len(times) >= 2:
+            break
+    timed = times[1:]
+    med = float(np.median(timed))
+    print(json.dumps({'value': round(cb / med, 2), 'unit': 'images/s', 'cores': CPU_LEG_THREADS, 'kind': 'port',
+                      'sample': 'oracle (plain PyTorch CPU fp32, %d threads) same network/loss/optimizer, batch %d, median of %d steps after 1 warm-up'
+                                % (torch.get_num_threads(), cb, len(timed))}))
+
+
+def cpu_baseline_subprocess(args, arch_name):
+    """Run the CPU leg in a child with a hard time limit so that the default bench run always finishes in minutes."""
+    import subprocess
+    env = dict(os.environ, OMP_NUM_THREADS=str(CPU_LEG_THREADS), MKL_NUM_THREADS=str(CPU_LEG_THREADS))
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-leg', arch_name, '--loss', args.loss]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=CPU_LEG_TIMEOUT_S)
+        line = [x for x in r.stdout.splitlines() if x.startswith('{')]
+        if r.returncode == 0 and line:
+            return json.loads(line[-1])
+        note = 'cpu leg failed: ' + (r.stderr.strip().splitlines() or ['?'])[-1][:200]
+    except subprocess.TimeoutExpired:
+        note = 'cpu leg exceeded %d s' % CPU_LEG_TIMEOUT_S
+    return {'value': None, 'unit': 'images/s', 'cores': CPU_LEG_THREADS, 'kind': 'port', 'sample': note}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -124,7 +181,11 @@ def main():
     ap.add_argument('--loss', default='lovasz', choices=['lovasz', 'bce_dice'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-iou', action='store_true')
+    ap.add_argument('--cpu-leg', default=None, help=argparse.SUPPRESS)       # child mode of the cpu_baseline leg
     args = ap.parse_args()
+    if args.cpu_leg:
+        cpu_baseline_leg(args.cpu_leg, args.loss, 1 if args.cpu_leg == 'VanillaUNet' else 3)
+        return
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -254,33 +315,7 @@ def main():
 
     # ------------------------------------------------------------------ CPU baseline: the oracle on the host cores (bounded sample)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import nets as ON, specs as OS, losses as OL
-        torch.set_num_threads(os.cpu_count())
-        spec = OS.SPECS[arch_name]() if arch_name != 'VanillaUNet' else OS.spec_vanilla_unet()
-        sd = OS.init_state(spec, seed=0)
-        keys = OS.trainable_keys(spec)
-        for k in keys:
-            sd[k].requires_grad_(True)
-        params = [sd[k] for k in keys]
-        m_ = [torch.zeros_like(p) for p in params]
-        v_ = [torch.zeros_like(p) for p in params]
-        cb = 8
-        xc, tc = batches[0][0][:cb].cpu().float(), batches[0][1][:cb].cpu().float()
-        times = []
-        for it in range(4):
-            t1 = time.perf_counter()
-            for p in params:
-                p.grad = None
-            o = ON.FORWARDS[arch_name](sd, xc, True)
-            l = OL.LOSSES[args.loss](o, tc)
-            l.backward()
-            with torch.no_grad():
-                OL.adam_l2_step([p.data for p in params], [p.grad for p in params], m_, v_, it + 1)
-            times.append(time.perf_counter() - t1)
-        med = float(np.median(times[1:]))
-        out['cpu_baseline'] = {'value': round(cb / med, 2), 'unit': 'images/s', 'cores': os.cpu_count(), 'kind': 'port',
-                               'sample': 'oracle (plain PyTorch CPU fp32, %d threads) same network/loss/optimizer, batch %d, median of 3 steps after 1 warm-up'
-                                         % (torch.get_num_threads(), cb)}
+        out['cpu_baseline'] = cpu_baseline_subprocess(args, arch_name)
     if rank == 0:
         print(json.dumps(out))
     if dist.is_initialized():
