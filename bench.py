@@ -113,6 +113,24 @@ def op_flops(name, s):
     return 0.0
 
 
+def op_bytes(name, s, es):
+    """Algorithmic HBM bytes of one convolution launch: input pixels once, packed weights once, output once (twice when accumulating)."""
+    if name == 'conv':
+        return es * (s.x.B * s.x.H * s.x.W * s.x.C + s.ntaps * s.x.C * s.y.C + s.x.B * s.OH * s.OW * s.y.C * (2 if s.accumulate else 1))
+    return 0.0
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json; tools/pmc_traffic.sh
+    regenerates it - PMC counters cannot be read from inside the timed process).  None when the file is absent."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+    try:
+        k = json.load(open(path))['kernels'][kernel]
+        return round((k['read_MB_per_launch'] + k['write_MB_per_launch']) * 1e6)
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 CPU_LEG_THREADS = 16        # a fixed, modest thread count: GPU boxes advertise 256 logical CPUs but oversubscribing them makes
 CPU_LEG_BATCH = 8           # the torch CPU kernels orders of magnitude slower; the sample is 1 warm-up + 3 timed steps of batch 8
 CPU_LEG_TIMEOUT_S = 150
@@ -283,16 +301,23 @@ def main():
             for prog in (net.fwd, net.loss_program(args.loss, 1.0), net.bwd):
                 for name, s, ms in prog.run_timed():
                     kname = name
-                    g = groups.setdefault(kname, [0.0, 0.0, 0])
+                    g = groups.setdefault(kname, [0.0, 0.0, 0, 0.0])
                     g[0] += ms; g[1] += op_flops(name, s); g[2] += 1
+                    if len(g) == 3:
+                        g.append(0.0)
+                    g[3] += op_bytes(name, s, 2 if args.dtype == 'bf16' else 4)
         total_ms = sum(g[0] for g in groups.values()) / reps
         dom = max(groups.items(), key=lambda kv: kv[1][0])
-        dn, (dms, dfl, dcnt) = dom
+        dn, (dms, dfl, dcnt, dby) = dom
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         ach = dfl / (dms * 1e-3) / 1e12 if dms > 0 else 0.0
         kern = {'conv': 'conv_mfma_kernel (fwd + dgrad launches)', 'conv_wgrad': 'conv_wgrad_kernel'}.get(dn, dn)
         out['roofline'] = {'kernel': kern, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                           'frac': round(ach / peak, 4), 'traffic': None, 'launches_per_step': dcnt // reps,
+                           'frac': round(ach / peak, 4),
+                           'traffic': pmc_traffic({'conv': 'conv_mfma_kernel', 'conv_wgrad': 'conv_wgrad_kernel'}.get(dn, dn)) if args.dtype == 'bf16' and args.workload == 'r34_hyper' and B == 32 else None,
+                           'traffic_unit': 'bytes per launch (rocprofv3 PMC FETCH_SIZE*2 + WRITE_SIZE, profiles/r01_pmc_traffic.json)',
+                           'algorithmic_bytes_per_launch': round(dby / dcnt) if dcnt else None,
+                           'launches_per_step': dcnt // reps,
                            'avg_launch_us': round(1e3 * dms / dcnt, 2), 'share_of_step': round(dms / reps / total_ms, 3),
                            'algorithmic_gflop_per_step': round(dfl / reps / 1e9, 2)}
         out['op_time_ms'] = {k: round(v[0] / reps, 3) for k, v in sorted(groups.items(), key=lambda kv: -kv[1][0])[:8]}
