@@ -8,6 +8,7 @@
 // pass does the label scan, the Jaccard gradient g_k, the dot with elu(errors) and the scatter of
 // d loss / d logit back to NCHW order.  Ties keep flat-index order (stable sort), so results are
 // deterministic; the loss value itself is tie-order invariant.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -162,6 +163,182 @@ __global__ __launch_bounds__(LT) void lovasz_kernel(salt_lovasz_args a) {
     }
 }
 
+// Prefetching variant (the one that is launched): same chunk order as lovasz_kernel (chunk c = elements c*1024 + tid, so the
+// result is identical), but
+//   * the (key, payload) pairs of the next group of 4 chunks are loaded while the current group is ranked and scattered (the
+//     ping-pong workspace is L2-resident; the per-chunk critical path becomes LDS-only), and
+//   * the digit histogram of pass p+1 is accumulated while pass p scatters (a histogram does not depend on element order),
+//     which removes the four separate counting sweeps.
+constexpr int LG = 4;                    // chunks per prefetch group
+__global__ __launch_bounds__(LT) void lovasz_pf_kernel(salt_lovasz_args a) {
+    __shared__ unsigned hist[2][256];
+    __shared__ unsigned base[256];
+    __shared__ unsigned wcount[LW][256];
+    __shared__ float red[LW];
+    __shared__ unsigned scan_w[LW];
+    __shared__ unsigned carry_s;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int P = a.P;
+    const float* z = a.logits + (int64_t)b * P;
+    const float* y = a.target + (int64_t)b * P;
+    unsigned* k0 = a.ws_keys + (int64_t)b * P;
+    unsigned* v0 = a.ws_vals + (int64_t)b * P;
+    unsigned* k1 = a.ws_keys + ((int64_t)a.B + b) * P;
+    unsigned* v1 = a.ws_vals + ((int64_t)a.B + b) * P;
+    const int nchunks = (P + LT - 1) / LT, ngroups = (nchunks + LG - 1) / LG;
+
+    // ---- keys + total positives + histogram of the first digit
+    if (tid < 256) { hist[0][tid] = 0; hist[1][tid] = 0; }
+    __syncthreads();
+    float gsum = 0.f;
+    for (int i = tid; i < P; i += LT) {
+        const float lab = y[i] > 0.5f ? 1.f : 0.f;              // target.long() of a {0.,1.} mask
+        const float e = 1.f - z[i] * (2.f * lab - 1.f);
+        const unsigned key = desc_key(e);
+        k0[i] = key;
+        v0[i] = ((unsigned)i << 1) | (lab > 0.5f ? 1u : 0u);
+        atomicAdd(&hist[0][key & 255u], 1u);
+        gsum += lab;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) gsum += __shfl_xor(gsum, o);
+    if (lane == 0) red[wave] = gsum;
+    __syncthreads();
+    float G = 0.f;
+    for (int w = 0; w < LW; ++w) G += red[w];
+    __syncthreads();
+
+    // ---- stable LSD radix sort, 8 bits per pass
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int pass = 0; pass < 4; ++pass) {
+        const unsigned* ki = (pass & 1) ? k1 : k0; const unsigned* vi = (pass & 1) ? v1 : v0;
+        unsigned* ko = (pass & 1) ? k0 : k1; unsigned* vo = (pass & 1) ? v0 : v1;
+        const int shift = pass * 8;
+        unsigned* hcur = hist[pass & 1];
+        unsigned* hnext = hist[(pass + 1) & 1];
+        unsigned ck[LG], cv[LG], nk[LG], nv[LG];
+#pragma unroll
+        for (int u = 0; u < LG; ++u) { const int i = u * LT + tid; ck[u] = i < P ? ki[i] : 0u; cv[u] = i < P ? vi[i] : 0u; }
+        if (tid < 64) {                                           // exclusive scan of 256 counters by one wave
+            unsigned c[4], s = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { c[j] = hcur[tid * 4 + j]; s += c[j]; }
+            unsigned incl = s;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+            unsigned run = incl - s;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { base[tid * 4 + j] = run; run += c[j]; }
+        }
+        __syncthreads();
+        if (tid < 256) hcur[tid] = 0;                             // becomes the histogram of pass+2 (written from pass+1 on)
+        for (int g = 0; g < ngroups; ++g) {
+            const int cn = (g + 1) * LG;
+#pragma unroll
+            for (int u = 0; u < LG; ++u) { const int i = (cn + u) * LT + tid; nk[u] = i < P ? ki[i] : 0u; nv[u] = i < P ? vi[i] : 0u; }
+#pragma unroll
+            for (int u = 0; u < LG; ++u) {
+                const int c0 = (g * LG + u) * LT;
+                if (c0 >= P) break;                               // uniform
+                for (int i = tid; i < LW * 256; i += LT) (&wcount[0][0])[i] = 0;
+                __syncthreads();
+                const bool ok = c0 + tid < P;
+                const unsigned key = ck[u];
+                const unsigned d = ok ? ((key >> shift) & 255u) : 256u;
+                unsigned long long m = __ballot(ok);              // lanes of this wave holding the same digit
+#pragma unroll
+                for (int bit = 0; bit < 8; ++bit) {
+                    const unsigned long long bm = __ballot((d >> bit) & 1u);
+                    m &= ((d >> bit) & 1u) ? bm : ~bm;
+                }
+                const unsigned rank = (unsigned)__popcll(m & lt_mask);
+                if (ok && rank == 0) wcount[wave][d] = (unsigned)__popcll(m);
+                __syncthreads();
+                if (tid < 256) {                                  // digit tid: prefix over waves, advance base
+                    unsigned run = base[tid];
+                    for (int w = 0; w < LW; ++w) { const unsigned c = wcount[w][tid]; wcount[w][tid] = run; run += c; }
+                    base[tid] = run;
+                }
+                __syncthreads();
+                if (ok) {
+                    const unsigned dst = wcount[wave][d] + rank;
+                    ko[dst] = key; vo[dst] = cv[u];
+                    if (pass < 3) atomicAdd(&hnext[(key >> (shift + 8)) & 255u], 1u);
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int u = 0; u < LG; ++u) { ck[u] = nk[u]; cv[u] = nv[u]; }
+        }
+        __syncthreads();
+    }
+    // after 4 passes the sorted sequence is back in (k0, v0)
+
+    // ---- fused scan + Jaccard gradient + dot + scatter
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    float lsum = 0.f;
+    const float gscale = a.loss_scale / (float)a.B;
+    float* dz = a.dlogits ? a.dlogits + (int64_t)b * P : nullptr;
+    unsigned ck[LG], cv[LG], nk[LG], nv[LG];
+#pragma unroll
+    for (int u = 0; u < LG; ++u) { const int i = u * LT + tid; ck[u] = i < P ? k0[i] : 0u; cv[u] = i < P ? v0[i] : 0u; }
+    for (int g = 0; g < ngroups; ++g) {
+        const int cn = (g + 1) * LG;
+#pragma unroll
+        for (int u = 0; u < LG; ++u) { const int i = (cn + u) * LT + tid; nk[u] = i < P ? k0[i] : 0u; nv[u] = i < P ? v0[i] : 0u; }
+#pragma unroll
+        for (int u = 0; u < LG; ++u) {
+            const int c0 = (g * LG + u) * LT;
+            if (c0 >= P) break;
+            const int i = c0 + tid;
+            const bool ok = i < P;
+            const unsigned val = ok ? cv[u] : 0u;
+            const unsigned lab = val & 1u;
+            unsigned incl = ok ? lab : 0u;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+            if (lane == 63) scan_w[wave] = incl;
+            __syncthreads();
+            unsigned woff = carry_s;
+            for (int w = 0; w < wave; ++w) woff += scan_w[w];
+            const unsigned c_k = woff + incl;                     // inclusive count of positives up to rank k
+            __syncthreads();
+            if (tid == LT - 1) carry_s = c_k;
+            if (ok) {
+                const float e = key_to_float(ck[u]);
+                const float kf = (float)(i + 1), ckf = (float)c_k, ckm = (float)(c_k - lab);
+                // exactly the reference's fp32 sequence (lovasz_losses.py:27-32): one correctly rounded division, one
+                // subtraction from 1, one first difference; no fma contraction (the difference cancels ~3 digits)
+                const float jk = __fsub_rn(1.f, __fdiv_rn(G - ckf, G + (kf - ckf)));
+                float jm = 0.f;
+                if (i > 0) jm = __fsub_rn(1.f, __fdiv_rn(G - ckm, G + ((kf - 1.f) - ckm)));
+                const float gk = (i > 0) ? __fsub_rn(jk, jm) : jk;
+                const float el = e > 0.f ? e : expm1f(e);
+                lsum += el * gk;
+                if (dz) {
+                    const float d = e > 0.f ? 1.f : __expf(e);
+                    const float sg = lab ? 1.f : -1.f;
+                    dz[val >> 1] = -sg * d * gk * gscale;
+                }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int u = 0; u < LG; ++u) { ck[u] = nk[u]; cv[u] = nv[u]; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
+    if (lane == 0) red[wave] = lsum;
+    __syncthreads();
+    if (tid == 0) {
+        float t = 0.f;
+        for (int w = 0; w < LW; ++w) t += red[w];
+        if (P == 0) t = 0.f;
+        a.loss_per_image[b] = t;
+    }
+}
+
 __global__ void mean_kernel(const float* v, int n, float scale, float* out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         float s = 0.f;
@@ -284,7 +461,9 @@ __global__ void flip_kernel(salt_flip_args a) {
 extern "C" int salt_lovasz_hinge(const salt_lovasz_args* a, void* stream) {
     if (!a || !a->logits || !a->target || a->B < 1 || a->P < 0 || !a->ws_keys || !a->ws_vals || !a->loss_per_image || !a->loss)
         SALT_FAIL(SALT_E_BADARG, "lovasz: bad args");
-    hipLaunchKernelGGL(lovasz_kernel, dim3(a->B), dim3(LT), 0, (hipStream_t)stream, *a);
+    static const bool plain = getenv("SALT_LOVASZ_PLAIN") != nullptr;       // A/B switch: the non-prefetching kernel
+    if (plain) hipLaunchKernelGGL(lovasz_kernel, dim3(a->B), dim3(LT), 0, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL(lovasz_pf_kernel, dim3(a->B), dim3(LT), 0, (hipStream_t)stream, *a);
     SALT_CHECK_LAUNCH();
     hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a->loss_per_image, a->B, a->loss_scale, a->loss);
     SALT_CHECK_LAUNCH();
