@@ -87,6 +87,16 @@ typedef struct {
     float* stats_cnt;         /* [nparts] */
     int stats_part0;          /* first partial index written by this launch (ConvT phases) */
     int cfg;                  /* 0 = auto; else tile-config id (tests / tuning) */
+    /* Fold mode (data-gradient of a replicate-padded convolution, architectures/base.py:21-27): the launch computes the gradient on
+     * the extended grid OH = y.H + fold_top + fold_bottom, OW = y.W + fold_left + fold_right; interior pixels go straight to y
+     * (the UNPADDED tensor, (+)= per `accumulate`), the pad ring goes to `strip` ([B][salt_fold_strip_pixels][strip_cs], always
+     * overwritten) and salt_pad_fold_strip adds the ring onto the edge pixels of y.  strip == NULL: normal mode. */
+    void* strip;
+    int strip_cs;
+    int fold_top;
+    int fold_bottom;
+    int fold_left;
+    int fold_right;
 } salt_conv_args;
 int salt_conv(const salt_conv_args*, void* stream);
 /* number of stats partials a launch with these args writes (host sizes the workspace with it) */
@@ -393,6 +403,20 @@ typedef struct {              /* adjoint of replicate padding: fold an extended 
     int accumulate;
 } salt_pad_fold_args;
 int salt_pad_fold(const salt_pad_fold_args*, void* stream);
+
+typedef struct {              /* second half of the fused fold: y edge pixels += the pad ring a fold-mode salt_conv left in `strip` */
+    int dtype;
+    const void* strip;
+    int strip_cs;
+    int top;
+    int bottom;
+    int left;
+    int right;
+    salt_view x;              /* [B,H,W,C]: the unpadded gradient the convolution wrote */
+} salt_pad_fold_strip_args;
+int salt_pad_fold_strip(const salt_pad_fold_strip_args*, void* stream);
+/* pixels per image of the ring: (top+bottom)*(W+left+right) + H*(left+right) */
+int64_t salt_fold_strip_pixels(int H, int W, int top, int bottom, int left, int right);
 
 typedef struct {              /* y = a + b (or y += a when b.p == NULL); also plain copy/cast between views */
     int dtype;

@@ -84,3 +84,12 @@ __device__ __forceinline__ float block_sum_256(float v, float* sm4) {
     __syncthreads();
     return sm4[0] + sm4[1] + sm4[2] + sm4[3];
 }
+
+// Pad ring of a replicate-padded H x W image (extended grid (H+top+bottom) x (W+left+right)): ring pixel (r, c) -> index in the
+// strip buffer.  Rows above / below the interior are stored whole, the interior rows contribute their left+right columns.
+__host__ __device__ inline int fold_ring_index(int r, int c, int H, int W, int top, int bottom, int left, int right) {
+    const int Wp = W + left + right;
+    if (r < top) return r * Wp + c;
+    if (r >= top + H) return (top + (r - top - H)) * Wp + c;
+    return (top + bottom) * Wp + (r - top) * (left + right) + (c < left ? c : c - W);
+}

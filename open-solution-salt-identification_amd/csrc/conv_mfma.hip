@@ -35,6 +35,7 @@ struct ConvKP {
     int tiles_y, tiles_x;
     int nchunk, a_bytes;
     int relu, accumulate, stats_part0;
+    void* strip; int strip_cs, fold_top, fold_bottom, fold_left, fold_right;     // fold mode (strip != nullptr)
 };
 
 template <typename T> struct Mma;
@@ -346,9 +347,22 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
             const int n = n0 + pc * VE;
             if (b >= p.B || oy >= p.OH || ox >= p.OW || n >= p.Cout) continue;
             T* dst = yg + (((int64_t)b * p.OHf + oy * p.out_step + p.out_oy) * p.OWf + ox * p.out_step + p.out_ox) * p.y_cs + n;
+            bool accum = p.accumulate != 0;
+            bool dvec = y_vec;
+            if (p.strip) {                                         // fold mode: interior -> y (unpadded), pad ring -> strip
+                const int iy = oy - p.fold_top, ix = ox - p.fold_left;
+                if (iy >= 0 && iy < p.OHf && ix >= 0 && ix < p.OWf) {
+                    dst = yg + (((int64_t)b * p.OHf + iy) * p.OWf + ix) * p.y_cs + n;
+                } else {
+                    const int64_t ring = (int64_t)(p.fold_top + p.fold_bottom) * p.OW + (int64_t)p.OHf * (p.fold_left + p.fold_right);
+                    dst = reinterpret_cast<T*>(p.strip) + ((int64_t)b * ring + fold_ring_index(oy, ox, p.OHf, p.OWf, p.fold_top, p.fold_bottom, p.fold_left, p.fold_right)) * p.strip_cs + n;
+                    accum = false;
+                    dvec = (p.strip_cs % VE) == 0;
+                }
+            }
             const u32x4 v = *reinterpret_cast<const u32x4*>(sO + m * PITCH + pc * VE);
-            if (y_vec && n + VE <= p.Cout) {
-                if (p.accumulate) {
+            if (dvec && n + VE <= p.Cout) {
+                if (accum) {
                     float f[VE], o[VE];
                     unpack16<T>(v, f);
                     unpack16<T>(*reinterpret_cast<const u32x4*>(dst), o);
@@ -363,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
                 unpack16<T>(v, f);
 #pragma unroll
                 for (int e = 0; e < VE; ++e)
-                    if (n + e < p.Cout) Elem<T>::st(dst + e, p.accumulate ? f[e] + Elem<T>::ld(dst + e) : f[e]);
+                    if (n + e < p.Cout) Elem<T>::st(dst + e, accum ? f[e] + Elem<T>::ld(dst + e) : f[e]);
             }
         }
     }
@@ -429,7 +443,7 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
     if (a->ntaps < 1 || a->ntaps > SALT_MAX_TAPS) SALT_FAIL(SALT_E_BADARG, "conv: ntaps %d", a->ntaps);
     if (a->in_step < 1 || a->in_step > 2 || a->out_step < 1 || a->out_step > 2) SALT_FAIL(SALT_E_BADARG, "conv: steps");
     if (a->OH < 1 || a->OW < 1) SALT_FAIL(SALT_E_BADARG, "conv: empty output grid");
-    if ((a->OH - 1) * a->out_step + a->out_oy >= a->y.H || (a->OW - 1) * a->out_step + a->out_ox >= a->y.W)
+    if (!a->strip && ((a->OH - 1) * a->out_step + a->out_oy >= a->y.H || (a->OW - 1) * a->out_step + a->out_ox >= a->y.W))
         SALT_FAIL(SALT_E_BADARG, "conv: output grid exceeds buffer");
     if (a->x.B != a->y.B) SALT_FAIL(SALT_E_BADARG, "conv: batch mismatch");
     const int Cout = a->y.C;
@@ -485,6 +499,7 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
     k.nchunk = cdiv(a->x.C, KCE);
     k.a_bytes = k.nb * k.hh * k.hw * 64;
     k.relu = a->relu; k.accumulate = a->accumulate; k.stats_part0 = a->stats_part0;
+    k.strip = a->strip; k.strip_cs = a->strip_cs; k.fold_top = a->fold_top; k.fold_bottom = a->fold_bottom; k.fold_left = a->fold_left; k.fold_right = a->fold_right;
     pl->grid = dim3((unsigned)(tiles_b * k.tiles_y * k.tiles_x), (unsigned)cdiv(Cout, BN), 1);
     pl->lds = (size_t)k.a_bytes + (size_t)a->ntaps * BN * 64;
     {   // the epilogue stages the BM x BN output tile through the same LDS
@@ -883,6 +898,12 @@ extern "C" int salt_conv(const salt_conv_args* a, void* stream) {
     int rc = make_plan(a, &pl);
     if (rc) return rc;
     if (a->stats && !a->stats_cnt) SALT_FAIL(SALT_E_BADARG, "conv: stats without stats_cnt");
+    if (a->strip) {
+        if (a->stats || a->out_step != 1 || a->out_oy || a->out_ox || a->fold_top < 0 || a->fold_bottom < 0 || a->fold_left < 0 || a->fold_right < 0 ||
+            a->OH != a->y.H + a->fold_top + a->fold_bottom || a->OW != a->y.W + a->fold_left + a->fold_right || a->strip_cs < a->y.C ||
+            (reinterpret_cast<uintptr_t>(a->strip) & 15))
+            SALT_FAIL(SALT_E_BADARG, "conv: fold mode needs OH/OW = y.H/y.W + pads, out_step 1, no stats, 16-byte aligned strip");
+    }
     if (a->dtype == SALT_F32) return launch_T<float>(pl, (hipStream_t)stream);
     if (a->dtype == SALT_BF16) return launch_T<bf16_t>(pl, (hipStream_t)stream);
     SALT_FAIL(SALT_E_BADARG, "conv: dtype %d", a->dtype);

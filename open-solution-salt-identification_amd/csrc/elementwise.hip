@@ -523,6 +523,44 @@ __global__ void pad_fold_kernel(salt_view xp, int top, int bottom, int left, int
     }
 }
 
+// second half of the fused fold: one unit per (image, perimeter pixel, channel piece); sums the pad-ring pixels that clamp onto it
+template <typename T, bool VEC>
+__global__ void pad_fold_strip_kernel(const T* strip, int strip_cs, int top, int bottom, int left, int right, salt_view x, int nperim) {
+    constexpr int N = Unit<T, VEC>::N;
+    const int cpv = x.C / N, H = x.H, W = x.W;
+    const int64_t ring = (int64_t)(top + bottom) * (W + left + right) + (int64_t)H * (left + right);
+    const int64_t units = (int64_t)x.B * nperim * cpv;
+    for (int64_t u = blockIdx.x * 256LL + threadIdx.x; u < units; u += gridDim.x * 256LL) {
+        int64_t r = u / cpv; const int c0 = (int)(u - r * cpv) * N;
+        const int e = (int)(r % nperim); const int b = (int)(r / nperim);
+        int iy, ix;
+        if (nperim == H * W) { iy = e / W; ix = e - iy * W; }                 // tiny maps: every pixel
+        else if (e < W) { iy = 0; ix = e; }
+        else if (e < 2 * W) { iy = H - 1; ix = e - W; }
+        else { const int k = e - 2 * W; iy = 1 + (k >> 1); ix = (k & 1) ? W - 1 : 0; }
+        const int py0 = iy == 0 ? 0 : iy + top, py1 = iy == H - 1 ? iy + top + bottom : iy + top;
+        const int px0 = ix == 0 ? 0 : ix + left, px1 = ix == W - 1 ? ix + left + right : ix + left;
+        if (py0 == py1 && px0 == px1) continue;                               // interior pixel of a tiny map
+        float o[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) o[j] = 0.f;
+        for (int py = py0; py <= py1; ++py)
+            for (int px = px0; px <= px1; ++px) {
+                if (py == iy + top && px == ix + left) continue;              // the interior value is already in x
+                float g[N];
+                Unit<T, VEC>::ld(strip + ((int64_t)b * ring + fold_ring_index(py, px, H, W, top, bottom, left, right)) * strip_cs + c0, g);
+#pragma unroll
+                for (int j = 0; j < N; ++j) o[j] += g[j];
+            }
+        T* dst = (T*)x.p + (((int64_t)b * H + iy) * W + ix) * x.cs + c0;
+        float old[N];
+        Unit<T, VEC>::ld(dst, old);
+#pragma unroll
+        for (int j = 0; j < N; ++j) o[j] += old[j];
+        Unit<T, VEC>::st(dst, o);
+    }
+}
+
 template <typename T, bool VEC>
 __global__ void add_kernel(salt_view a, salt_view b, salt_view y, int accumulate) {
     constexpr int N = Unit<T, VEC>::N;
@@ -739,6 +777,25 @@ extern "C" int salt_pad_fold(const salt_pad_fold_args* a, void* stream) {
         const bool v = vec_ok(a->x, ve) && vec_ok(a->xp, ve);
         const int64_t units = view_pixels(a->x) * (a->x.C / (v ? ve : 1));
         EW_LAUNCH(pad_fold_kernel, T, v, units, (hipStream_t)stream, a->xp, a->top, a->bottom, a->left, a->right, a->x, a->accumulate);
+    })
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}
+
+extern "C" int64_t salt_fold_strip_pixels(int H, int W, int top, int bottom, int left, int right) {
+    return (int64_t)(top + bottom) * (W + left + right) + (int64_t)H * (left + right);
+}
+
+extern "C" int salt_pad_fold_strip(const salt_pad_fold_strip_args* a, void* stream) {
+    if (!a || !view_ok(a->x) || !a->strip || a->strip_cs < a->x.C || a->top < 0 || a->bottom < 0 || a->left < 0 || a->right < 0)
+        SALT_FAIL(SALT_E_BADARG, "pad_fold_strip: bad args");
+    const int H = a->x.H, W = a->x.W;
+    const int nperim = (H < 3 || W < 3) ? H * W : 2 * W + 2 * (H - 2);
+    SALT_DISPATCH_DTYPE(a->dtype, T, {
+        const int ve = Elem<T>::VE;
+        const bool v = vec_ok(a->x, ve) && (a->strip_cs % ve) == 0 && (reinterpret_cast<uintptr_t>(a->strip) & 15) == 0;
+        const int64_t units = (int64_t)a->x.B * nperim * (a->x.C / (v ? ve : 1));
+        EW_LAUNCH(pad_fold_strip_kernel, T, v, units, (hipStream_t)stream, (const T*)a->strip, a->strip_cs, a->top, a->bottom, a->left, a->right, a->x, nperim);
     })
     SALT_CHECK_LAUNCH();
     return SALT_OK;

@@ -12,6 +12,7 @@ buffers that their producers write in place, so ``torch.cat`` never copies anyth
 PyTorch is used for device memory (tensors), streams and nothing else on this path.
 """
 import ctypes
+import os
 import math
 
 import numpy as np
@@ -280,11 +281,12 @@ class Graph:
         return 4 if self.dtype == 'f32' else 2
 
     def _conv_launch(self, prog, x_view, wp, taps_dydx, in_step, pad_mode, y_view, OH, OW, out_step=1, out_oy=0, out_ox=0,
-                     bias=None, scale=None, shift=None, relu=0, accumulate=0, stats=None, stats_cnt=None, part0=0, cfg=0):
+                     bias=None, scale=None, shift=None, relu=0, accumulate=0, stats=None, stats_cnt=None, part0=0, cfg=0, **fold):
         kw = dict(dtype=self.dt, x=x_view, w=wp, ntaps=len(taps_dydx), tap_dy=[t[0] for t in taps_dydx], tap_dx=[t[1] for t in taps_dydx],
                   in_step=in_step, pad_mode=pad_mode, y=y_view, OH=OH, OW=OW, out_step=out_step, out_oy=out_oy, out_ox=out_ox,
                   bias=bias, scale=scale, shift=shift, relu=relu, accumulate=accumulate, stats=stats, stats_cnt=stats_cnt,
                   stats_part0=part0, cfg=cfg)
+        kw.update(fold)
         return prog.add('conv', **kw)
 
     def _conv_parts(self, x_view, taps_dydx, in_step, y_view, OH, OW, cfg=0):
@@ -423,13 +425,22 @@ class Graph:
             # gradient w.r.t. the replicate-padded input on the extended domain, then fold the pad back
             top, right = KH - 1, KW - 1
             Hp, Wp = x.H + top, x.W + right
-            ext = shaped_view(0, x.B, Hp, Wp, x.C, _round_up(x.C, self.ve))
-            nbytes = x.B * Hp * Wp * ext.cs * self._es()
             td = [(-(t[2]) - top, -(t[3])) for t in taps]
-            self._conv_launch(self.bwd, dy.gview(), pk.data_ptr(), td, 1, 0, (ext, Scratch('dgrad_ext', nbytes)), Hp, Wp)
             acc = x.grad_state()
-            self.bwd.add('pad_fold', dtype=self.dt, xp=(ext, Scratch('dgrad_ext', nbytes)), top=top, bottom=0, left=0, right=right,
-                         x=x.gview(), accumulate=acc)
+            if os.environ.get('SALT_FOLD_FULL'):            # A/B: gradient on the extended grid in scratch, then a full fold pass
+                ext = shaped_view(0, x.B, Hp, Wp, x.C, _round_up(x.C, self.ve))
+                nbytes = x.B * Hp * Wp * ext.cs * self._es()
+                self._conv_launch(self.bwd, dy.gview(), pk.data_ptr(), td, 1, 0, (ext, Scratch('dgrad_ext', nbytes)), Hp, Wp)
+                self.bwd.add('pad_fold', dtype=self.dt, xp=(ext, Scratch('dgrad_ext', nbytes)), top=top, bottom=0, left=0, right=right,
+                             x=x.gview(), accumulate=acc)
+                return
+            # fused fold: interior pixels go straight into x.grad, only the pad ring takes the detour through scratch
+            scs = _round_up(x.C, self.ve)
+            ring = lib.salt_fold_strip_pixels(x.H, x.W, top, 0, 0, right)
+            strip = Scratch('dgrad_ring', x.B * ring * scs * self._es())
+            self._conv_launch(self.bwd, dy.gview(), pk.data_ptr(), td, 1, 0, x.gview(), Hp, Wp, accumulate=acc,
+                              strip=strip, strip_cs=scs, fold_top=top, fold_right=right)
+            self.bwd.add('pad_fold_strip', dtype=self.dt, strip=strip, strip_cs=scs, top=top, bottom=0, left=0, right=right, x=x.gview())
             return
         acc = x.grad_state()
         if stride == 1:
