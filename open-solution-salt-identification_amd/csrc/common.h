@@ -13,11 +13,13 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {            // round-to-nearest-even
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// fp32 -> bf16, round-to-nearest-even: gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32, two values per instruction)
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ unsigned f2bf_pk(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 
 template <typename T> struct Elem;
@@ -50,10 +52,7 @@ template <> __device__ __forceinline__ u32x4 pack16<float>(const float* f) {
 }
 template <> __device__ __forceinline__ u32x4 pack16<bf16_t>(const float* f) {
     u32x4 v;
-    v.x = (unsigned)f2bf(f[0]) | ((unsigned)f2bf(f[1]) << 16);
-    v.y = (unsigned)f2bf(f[2]) | ((unsigned)f2bf(f[3]) << 16);
-    v.z = (unsigned)f2bf(f[4]) | ((unsigned)f2bf(f[5]) << 16);
-    v.w = (unsigned)f2bf(f[6]) | ((unsigned)f2bf(f[7]) << 16);
+    v.x = f2bf_pk(f[0], f[1]); v.y = f2bf_pk(f[2], f[3]); v.z = f2bf_pk(f[4], f[5]); v.w = f2bf_pk(f[6], f[7]);
     return v;
 }
 

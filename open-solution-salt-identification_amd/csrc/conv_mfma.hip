@@ -36,6 +36,7 @@ struct ConvKP {
     int nchunk, a_bytes;
     int relu, accumulate, stats_part0;
     void* strip; int strip_cs, fold_top, fold_bottom, fold_left, fold_right;     // fold mode (strip != nullptr)
+    unsigned hhw_magic, hw_magic;                                                // x / d == umulhi(x, 2^32 / d + 1) for x * d < 2^32
 };
 
 template <typename T> struct Mma;
@@ -113,9 +114,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
             const int q = tid + (k << 8);
             const int pix = q >> 2;
             if (pix < phalo) {
-                const int bl = pix / hhw;
+                const int bl = (int)__umulhi((unsigned)pix, p.hhw_magic);
                 const int r = pix - bl * hhw;
-                const int hy = r / p.hw;
+                const int hy = (int)__umulhi((unsigned)r, p.hw_magic);
                 const int hx = r - hy * p.hw;
                 int iy = iy0 + hy, ix = ix0 + hx;
                 bool valid = b0 + bl < p.B;
@@ -498,6 +499,8 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
     const int tiles_b = cdiv(a->x.B, k.nb);
     k.nchunk = cdiv(a->x.C, KCE);
     k.a_bytes = k.nb * k.hh * k.hw * 64;
+    k.hhw_magic = (unsigned)((1ull << 32) / (unsigned)(k.hh * k.hw)) + 1u;
+    k.hw_magic = (unsigned)((1ull << 32) / (unsigned)k.hw) + 1u;
     k.relu = a->relu; k.accumulate = a->accumulate; k.stats_part0 = a->stats_part0;
     k.strip = a->strip; k.strip_cs = a->strip_cs; k.fold_top = a->fold_top; k.fold_bottom = a->fold_bottom; k.fold_left = a->fold_left; k.fold_right = a->fold_right;
     pl->grid = dim3((unsigned)(tiles_b * k.tiles_y * k.tiles_x), (unsigned)cdiv(Cout, BN), 1);
