@@ -426,6 +426,100 @@ class TernausUNetResNet(HipNetwork):
         g.head(d1, self.final, logits)
 
 
+class _SaltResNet34Stub(HipNetwork):
+    """Shared plumbing of SaltUNet / SaltLinkNet: a whole torchvision-layout resnet34 is constructed (its unused blocks stay in
+    ``state_dict()`` and ``parameters()`` exactly like the reference) but only a few BasicBlocks are on the path."""
+
+    used_blocks = ()
+
+    def _make(self, num_classes, dropout_2d, pretrained):
+        self.num_classes, self.dropout_2d = num_classes, dropout_2d
+        self.encoder = resnet(34, pretrained)
+        self.relu = nn.ReLU(inplace=True)
+        self.input_adjust = nn.Sequential(self.encoder.conv1, self.encoder.bn1, self.encoder.relu)
+
+    def dead_parameter_names(self):
+        live = ['encoder.conv1.', 'encoder.bn1.'] + ['encoder.%s.' % b for b in self.used_blocks]
+        dead = [k for k, _ in self.encoder.named_parameters(prefix='encoder') if not any(k.startswith(l) for l in live)]
+        for n in self.decoders:
+            blk = getattr(self, n)
+            dead += ['%s.%s' % (n, k) for k, _ in blk.named_parameters() if k.startswith(blk.dead_prefix())]
+        return dead
+
+
+class SaltUNet(_SaltResNet34Stub):
+    """unet_models.SaltUNet (unet_models.py:154-189): stem, layer1[1], layer1[2], layer2[0], layer2[1]; DecoderBlockV2 / ConvBnRelu
+    decoders over concatenated skips; 1x1 head.  layer1[0] and everything after layer2[1] is constructed but never called."""
+
+    used_blocks = ('layer1.1', 'layer1.2', 'layer2.0', 'layer2.1')
+    decoders = ('dec3', 'dec1')
+
+    def __init__(self, num_classes, dropout_2d=0.2, pretrained=False, is_deconv=False):
+        super().__init__()
+        self._make(num_classes, dropout_2d, pretrained)
+        self.conv1 = self.encoder.layer1[1]
+        self.conv2 = self.encoder.layer1[2]
+        self.conv3 = self.encoder.layer2[0]
+        self.conv4 = self.encoder.layer2[1]
+        self.dec3 = DecoderBlockV2(256, 512, 256, is_deconv)
+        self.dec2 = ConvBnRelu(256 + 64, 256)
+        self.dec1 = DecoderBlockV2(256 + 64, (256 + 64) * 2, 256, is_deconv)
+        self.final = nn.Conv2d(256, num_classes, kernel_size=1)
+
+    def emit(self, g, x_nchw, logits):
+        enc = self.encoder
+        B, _, H, W = x_nchw.shape
+        a = g.conv_first(x_nchw, enc.conv1, enc.bn1, relu=True, name='stem')
+        cat1 = g.new_act(B, H // 2, W // 2, 256 + 64, 'cat1')            # [dec2 | conv1]
+        cat2 = g.new_act(B, H // 2, W // 2, 256 + 64, 'cat2')            # [dec3 | conv2]
+        cat3 = g.new_act(B, H // 4, W // 4, 128 + 128, 'cat3')           # [center | conv3]
+        c1 = self.conv1.emit(g, a, out=cat1.slice(256, 64))
+        c2 = self.conv2.emit(g, c1, out=cat2.slice(256, 64))
+        c3 = self.conv3.emit(g, c2, out=cat3.slice(128, 128))
+        self.conv4.emit(g, c3, out=cat3.slice(0, 128))
+        self.dec3.emit(g, cat3, out=cat2.slice(0, 256))
+        self.dec2.emit(g, cat2, out=cat1.slice(0, 256))
+        d1 = self.dec1.emit(g, cat1)
+        g.head(d1, self.final, logits)
+
+
+class SaltLinkNet(_SaltResNet34Stub):
+    """unet_models.SaltLinkNet (unet_models.py:192-233): block outputs of layer1[1..2] and layer2[0..3] are summed per stage."""
+
+    used_blocks = ('layer1.1', 'layer1.2', 'layer2.0', 'layer2.1', 'layer2.2', 'layer2.3')
+    decoders = ('dec2', 'dec1')
+
+    def __init__(self, num_classes, dropout_2d=0.2, pretrained=False, is_deconv=False):
+        super().__init__()
+        self._make(num_classes, dropout_2d, pretrained)
+        self.conv1_1 = self.encoder.layer1[1]
+        self.conv1_2 = self.encoder.layer1[2]
+        self.conv2_0 = self.encoder.layer2[0]
+        self.conv2_1 = self.encoder.layer2[1]
+        self.conv2_2 = self.encoder.layer2[2]
+        self.conv2_3 = self.encoder.layer2[3]
+        self.dec2 = DecoderBlockV2(128, 256, 256, is_deconv=is_deconv)
+        self.dec1 = DecoderBlockV2(256 + 64, 512, 256, is_deconv=is_deconv)
+        self.final = nn.Conv2d(256, num_classes, kernel_size=1)
+
+    def emit(self, g, x_nchw, logits):
+        enc = self.encoder
+        B, _, H, W = x_nchw.shape
+        a = g.conv_first(x_nchw, enc.conv1, enc.bn1, relu=True, name='stem')
+        c11 = self.conv1_1.emit(g, a)
+        c12 = self.conv1_2.emit(g, c11)
+        c20 = self.conv2_0.emit(g, c12)
+        c21 = self.conv2_1.emit(g, c20)
+        c22 = self.conv2_2.emit(g, c21)
+        c23 = self.conv2_3.emit(g, c22)
+        cat1 = g.new_act(B, H // 2, W // 2, 256 + 64, 'cat1')            # [dec2 | conv1_sum]
+        g.add(c11, c12, out=cat1.slice(256, 64), name='conv1_sum')
+        s2 = g.add(g.add(g.add(c20, c21), c22), c23, name='conv2_sum')   # left-to-right like the reference expression
+        self.dec2.emit(g, s2, out=cat1.slice(0, 256))
+        d1 = self.dec1.emit(g, cat1)
+        g.head(d1, self.final, logits)
+
+
 class VanillaUNet(HipNetwork):
     """BASELINE C0/C1 "vanilla 4-level U-Net": the reference has no in-tree definition; it is
     assembled from the reference's own blocks: per level 2 x ConvBnRelu + MaxPool2d(2,2); centre 2 x ConvBnRelu;

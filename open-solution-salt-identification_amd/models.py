@@ -31,6 +31,8 @@ ARCHITECTURES = {
     'UNetResNet152': {'model': A.UNetResNet,
                       'model_config': {'encoder_depth': 152, 'use_hypercolumn': True, 'dropout_2d': 0.0, 'pretrained': False, 'pool0': False},
                       'init_weights': False},
+    'SaltUNet': {'model': A.SaltUNet, 'model_config': {'dropout_2d': 0.0, 'pretrained': False, 'is_deconv': True}, 'init_weights': False},
+    'SaltLinkNet': {'model': A.SaltLinkNet, 'model_config': {'dropout_2d': 0.0, 'pretrained': False, 'is_deconv': True}, 'init_weights': False},
     'VanillaUNet': {'model': A.VanillaUNet, 'model_config': {'in_channels': 1, 'base_filters': 16, 'levels': 4}, 'init_weights': False},
 }
 

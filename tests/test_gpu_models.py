@@ -59,10 +59,12 @@ def _nets():
     from salt_amd import architectures as A
     return {'unet_resnet34_hyper': lambda: A.UNetResNet(34, 2, dropout_2d=0.0, pretrained=False, use_hypercolumn=True),
             'ternaus_resnet34_deconv': lambda: A.TernausUNetResNet(34, 2, dropout_2d=0.0, pretrained=False, is_deconv=True),
-            'ternaus_resnet34_upsample': lambda: A.TernausUNetResNet(34, 2, dropout_2d=0.0, pretrained=False, is_deconv=False)}
+            'ternaus_resnet34_upsample': lambda: A.TernausUNetResNet(34, 2, dropout_2d=0.0, pretrained=False, is_deconv=False),
+            'salt_unet': lambda: A.SaltUNet(2, dropout_2d=0.0, is_deconv=True),
+            'salt_linknet': lambda: A.SaltLinkNet(2, dropout_2d=0.0, is_deconv=True)}
 
 
-@pytest.mark.parametrize('tag', ['unet_resnet34_hyper', 'ternaus_resnet34_deconv', 'ternaus_resnet34_upsample'])
+@pytest.mark.parametrize('tag', ['unet_resnet34_hyper', 'ternaus_resnet34_deconv', 'ternaus_resnet34_upsample', 'salt_unet', 'salt_linknet'])
 def test_eval_logits_and_masks_match_reference(tag):
     fx = golden('F8_' + tag)
     net = _fill_closed_form(_nets()[tag]()).to(DEV)
@@ -74,7 +76,7 @@ def test_eval_logits_and_masks_match_reference(tag):
     assert np.array_equal((logits[:, 1] > 0).numpy().astype(np.uint8), fx['eval_mask'])
 
 
-@pytest.mark.parametrize('tag', ['unet_resnet34_hyper', 'ternaus_resnet34_deconv'])
+@pytest.mark.parametrize('tag', ['unet_resnet34_hyper', 'ternaus_resnet34_deconv', 'salt_unet', 'salt_linknet'])
 def test_one_training_step_matches_reference(tag):
     """zero_grad -> forward -> lovasz -> backward -> Adam(lr 1e-4, L2 1e-4) exactly as models.py:105-136."""
     from salt_amd.optim import FusedAdam, weight_regularization
@@ -106,7 +108,7 @@ def test_one_training_step_matches_reference(tag):
             rel = abs(gn - fx['grad_norm'][i]) / fx['grad_norm'][i]
             worst = max(worst, (rel, k))
             checked += 1
-    assert checked > 100 and worst[0] < 1e-2, worst
+    assert checked > (100 if 'salt' not in tag else 30) and worst[0] < 1e-2, (checked, worst)
     for k in fx:
         if k.startswith('fullgrad:'):
             p = own[k[9:]]
@@ -176,7 +178,7 @@ def test_vanilla_unet_matches_oracle_c1_shape():
             assert_close(eng.grads[off:off + cnt].view(p.shape).cpu(), sd0[k].grad, 1e-4 if kind == 'bce_dice' else 5e-3, kind + ' ' + k)
 
 
-@pytest.mark.parametrize('arch', ['UNetResNet', 'TernausUNetResNet'])
+@pytest.mark.parametrize('arch', ['UNetResNet', 'TernausUNetResNet', 'SaltUNet', 'SaltLinkNet'])
 def test_resnet34_unets_train_step_vs_oracle_default_init(arch):
     """ResNet34 U-Nets with default initialisation (well conditioned): logits, loss and EVERY parameter gradient vs the oracle."""
     from salt_amd import architectures as A, losses
@@ -184,8 +186,10 @@ def test_resnet34_unets_train_step_vs_oracle_default_init(arch):
     torch.manual_seed(5)
     if arch == 'UNetResNet':
         net, kw = A.UNetResNet(34, 2, use_hypercolumn=True), {}
-    else:
+    elif arch == 'TernausUNetResNet':
         net, kw = A.TernausUNetResNet(34, 2, dropout_2d=0.0, is_deconv=True), {'is_deconv': True}
+    else:
+        net, kw = getattr(A, arch)(2, dropout_2d=0.0, is_deconv=True), {'is_deconv': True}
     spec = OS.SPECS[arch](with_fc=True)
     sd = OS.init_state(spec, seed=7)
     net.load_state_dict({k: sd[k] for k in net.state_dict() if k in sd}, strict=False)
@@ -207,7 +211,7 @@ def test_resnet34_unets_train_step_vs_oracle_default_init(arch):
     for k in dead:
         assert sd[k].grad is None, k
     worst, cos, n = _grad_report(net, {k: v.grad for k, v in sd.items() if k not in dead})
-    assert n > 120 and worst[0] < 5e-2 and cos > 0.9999, (worst, cos, n)
+    assert n > (120 if 'Salt' not in arch else 30) and worst[0] < 5e-2 and cos > 0.9999, (worst, cos, n)
     eng = net.engine()
     for k in ('final.1.weight', 'final.1.bias') if arch == 'UNetResNet' else ('final.weight', 'final.bias'):
         p = dict(net.named_parameters())[k]

@@ -43,6 +43,8 @@ def test_every_operator_rejects_null_args_without_touching_a_gpu():
     ('unet_resnet34_hyper', lambda A: A.UNetResNet(34, 2, dropout_2d=0.0, pretrained=False, use_hypercolumn=True)),
     ('ternaus_resnet34_deconv', lambda A: A.TernausUNetResNet(34, 2, dropout_2d=0.0, pretrained=False, is_deconv=True)),
     ('ternaus_resnet34_upsample', lambda A: A.TernausUNetResNet(34, 2, dropout_2d=0.0, pretrained=False, is_deconv=False)),
+    ('salt_unet', lambda A: A.SaltUNet(2, dropout_2d=0.0, is_deconv=True)),
+    ('salt_linknet', lambda A: A.SaltLinkNet(2, dropout_2d=0.0, is_deconv=True)),
 ])
 def test_state_dict_layout_equals_reference(tag, make):
     from salt_amd import architectures as A
@@ -51,7 +53,7 @@ def test_state_dict_layout_equals_reference(tag, make):
     net = make(A)
     sd = net.state_dict()
     assert list(sd.keys()) == fx['keys'].tolist()
-    arch = 'UNetResNet' if 'hyper' in tag else 'TernausUNetResNet'
+    arch = {'unet': 'UNetResNet', 'tern': 'TernausUNetResNet', 'salt_unet': 'SaltUNet', 'salt_link': 'SaltLinkNet'}[tag[:9] if tag.startswith('salt') else tag[:4]]
     spec = OS.SPECS[arch](with_fc=True)
     for k, (shape, _) in spec.items():
         assert tuple(sd[k].shape) == tuple(shape), k
