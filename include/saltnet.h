@@ -574,6 +574,47 @@ typedef struct {              /* x_out[b] = flip(x[b]) for NCHW fp32 batches (TT
 } salt_flip_args;
 int salt_flip(const salt_flip_args*, void* stream);
 
+/* centre crop + binarize one class of a probability map (postprocessing.py:24-43, utils.py:308-313): mask = prob[cls] > threshold */
+typedef struct {
+    const float* prob;        /* fp32 NCHW [B,C,H,W] */
+    int B;
+    int C;
+    int H;
+    int W;
+    int cls;
+    int top;                  /* crop window [top, top+h) x [left, left+w) */
+    int left;
+    int h;
+    int w;
+    float threshold;
+    uint8_t* mask;            /* out [B,h,w] in {0,1} */
+} salt_crop_threshold_args;
+int salt_crop_threshold(const salt_crop_threshold_args*, void* stream);
+
+/* validation metric counts for a whole threshold sweep in one pass (callbacks.py:503-513, metrics.py:21-66): per image and
+ * threshold t: |pred_t| and |pred_t & gt| with pred_t = (double)prob[cls] > t on the cropped window; plus |gt| per image.
+ * IoU / IOUT (with the reference's empty-mask conventions) follow on the host from these integers. */
+#define SALT_MAX_THRESHOLDS 32
+typedef struct {
+    const float* prob;        /* fp32 NCHW [B,C,H,W] */
+    int B;
+    int C;
+    int H;
+    int W;
+    int cls;
+    int top;
+    int left;
+    int h;
+    int w;
+    const uint8_t* gt;        /* [B,h,w] in {0,1} */
+    int T;
+    const double* thresholds; /* HOST array [T], T <= SALT_MAX_THRESHOLDS */
+    int* inter;               /* out [B][T] */
+    int* pred;                /* out [B][T] */
+    int* gt_count;            /* out [B] */
+} salt_iou_sweep_args;
+int salt_iou_sweep(const salt_iou_sweep_args*, void* stream);
+
 /* ------------------------------------------------------------------ program executor
  * A training/inference step is a static list of the operators above.  The host builds it once per
  * (model, batch shape); running it is one call.  capture/replay wraps it in a hipGraph. */

@@ -456,6 +456,56 @@ __global__ void flip_kernel(salt_flip_args a) {
     }
 }
 
+// ---------------------------------------------------------------- inference epilogue: crop + threshold, metric counts
+__global__ void crop_threshold_kernel(salt_crop_threshold_args a) {
+    const int64_t n = (int64_t)a.B * a.h * a.w;
+    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < n; i += gridDim.x * 256LL) {
+        const int x = (int)(i % a.w); int64_t r = i / a.w; const int y = (int)(r % a.h); const int b = (int)(r / a.h);
+        const float p = a.prob[(((int64_t)b * a.C + a.cls) * a.H + a.top + y) * a.W + a.left + x];
+        a.mask[i] = p > a.threshold ? 1 : 0;
+    }
+}
+
+struct IouKP { salt_iou_sweep_args a; double th[SALT_MAX_THRESHOLDS]; };
+__global__ __launch_bounds__(256) void iou_sweep_kernel(IouKP k) {
+    __shared__ int s_inter[SALT_MAX_THRESHOLDS], s_pred[SALT_MAX_THRESHOLDS], s_gt;
+    const salt_iou_sweep_args& a = k.a;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid < SALT_MAX_THRESHOLDS) { s_inter[tid] = 0; s_pred[tid] = 0; }
+    if (tid == 0) s_gt = 0;
+    __syncthreads();
+    int ci[SALT_MAX_THRESHOLDS], cp[SALT_MAX_THRESHOLDS], cg = 0;
+#pragma unroll
+    for (int t = 0; t < SALT_MAX_THRESHOLDS; ++t) { ci[t] = 0; cp[t] = 0; }
+    const int n = a.h * a.w;
+    for (int i = tid; i < n; i += 256) {
+        const int y = i / a.w, x = i - y * a.w;
+        const double p = (double)a.prob[(((int64_t)b * a.C + a.cls) * a.H + a.top + y) * a.W + a.left + x];
+        const int g = a.gt[(int64_t)b * n + i] ? 1 : 0;
+        cg += g;
+#pragma unroll
+        for (int t = 0; t < SALT_MAX_THRESHOLDS; ++t) {
+            const int pr = (t < a.T && p > k.th[t]) ? 1 : 0;
+            cp[t] += pr; ci[t] += pr & g;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < SALT_MAX_THRESHOLDS; ++t) {
+        if (t < a.T) {                                   // uniform
+            int vi = ci[t], vp = cp[t];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { vi += __shfl_xor(vi, o); vp += __shfl_xor(vp, o); }
+            if ((tid & 63) == 0) { atomicAdd(&s_inter[t], vi); atomicAdd(&s_pred[t], vp); }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cg += __shfl_xor(cg, o);
+    if ((tid & 63) == 0) atomicAdd(&s_gt, cg);
+    __syncthreads();
+    if (tid < a.T) { a.inter[b * a.T + tid] = s_inter[tid]; a.pred[b * a.T + tid] = s_pred[tid]; }
+    if (tid == 0) a.gt_count[b] = s_gt;
+}
+
 }  // namespace
 
 extern "C" int salt_lovasz_hinge(const salt_lovasz_args* a, void* stream) {
@@ -530,6 +580,30 @@ extern "C" int salt_flip(const salt_flip_args* a, void* stream) {
     const int64_t n = (int64_t)a->B * a->C * a->H * a->W;
     const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     hipLaunchKernelGGL(flip_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *a);
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}
+
+static bool crop_ok(int B, int C, int H, int W, int cls, int top, int left, int h, int w) {
+    return B >= 1 && C >= 1 && cls >= 0 && cls < C && h >= 1 && w >= 1 && top >= 0 && left >= 0 && top + h <= H && left + w <= W;
+}
+
+extern "C" int salt_crop_threshold(const salt_crop_threshold_args* a, void* stream) {
+    if (!a || !a->prob || !a->mask || !crop_ok(a->B, a->C, a->H, a->W, a->cls, a->top, a->left, a->h, a->w)) SALT_FAIL(SALT_E_BADARG, "crop_threshold: bad args");
+    const int64_t n = (int64_t)a->B * a->h * a->w;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(crop_threshold_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, *a);
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}
+
+extern "C" int salt_iou_sweep(const salt_iou_sweep_args* a, void* stream) {
+    if (!a || !a->prob || !a->gt || !a->thresholds || !a->inter || !a->pred || !a->gt_count || a->T < 1 || a->T > SALT_MAX_THRESHOLDS ||
+        !crop_ok(a->B, a->C, a->H, a->W, a->cls, a->top, a->left, a->h, a->w)) SALT_FAIL(SALT_E_BADARG, "iou_sweep: bad args");
+    IouKP k;
+    k.a = *a;
+    for (int t = 0; t < SALT_MAX_THRESHOLDS; ++t) k.th[t] = t < a->T ? a->thresholds[t] : 2.0;
+    hipLaunchKernelGGL(iou_sweep_kernel, dim3(a->B), dim3(256), 0, (hipStream_t)stream, k);
     SALT_CHECK_LAUNCH();
     return SALT_OK;
 }

@@ -1,0 +1,168 @@
+"""GPU inference epilogue and validation metric (SURVEY.md §8 a18/a19 and the "next" rows f-2 / f-3).
+
+What the reference does on the host with numpy (after copying the full fp32 logits of every batch to the CPU,
+models.py:167) happens here on the device:
+
+  test-time augmentation   loaders.py:662-682 (variants), augmentation.py:143-163 (transform / inverse),
+                           loaders.py:722-760 (mean aggregation)            -> salt_flip, salt_tta_mean
+  post-processing          postprocessing.py:24-43 + utils.py:308-313 (centre crop 128 -> 101, binarize)
+                                                                             -> salt_crop_threshold
+  validation metric        callbacks.py:503-513 (threshold sweep linspace(0.5, 0.3, 21) with early stop),
+                           metrics.py:21-66 (IoU / IOUT with the empty-mask conventions)
+                                                                             -> salt_iou_sweep (+ a few host floats)
+
+Everything here needs the HIP library; there is no CPU path.
+"""
+import ctypes
+import itertools
+
+import numpy as np
+import torch
+
+from ._abi import OP_FUNCS, SaltError, check, fill, lib
+
+IOUT_THRESHOLDS = (0.5, 0.55, 0.6, 0.65, 0.7, 0.75, 0.8, 0.85, 0.9, 0.95)        # metrics.py:37-50
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _run(op, **fields):
+    fn, S = OP_FUNCS['salt_' + op]
+    s = S()
+    fill(s, **fields)
+    check(fn(ctypes.byref(s), _stream()), op)
+
+
+def _f32c(t):
+    if not t.is_cuda:
+        raise SaltError('inference epilogue: tensors must live on the GPU (there is no CPU path)')
+    return t.contiguous().float()
+
+
+# ----------------------------------------------------------------------------- test-time augmentation
+def tta_variants(flip_ud=True, flip_lr=True):
+    """[(ud, lr)] in the order of the reference generator (loaders.py:662-682 via itertools.product): identity first."""
+    out = [(False, False)]
+    for ud, lr in itertools.product([True, False] if flip_ud else [False], [True, False] if flip_lr else [False]):
+        if ud or lr:
+            out.append((ud, lr))
+    return out
+
+
+def flip(x, ud, lr):
+    """augmentation.py:143-153 on an NCHW batch: flipud / fliplr of every image."""
+    x = _f32c(x)
+    y = torch.empty_like(x)
+    B, C, H, W = x.shape
+    _run('flip', x=x.data_ptr(), B=B, C=C, H=H, W=W, flip_ud=int(ud), flip_lr=int(lr), y=y.data_ptr())
+    return y
+
+
+def tta_mean(logits, variants, batch):
+    """sigmoid -> inverse flip -> mean over variants; ``logits`` is variant-major [V*B, C, H, W]."""
+    logits = _f32c(logits)
+    VB, C, H, W = logits.shape
+    V = len(variants)
+    if VB != V * batch:
+        raise SaltError('tta_mean: %d logits for %d variants x batch %d' % (VB, V, batch))
+    ud = (ctypes.c_int * V)(*[int(v[0]) for v in variants])
+    lr = (ctypes.c_int * V)(*[int(v[1]) for v in variants])
+    prob = torch.empty((batch, C, H, W), dtype=torch.float32, device=logits.device)
+    _run('tta_mean', logits=logits.data_ptr(), V=V, B=batch, C=C, H=H, W=W, flip_ud=ctypes.cast(ud, ctypes.c_void_p).value,
+         flip_lr=ctypes.cast(lr, ctypes.c_void_p).value, prob=prob.data_ptr())
+    return prob
+
+
+def predict_tta(net, X, flip_ud=True, flip_lr=True, variants_per_pass=None):
+    """Probabilities [B, C, H, W] of an eval-mode HipNetwork averaged over the flip variants (C4: 4 flips).
+
+    The variants are forwarded ``variants_per_pass`` at a time as one larger batch (default: all of them)."""
+    if net.training:
+        raise SaltError('predict_tta: call net.eval() first')
+    X = _f32c(X)
+    B = X.shape[0]
+    variants = tta_variants(flip_ud, flip_lr)
+    per = len(variants) if not variants_per_pass else int(variants_per_pass)
+    outs = []
+    with torch.no_grad():
+        for i in range(0, len(variants), per):
+            xs = [X if not (ud or lr) else flip(X, ud, lr) for ud, lr in variants[i:i + per]]
+            outs.append(net(torch.cat(xs, 0) if len(xs) > 1 else xs[0]).float())
+    logits = torch.cat(outs, 0) if len(outs) > 1 else outs[0]
+    return tta_mean(logits, variants, B)
+
+
+# ----------------------------------------------------------------------------- post-processing
+def crop_window(H, W, target_size):
+    """utils.py:308-313 get_crop_pad_sequence: (top, left) of the centre crop; 128 -> 101 gives rows 13:114, cols 14:115."""
+    vertical, horizontal = H - target_size[0], W - target_size[1]
+    top, right = int(vertical / 2), int(horizontal / 2)
+    return top, horizontal - right
+
+
+def crop_threshold(prob, target_size=(101, 101), threshold=0.5, cls=1):
+    """postprocessing.py crop_image + binarize on the device: uint8 masks [B, h, w] of ``prob[:, cls] > threshold``."""
+    prob = _f32c(prob)
+    B, C, H, W = prob.shape
+    h, w = target_size
+    top, left = crop_window(H, W, target_size)
+    mask = torch.empty((B, h, w), dtype=torch.uint8, device=prob.device)
+    _run('crop_threshold', prob=prob.data_ptr(), B=B, C=C, H=H, W=W, cls=cls, top=top, left=left, h=h, w=w,
+         threshold=float(threshold), mask=mask.data_ptr())
+    return mask
+
+
+# ----------------------------------------------------------------------------- validation metric
+def iou_counts(prob, gt, thresholds, cls=1):
+    """Per image and threshold: |pred & gt|, |pred|; per image |gt|.  ``gt`` is uint8 [B, h, w]; prob is cropped to it."""
+    prob = _f32c(prob)
+    if not gt.is_cuda:
+        raise SaltError('iou_counts: gt must live on the GPU')
+    gt = gt.contiguous().to(torch.uint8)
+    B, C, H, W = prob.shape
+    h, w = gt.shape[1:]
+    top, left = crop_window(H, W, (h, w))
+    T = len(thresholds)
+    th = (ctypes.c_double * T)(*[float(t) for t in thresholds])
+    inter = torch.empty((B, T), dtype=torch.int32, device=prob.device)
+    pred = torch.empty((B, T), dtype=torch.int32, device=prob.device)
+    gtc = torch.empty((B,), dtype=torch.int32, device=prob.device)
+    _run('iou_sweep', prob=prob.data_ptr(), B=B, C=C, H=H, W=W, cls=cls, top=top, left=left, h=h, w=w, gt=gt.data_ptr(), T=T,
+         thresholds=ctypes.cast(th, ctypes.c_void_p).value, inter=inter.data_ptr(), pred=pred.data_ptr(), gt_count=gtc.data_ptr())
+    return inter.cpu().numpy().astype(np.int64), pred.cpu().numpy().astype(np.int64), gtc.cpu().numpy().astype(np.int64)
+
+
+def scores_from_counts(inter, pred, gt):
+    """(iou[T], iout[T]): dataset means per threshold, metrics.py:21-66 semantics (both empty -> 1, exactly one empty -> 0)."""
+    inter, pred, gt = np.asarray(inter, np.float64), np.asarray(pred, np.float64), np.asarray(gt, np.float64)[:, None]
+    union = pred + gt - inter
+    both_empty = (pred == 0) & (gt == 0)
+    one_empty = (pred == 0) != (gt == 0)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        iou = np.where(both_empty, 1.0, np.where(one_empty, 0.0, inter / np.where(union > 0, union, 1.0)))
+    iout = np.mean(np.stack([(iou >= t).astype(np.float64) for t in IOUT_THRESHOLDS], 0), 0)
+    return iou.mean(0), iout.mean(0)
+
+
+def select_threshold(counts_batches, thresholds=None):
+    """callbacks.py:503-513: walk ``np.linspace(0.5, 0.3, 21)`` while IOUT improves, keep the best.
+
+    ``counts_batches``: list of ``iou_counts`` results (one per validation batch, all with the same thresholds).
+    Returns (threshold_best, iou, iout)."""
+    thresholds = np.linspace(0.5, 0.3, 21) if thresholds is None else np.asarray(thresholds)
+    inter = np.concatenate([c[0] for c in counts_batches], 0)
+    pred = np.concatenate([c[1] for c in counts_batches], 0)
+    gt = np.concatenate([c[2] for c in counts_batches], 0)
+    iou, iout = scores_from_counts(inter, pred, gt)
+    best, t_best = 0.0, 0.5
+    k_best = None
+    for k, t in enumerate(thresholds):
+        if iout[k] > best:
+            best, t_best, k_best = iout[k], float(t), k
+        else:
+            break
+    if k_best is None:                       # no threshold beat 0.0: the reference scores its default 0.5
+        k_best = int(np.argmin(np.abs(thresholds - 0.5)))
+    return t_best, float(iou[k_best]), float(iout[k_best])

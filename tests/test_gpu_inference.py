@@ -1,0 +1,126 @@
+"""GPU parity of the inference epilogue (TTA, crop + threshold) and the validation metric vs the reference goldens (F9, F10) and
+the oracle (oracle/metrics.py restates augmentation.py / postprocessing.py / metrics.py / callbacks.py:503-513)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden, T, assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def test_flip_and_inverse_vs_reference_golden():
+    """augmentation.py:143-163: forward flips of an HWC image and inverse flips of CHW predictions (rotation-free variants)."""
+    from salt_amd import inference as I
+    fx = golden('F9_tta')
+    img = T(fx['img']).permute(2, 0, 1)[None].contiguous().to(DEV)          # HWC -> NCHW
+    pred = T(fx['pred']).to(DEV)
+    for i, (ud, lr, rot) in enumerate(fx['specs'].tolist()):
+        if rot:
+            continue
+        y = I.flip(img, ud, lr)[0].permute(1, 2, 0).cpu().numpy()
+        assert np.array_equal(y, fx['fwd%d' % i]), i
+        inv = I.flip(pred[i % 4][None], ud, lr)[0].cpu().numpy()              # a flip is its own inverse
+        assert np.array_equal(inv, fx['inv%d' % i]), i
+
+
+@pytest.mark.parametrize('ud,lr', [(True, True), (False, True), (True, False), (False, False)])
+def test_tta_mean_vs_oracle(ud, lr):
+    from salt_amd import inference as I
+    from oracle import metrics as OM
+    g = torch.Generator().manual_seed(11)
+    B, C, H, W = 3, 2, 16, 24
+    variants = I.tta_variants(ud, lr)
+    specs = OM.tta_specs(ud, lr)
+    assert [(s['ud_flip'], s['lr_flip']) for s in specs] == variants           # same order as the reference generator
+    logits = torch.randn(len(variants) * B, C, H, W, generator=g) * 3
+    prob = I.tta_mean(logits.to(DEV), variants, B).cpu().numpy()
+    for b in range(B):
+        preds = [OM.sigmoid(logits[v * B + b].numpy()) for v in range(len(variants))]
+        ref = OM.tta_aggregate(preds, specs, 'mean')
+        assert_close(prob[b], ref, 2e-6, 'tta mean')
+
+
+def test_crop_threshold_vs_reference_golden_and_oracle():
+    from salt_amd import inference as I
+    from oracle import metrics as OM
+    fx = golden('F10_post_metric')
+    p128 = fx['p128']                                                        # (2,128,128) "probability" planes
+    assert I.crop_window(128, 128, (101, 101)) == (13, 14)
+    prob = T(OM.sigmoid(p128).astype(np.float32))[None].to(DEV)              # [1, 2, 128, 128]
+    m = I.crop_threshold(prob, (101, 101), 0.5, cls=1).cpu().numpy()[0]
+    ref = OM.binarize(OM.crop_image(OM.sigmoid(p128).astype(np.float32), (101, 101)), 0.5)
+    assert np.array_equal(m, ref)
+    assert np.array_equal(OM.crop_image(p128, (101, 101)), fx['crop101'])
+    # other geometry + threshold
+    g = torch.Generator().manual_seed(5)
+    pr = torch.rand(4, 2, 64, 96, generator=g)
+    for th in (0.3, 0.5, 0.72):
+        m = I.crop_threshold(pr.to(DEV), (50, 71), th, cls=0).cpu().numpy()
+        for b in range(4):
+            ref = (OM.crop_image(pr[b].numpy(), (50, 71))[0] > np.float32(th)).astype(np.uint8)
+            assert np.array_equal(m[b], ref)
+
+
+def test_iou_sweep_vs_oracle_metric():
+    """Counts -> IoU / IOUT for the whole callbacks.py:503-513 sweep equal the per-threshold numpy restatement, incl. empty masks."""
+    from salt_amd import inference as I
+    from oracle import metrics as OM
+    g = torch.Generator().manual_seed(9)
+    B, H, W, h, w = 12, 128, 128, 101, 101
+    prob = torch.rand(B, 2, H, W, generator=g)
+    yy, xx = torch.meshgrid(torch.arange(h), torch.arange(w), indexing='ij')
+    gt = torch.zeros(B, h, w, dtype=torch.uint8)
+    for b in range(B):
+        if b % 4 == 0:
+            continue                                                         # empty ground truth
+        r = 10 + 6 * b
+        gt[b] = (((yy - 50) ** 2 + (xx - 40 - b) ** 2) < r * r).to(torch.uint8)
+        top, left = I.crop_window(H, W, (h, w))
+        prob[b, 1, top:top + h, left:left + w] = 0.15 + 0.6 * gt[b].float() + 0.2 * torch.rand(h, w, generator=g)
+    prob[0, 1] = 0.05                                                        # empty prediction on an empty mask -> IoU 1
+    prob[4, 1] = 0.9                                                         # full prediction on an empty mask -> IoU 0
+    ths = np.linspace(0.5, 0.3, 21)
+    counts = I.iou_counts(prob.to(DEV), gt.to(DEV), ths, cls=1)
+    iou, iout = I.scores_from_counts(*counts)
+    for k, th in enumerate(ths):
+        preds = [(OM.crop_image(prob[b].numpy(), (h, w))[1].astype(np.float64) > th).astype(np.uint8) for b in range(B)]
+        gts = [gt[b].numpy() for b in range(B)]
+        assert abs(iou[k] - OM.intersection_over_union(gts, preds)) < 1e-12, k
+        assert abs(iout[k] - OM.intersection_over_union_thresholds(gts, preds)) < 1e-12, k
+    # threshold selection walks the sweep while IOUT improves
+    t_best, iou_b, iout_b = I.select_threshold([counts])
+    best, tb = 0.0, 0.5
+    for k, th in enumerate(ths):
+        if iout[k] > best:
+            best, tb = iout[k], float(th)
+        else:
+            break
+    assert t_best == tb and abs(iout_b - best) < 1e-12
+
+
+def test_predict_tta_end_to_end_vs_oracle():
+    """4-flip TTA of an eval-mode network: device pipeline vs oracle forward of numpy-flipped inputs + numpy aggregation."""
+    from salt_amd import architectures as A, inference as I
+    from oracle import nets as ON, specs as OS, metrics as OM
+    torch.manual_seed(3)
+    net = A.VanillaUNet(2, in_channels=1, base_filters=8, levels=3)
+    spec = OS.spec_vanilla_unet(2, 1, 8, 3)
+    sd = OS.init_state(spec, seed=2)
+    net.load_state_dict(sd)
+    net.to(DEV).eval()
+    X = torch.randn(2, 1, 32, 48)
+    prob = I.predict_tta(net, X.to(DEV), True, True).cpu().numpy()
+    specs = OM.tta_specs(True, True)
+    for b in range(2):
+        preds = []
+        for s in specs:
+            xv = OM.tta_transform(X[b].permute(1, 2, 0).numpy(), s)
+            xv = torch.from_numpy(np.ascontiguousarray(xv)).permute(2, 0, 1)[None]
+            with torch.no_grad():
+                preds.append(OM.sigmoid(ON.vanilla_unet(sd, xv, False, levels=3)[0].numpy()))
+        ref = OM.tta_aggregate(preds, specs, 'mean')
+        assert_close(prob[b], ref, 1e-4, 'tta probabilities')
+    with pytest.raises(Exception):
+        net.train(); I.predict_tta(net, X.to(DEV))

@@ -155,3 +155,33 @@ def test_product_never_imports_the_oracle_or_reads_the_reference():
     for f in os.listdir(os.path.join(ROOT, 'tests')):
         if f.startswith('test_gpu') and f.endswith('.py'):
             assert 'ref_import' not in open(os.path.join(ROOT, 'tests', f)).read(), f
+
+
+def test_inference_host_logic_matches_oracle():
+    """Host halves of the inference epilogue: variant order, crop window, IoU/IOUT from counts, threshold selection."""
+    from salt_amd import inference as I
+    from oracle import metrics as OM
+    for ud in (False, True):
+        for lr in (False, True):
+            assert I.tta_variants(ud, lr) == [(s['ud_flip'], s['lr_flip']) for s in OM.tta_specs(ud, lr)]
+    for H, W, tgt in [(128, 128, (101, 101)), (256, 256, (202, 202)), (64, 96, (50, 71)), (128, 128, (128, 128))]:
+        top, right, bottom, left = OM.crop_pad_sequence(H - tgt[0], W - tgt[1])
+        assert I.crop_window(H, W, tgt) == (top, left)
+    r = np.random.RandomState(0)
+    B, h, w = 9, 20, 17
+    gt = (r.rand(B, h, w) > 0.6).astype(np.uint8)
+    gt[0] = 0; gt[1] = 0
+    prob = r.rand(B, h, w)
+    prob[0] = 0.0                                         # both empty
+    ths = np.linspace(0.5, 0.3, 21)
+    inter = np.array([[int(((prob[b] > t) & (gt[b] > 0)).sum()) for t in ths] for b in range(B)])
+    pred = np.array([[int((prob[b] > t).sum()) for t in ths] for b in range(B)])
+    iou, iout = I.scores_from_counts(inter, pred, gt.reshape(B, -1).sum(1))
+    for k, t in enumerate(ths):
+        preds = [(prob[b] > t).astype(np.uint8) for b in range(B)]
+        assert abs(iou[k] - OM.intersection_over_union(list(gt), preds)) < 1e-12
+        assert abs(iout[k] - OM.intersection_over_union_thresholds(list(gt), preds)) < 1e-12
+    t_best, iou_b, iout_b = I.select_threshold([(inter, pred, gt.reshape(B, -1).sum(1))])
+    assert 0.3 <= t_best <= 0.5 and 0.0 <= iou_b <= 1.0 and 0.0 <= iout_b <= 1.0
+    with pytest.raises(I.SaltError):
+        I.crop_threshold(torch.zeros(1, 2, 8, 8))         # CPU tensor: loud failure, no fallback
