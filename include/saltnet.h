@@ -574,6 +574,31 @@ typedef struct {              /* x_out[b] = flip(x[b]) for NCHW fp32 batches (TT
 } salt_flip_args;
 int salt_flip(const salt_flip_args*, void* stream);
 
+/* ------------------------------------------------------------------ on-device input pipeline
+ * gray tile -> [bilinear resize] -> edge pad -> Normalize -> AddDepthChannels; mask -> nearest resize -> pad -> one-hot
+ * (loaders.py:603-612,763-769; augmentation.py:79-96,247-284; utils.py:494-500).  Normalisation divides by std exactly as
+ * torchvision ((g - mean) / std is evaluated as (g - mean) * (1 / std), agreement 1 ulp). */
+typedef struct {
+    const void* img;          /* [B,h,w] uint8 (img_is_u8) or fp32 in [0,1] */
+    int img_is_u8;
+    const uint8_t* mask;      /* [B,h,w] {0,1} or NULL */
+    int B;
+    int h;
+    int w;
+    int resize_h;             /* 0 = no resize */
+    int resize_w;
+    int top;                  /* rows / columns of edge padding before the tile; the rest of [H,W] is padded after it */
+    int left;
+    int H;
+    int W;
+    int channels;             /* 1 (gray only) | 3 (gray, depth ramp, gray*ramp) */
+    float mean[3];
+    float std[3];
+    float* x;                 /* out fp32 NCHW [B,channels,H,W] */
+    float* target;            /* out fp32 NCHW [B,2,H,W] one-hot {background, salt}; required when mask != NULL */
+} salt_preprocess_args;
+int salt_preprocess(const salt_preprocess_args*, void* stream);
+
 /* centre crop + binarize one class of a probability map (postprocessing.py:24-43, utils.py:308-313): mask = prob[cls] > threshold */
 typedef struct {
     const float* prob;        /* fp32 NCHW [B,C,H,W] */

@@ -1,0 +1,89 @@
+// input.hip — on-device input pipeline.
+//
+// What the reference does per image on the CPU with PIL / imgaug / torchvision (loaders.py:603-612, augmentation.py:79-96,
+// 247-284, utils.py:494-500, loaders.py:763-769) is one pass here:
+//   gray tile [h, w] (uint8 or float in [0,1])
+//     -> optional bilinear resize to [rh, rw] (half-pixel centres, as torch's align_corners=False)      train: 101 -> 102
+//     -> edge (replicate) pad: `top` rows / `left` columns, rest to [H, W]                                train: 13; inference 13/14
+//     -> Grayscale(3) + ToTensor + Normalize(mean, std) per channel
+//     -> AddDepthChannels: ch1 := linspace(0, 1, H)[row], ch2 := ch0 * ch1                                (3-channel mode)
+//   mask tile [h, w] -> nearest resize -> same pad -> one-hot {1 - m, m} target [2, H, W]
+#include "common.h"
+
+namespace {
+
+struct PreKP {
+    const void* img; const unsigned char* mask; float* x; float* target;
+    int img_is_u8, B, h, w, rh, rw, top, left, H, W, channels;
+    float mean[3], inv_std[3];
+};
+
+__device__ __forceinline__ float src_index(int dst, float scale) {      // torch area_pixel_compute_source_index, align_corners=False
+    const float s = scale * ((float)dst + 0.5f) - 0.5f;
+    return s < 0.f ? 0.f : s;
+}
+
+__global__ void preprocess_kernel(PreKP p) {
+    const int64_t n = (int64_t)p.B * p.H * p.W;
+    const float sy = (float)p.h / (float)p.rh, sx = (float)p.w / (float)p.rw;
+    for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < n; i += gridDim.x * 256LL) {
+        const int X = (int)(i % p.W); int64_t r = i / p.W; const int Y = (int)(r % p.H); const int b = (int)(r / p.H);
+        const int ry = min(max(Y - p.top, 0), p.rh - 1), rx = min(max(X - p.left, 0), p.rw - 1);      // edge pad = clamp
+        auto px = [&](int yy, int xx) -> float {
+            const int64_t o = ((int64_t)b * p.h + yy) * p.w + xx;
+            return p.img_is_u8 ? (float)reinterpret_cast<const unsigned char*>(p.img)[o] * (1.f / 255.f) : reinterpret_cast<const float*>(p.img)[o];
+        };
+        float g;
+        if (p.rh == p.h && p.rw == p.w) {
+            g = px(ry, rx);
+        } else {
+            const float fy = src_index(ry, sy), fx = src_index(rx, sx);
+            const int y0 = (int)fy, x0 = (int)fx;
+            const int y1 = y0 + (y0 < p.h - 1 ? 1 : 0), x1 = x0 + (x0 < p.w - 1 ? 1 : 0);
+            const float ly = fy - (float)y0, lx = fx - (float)x0;
+            const float hy = 1.f - ly, hx = 1.f - lx;
+            g = hy * (hx * px(y0, x0) + lx * px(y0, x1)) + ly * (hx * px(y1, x0) + lx * px(y1, x1));
+        }
+        const int64_t hw = (int64_t)p.H * p.W;
+        float* xo = p.x + (int64_t)b * p.channels * hw + (int64_t)Y * p.W + X;
+        const float c0 = (g - p.mean[0]) * p.inv_std[0];
+        xo[0] = c0;
+        if (p.channels == 3) {
+            const float depth = p.H > 1 ? (float)((double)Y / (double)(p.H - 1)) : 0.f;              // np.linspace(0, 1, H)[Y]
+            xo[hw] = depth;
+            xo[2 * hw] = c0 * depth;
+        }
+        if (p.mask) {
+            // nearest: torch 'nearest' picks floor(dst * in / out)
+            const int my = p.rh == p.h ? ry : min((int)floorf((float)ry * sy), p.h - 1);
+            const int mx = p.rw == p.w ? rx : min((int)floorf((float)rx * sx), p.w - 1);
+            const float m = p.mask[((int64_t)b * p.h + my) * p.w + mx] ? 1.f : 0.f;
+            float* to = p.target + (int64_t)b * 2 * hw + (int64_t)Y * p.W + X;
+            to[0] = 1.f - m;
+            to[hw] = m;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int salt_preprocess(const salt_preprocess_args* a, void* stream) {
+    if (!a || !a->img || !a->x || a->B < 1 || a->h < 1 || a->w < 1 || a->H < 1 || a->W < 1 || (a->channels != 1 && a->channels != 3) ||
+        a->top < 0 || a->left < 0 || (a->mask && !a->target))
+        SALT_FAIL(SALT_E_BADARG, "preprocess: bad args");
+    PreKP p;
+    p.img = a->img; p.mask = a->mask; p.x = a->x; p.target = a->target;
+    p.img_is_u8 = a->img_is_u8; p.B = a->B; p.h = a->h; p.w = a->w;
+    p.rh = a->resize_h > 0 ? a->resize_h : a->h; p.rw = a->resize_w > 0 ? a->resize_w : a->w;
+    p.top = a->top; p.left = a->left; p.H = a->H; p.W = a->W; p.channels = a->channels;
+    if (p.top + p.rh > p.H || p.left + p.rw > p.W) SALT_FAIL(SALT_E_BADARG, "preprocess: resized tile + pad offset exceeds the output");
+    for (int c = 0; c < 3; ++c) {
+        if (a->std[c] <= 0.f) SALT_FAIL(SALT_E_BADARG, "preprocess: std must be positive");
+        p.mean[c] = a->mean[c]; p.inv_std[c] = 1.f / a->std[c];
+    }
+    const int64_t n = (int64_t)a->B * a->H * a->W;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(preprocess_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}

@@ -19,7 +19,7 @@ void salt_set_error(const char* fmt, ...) {
 
 extern "C" const char* salt_last_error(void) { return g_err; }
 
-extern "C" int salt_abi_version(void) { return 8; }
+extern "C" int salt_abi_version(void) { return 9; }
 
 extern "C" int salt_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name_len) {
     int dev = 0;
@@ -196,6 +196,7 @@ extern "C" int salt_abi_struct_sizes(int* out, int n) {
     (int)sizeof(salt_zero_args),
     (int)sizeof(salt_tta_mean_args),
     (int)sizeof(salt_flip_args),
+    (int)sizeof(salt_preprocess_args),
     (int)sizeof(salt_crop_threshold_args),
     (int)sizeof(salt_iou_sweep_args),
     (int)sizeof(salt_program_entry)};

@@ -124,3 +124,46 @@ def test_predict_tta_end_to_end_vs_oracle():
         assert_close(prob[b], ref, 1e-4, 'tta probabilities')
     with pytest.raises(Exception):
         net.train(); I.predict_tta(net, X.to(DEV))
+
+
+@pytest.mark.parametrize('train', [True, False])
+@pytest.mark.parametrize('channels', [1, 3])
+@pytest.mark.parametrize('as_u8', [False, True])
+def test_device_input_pipeline_vs_oracle(train, channels, as_u8):
+    """f-1: resize + edge-pad + normalise + depth channels + one-hot target in one kernel vs the CPU restatement."""
+    from salt_amd.input_pipeline import DevicePreprocessor
+    from oracle import inputs as OI
+    r = np.random.RandomState(4)
+    B, h, w = 5, 101, 101
+    img = r.rand(B, h, w).astype(np.float32)
+    if as_u8:
+        u8 = (img * 255).astype(np.uint8)
+        img = u8.astype(np.float32) * np.float32(1.0 / 255.0)              # what the kernel sees
+        dev_img = T(u8).to(DEV)
+    else:
+        dev_img = T(img).to(DEV)
+    msk = (r.rand(B, h, w) > 0.5).astype(np.uint8)
+    msk[0] = 0
+    X, Tg = DevicePreprocessor(train, channels)(dev_img, T(msk).to(DEV))
+    Xr, Tr = OI.preprocess(img, msk, train, channels)
+    assert tuple(X.shape) == tuple(Xr.shape) == (B, channels, 128, 128)
+    assert_close(X.cpu(), Xr, 2e-6, 'input batch')
+    assert torch.equal(Tg.cpu(), Tr)                                         # one-hot target: exact
+    X2, T2 = DevicePreprocessor(train, channels)(dev_img)                    # inference batches carry no target
+    assert T2 is None and torch.equal(X2, X)
+
+
+def test_device_input_pipeline_other_sizes():
+    from salt_amd.input_pipeline import DevicePreprocessor
+    from oracle import inputs as OI
+    r = np.random.RandomState(6)
+    img = r.rand(2, 202, 202).astype(np.float32)                            # C4: 256x256 inputs (pad/resize x2)
+    X, _ = DevicePreprocessor(False, 3)(T(img).to(DEV))
+    Xr, _ = OI.preprocess(img, None, False, 3)
+    assert tuple(X.shape) == (2, 3, 256, 256)
+    assert_close(X.cpu(), Xr, 2e-6, 'inference pad 202 -> 256')
+    X, Tg = DevicePreprocessor(True, 3, resize=204, pad=26)(T(img).to(DEV), T((img > 0.5).astype(np.uint8)).to(DEV))
+    Xr, Tr = OI.preprocess(img, (img > 0.5).astype(np.uint8), True, 3, resize=204, pad=26)
+    assert tuple(X.shape) == (2, 3, 256, 256)
+    assert_close(X.cpu(), Xr, 2e-6, 'train resize 202 -> 204 + pad 26')
+    assert torch.equal(Tg.cpu(), Tr)
