@@ -50,42 +50,7 @@ def get_list_of_image_predictions(batch_predictions):      # utils.py:316-320
     return [img for batch in batch_predictions for img in list(batch)]
 
 
-class Callback:
-    """Minimal hook surface of the reference's callbacks (callbacks.py:30-78); real callback objects from the
-    reference can be passed in via ``callbacks_config={'callbacks': [...]}`` — they only use the attributes
-    SegmentationModel exposes (model, optimizer, loss_function, output_names, validation_loss)."""
-
-    def set_params(self, transformer, validation_datagen=None, *a, **k):
-        self.transformer, self.model, self.optimizer = transformer, transformer.model, transformer.optimizer
-        self.loss_function, self.output_names, self.validation_datagen = transformer.loss_function, transformer.output_names, validation_datagen
-
-    def on_train_begin(self, *a, **k): self.epoch_id, self.batch_id = 0, 0
-    def on_train_end(self, *a, **k): pass
-    def on_epoch_begin(self, *a, **k): pass
-    def on_epoch_end(self, *a, **k): self.epoch_id += 1
-    def on_batch_begin(self, *a, **k): pass
-    def on_batch_end(self, *a, **k): self.batch_id += 1
-    def training_break(self, *a, **k): return False
-
-
-class CallbackList:
-    def __init__(self, callbacks=None):
-        self.callbacks = list(callbacks or [])
-
-    def __getattr__(self, name):
-        if name.startswith('on_') or name == 'set_params':
-            def call(*a, **k):
-                for c in self.callbacks:
-                    getattr(c, name)(*a, **k)
-            return call
-        raise AttributeError(name)
-
-    def training_break(self, *a, **k):
-        return any([c.training_break(*a, **k) for c in self.callbacks])
-
-
-def callbacks_network(callbacks_config):
-    return CallbackList((callbacks_config or {}).get('callbacks', []))
+from .callbacks import Callback, CallbackList, callbacks_network, score_validation  # noqa: E402,F401  (callbacks.py surface)
 
 
 class Model:
@@ -108,6 +73,10 @@ class Model:
 
     def fit_transform(self, *args, **kwargs):
         return self.fit(*args, **kwargs).transform(*args, **kwargs)
+
+    def score_validation(self, validation_datagen):
+        """{'sum', 'iou', 'iout'} of one pass over the validation generator (callbacks.py:503-568), threshold sweep on the GPU."""
+        return score_validation(self, validation_datagen)
 
     def persist(self, filepath):
         """Reference checkpoints are written through nn.DataParallel, so every key carries a 'module.' prefix

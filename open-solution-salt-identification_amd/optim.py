@@ -21,18 +21,19 @@ def weight_regularization(model, regularize, weight_decay_conv2d):
     return [params]
 
 
-class FusedAdam:
+class FusedAdam(torch.optim.Optimizer):
+    """A real ``torch.optim.Optimizer`` (so torch's LR schedulers - ReduceLROnPlateau, ExponentialLR: callbacks.py:170-241 - accept
+    it) whose ``step`` is one fused kernel over the flat buffers; ``param_groups[0]['lr']`` is re-read every step."""
+
     def __init__(self, param_groups, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, model=None):
         if isinstance(param_groups, (list, tuple)) and param_groups and isinstance(param_groups[0], dict):
             g = dict(param_groups[0])
         else:
             g = {'params': list(param_groups[0] if param_groups and isinstance(param_groups[0], (list, tuple)) else param_groups)}
-        g.setdefault('lr', lr)
-        g.setdefault('betas', betas)
-        g.setdefault('eps', eps)
-        g.setdefault('weight_decay', weight_decay)
-        g['initial_lr'] = g['lr']
-        self.param_groups = [g]
+        super().__init__([g], dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        if len(self.param_groups) != 1:
+            raise SaltError('FusedAdam: one parameter group (models.py:289-297)')
+        self.param_groups[0].setdefault('initial_lr', self.param_groups[0]['lr'])
         self.model = model
         self._eng = None
         self._host_hyper = None

@@ -198,3 +198,74 @@ def test_input_pipeline_geometry_matches_reference_pad_sequence():
     assert DevicePreprocessor(True).geometry(101, 101) == (102, 102, 13, 13, 128, 128)
     top, right, bottom, left = OI.crop_pad_sequence(155 % 64 and 64 - 155 % 64, 0)
     assert DevicePreprocessor(False).geometry(155, 128)[2] == top
+
+
+class _FakeTransformer:
+    """Just the attributes the callbacks touch (callbacks.py:42-48)."""
+
+    def __init__(self, scores):
+        self.model = torch.nn.Linear(2, 2)
+        self.optimizer = torch.optim.SGD(self.model.parameters(), lr=0.1)
+        self.loss_function = [('mask', None, 1.0)]
+        self.output_names = ['mask']
+        self.validation_loss = {}
+        self.scores = list(scores)
+        self.calls = 0
+        self.saved = []
+
+    def score_validation(self, datagen):
+        v = self.scores[self.calls]
+        self.calls += 1
+        return {'sum': torch.tensor([1.0 - v]), 'iou': torch.tensor([v]), 'iout': torch.tensor([v])}
+
+    def persist(self, path):
+        self.saved.append((len(self.validation_loss) - 1, path))
+
+
+def test_callbacks_follow_reference_semantics(tmp_path):
+    """ModelCheckpoint / EarlyStopping / ReduceLROnPlateau driven by a metric sequence (callbacks.py:204-241,758-829); the
+    validation pass runs once per epoch and is shared through transformer.validation_loss (callbacks.py:522-527)."""
+    from salt_amd import callbacks as C
+    scores = [0.50, 0.60, 0.55, 0.58, 0.59, 0.40, 0.30]
+    tr = _FakeTransformer(scores)
+    cfg = {'model_checkpoint': {'filepath': str(tmp_path / 'ck' / 'best.torch'), 'epoch_every': 1, 'metric_name': 'iout', 'minimize': False},
+           'reduce_lr_on_plateau_scheduler': {'metric_name': 'iout', 'minimize': False, 'reduce_factor': 0.1, 'reduce_patience': 1, 'min_lr': 1e-7},
+           'training_monitor': {'batch_every': 0, 'epoch_every': 1}, 'experiment_timing': {'batch_every': 0, 'epoch_every': 1},
+           'validation_monitor': {'epoch_every': 1, 'data_dir': None, 'loader_mode': 'resize_and_pad', 'use_depth': False},
+           'neptune_monitor': {'model_name': 'network'},
+           'early_stopping': {'patience': 2, 'metric_name': 'iout', 'minimize': False}}
+    cl = C.callbacks_network(cfg)
+    assert [type(c).__name__ for c in cl.callbacks] == ['ExperimentTiming', 'TrainingMonitor', 'ValidationMonitor', 'ModelCheckpoint',
+                                                        'ReduceLROnPlateauScheduler', 'EarlyStopping']
+    cl.set_params(tr, validation_datagen=('gen', 0), meta_valid=None)
+    cl.on_train_begin()
+    lrs, stopped_at = [], None
+    for epoch in range(len(scores)):
+        cl.on_epoch_begin()
+        cl.on_batch_begin()
+        cl.on_batch_end(metrics={'sum': torch.tensor([0.5])})
+        cl.on_epoch_end()
+        lrs.append(tr.optimizer.param_groups[0]['lr'])
+        if cl.training_break():
+            stopped_at = epoch
+            break
+    assert tr.calls == stopped_at + 1                                    # one validation pass per epoch, shared by 4 callbacks
+    assert [e for e, _ in tr.saved] == [0, 1]                            # epoch 0 always, then only strict improvements (0.60)
+    # ReduceLROnPlateau(max, 0.1, patience 1): best 0.60 at epoch 1; bad epochs 2,3 -> reduced at epoch 3
+    assert lrs[:3] == [0.1, 0.1, 0.1] and abs(lrs[3] - 0.01) < 1e-12 and abs(lrs[4] - 0.01) < 1e-12
+    # EarlyStopping(patience 2): epochs since best (epoch 1) = 1,2,3 at epochs 2,3,4 -> break when > 2, i.e. after epoch 4
+    assert stopped_at == 4
+    tm = [c for c in cl.callbacks if isinstance(c, C.TrainingMonitor)][0]
+    assert len(tm.history) == stopped_at + 1 and abs(tm.history[0]['sum'] - 0.5) < 1e-7
+
+
+def test_fused_adam_is_a_torch_optimizer_for_schedulers():
+    from salt_amd import models
+    arch = {'model_params': {'architecture': 'VanillaUNet', 'out_channels': 2, 'activation': 'sigmoid'},
+            'optimizer_params': {'lr': 1e-3}, 'regularizer_params': {'regularize': False, 'weight_decay_conv2d': 0.0}}
+    m = models.SegmentationModel(arch, {'epochs': 1}, {})
+    assert isinstance(m.optimizer, torch.optim.Optimizer) and m.optimizer.param_groups[0]['weight_decay'] == 0.0
+    sch = torch.optim.lr_scheduler.ExponentialLR(m.optimizer, gamma=0.5)     # callbacks.py:170-201
+    m.optimizer.steps = 1
+    sch.step()
+    assert abs(m.optimizer.param_groups[0]['lr'] - 5e-4) < 1e-12

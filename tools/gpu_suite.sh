@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 export PYTHONUNBUFFERED=1
 K="$1"
 rc=0
-for f in tests/test_gpu_loss_optim.py tests/test_gpu_inference.py tests/test_gpu_blocks.py tests/test_gpu_models.py; do
+for f in tests/test_gpu_loss_optim.py tests/test_gpu_inference.py tests/test_gpu_trainer.py tests/test_gpu_blocks.py tests/test_gpu_models.py; do
   n=$(basename $f .py)
   if [ -n "$K" ]; then
     timeout 900 python -m pytest $f -q -m gpu --tb=short --timeout 300 -k "$K" > gpurun_out/$n.log 2>&1
