@@ -461,8 +461,11 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
         if (Cout <= 32) id = 4;
         else if (big) id = 2;                 // 256-pixel tiles: the chunk's weights are staged once per 256 pixels
         else id = 1;
+        // few pixels, many channels (ResNet stages 3-4, the 8x8 / 16x16 decoder levels): 128x32 tiles double the workgroup count and
+        // run at 3 workgroups per CU - measured 8-15 % faster than 128x64 / 64x64 there (tools/cfg_sweep.sh)
         const int64_t wgs = ((pixels + 127) / 128) * cdiv(Cout, 64);
-        if (id == 1 && wgs < 256) id = 5;
+        static const int small_cfg = getenv("SALT_CONV_SMALL_CFG") ? atoi(getenv("SALT_CONV_SMALL_CFG")) : 4;
+        if (id == 1 && wgs < 512) id = (small_cfg == 5 && wgs >= 256) ? 1 : small_cfg;
     }
     const TileCfg* cfg = nullptr;
     for (const auto& c : kCfgs) if (c.id == id) cfg = &c;
