@@ -181,39 +181,39 @@ __global__ void se_parts_reduce_kernel(float* partials, int nparts, int width) {
 
 // FC backward: single block (sizes are B x C x R = tiny).  dgap[b][c] out; parameter grads written (not accumulated).
 // `partials` rows have already been reduced over parts (row 0 of every image holds the sums).
-__global__ void se_fc_bwd_kernel(const float* partials, int nparts, int B, int C, int R, const float* w1, const float* w2,
+__global__ __launch_bounds__(1024) void se_fc_bwd_kernel(const float* partials, int nparts, int B, int C, int R, const float* w1, const float* w2,
                                  const float* gap, const float* hidden, const float* gate_c,
                                  float* g_w1, float* g_b1, float* g_w2, float* g_b2, float* g_ws, float* g_bs, float* dgap, float inv_hw) {
-    extern __shared__ float sm[];       // du [B][C], dh [B][R]
-    float* du = sm; float* dh = sm + B * C;
+    // everything the loops touch repeatedly is staged in LDS first (one coalesced sweep); the batch loops then run out of LDS
+    extern __shared__ float sm[];       // du [B][C], dh [B][R], gp [B][C], hd [B][R], ps [B][C+1] (spatial-SE sums)
+    float* du = sm; float* dh = du + B * C; float* gp = dh + B * R; float* hd = gp + B * C; float* ps = hd + B * R;
     const int tid = threadIdx.x, nt = blockDim.x;
     for (int i = tid; i < B * C; i += nt) {
         const int b = i / C, c = i - b * C;
-        const float t = partials[((int64_t)b * nparts) * (2 * C + 1) + c];
+        const float* row = partials + ((int64_t)b * nparts) * (2 * C + 1);
         const float g = gate_c[i];
-        du[i] = t * g * (1.f - g);
+        du[i] = row[c] * g * (1.f - g);
+        gp[i] = gap[i];
+        ps[b * (C + 1) + c] = row[C + c];
+        if (c == 0) ps[b * (C + 1) + C] = row[2 * C];
     }
-    for (int c = tid; c < C; c += nt) {
-        float t = 0.f;
-        for (int b = 0; b < B; ++b) t += partials[((int64_t)b * nparts) * (2 * C + 1) + C + c];
-        g_ws[c] = t;
-    }
-    if (tid == 0) {
-        float t = 0.f;
-        for (int b = 0; b < B; ++b) t += partials[((int64_t)b * nparts) * (2 * C + 1) + 2 * C];
-        g_bs[0] = t;
-    }
+    for (int i = tid; i < B * R; i += nt) hd[i] = hidden[i];
     __syncthreads();
+    for (int c = tid; c < C + 1; c += nt) {
+        float t = 0.f;
+        for (int b = 0; b < B; ++b) t += ps[b * (C + 1) + c];
+        if (c < C) g_ws[c] = t; else g_bs[0] = t;
+    }
     for (int i = tid; i < B * R; i += nt) {
         const int b = i / R, r = i - b * R;
         float t = 0.f;
         for (int c = 0; c < C; ++c) t += du[b * C + c] * w2[c * R + r];
-        dh[i] = hidden[i] > 0.f ? t : 0.f;
+        dh[i] = hd[i] > 0.f ? t : 0.f;
     }
     for (int i = tid; i < C * R; i += nt) {
         const int c = i / R, r = i - c * R;
         float t = 0.f;
-        for (int b = 0; b < B; ++b) t += du[b * C + c] * hidden[b * R + r];
+        for (int b = 0; b < B; ++b) t += du[b * C + c] * hd[b * R + r];
         g_w2[i] = t;
     }
     for (int c = tid; c < C; c += nt) { float t = 0.f; for (int b = 0; b < B; ++b) t += du[b * C + c]; g_b2[c] = t; }
@@ -221,7 +221,7 @@ __global__ void se_fc_bwd_kernel(const float* partials, int nparts, int B, int C
     for (int i = tid; i < R * C; i += nt) {
         const int r = i / C, c = i - r * C;
         float t = 0.f;
-        for (int b = 0; b < B; ++b) t += dh[b * R + r] * gap[b * C + c];
+        for (int b = 0; b < B; ++b) t += dh[b * R + r] * gp[b * C + c];
         g_w1[i] = t;
     }
     for (int r = tid; r < R; r += nt) { float t = 0.f; for (int b = 0; b < B; ++b) t += dh[b * R + r]; g_b1[r] = t; }
@@ -308,8 +308,16 @@ extern "C" int salt_scse_bwd(const salt_scse_bwd_args* a, void* stream) {
     if (a->nparts != nparts) SALT_FAIL(SALT_E_BADARG, "scse_bwd: nparts %d, expected %d", a->nparts, nparts);
     hipStream_t st = (hipStream_t)stream;
     const int C = a->x.C, B = a->x.B;
-    const size_t fc_lds = (size_t)B * (C + a->R) * sizeof(float);
-    if (fc_lds > 64 * 1024) SALT_FAIL(SALT_E_LDS, "scse_bwd: batch*channels too large for the FC backward (%zu B)", fc_lds);
+    const size_t fc_lds = (size_t)B * (3 * C + 2 * a->R + 1) * sizeof(float);
+    if (fc_lds > 160 * 1024) SALT_FAIL(SALT_E_LDS, "scse_bwd: batch*channels too large for the FC backward (%zu B)", fc_lds);
+    if (fc_lds > 64 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(se_fc_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) SALT_FAIL((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+            attr_set = true;
+        }
+    }
     SALT_DISPATCH_DTYPE(a->dtype, T, {
         if (!se_ok<T>(a->x) || !se_ok<T>(a->y) || !se_ok<T>(a->dy) || !se_ok<T>(a->dx)) SALT_FAIL(SALT_E_UNSUPPORTED, "scse_bwd: layout");
         constexpr int VE = Elem<T>::VE;
@@ -319,7 +327,7 @@ extern "C" int salt_scse_bwd(const salt_scse_bwd_args* a, void* stream) {
         SALT_CHECK_LAUNCH();
         hipLaunchKernelGGL(se_parts_reduce_kernel, dim3(B), dim3(256), 0, st, a->partials, nparts, 2 * C + 1);
         SALT_CHECK_LAUNCH();
-        hipLaunchKernelGGL(se_fc_bwd_kernel, dim3(1), dim3(256), fc_lds, st, a->partials, nparts, B, C, a->R, a->w1, a->w2, a->gap, a->hidden,
+        hipLaunchKernelGGL(se_fc_bwd_kernel, dim3(1), dim3(1024), fc_lds, st, a->partials, nparts, B, C, a->R, a->w1, a->w2, a->gap, a->hidden,
                            a->gate_c, a->g_w1, a->g_b1, a->g_w2, a->g_b2, a->g_ws, a->g_bs, a->dgap, 1.0f / (float)(a->x.H * a->x.W));
         SALT_CHECK_LAUNCH();
         const int64_t units = view_pixels(a->dx) * (C / VE);
