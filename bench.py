@@ -321,6 +321,8 @@ def main():
                            'avg_launch_us': round(1e3 * dms / dcnt, 2), 'share_of_step': round(dms / reps / total_ms, 3),
                            'algorithmic_gflop_per_step': round(dfl / reps / 1e9, 2)}
         out['op_time_ms'] = {k: round(v[0] / reps, 3) for k, v in sorted(groups.items(), key=lambda kv: -kv[1][0])[:8]}
+        out['op_time_serial_ms'] = round(total_ms, 3)          # every operator run back to back on ONE stream (no wgrad overlap)
+        out['op_time_side_stream_ms'] = round(sum(v[0] for k, v in groups.items() if k in ('conv_wgrad', 'wgrad_reduce', 'conv_first_wgrad', 'stem_grad_unfold')) / reps, 3)
         all_fl = sum(g[1] for g in groups.values()) / reps
         out['step_tflops'] = round(all_fl * world / (elapsed / args.steps) / 1e12 / world, 2)
 

@@ -37,6 +37,7 @@ struct ConvKP {
     int relu, accumulate, stats_part0;
     void* strip; int strip_cs, fold_top, fold_bottom, fold_left, fold_right;     // fold mode (strip != nullptr)
     unsigned hhw_magic, hw_magic;                                                // x / d == umulhi(x, 2^32 / d + 1) for x * d < 2^32
+    int m_tiles, n_tiles;
 };
 
 template <typename T> struct Mma;
@@ -89,12 +90,18 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
     const int wm = wave / WN, wn = wave % WN;
     const int khalf = lane >> 5, l31 = lane & 31;
 
-    int tile = blockIdx.x;
+    // 1-D grid, XCD-aware order: consecutive block ids go round-robin to the 8 XCDs, so within one XCD (id % 8) the channel tiles of
+    // ONE pixel tile are adjacent in dispatch order and share its halo rows through that XCD's L2 (re-read n_tiles times otherwise).
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int n_tile = local % p.n_tiles;
+    const int m_tile = (local / p.n_tiles) * 8 + xcd;
+    if (m_tile >= p.m_tiles) return;
+    int tile = m_tile;
     const int txi = tile % p.tiles_x; tile /= p.tiles_x;
     const int tyi = tile % p.tiles_y;
     const int tbi = tile / p.tiles_y;
     const int oy0 = tyi << p.th_log2, ox0 = txi << p.tw_log2, b0 = tbi * p.nb;
-    const int n0 = blockIdx.y * BN;
+    const int n0 = n_tile * BN;
     const int hhw = p.hh * p.hw;
     const int phalo = p.nb * hhw;
     const int iy0 = oy0 * p.in_step + p.min_dy, ix0 = ox0 * p.in_step + p.min_dx;
@@ -404,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
         }
         if (lane == 0 && wn == 0) sC[wm] = cntf;
         __syncthreads();
-        const int part = p.stats_part0 + blockIdx.x;
+        const int part = p.stats_part0 + m_tile;
         if (tid < BN) {
             float N = 0.f, S = 0.f, M2 = 0.f;
 #pragma unroll
@@ -425,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
                 p.stats[((int64_t)part * 2 + 0) * p.Cout + n] = S;
                 p.stats[((int64_t)part * 2 + 1) * p.Cout + n] = M2;
             }
-            if (tid == 0 && blockIdx.y == 0) p.stats_cnt[part] = N;
+            if (tid == 0 && n_tile == 0) p.stats_cnt[part] = N;
         }
     }
 }
@@ -506,7 +513,8 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
     k.hw_magic = (unsigned)((1ull << 32) / (unsigned)k.hw) + 1u;
     k.relu = a->relu; k.accumulate = a->accumulate; k.stats_part0 = a->stats_part0;
     k.strip = a->strip; k.strip_cs = a->strip_cs; k.fold_top = a->fold_top; k.fold_bottom = a->fold_bottom; k.fold_left = a->fold_left; k.fold_right = a->fold_right;
-    pl->grid = dim3((unsigned)(tiles_b * k.tiles_y * k.tiles_x), (unsigned)cdiv(Cout, BN), 1);
+    k.m_tiles = tiles_b * k.tiles_y * k.tiles_x; k.n_tiles = cdiv(Cout, BN);
+    pl->grid = dim3((unsigned)(cdiv(k.m_tiles, 8) * 8 * k.n_tiles), 1, 1);
     pl->lds = (size_t)k.a_bytes + (size_t)a->ntaps * BN * 64;
     {   // the epilogue stages the BM x BN output tile through the same LDS
         const size_t es = a->dtype == SALT_F32 ? 4 : 2;
