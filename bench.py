@@ -256,9 +256,6 @@ def main():
     def step(i):
         return model._fit_loop(list(batches[i % pool_batches]))
 
-    if os.environ.get('SALT_MAIN_PRIO'):        # experiment: run the step on a prioritised stream
-        torch.cuda.synchronize()
-        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=int(os.environ['SALT_MAIN_PRIO'])))
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()

@@ -95,9 +95,7 @@ class Engine:
         self._packed_version = -1
         self._folded_version = None
         self.world = 1
-        import os
-        # weight-gradient kernels overlap the data-gradient chain
-        self.side_stream = torch.cuda.Stream(device=device, priority=int(os.environ.get('SALT_SIDE_PRIO', '0')))
+        self.side_stream = torch.cuda.Stream(device=device)     # weight-gradient kernels overlap the data-gradient chain
 
     # ------------------------------------------------------------------ flat parameter storage
     def _flatten(self):
