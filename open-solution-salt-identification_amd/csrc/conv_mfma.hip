@@ -18,6 +18,7 @@
 // Epilogue: bias, optional folded-BN affine + ReLU (eval), optional accumulate, and deterministic
 // per-wave BatchNorm partial statistics (sum, M2) for train mode.
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -309,39 +310,63 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
     for (int j = 0; j < NI; ++j) ssum[j] = 0.f;
     unsigned vmask[MI];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        vmask[i] = 0u;
+    for (int i = 0; i < MI; ++i) vmask[i] = 0xffffu;
+    // everything below is specialised on three workgroup-uniform facts so that the common launches do not pay for the rare ones:
+    // statistics wanted (train-mode forward only), an affine / ReLU epilogue present (eval only), tile fully inside the output grid
+    const bool want_stats = p.stats != nullptr;
+    const bool has_affine = p.bias || p.scale || p.shift || p.relu;
+    const bool full_tile = (b0 + p.nb <= p.B) && (oy0 + (1 << p.th_log2) <= p.OH) && (ox0 + (1 << p.tw_log2) <= p.OW);
+    if (want_stats) {
+        if (full_tile) {
+            cntf = 16.f * MI;
+        } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-            const int tx = m & ((1 << p.tw_log2) - 1);
-            const int ty = (m >> p.tw_log2) & ((1 << p.th_log2) - 1);
-            const int bl = m >> (p.tw_log2 + p.th_log2);
-            const bool valid = (b0 + bl < p.B) && (oy0 + ty < p.OH) && (ox0 + tx < p.OW);
-            if (valid) { vmask[i] |= 1u << r; cntf += 1.f; }
-        }
-    }
-    __syncthreads();                                               // every wave is done reading sA / sB
+            for (int i = 0; i < MI; ++i) {
+                vmask[i] = 0u;
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int n = n0 + nrow[j];
-        const bool nok = n < p.Cout;
-        const float bias = (nok && p.bias) ? p.bias[n] : 0.f;
-        const float sc = (nok && p.scale) ? p.scale[n] : 1.f;
-        const float sh = (nok && p.shift) ? p.shift[n] : 0.f;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = (acc[i][j][r] + bias) * sc + sh;
-                if (p.relu) v = fmaxf(v, 0.f);
-                acc[i][j][r] = v;
-                if ((vmask[i] >> r) & 1u) ssum[j] += v;
-                const int ml = (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                Elem<T>::st(sO + ml * PITCH + nrow[j], v);
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                    const int tx = m & ((1 << p.tw_log2) - 1);
+                    const int ty = (m >> p.tw_log2) & ((1 << p.th_log2) - 1);
+                    const int bl = m >> (p.tw_log2 + p.th_log2);
+                    const bool valid = (b0 + bl < p.B) && (oy0 + ty < p.OH) && (ox0 + tx < p.OW);
+                    if (valid) { vmask[i] |= 1u << r; cntf += 1.f; }
+                }
             }
         }
     }
+    __syncthreads();                                               // every wave is done reading sA / sB
+    auto stage = [&](auto affine_c, auto stats_c) {
+        constexpr bool AFF = decltype(affine_c)::value, ST = decltype(stats_c)::value;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            float bias = 0.f, sc = 1.f, sh = 0.f;
+            if constexpr (AFF) {
+                const int n = n0 + nrow[j];
+                const bool nok = n < p.Cout;
+                bias = (nok && p.bias) ? p.bias[n] : 0.f;
+                sc = (nok && p.scale) ? p.scale[n] : 1.f;
+                sh = (nok && p.shift) ? p.shift[n] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r];
+                    if constexpr (AFF) {
+                        v = (v + bias) * sc + sh;
+                        if (p.relu) v = fmaxf(v, 0.f);
+                        acc[i][j][r] = v;
+                    }
+                    if constexpr (ST) { if ((vmask[i] >> r) & 1u) ssum[j] += v; }
+                    const int ml = (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                    Elem<T>::st(sO + ml * PITCH + nrow[j], v);
+                }
+            }
+        }
+    };
+    if (has_affine) { if (want_stats) stage(std::true_type{}, std::true_type{}); else stage(std::true_type{}, std::false_type{}); }
+    else { if (want_stats) stage(std::false_type{}, std::true_type{}); else stage(std::false_type{}, std::false_type{}); }
     __syncthreads();
     {
         T* yg = reinterpret_cast<T*>(p.y);
