@@ -647,7 +647,7 @@ typedef int (*salt_op_fn)(const void* args, void* stream);
 typedef struct {
     salt_op_fn fn;
     const void* args;
-    int stream;               /* 0 = main stream, 1 = side stream (salt_program_run_streams) */
+    int stream;               /* 0 = main stream, 1 = side stream, 2 = main stream after joining the side stream (salt_program_run_streams) */
     int reserved;
 } salt_program_entry;
 int salt_program_run(const salt_program_entry* entries, int n, void* stream);
@@ -656,7 +656,8 @@ int salt_program_run_range(const salt_program_entry* entries, int begin, int end
 int salt_program_run_timed(const salt_program_entry* entries, int begin, int end, void* stream, float* ms_out);
 /* Two-stream execution: entries with stream == 1 (weight-gradient kernels) are enqueued on `side`, ordered after every
  * main-stream entry that precedes them in the list (event record/wait), and `main` re-joins `side` at the end of the range.
- * Nothing on the main stream may depend on a side entry inside the range (the host guarantees it: side entries only
+ * A main-stream entry that depends on side entries inside the range is tagged stream == 2: main waits for the side stream
+ * right before it (forward: independent branches such as the hypercolumn up-samplings; backward: nothing - side entries only
  * produce parameter gradients).  side == NULL or side == main degenerates to salt_program_run_range. */
 int salt_program_run_streams(const salt_program_entry* entries, int begin, int end, void* main_stream, void* side_stream);
 int salt_graph_capture(const salt_program_entry* entries, int n, void* stream, void** graph_exec_out);

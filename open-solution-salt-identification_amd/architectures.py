@@ -158,7 +158,10 @@ class BasicBlock(EmitOnly):
         self.stride = stride
 
     def emit(self, g, x, out=None):
-        idt = x if self.downsample is None else g.conv(x, self.downsample[0], self.downsample[1], relu=False, name='down')
+        idt = x
+        if self.downsample is not None:          # the projection shortcut is independent of conv1 -> conv2: side stream, joined at the add
+            with g.side():
+                idt = g.conv(x, self.downsample[0], self.downsample[1], relu=False, name='down')
         a = g.conv(x, self.conv1, self.bn1, relu=True, name='block.conv1')
         return g.conv(a, self.conv2, self.bn2, relu=True, res=idt, out=out, name='block.conv2')
 
@@ -179,7 +182,10 @@ class Bottleneck(EmitOnly):
         self.stride = stride
 
     def emit(self, g, x, out=None):
-        idt = x if self.downsample is None else g.conv(x, self.downsample[0], self.downsample[1], relu=False, name='down')
+        idt = x
+        if self.downsample is not None:
+            with g.side():
+                idt = g.conv(x, self.downsample[0], self.downsample[1], relu=False, name='down')
         a = g.conv(x, self.conv1, self.bn1, relu=True, name='bneck.conv1')
         a = g.conv(a, self.conv2, self.bn2, relu=True, name='bneck.conv2')
         return g.conv(a, self.conv3, self.bn3, relu=True, res=idt, out=out, name='bneck.conv3')
@@ -357,16 +363,23 @@ class UNetResNet(HipNetwork):
         c = g.avgpool2(c, name='center.pool')
         if self.use_hypercolumn:
             hyper = g.new_act(B, H, W, 5 * d, 'hypercolumn')
+        # the hypercolumn up-samplings only feed the final convolution: each one goes to the side stream as soon as its decoder
+        # level exists and overlaps the remaining decoder levels; the final convolution joins
+        def hyper_up(x, R, k):
+            if self.use_hypercolumn:
+                with g.side():
+                    g.upsample(x, R, out=hyper.slice(k * d, d))
         d5 = self.dec5.emit(g, c, e5, cat=cat5)
+        hyper_up(d5, 16, 4)
         d4 = self.dec4.emit(g, d5, e4, cat=cat4)
+        hyper_up(d4, 8, 3)
         d3 = self.dec3.emit(g, d4, e3, cat=cat3)
+        hyper_up(d3, 4, 2)
         d2 = self.dec2.emit(g, d3, e2, cat=cat2)
+        hyper_up(d2, 2, 1)
         if self.use_hypercolumn:
             d1 = self.dec1.emit(g, d2, None, out=hyper.slice(0, d))
-            g.upsample(d2, 2, out=hyper.slice(d, d))
-            g.upsample(d3, 4, out=hyper.slice(2 * d, d))
-            g.upsample(d4, 8, out=hyper.slice(3 * d, d))
-            g.upsample(d5, 16, out=hyper.slice(4 * d, d))
+            g.join()
             f = self.final[0].emit(g, hyper)
         else:
             d1 = self.dec1.emit(g, d2, None)

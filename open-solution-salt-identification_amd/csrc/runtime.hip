@@ -89,6 +89,11 @@ extern "C" int salt_program_run_streams(const salt_program_entry* e, int begin, 
     bool main_dirty = true, side_used = false;       // main_dirty: main has work the side stream has not been ordered after
     for (int i = begin; i < end; ++i) {
         const bool side = e[i].stream == 1;
+        if (e[i].stream == 2 && side_used) {            // a main-stream entry that consumes what the side stream produced so far
+            (void)hipEventRecord(g_events.ev[1], ss);
+            (void)hipStreamWaitEvent(ms, g_events.ev[1], 0);
+            side_used = false;
+        }
         if (side && main_dirty) {
             (void)hipEventRecord(g_events.ev[0], ms);
             (void)hipStreamWaitEvent(ss, g_events.ev[0], 0);

@@ -43,14 +43,20 @@ class Program:
     def __init__(self, name=''):
         self.name = name
         self.ops = []          # (opname, fn, struct)
+        self.default_stream = 0
+        self.join_next = False
         self.streams = []      # 0 main / 1 side, per op
         self.patches = []      # (struct, path, Scratch)
         self._entries = None
         self.marks = {}
 
-    def add(self, opname, stream=0, **fields):
+    def add(self, opname, stream=None, **fields):
         fn, S = OP_FUNCS['salt_' + opname]
         s = S()
+        if stream is None:                       # default tag: the enclosing Graph.side() block, or a pending join
+            stream = self.default_stream
+            if stream == 0 and self.join_next:
+                stream, self.join_next = 2, False
         self.streams.append(stream)
         plain = {}
         for k, v in fields.items():
@@ -229,6 +235,7 @@ class Graph:
         self.bytes = 0
         self._touched = []
         self.grad_ready = []
+        self._scratch_sfx = ''
 
     # ------------------------------------------------------------------ memory
     def alloc(self, shape, dtype, zero=True):
@@ -239,6 +246,25 @@ class Graph:
 
     def new_act(self, B, H, W, C, name=''):
         return Act(Buffer(self, B, H, W, C, name))
+
+    # ------------------------------------------------------------------ forward branches on the side stream
+    def side(self):
+        """``with g.side():`` - forward operators emitted inside run on the side stream, concurrently with the main-stream operators
+        emitted after the block.  The caller must call ``g.join()`` before emitting the first consumer of their results.  Shared
+        scratch workspaces get their own copies ('@side').  Backward operators of the same layers are unaffected."""
+        g = self
+
+        class _Side:
+            def __enter__(self_):
+                g.fwd.default_stream, g._scratch_sfx = 1, '@side'
+
+            def __exit__(self_, *a):
+                g.fwd.default_stream, g._scratch_sfx = 0, ''
+        return _Side()
+
+    def join(self):
+        """The next main-stream forward operator waits for everything the side stream has been given so far."""
+        self.fwd.join_next = True
 
     def f32(self, n):
         return self.alloc((max(int(n), 1),), torch.float32)
@@ -306,6 +332,8 @@ class Graph:
                      beta=bn.bias.data_ptr(), running_mean=bn.running_mean.data_ptr(), running_var=bn.running_var.data_ptr(),
                      num_batches_tracked=nbt, momentum=bn.momentum, eps=bn.eps, mean=w['mean'].data_ptr(), invstd=w['invstd'].data_ptr(),
                      scale=w['scale'].data_ptr(), shift=w['shift'].data_ptr())
+        if res is not None and getattr(res, 'on_side', False):
+            self.join()                          # the residual branch ran on the side stream
         self.fwd.add('affine_act', dtype=self.dt, y=y.view(), scale=w['scale'].data_ptr(), shift=w['shift'].data_ptr(),
                      res=res.view() if res is not None else null_view(), relu=int(relu), a=out.view())
         return w
@@ -362,7 +390,7 @@ class Graph:
         if bn is not None and self.train:
             y = self.new_act(x.B, OH, OW, Cout, name + '.y')
             nparts = self._conv_parts(x.view(), td, stride, y.view(), OH, OW)
-            stats, cnt = Scratch('stats', 4 * lib.salt_bn_stats_floats(nparts, Cout)), Scratch('stats_cnt', nparts * 4)
+            stats, cnt = Scratch('stats' + self._scratch_sfx, 4 * lib.salt_bn_stats_floats(nparts, Cout)), Scratch('stats_cnt' + self._scratch_sfx, nparts * 4)
             self._conv_launch(self.fwd, x.view(), pk.data_ptr(), td, stride, pad_mode, y.view(), OH, OW, bias=bias, stats=stats, stats_cnt=cnt)
             w = self._bn_train_fwd(y, bn, relu, res, out, nparts, stats, cnt)
         elif bn is not None:
@@ -373,11 +401,14 @@ class Graph:
             else:
                 self._conv_launch(self.fwd, x.view(), pk.data_ptr(), td, stride, pad_mode, out.view(), OH, OW, bias=bias,
                                   scale=w['scale'].data_ptr(), shift=w['shift'].data_ptr(), relu=0)
+                if getattr(res, 'on_side', False):
+                    self.join()
                 self.fwd.add('affine_act', dtype=self.dt, y=out.view(), scale=None, shift=None, res=res.view(), relu=int(relu), a=out.view())
         else:
             assert res is None
             self._conv_launch(self.fwd, x.view(), pk.data_ptr(), td, stride, pad_mode, out.view(), OH, OW, bias=bias, relu=int(relu))
 
+        out.on_side = self.fwd.default_stream == 1
         if self.train:
             def backward():
                 if bn is not None:
@@ -553,7 +584,7 @@ class Graph:
             S = STRUCTS['salt_conv_first_args']()
             fill(S, B=B, Cin=Cin, H=H, W=W, K=K, stride=stride, pad=pad)
             nparts = lib.salt_conv_first_stats_parts(ctypes.byref(S))
-            stats, cnt = Scratch('stats', 4 * lib.salt_bn_stats_floats(nparts, Cout)), Scratch('stats_cnt', nparts * 4)
+            stats, cnt = Scratch('stats' + self._scratch_sfx, 4 * lib.salt_bn_stats_floats(nparts, Cout)), Scratch('stats_cnt' + self._scratch_sfx, nparts * 4)
             self.fwd.add('conv_first', y=y.view(), relu=0, stats=stats, stats_cnt=cnt, **common)
             w = self._bn_train_fwd(y, bn, relu, None, out, nparts, stats, cnt)
 
@@ -588,7 +619,7 @@ class Graph:
         if self.train:
             y = self.new_act(B, OH, OW, Cout, name + '.y')
             nparts = self._conv_parts(z.view(), taps, 1, y.view(), OH, OW)
-            stats, cnt = Scratch('stats', 4 * lib.salt_bn_stats_floats(nparts, Cout)), Scratch('stats_cnt', nparts * 4)
+            stats, cnt = Scratch('stats' + self._scratch_sfx, 4 * lib.salt_bn_stats_floats(nparts, Cout)), Scratch('stats_cnt' + self._scratch_sfx, nparts * 4)
             self._conv_launch(self.fwd, z.view(), wp.data_ptr(), taps, 1, 0, y.view(), OH, OW, stats=stats, stats_cnt=cnt)
             w = self._bn_train_fwd(y, bn, relu, None, out, nparts, stats, cnt)
 

@@ -12,6 +12,7 @@ Design notes (MI355X-first):
     stream) -> fused Adam; each is one call into the native executor.
 """
 import ctypes
+import os
 
 import torch
 from torch import nn
@@ -235,7 +236,7 @@ class Engine:
         net = self.net(x.shape, train)
         net.x.copy_(x)
         self.refresh(train)
-        net.fwd.run()
+        net.fwd.run(side=None if os.environ.get('SALT_NO_FWD_SIDE') else self.side_stream)
         if train:
             self.touch(weights=False, stats=True)            # BN running statistics moved
         return net

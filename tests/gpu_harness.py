@@ -31,7 +31,7 @@ class BlockRun:
 
     def forward(self):
         self.eng.refresh(self.g.train)
-        self.g.fwd.run()
+        self.g.fwd.run(side=self.eng.side_stream)
         torch.cuda.synchronize()
         return self.out.cpu()
 
