@@ -295,6 +295,7 @@ def main():
         reps = 3
         for _ in range(reps):
             eng.refresh(True)
+            torch.cuda.synchronize()                     # the data-gradient weight packs run on the side stream
             for prog in (net.fwd, net.loss_program(args.loss, 1.0), net.bwd):
                 for name, s, ms in prog.run_timed():
                     kname = name

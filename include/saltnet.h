@@ -647,7 +647,8 @@ typedef int (*salt_op_fn)(const void* args, void* stream);
 typedef struct {
     salt_op_fn fn;
     const void* args;
-    int stream;               /* 0 = main stream, 1 = side stream, 2 = main stream after joining the side stream (salt_program_run_streams) */
+    int stream;               /* 0 = main, 1 = side, 2 = main after joining side work of this range, 3 = main after joining the side
+                                 stream unconditionally (work enqueued there before the call) - salt_program_run_streams */
     int reserved;
 } salt_program_entry;
 int salt_program_run(const salt_program_entry* entries, int n, void* stream);

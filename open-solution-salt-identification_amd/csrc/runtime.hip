@@ -89,9 +89,9 @@ extern "C" int salt_program_run_streams(const salt_program_entry* e, int begin, 
     bool main_dirty = true, side_used = false;       // main_dirty: main has work the side stream has not been ordered after
     for (int i = begin; i < end; ++i) {
         const bool side = e[i].stream == 1;
-        if (e[i].stream == 2 && side_used) {            // a main-stream entry that consumes what the side stream produced so far
-            (void)hipEventRecord(g_events.ev[1], ss);
-            (void)hipStreamWaitEvent(ms, g_events.ev[1], 0);
+        if ((e[i].stream == 2 && side_used) || e[i].stream == 3) {   // a main-stream entry that consumes side-stream results:
+            (void)hipEventRecord(g_events.ev[1], ss);                 // 2 = produced inside this range, 3 = enqueued on the side
+            (void)hipStreamWaitEvent(ms, g_events.ev[1], 0);          // stream before the call (data-gradient weight packs)
             side_used = false;
         }
         if (side && main_dirty) {

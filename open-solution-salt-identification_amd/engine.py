@@ -100,6 +100,8 @@ class Program:
             self.finalize()
         end = len(self.ops) if end is None else end
         st = _stream_ptr(stream)
+        if side is None and 3 in self.streams[begin:end]:
+            raise SaltError('program %s joins the side stream (data-gradient weight packs): run it with side=engine.side_stream' % self.name)
         if side is not None:
             rc = lib.salt_program_run_streams(ctypes.cast(self._entries, ctypes.c_void_p), begin, end, st, ctypes.c_void_p(side.cuda_stream))
         else:
@@ -312,8 +314,9 @@ class Graph:
                   in_step=in_step, pad_mode=pad_mode, y=y_view, OH=OH, OW=OW, out_step=out_step, out_oy=out_oy, out_ox=out_ox,
                   bias=bias, scale=scale, shift=shift, relu=relu, accumulate=accumulate, stats=stats, stats_cnt=stats_cnt,
                   stats_part0=part0, cfg=cfg)
+        stream = fold.pop('stream', None)
         kw.update(fold)
-        return prog.add('conv', **kw)
+        return prog.add('conv', stream=stream, **kw)
 
     def _conv_parts(self, x_view, taps_dydx, in_step, y_view, OH, OW, cfg=0):
         S = STRUCTS['salt_conv_args']()
@@ -448,10 +451,18 @@ class Graph:
                          tap_kh=[taps_khkw[j][0] for j in chunk], tap_kw=[taps_khkw[j][1] for j in chunk], grad=gw, accumulate=0)
             first = False
 
+    def _bwd_pack_tag(self):
+        """Stream tag of a data-gradient convolution: the first one of the backward program joins the side stream, where the
+        data-gradient weight packs of this step were enqueued during forward (Engine.refresh)."""
+        if getattr(self, '_bwd_pack_joined', False):
+            return None
+        self._bwd_pack_joined = True
+        return 3
+
     def _dgrad(self, conv, x, dy, taps, stride, replicate, KH, KW):
         eng = self.engine
         tk = [(t[0], t[1]) for t in taps]
-        pk = eng.packed(conv, tk, transposed=True)       # n = cin, c = cout
+        pk = eng.packed(conv, tk, transposed=True, bwd=True)       # n = cin, c = cout
         if replicate:
             # gradient w.r.t. the replicate-padded input on the extended domain, then fold the pad back
             top, right = KH - 1, KW - 1
@@ -461,7 +472,7 @@ class Graph:
             if os.environ.get('SALT_FOLD_FULL'):            # A/B: gradient on the extended grid in scratch, then a full fold pass
                 ext = shaped_view(0, x.B, Hp, Wp, x.C, _round_up(x.C, self.ve))
                 nbytes = x.B * Hp * Wp * ext.cs * self._es()
-                self._conv_launch(self.bwd, dy.gview(), pk.data_ptr(), td, 1, 0, (ext, Scratch('dgrad_ext', nbytes)), Hp, Wp)
+                self._conv_launch(self.bwd, dy.gview(), pk.data_ptr(), td, 1, 0, (ext, Scratch('dgrad_ext', nbytes)), Hp, Wp, stream=self._bwd_pack_tag())
                 self.bwd.add('pad_fold', dtype=self.dt, xp=(ext, Scratch('dgrad_ext', nbytes)), top=top, bottom=0, left=0, right=right,
                              x=x.gview(), accumulate=acc)
                 return
@@ -470,13 +481,13 @@ class Graph:
             ring = lib.salt_fold_strip_pixels(x.H, x.W, top, 0, 0, right)
             strip = Scratch('dgrad_ring', x.B * ring * scs * self._es())
             self._conv_launch(self.bwd, dy.gview(), pk.data_ptr(), td, 1, 0, x.gview(), Hp, Wp, accumulate=acc,
-                              strip=strip, strip_cs=scs, fold_top=top, fold_right=right)
+                              strip=strip, strip_cs=scs, fold_top=top, fold_right=right, stream=self._bwd_pack_tag())
             self.bwd.add('pad_fold_strip', dtype=self.dt, strip=strip, strip_cs=scs, top=top, bottom=0, left=0, right=right, x=x.gview())
             return
         acc = x.grad_state()
         if stride == 1:
             td = [(-t[2], -t[3]) for t in taps]
-            self._conv_launch(self.bwd, dy.gview(), pk.data_ptr(), td, 1, 0, x.gview(), x.H, x.W, accumulate=acc)
+            self._conv_launch(self.bwd, dy.gview(), pk.data_ptr(), td, 1, 0, x.gview(), x.H, x.W, accumulate=acc, stream=self._bwd_pack_tag())
             return
         # stride 2: one launch per output parity phase (a transposed convolution)
         phases = []
@@ -491,9 +502,10 @@ class Graph:
             oh, ow = (x.H - ay + 1) // 2, (x.W - ax + 1) // 2
             if not sel or oh <= 0 or ow <= 0:
                 continue
-            pk_s = eng.packed(conv, [tk[i] for i in sel], transposed=True)
+            pk_s = eng.packed(conv, [tk[i] for i in sel], transposed=True, bwd=True)
             td = [((ay - taps[i][2]) // 2, (ax - taps[i][3]) // 2) for i in sel]
-            self._conv_launch(self.bwd, dy.gview(), pk_s.data_ptr(), td, 1, 0, x.gview(), oh, ow, out_step=2, out_oy=ay, out_ox=ax, accumulate=acc)
+            self._conv_launch(self.bwd, dy.gview(), pk_s.data_ptr(), td, 1, 0, x.gview(), oh, ow, out_step=2, out_oy=ay, out_ox=ax, accumulate=acc,
+                              stream=self._bwd_pack_tag())
 
     def fill(self, act, value, grad=False):
         assert value == 0.0
@@ -560,9 +572,10 @@ class Graph:
                 self._wgrad(x.view(), tgt.gview(), [(t[2], t[3]) for t in taps_all], [(t[0], t[1]) for t in taps_all], 2, 0,
                             deconv.weight, KH, KW)
                 # data gradient: stride-2 convolution of dY with W[cin][cout] (n = cin, c = cout)
-                pk = eng.packed(deconv, [(t[0], t[1]) for t in taps_all], transposed=False)
+                pk = eng.packed(deconv, [(t[0], t[1]) for t in taps_all], transposed=False, bwd=True)
                 acc = x.grad_state()
-                self._conv_launch(self.bwd, tgt.gview(), pk.data_ptr(), [(t[2], t[3]) for t in taps_all], 2, 0, x.gview(), x.H, x.W, accumulate=acc)
+                self._conv_launch(self.bwd, tgt.gview(), pk.data_ptr(), [(t[2], t[3]) for t in taps_all], 2, 0, x.gview(), x.H, x.W, accumulate=acc,
+                                  stream=self._bwd_pack_tag())
             self.tape.append(backward)
         return out
 

@@ -88,6 +88,8 @@ class Engine:
         self._flatten()
         self._packed = {}
         self._pack_ops = Program('pack')
+        self._packed_bwd_version = -1
+        self._pack_is_bwd, self._pack_keys = {}, []      # conv-weight pack jobs in _pack_ops order; True = only backward reads it
         self._bn = {}
         self._fold_ops = Program('bn_fold')
         self.nets = {}
@@ -142,10 +144,17 @@ class Engine:
         return self._off[id(param)]
 
     # ------------------------------------------------------------------ packed conv weights
-    def packed(self, conv, taps_khkw, transposed):
+    def packed(self, conv, taps_khkw, transposed, bwd=False):
+        """Packed copy of a convolution weight.  ``bwd``: only the backward program reads it (data-gradient packs): such copies are
+        refreshed on the side stream while the forward pass runs."""
         key = (id(conv), tuple(taps_khkw), bool(transposed))
         if key in self._packed:
+            if not bwd and self._pack_is_bwd.get(key, False):
+                self._pack_is_bwd[key] = False
+                self._pack_batched_n = -1
             return self._packed[key]
+        self._pack_is_bwd[key] = bool(bwd)
+        self._pack_keys.append(key)
         D0, D1, KH, KW = conv.weight.shape
         n, c = (D1, D0) if transposed else (D0, D1)
         elems = lib.salt_packed_weight_elems(DT_CODE[self.dtype], len(taps_khkw), n, c)
@@ -156,6 +165,7 @@ class Engine:
         self._pack_ops._entries = None
         self._packed[key] = t
         self._packed_version = -1
+        self._pack_batched_n = -1
         return t
 
     def packed_stem(self, conv):
@@ -192,34 +202,52 @@ class Engine:
             self.sver += 1
 
     def _build_pack_batch(self):
-        """One launch packs every convolution weight: the per-job argument structs are copied to a device table."""
+        """Two launches pack every convolution weight (per-job argument structs live in device tables): the copies the forward
+        pass reads on the main stream, the data-gradient copies on the side stream (they are not needed before backward)."""
         import numpy as np
-        S = _abi.STRUCTS['salt_pack_conv_weight_args']
-        jobs = [(name, s) for (name, fn, s) in self._pack_ops.ops if name == 'pack_conv_weight']
+        jobs = [s for (name, fn, s) in self._pack_ops.ops if name == 'pack_conv_weight']
+        assert len(jobs) == len(self._pack_keys)
         others = Program('pack_misc')
         for (name, fn, s), st in zip(self._pack_ops.ops, self._pack_ops.streams):
             if name != 'pack_conv_weight':
                 others.ops.append((name, fn, s)); others.streams.append(st)
-        batched = Program('pack')
-        if jobs:
-            raw = b''.join(bytes(s) for _, s in jobs)
-            blocks = [lib.salt_pack_job_blocks(ctypes.byref(s)) for _, s in jobs]
-            pref = np.concatenate([[0], np.cumsum(blocks)]).astype(np.int32)
-            self._pack_table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
-            self._pack_pref = torch.from_numpy(pref).to(self.device)
-            batched.add('pack_batched', jobs=self._pack_table.data_ptr(), job_block0=self._pack_pref.data_ptr(), njobs=len(jobs),
-                        total_blocks=int(pref[-1]), dtype=DT_CODE[self.dtype])
-        batched.extend(others)
-        batched.finalize()
-        self._pack_batched = batched
+        self._pack_tables = []
+
+        def batch(sel, name):
+            prog = Program(name)
+            if sel:
+                raw = b''.join(bytes(s) for s in sel)
+                blocks = [lib.salt_pack_job_blocks(ctypes.byref(s)) for s in sel]
+                pref = np.concatenate([[0], np.cumsum(blocks)]).astype(np.int32)
+                table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+                pref_t = torch.from_numpy(pref).to(self.device)
+                self._pack_tables += [table, pref_t]
+                prog.add('pack_batched', jobs=table.data_ptr(), job_block0=pref_t.data_ptr(), njobs=len(sel), total_blocks=int(pref[-1]),
+                         dtype=DT_CODE[self.dtype])
+            return prog
+        fwd = batch([s for s, k in zip(jobs, self._pack_keys) if not self._pack_is_bwd[k]], 'pack')
+        fwd.extend(others)
+        fwd.finalize()
+        bwd = batch([s for s, k in zip(jobs, self._pack_keys) if self._pack_is_bwd[k]], 'pack_bwd')
+        bwd.finalize()
+        self._pack_batched, self._pack_batched_bwd = fwd, bwd
         self._pack_batched_n = len(self._pack_ops)
 
     def refresh(self, train):
+        if getattr(self, '_pack_batched_n', -1) != len(self._pack_ops):
+            self._build_pack_batch()
+            self._packed_version = self._packed_bwd_version = -1
         if self._packed_version != self.wver:
-            if getattr(self, '_pack_batched_n', -1) != len(self._pack_ops):
-                self._build_pack_batch()
             self._pack_batched.run()
             self._packed_version = self.wver
+        if train and self._packed_bwd_version != self.wver and len(self._pack_batched_bwd):
+            # ordered after the optimizer step on the main stream; the backward program's first data-gradient joins (engine.py)
+            if os.environ.get('SALT_PACK_BWD_MAIN'):                 # A/B: everything on the main stream
+                self._pack_batched_bwd.run()
+            else:
+                self.side_stream.wait_stream(torch.cuda.current_stream())
+                self._pack_batched_bwd.run(stream=self.side_stream)
+            self._packed_bwd_version = self.wver
         if not train and self._folded_version != (self.wver, self.sver):
             self._fold_ops.run()
             self._folded_version = (self.wver, self.sver)
