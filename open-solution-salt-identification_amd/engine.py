@@ -303,6 +303,16 @@ class Graph:
                 off, n = self.engine.grad_range(p)
                 self.grad_ready.append((off, n, len(self.bwd.ops)))
         self.tape = []
+        # The data-gradient weight packs of the step were enqueued on the side stream during forward (Engine.refresh): the FIRST
+        # main-stream operator of the backward program joins the side stream - before any weight-gradient kernel is enqueued there,
+        # so the join waits for the packs only.
+        if getattr(self, '_uses_bwd_packs', False):
+            for i, st in enumerate(self.bwd.streams):
+                if st == 0:
+                    self.bwd.streams[i] = 3
+                    break
+                if st == 1:
+                    raise SaltError('backward program starts with a side-stream operator')
 
     # ------------------------------------------------------------------ helpers
     def _es(self):
@@ -454,10 +464,8 @@ class Graph:
     def _bwd_pack_tag(self):
         """Stream tag of a data-gradient convolution: the first one of the backward program joins the side stream, where the
         data-gradient weight packs of this step were enqueued during forward (Engine.refresh)."""
-        if getattr(self, '_bwd_pack_joined', False):
-            return None
-        self._bwd_pack_joined = True
-        return 3
+        self._uses_bwd_packs = True
+        return None
 
     def _dgrad(self, conv, x, dy, taps, stride, replicate, KH, KW):
         eng = self.engine
