@@ -657,11 +657,13 @@ class Graph:
                          tap_dx=[taps[j][1] for j in chunk], q_step=1, pad_mode=0)
                     ns = lib.salt_conv_wgrad_nsplit(ctypes.byref(S))
                     nbytes = ns * len(chunk) * Cout * 16 * 4
-                    self.bwd.add('conv_wgrad', stream=1, dtype=self.dt, p=y.gview(), q=z.view(), ntaps=len(chunk), tap_dy=[taps[j][0] for j in chunk],
-                                 tap_dx=[taps[j][1] for j in chunk], q_step=1, pad_mode=0, partials=Scratch('wgrad', nbytes), nsplit=ns)
-                    self.bwd.add('wgrad_reduce', stream=1, partials=Scratch('wgrad', nbytes), nsplit=ns, ntaps=len(chunk), Ca=Cout, Cb=16, KH=TT, KW=TT,
+                    # the stem is the last layer of backward: its weight gradient runs on the MAIN stream (own workspace), which is
+                    # idle by then, instead of queueing behind the side stream's remaining weight gradients
+                    self.bwd.add('conv_wgrad', stream=0, dtype=self.dt, p=y.gview(), q=z.view(), ntaps=len(chunk), tap_dy=[taps[j][0] for j in chunk],
+                                 tap_dx=[taps[j][1] for j in chunk], q_step=1, pad_mode=0, partials=Scratch('wgrad@main', nbytes), nsplit=ns)
+                    self.bwd.add('wgrad_reduce', stream=0, partials=Scratch('wgrad@main', nbytes), nsplit=ns, ntaps=len(chunk), Ca=Cout, Cb=16, KH=TT, KW=TT,
                                  tap_kh=[j // TT for j in chunk], tap_kw=[j % TT for j in chunk], grad=gw_tmp, accumulate=0)
-                self.bwd.add('stem_grad_unfold', stream=1, g16=gw_tmp, Cout=Cout, Cin=Cin, K=K, grad=self._gp(conv.weight), accumulate=0)
+                self.bwd.add('stem_grad_unfold', stream=0, g16=gw_tmp, Cout=Cout, Cin=Cin, K=K, grad=self._gp(conv.weight), accumulate=0)
             self.tape.append(backward)
         else:
             w = eng.bn_work(bn)
