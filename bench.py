@@ -226,6 +226,11 @@ def main():
             torch.cuda.synchronize()
         finally:
             sys.stdout.flush()
+            try:                                 # the banner sits in the C stdio buffer (fully buffered on a pipe): flush it to stderr
+                import ctypes
+                ctypes.CDLL(None).fflush(None)
+            except OSError:
+                pass
             os.dup2(saved, 1)
             os.close(saved)
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus

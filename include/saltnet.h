@@ -661,6 +661,8 @@ int salt_program_run_timed(const salt_program_entry* entries, int begin, int end
  * right before it (forward: independent branches such as the hypercolumn up-samplings; backward: nothing - side entries only
  * produce parameter gradients).  side == NULL or side == main degenerates to salt_program_run_range. */
 int salt_program_run_streams(const salt_program_entry* entries, int begin, int end, void* main_stream, void* side_stream);
+/* join_at_end == 0: the caller orders its consumers after BOTH streams itself (bucketed all-reduce between backward segments) */
+int salt_program_run_streams_ex(const salt_program_entry* entries, int begin, int end, void* main_stream, void* side_stream, int join_at_end);
 int salt_graph_capture(const salt_program_entry* entries, int n, void* stream, void** graph_exec_out);
 int salt_graph_launch(void* graph_exec, void* stream);
 int salt_graph_destroy(void* graph_exec);

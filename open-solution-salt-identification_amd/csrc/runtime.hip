@@ -82,6 +82,10 @@ thread_local EventPool g_events;
 }  // namespace
 
 extern "C" int salt_program_run_streams(const salt_program_entry* e, int begin, int end, void* main_stream, void* side_stream) {
+    return salt_program_run_streams_ex(e, begin, end, main_stream, side_stream, 1);
+}
+
+extern "C" int salt_program_run_streams_ex(const salt_program_entry* e, int begin, int end, void* main_stream, void* side_stream, int join_at_end) {
     if (!side_stream || side_stream == main_stream) return salt_program_run_range(e, begin, end, main_stream);
     if (!e || begin < 0 || end < begin) SALT_FAIL(SALT_E_BADARG, "program: bad range");
     if (g_events.ensure()) SALT_FAIL(SALT_E_BADARG, "hipEventCreate failed");
@@ -108,7 +112,7 @@ extern "C" int salt_program_run_streams(const salt_program_entry* e, int begin, 
         }
         if (side) side_used = true; else main_dirty = true;
     }
-    if (side_used) {
+    if (side_used && join_at_end) {
         (void)hipEventRecord(g_events.ev[1], ss);
         (void)hipStreamWaitEvent(ms, g_events.ev[1], 0);
     }

@@ -94,8 +94,9 @@ class Program:
     def __len__(self):
         return len(self.ops)
 
-    def run(self, stream=None, begin=0, end=None, side=None):
-        """Enqueue ops [begin, end).  With ``side`` (a torch.cuda.Stream) ops tagged stream=1 run on it concurrently."""
+    def run(self, stream=None, begin=0, end=None, side=None, join=True):
+        """Enqueue ops [begin, end).  With ``side`` (a torch.cuda.Stream) ops tagged stream=1 run on it concurrently; ``join=False``
+        leaves the side stream un-joined at the end of the range (the caller orders its consumers after both streams)."""
         if self._entries is None:
             self.finalize()
         end = len(self.ops) if end is None else end
@@ -103,7 +104,8 @@ class Program:
         if side is None and 3 in self.streams[begin:end]:
             raise SaltError('program %s joins the side stream (data-gradient weight packs): run it with side=engine.side_stream' % self.name)
         if side is not None:
-            rc = lib.salt_program_run_streams(ctypes.cast(self._entries, ctypes.c_void_p), begin, end, st, ctypes.c_void_p(side.cuda_stream))
+            rc = lib.salt_program_run_streams_ex(ctypes.cast(self._entries, ctypes.c_void_p), begin, end, st, ctypes.c_void_p(side.cuda_stream),
+                                                 1 if join else 0)
         else:
             rc = lib.salt_program_run_range(ctypes.cast(self._entries, ctypes.c_void_p), begin, end, st)
         if rc != 0:

@@ -122,12 +122,16 @@ class DataParallel:
         for lo, hi, ridx in self._plans[key]:
             ridx = min(max(ridx, pos), n_ops)
             if ridx > pos:
-                net.bwd.run(begin=pos, end=ridx, side=eng.side_stream)
+                # no join between segments: the main stream keeps running ahead of the weight-gradient stream; the bucket's
+                # gradients come from both, so the communication stream waits for both
+                net.bwd.run(begin=pos, end=ridx, side=eng.side_stream, join=False)
                 pos = ridx
-            ev = torch.cuda.Event()
+            ev, ev_side = torch.cuda.Event(), torch.cuda.Event()
             ev.record(cur)
+            ev_side.record(eng.side_stream)
             with torch.cuda.stream(comm):
                 comm.wait_event(ev)
+                comm.wait_event(ev_side)
                 works.append(dist.all_reduce(eng.grads[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
         if pos < n_ops:
             net.bwd.run(begin=pos, end=n_ops, side=eng.side_stream)
