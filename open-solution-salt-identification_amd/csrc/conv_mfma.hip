@@ -39,6 +39,7 @@ struct ConvKP {
     void* strip; int strip_cs, fold_top, fold_bottom, fold_left, fold_right;     // fold mode (strip != nullptr)
     unsigned hhw_magic, hw_magic;                                                // x / d == umulhi(x, 2^32 / d + 1) for x * d < 2^32
     int m_tiles, n_tiles;
+    int vt;                          // virtual taps of a 1x1 convolution: vt channel chunks staged per barrier round (1 = off)
 };
 
 template <typename T> struct Mma;
@@ -114,14 +115,18 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
     constexpr int MAXA = maxa_for(32 * MI * WM);
     const T* xg0 = xg + (int64_t)b0 * p.H * p.W * p.x_cs;
     int a_goff[MAXA];
-    const int npa = (phalo * 4 + 255) >> 8;
+    // A 1x1 convolution stages vt consecutive channel chunks per round as "virtual taps": LDS row = vtap * phalo + pixel, the packed
+    // weights [chunk][1][Cout][KC] are the same bytes as [chunk / vt][vt][Cout][KC], and the pipelined NT = vt tap loop applies.
+    const int npa = (phalo * p.vt * 4 + 255) >> 8;
 #pragma unroll
     for (int k = 0; k < MAXA; ++k) {
         a_goff[k] = -2;
         if (k < npa) {
             const int q = tid + (k << 8);
-            const int pix = q >> 2;
-            if (pix < phalo) {
+            const int prow = q >> 2;
+            if (prow < phalo * p.vt) {
+                int vtap = 0, pix = prow;
+                if (p.vt > 1) { vtap = prow / phalo; pix = prow - vtap * phalo; }
                 const int bl = (int)__umulhi((unsigned)pix, p.hhw_magic);
                 const int r = pix - bl * hhw;
                 const int hy = (int)__umulhi((unsigned)r, p.hw_magic);
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
                 } else {
                     valid = valid && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
                 }
-                a_goff[k] = valid ? ((bl * p.H + iy) * p.W + ix) * p.x_cs + (q & 3) * VE : -1;
+                a_goff[k] = valid ? ((bl * p.H + iy) * p.W + ix) * p.x_cs + vtap * KCE + (q & 3) * VE : -1;
             }
         }
     }
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
         // next barrier.  HBM/L2 latency is hidden behind compute instead of being paid once per chunk.
         u32x4 ra[MAXA], rb[MAXBP];
         auto load_chunk = [&](int c) {
-            const int ch_base = c * KCE;
+            const int ch_base = c * KCE * p.vt;
 #pragma unroll
             for (int k = 0; k < MAXA; ++k) {
                 ra[k] = u32x4{0u, 0u, 0u, 0u};
@@ -273,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
         }
     } else {
         for (int c = 0; c < p.nchunk; ++c) {
-            const int ch_base = c * KCE;
+            const int ch_base = c * KCE * p.vt;
             __syncthreads();                        // previous chunk's fragment reads are done
 #pragma unroll
             for (int k = 0; k < MAXA; ++k) {
@@ -486,12 +491,17 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
         min_dx = a->tap_dx[t] < min_dx ? a->tap_dx[t] : min_dx; max_dx = a->tap_dx[t] > max_dx ? a->tap_dx[t] : max_dx;
     }
     const int64_t pixels = (int64_t)a->x.B * a->OH * a->OW;
+    // 1x1 stride-1 convolution with Cin a multiple of 4 chunks: 4 channel chunks per barrier round (virtual taps, see the kernel)
+    const int KCE_ = a->dtype == SALT_F32 ? 16 : 32;
+    static const bool vt_off = getenv("SALT_CONV_NO_VT") != nullptr;
+    const int vt = (!vt_off && a->ntaps == 1 && a->in_step == 1 && a->x.C % (4 * KCE_) == 0) ? 4 : 1;
     // ---- tile config heuristic (overridable for tests/tuning)
     int id = a->cfg;
+    if (id == 2 && vt > 1) id = 1;            // 256-pixel tiles x 4 virtual taps exceed the halo-piece budget
     if (id == 0) {
         const bool big = a->in_step == 1 && a->OH >= 16 && a->OW >= 16 && pixels >= 256 * 256 * 2;
         if (Cout <= 32) id = 4;
-        else if (big) id = 2;                 // 256-pixel tiles: the chunk's weights are staged once per 256 pixels
+        else if (big && vt == 1) id = 2;      // 256-pixel tiles: the chunk's weights are staged once per 256 pixels
         else id = 1;
         // few pixels, many channels (ResNet stages 3-4, the 8x8 / 16x16 decoder levels): 128x32 tiles double the workgroup count and
         // run at 3 workgroups per CU - measured 8-15 % faster than 128x64 / 64x64 there (tools/cfg_sweep.sh)
@@ -512,7 +522,7 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
         const int th = 1 << k.th_log2, tw = 1 << k.tw_log2;
         k.hh = (th - 1) * a->in_step + (max_dy - min_dy) + 1;
         k.hw = (tw - 1) * a->in_step + (max_dx - min_dx) + 1;
-        const int phalo = k.nb * k.hh * k.hw;
+        const int phalo = k.nb * k.hh * k.hw * vt;
         if (phalo * 4 > maxa_for(BM) * 256) {
             if (attempt == 0 && cfg->id != 5) { for (const auto& c : kCfgs) if (c.id == 5) cfg = &c; continue; }
             SALT_FAIL(SALT_E_UNSUPPORTED, "conv: halo tile of %d pixels too large", phalo);
@@ -530,17 +540,19 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
     k.out_step = a->out_step; k.out_oy = a->out_oy; k.out_ox = a->out_ox;
     k.ntaps = a->ntaps; k.in_step = a->in_step; k.pad_mode = a->pad_mode; k.min_dy = min_dy; k.min_dx = min_dx;
     for (int t = 0; t < a->ntaps; ++t) k.tap_off[t] = (a->tap_dy[t] - min_dy) * k.hw + (a->tap_dx[t] - min_dx);
+    k.vt = vt;
+    if (vt > 1) { k.ntaps = vt; for (int t = 0; t < vt; ++t) k.tap_off[t] = t * k.nb * k.hh * k.hw; }
     k.tiles_y = cdiv(a->OH, 1 << k.th_log2); k.tiles_x = cdiv(a->OW, 1 << k.tw_log2);
     const int tiles_b = cdiv(a->x.B, k.nb);
-    k.nchunk = cdiv(a->x.C, KCE);
-    k.a_bytes = k.nb * k.hh * k.hw * 64;
+    k.nchunk = cdiv(a->x.C, KCE * vt);
+    k.a_bytes = k.nb * k.hh * k.hw * 64 * vt;
     k.hhw_magic = (unsigned)((1ull << 32) / (unsigned)(k.hh * k.hw)) + 1u;
     k.hw_magic = (unsigned)((1ull << 32) / (unsigned)k.hw) + 1u;
     k.relu = a->relu; k.accumulate = a->accumulate; k.stats_part0 = a->stats_part0;
     k.strip = a->strip; k.strip_cs = a->strip_cs; k.fold_top = a->fold_top; k.fold_bottom = a->fold_bottom; k.fold_left = a->fold_left; k.fold_right = a->fold_right;
     k.m_tiles = tiles_b * k.tiles_y * k.tiles_x; k.n_tiles = cdiv(Cout, BN);
     pl->grid = dim3((unsigned)(cdiv(k.m_tiles, 8) * 8 * k.n_tiles), 1, 1);
-    pl->lds = (size_t)k.a_bytes + (size_t)a->ntaps * BN * 64;
+    pl->lds = (size_t)k.a_bytes + (size_t)k.ntaps * BN * 64;
     {   // the epilogue stages the BM x BN output tile through the same LDS
         const size_t es = a->dtype == SALT_F32 ? 4 : 2;
         const size_t out_bytes = (size_t)(32 * cfg->MI * cfg->WM) * (BN * es + 16);
@@ -568,6 +580,7 @@ int launch_cfg_nt(const Plan& pl, hipStream_t st) {
 template <typename T, int MI, int NI, int WM, int WN>
 int launch_cfg(const Plan& pl, hipStream_t st) {
     if (pl.kp.ntaps == 9) return launch_cfg_nt<T, MI, NI, WM, WN, 9>(pl, st);
+    if (pl.kp.ntaps == 4) return launch_cfg_nt<T, MI, NI, WM, WN, 4>(pl, st);      // 1x1 with 4 virtual taps, ConvT k4 output phases
     return launch_cfg_nt<T, MI, NI, WM, WN, 0>(pl, st);
 }
 

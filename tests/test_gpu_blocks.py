@@ -96,6 +96,9 @@ CONV_CASES = [
     (2, 32, 15, 13, 48, 3, 2, 1),
     (2, 64, 8, 8, 128, 1, 2, 0),
     (2, 96, 8, 8, 32, 1, 1, 0),
+    (2, 128, 8, 8, 64, 1, 1, 0),      # 1x1 with Cin a multiple of 4 chunks: virtual-tap path (Bottleneck convs of ResNet101/152)
+    (2, 256, 9, 7, 96, 1, 1, 0),
+    (1, 512, 20, 12, 40, 1, 1, 0),
     (3, 128, 4, 4, 256, 3, 1, 1),
     (4, 256, 2, 2, 128, 3, 1, 1),
     (2, 13, 7, 5, 10, 3, 1, 1),       # ragged channels: scalar load path
@@ -156,8 +159,20 @@ def test_conv_fwd_dgrad_wgrad_vs_torch(case, dtype, cfg):
     gy = _rand(tuple(yr.shape), 5)
     yr.backward(gy)
     gx, grads = run.backward(gy.to('cuda:0'))
-    assert_close(gx[0], xr.grad, tol * 2, 'dgrad')
-    assert_close(grads['0.weight'], ref_conv.weight.grad, tol * 3, 'wgrad')
+    if dtype == 'f32':
+        assert_close(gx[0], xr.grad, tol * 2, 'dgrad')
+    else:
+        # bf16 rounding of y flips the ReLU mask of the few outputs that sit within 2^-8 of zero; each flip moves one pixel's
+        # gradient by O(|g w|), which a max-norm over a large tensor always catches.  The L2 norm is the meaningful statistic.
+        d, r = gx[0].double(), xr.grad.double()
+        l2 = float((d - r).norm() / r.norm())
+        assert l2 <= tol, 'dgrad: rel-L2 %.3e > %.1e' % (l2, tol)
+    if dtype == 'f32':
+        assert_close(grads['0.weight'], ref_conv.weight.grad, tol * 3, 'wgrad')
+    else:
+        d, r = grads['0.weight'].double(), ref_conv.weight.grad.double()
+        l2 = float((d - r).norm() / r.norm())
+        assert l2 <= tol, 'wgrad: rel-L2 %.3e > %.1e' % (l2, tol)
     assert_close(grads['1.weight'], ref_bn.weight.grad, tol * 3, 'dgamma')
     assert_close(grads['1.bias'], ref_bn.bias.grad, tol * 3, 'dbeta')
 
