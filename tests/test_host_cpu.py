@@ -45,6 +45,8 @@ def test_every_operator_rejects_null_args_without_touching_a_gpu():
     ('ternaus_resnet34_upsample', lambda A: A.TernausUNetResNet(34, 2, dropout_2d=0.0, pretrained=False, is_deconv=False)),
     ('salt_unet', lambda A: A.SaltUNet(2, dropout_2d=0.0, is_deconv=True)),
     ('salt_linknet', lambda A: A.SaltLinkNet(2, dropout_2d=0.0, is_deconv=True)),
+    ('unet_resnet152_hyper', lambda A: A.UNetResNet(152, 2, dropout_2d=0.0, pretrained=False, use_hypercolumn=True)),
+    ('ternaus_resnet101_deconv', lambda A: A.TernausUNetResNet(101, 2, dropout_2d=0.0, pretrained=False, is_deconv=True)),
 ])
 def test_state_dict_layout_equals_reference(tag, make):
     from salt_amd import architectures as A
@@ -54,7 +56,8 @@ def test_state_dict_layout_equals_reference(tag, make):
     sd = net.state_dict()
     assert list(sd.keys()) == fx['keys'].tolist()
     arch = {'unet': 'UNetResNet', 'tern': 'TernausUNetResNet', 'salt_unet': 'SaltUNet', 'salt_link': 'SaltLinkNet'}[tag[:9] if tag.startswith('salt') else tag[:4]]
-    spec = OS.SPECS[arch](with_fc=True)
+    depth = {'unet_resnet152_hyper': 152, 'ternaus_resnet101_deconv': 101}.get(tag)
+    spec = OS.SPECS[arch](with_fc=True, **({'depth': depth} if depth else {}))
     for k, (shape, _) in spec.items():
         assert tuple(sd[k].shape) == tuple(shape), k
     # parameters that never receive a gradient in the reference are exactly the ones kept out of the flat buffers

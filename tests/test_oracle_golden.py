@@ -157,14 +157,16 @@ def test_kat_values():
 
 NETS = {'unet_resnet34_hyper': ('UNetResNet', {}), 'ternaus_resnet34_deconv': ('TernausUNetResNet', {'is_deconv': True}),
         'ternaus_resnet34_upsample': ('TernausUNetResNet', {'is_deconv': False}),
-        'salt_unet': ('SaltUNet', {}), 'salt_linknet': ('SaltLinkNet', {})}
+        'salt_unet': ('SaltUNet', {}), 'salt_linknet': ('SaltLinkNet', {}),
+        # Bottleneck encoders (C4 runs ResNet152): spec / forward take the depth
+        'unet_resnet152_hyper': ('UNetResNet', {'depth': 152}), 'ternaus_resnet101_deconv': ('TernausUNetResNet', {'depth': 101, 'is_deconv': True})}
 
 
 @pytest.mark.parametrize('tag', sorted(NETS))
 def test_whole_model_matches_reference(tag):
     fx = golden('F8_' + tag)
     arch, kw = NETS[tag]
-    spec = OS.SPECS[arch](with_fc=True)
+    spec = OS.SPECS[arch](with_fc=True, **({'depth': kw['depth']} if 'depth' in kw else {}))
     # key set (with aliases) equals the reference's state_dict
     assert set(OS.expand_aliases(arch, {k: None for k in spec})) == set(fx['keys'].tolist())
     sd = CF.state_for((k, s) for k, (s, _) in spec.items())
