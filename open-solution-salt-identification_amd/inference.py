@@ -114,6 +114,28 @@ def crop_threshold(prob, target_size=(101, 101), threshold=0.5, cls=1):
     return mask
 
 
+def run_length_encoding(mask):
+    """Submission encoding of one binary mask (utils.py:99-111): runs over the column-major pixel order as a flat list
+    [start_1-based, length, start, length, ...].  Host side (the mask is a 10 KB array that leaves the device anyway)."""
+    m = mask.detach().cpu().numpy() if torch.is_tensor(mask) else np.asarray(mask)
+    flat = np.concatenate([[0], (m.T.reshape(-1) != 0).astype(np.int8), [0]])
+    edges = np.flatnonzero(np.diff(flat))                  # run starts at even positions, run ends (exclusive) at odd ones
+    starts, ends = edges[0::2], edges[1::2]
+    out = np.empty(2 * len(starts), dtype=np.int64)
+    out[0::2] = starts + 1
+    out[1::2] = ends - starts
+    return out.tolist()
+
+
+def run_length_decoding(mask_rle, shape):
+    """Inverse (utils.py:114-133); ``mask_rle``: 'start length start length ...' or the list run_length_encoding returns."""
+    vals = [int(v) for v in (mask_rle.split() if isinstance(mask_rle, str) else mask_rle)]
+    img = np.zeros(shape[0] * shape[1], dtype=np.uint8)
+    for lo, n in zip(vals[0::2], vals[1::2]):
+        img[lo - 1:lo - 1 + n] = 1
+    return img.reshape((shape[1], shape[0])).T
+
+
 # ----------------------------------------------------------------------------- validation metric
 def iou_counts(prob, gt, thresholds, cls=1):
     """Per image and threshold: |pred & gt|, |pred|; per image |gt|.  ``gt`` is uint8 [B, h, w]; prob is cropped to it."""

@@ -269,6 +269,30 @@ def main():
     out['iout_values'] = np.array([np.mean([ns['compute_precision_at'](np.array([[v]]), th) for th in ths]) for v in ious])
     save('F10_post_metric', **out)
 
+    # ---- F12: run-length encoding / decoding of submission masks (utils.py:99-133), executed unmodified
+    extract_functions('common_blocks/utils.py', {'run_length_encoding', 'run_length_decoding'}, ns)
+    r = np.random.RandomState(12)
+    yy, xx = np.mgrid[0:101, 0:101]
+    masks = [np.zeros((101, 101), np.uint8), np.ones((101, 101), np.uint8)]
+    m = np.zeros((101, 101), np.uint8); m[0, 0] = 1; masks.append(m)
+    m = np.zeros((101, 101), np.uint8); m[100, 100] = 1; m[100, 0] = 1; m[0, 100] = 1; masks.append(m)
+    m = np.zeros((101, 101), np.uint8); m[:, 50] = 1; m[37, :] = 1; masks.append(m)          # runs that wrap a column end
+    for _ in range(5):
+        cy, cx, ry, rx = r.uniform(0, 101), r.uniform(0, 101), r.uniform(5, 60), r.uniform(5, 60)
+        masks.append(((((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2) <= 1).astype(np.uint8))
+    masks.append((r.rand(101, 101) > 0.5).astype(np.uint8))
+    m = (r.rand(7, 13) > 0.4).astype(np.uint8); masks_small = [m]
+    out = {'masks': np.stack(masks), 'small': masks_small[0]}
+    flat, offs = [], [0]
+    for mk in masks + masks_small:
+        rle = ns['run_length_encoding'](mk)
+        dec = ns['run_length_decoding'](' '.join(str(v) for v in rle), mk.shape) if rle else np.zeros(mk.shape, np.uint8)
+        assert np.array_equal(dec, mk)
+        flat += list(rle); offs.append(len(flat))
+    out['rle_flat'] = np.array(flat, np.int64)
+    out['rle_offsets'] = np.array(offs, np.int64)
+    save('F12_rle', **out)
+
 
 if __name__ == '__main__':
     main()

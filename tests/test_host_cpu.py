@@ -272,3 +272,17 @@ def test_fused_adam_is_a_torch_optimizer_for_schedulers():
     m.optimizer.steps = 1
     sch.step()
     assert abs(m.optimizer.param_groups[0]['lr'] - 5e-4) < 1e-12
+
+
+def test_run_length_encoding_matches_reference_golden():
+    """utils.py:99-133 executed by the reference (fixture F12) vs the vectorised host implementation."""
+    from salt_amd import inference as I
+    fx = golden('F12_rle')
+    masks = list(fx['masks']) + [fx['small']]
+    offs = fx['rle_offsets']
+    for i, m in enumerate(masks):
+        ref = fx['rle_flat'][offs[i]:offs[i + 1]].tolist()
+        assert I.run_length_encoding(m) == ref, i
+        assert I.run_length_encoding(torch.from_numpy(m)) == ref
+        assert np.array_equal(I.run_length_decoding(ref, m.shape), m)
+        assert np.array_equal(I.run_length_decoding(' '.join(str(v) for v in ref), m.shape), m)
