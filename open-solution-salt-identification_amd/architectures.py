@@ -247,6 +247,8 @@ class ResNetEncoders(EmitOnly):
         if encoder_depth not in ResNet.CFG:
             raise NotImplementedError('only 18, 34, 50, 101, 152 version of Resnet are implemented')
         if pool0:
+            # with the stem max-pool the reference's forward (unet.py:89-109) has no compensating up-sampling: its logits come out at
+            # half the input resolution and no longer match the loaders' targets - the registry never sets it (models.py:15-19)
             raise NotImplementedError('pool0=True (stem max-pool) is off the reference default path (models.py:15-19)')
         self.encoder = resnet(encoder_depth, pretrained)
         self.conv1 = nn.Sequential(self.encoder.conv1, self.encoder.bn1, self.encoder.relu)
