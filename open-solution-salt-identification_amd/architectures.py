@@ -328,8 +328,8 @@ class UNetResNet(HipNetwork):
 
     def __init__(self, encoder_depth, num_classes, dropout_2d=0.0, pretrained=False, use_hypercolumn=False, pool0=False):
         super().__init__()
-        if dropout_2d != 0.0:
-            raise NotImplementedError('dropout_2d > 0 is off the reference default path (models.py:16)')
+        # F.dropout2d(encoder5, p=self.dropout_2d) (unet.py:91): the reference environment pins torch==0.3.1 (environment.yml:17), whose
+        # F.dropout2d defaults to training=False - the call is an identity for every p there, and the registry passes p = 0 anyway
         self.num_classes, self.dropout_2d, self.use_hypercolumn = num_classes, dropout_2d, use_hypercolumn
         self.encoders = ResNetEncoders(encoder_depth, pretrained=pretrained, pool0=pool0)
         b = 512 if encoder_depth in (18, 34) else 2048

@@ -118,6 +118,27 @@ class Program:
             where = (' [%s]' % self.ops[m][0]) if m is not None and m < len(self.ops) else ''
             raise SaltError('program %s failed (%d)%s: %s' % (self.name, rc, where, msg))
 
+    def capture(self, stream):
+        """Capture the whole program (single stream, tags ignored) into a hipGraph on ``stream`` (not the default stream)."""
+        if self._entries is None:
+            self.finalize()
+        self.release_graph()
+        h = ctypes.c_void_p()
+        check(lib.salt_graph_capture(ctypes.cast(self._entries, ctypes.c_void_p), len(self.ops), ctypes.c_void_p(stream.cuda_stream),
+                                     ctypes.byref(h)), 'graph_capture')
+        self._graph = h
+        return self
+
+    def replay(self, stream=None):
+        if getattr(self, '_graph', None) is None:
+            raise SaltError('program %s has no captured graph' % self.name)
+        check(lib.salt_graph_launch(self._graph, _stream_ptr(stream)), 'graph_launch')
+
+    def release_graph(self):
+        if getattr(self, '_graph', None) is not None:
+            lib.salt_graph_destroy(self._graph)
+            self._graph = None
+
     def run_timed(self, stream=None):
         """Run with a HIP event pair around every entry (on the launch stream); returns [(opname, struct, ms)]."""
         if self._entries is None:

@@ -167,3 +167,29 @@ def test_device_input_pipeline_other_sizes():
     assert tuple(X.shape) == (2, 3, 256, 256)
     assert_close(X.cpu(), Xr, 2e-6, 'train resize 202 -> 204 + pad 26')
     assert torch.equal(Tg.cpu(), Tr)
+
+
+def test_hipgraph_capture_replays_the_eval_program():
+    """salt_graph_capture / salt_graph_launch: a captured eval forward gives the same logits as the op-by-op executor."""
+    from salt_amd import architectures as A
+    torch.manual_seed(1)
+    net = A.VanillaUNet(2, in_channels=1, base_filters=8, levels=3).to(DEV).eval()
+    x1 = torch.randn(2, 1, 32, 32, device=DEV)
+    x2 = torch.randn(2, 1, 32, 32, device=DEV)
+    with torch.no_grad():
+        ref1 = net(x1).clone()
+        ref2 = net(x2).clone()
+    eng = net.engine()
+    cn = eng.net((2, 1, 32, 32), False)
+    st = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    cn.fwd.capture(st)
+    for x, ref in ((x1, ref1), (x2, ref2), (x1, ref1)):
+        with torch.cuda.stream(st):
+            cn.x.copy_(x)
+            cn.fwd.replay(st)
+        st.synchronize()
+        assert torch.equal(cn.logits, ref)
+    cn.fwd.release_graph()
+    with pytest.raises(Exception):
+        cn.fwd.replay(st)
