@@ -200,10 +200,18 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
     // MFMAs of stage s, and sched_group_barrier pins that interleave (the default schedule sinks every read to its first use,
     // which exposes the full LDS latency to a wave that has only one partner on its SIMD).
     struct Frag { u32x4 a[MI], b[NI]; };
+    constexpr int NTA = NT > 0 ? NT : 1;
+    int a_addr[NTA][MI];                                          // LDS address of the lane's A fragment per (tap, M sub-tile): chunk invariant
+    if constexpr (NT > 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < MI; ++i) a_addr[t][i] = swz_addr(pbase[i] + p.tap_off[t], khalf);
+    }
     auto load_frag = [&](int s, Frag& f) {
         const int t = s >> 1, hx = (s & 1) << 5;
 #pragma unroll
-        for (int i = 0; i < MI; ++i) f.a[i] = *reinterpret_cast<const u32x4*>(sA + (swz_addr(pbase[i] + p.tap_off[t], khalf) ^ hx));
+        for (int i = 0; i < MI; ++i) f.a[i] = *reinterpret_cast<const u32x4*>(sA + (a_addr[NT > 0 ? t : 0][i] ^ hx));
 #pragma unroll
         for (int j = 0; j < NI; ++j) f.b[j] = *reinterpret_cast<const u32x4*>(sB + t * (BN * 64) + (b_addr[j] ^ hx));
     };
@@ -239,6 +247,24 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
         // phase of chunk c and land in registers while the matrix cores work; they are written to LDS only after the
         // next barrier.  HBM/L2 latency is hidden behind compute instead of being paid once per chunk.
         u32x4 ra[MAXA], rb[MAXBP];
+        // Piece q = tid + 256 k sits in LDS row (tid >> 2) + 64 k, slot tid & 3.  64 % 4 == 0, so the swizzle term is the same for every
+        // k: LDS store address = lane constant + 4096 k.  The weight row of piece k is t * BN + n with (64 k + (tid >> 2)) = t * BN + n:
+        // its global offset splits into a lane constant and a part that only depends on k (uniform) - no per-piece index math per chunk.
+        const int lds_lane = swz_addr(tid >> 2, tid & 3);
+        constexpr int RPP = 64;                                     // LDS rows per 256-thread pass
+        const int lrow = tid >> 2;
+        int b_lane_off, b_lane_n;                                   // element offset / output channel of the lane inside a pass
+        if constexpr (BN >= RPP) { b_lane_n = lrow; b_lane_off = 0; }
+        else { b_lane_n = lrow % BN; b_lane_off = (lrow / BN) * p.Cout * KCE; }
+        b_lane_off += (n0 + b_lane_n) * KCE + (tid & 3) * VE;
+        auto b_uniform = [&](int k) -> int {                        // element offset of pass k relative to the chunk's weights
+            if constexpr (BN >= RPP) return ((k * RPP) / BN) * p.Cout * KCE + ((k * RPP) % BN) * KCE;
+            else return (k * (RPP / BN)) * p.Cout * KCE;
+        };
+        auto b_ok = [&](int k) -> bool {
+            if constexpr (BN > RPP) return n0 + b_lane_n + (k * RPP) % BN < p.Cout;
+            else return n0 + b_lane_n < p.Cout;
+        };
         auto load_chunk = [&](int c) {
             const int ch_base = c * KCE * p.vt;
 #pragma unroll
@@ -249,16 +275,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
                     if (ch0 < p.Cin) ra[k] = load_piece<T>(xg0, a_goff[k] + ch_base, ch0, p.Cin, x_vec);
                 }
             }
+            const T* wc = wg + (int64_t)c * p.ntaps * p.Cout * KCE;            // uniform
 #pragma unroll
             for (int k = 0; k < MAXBP; ++k) {
                 rb[k] = u32x4{0u, 0u, 0u, 0u};
-                const int q = tid + (k << 8);
-                if (q < nbp) {
-                    const int row = q >> 2;
-                    const int t = row / BN, n = row - t * BN;
-                    if (n0 + n < p.Cout)
-                        rb[k] = *reinterpret_cast<const u32x4*>(wg + (((int64_t)c * p.ntaps + t) * p.Cout + n0 + n) * KCE + (q & 3) * VE);
-                }
+                if (tid + (k << 8) < nbp && b_ok(k)) rb[k] = *reinterpret_cast<const u32x4*>(wc + b_uniform(k) + b_lane_off);
             }
         };
         load_chunk(0);
@@ -266,12 +287,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
             __syncthreads();                    // fragment reads of chunk c-1 are done
 #pragma unroll
             for (int k = 0; k < MAXA; ++k)
-                if (k < npa && a_goff[k] != -2) { const int q = tid + (k << 8); *reinterpret_cast<u32x4*>(sA + swz_addr(q >> 2, q & 3)) = ra[k]; }
+                if (k < npa && a_goff[k] != -2) *reinterpret_cast<u32x4*>(sA + lds_lane + k * (RPP * 64)) = ra[k];
 #pragma unroll
-            for (int k = 0; k < MAXBP; ++k) {
-                const int q = tid + (k << 8);
-                if (q < nbp) *reinterpret_cast<u32x4*>(sB + swz_addr(q >> 2, q & 3)) = rb[k];
-            }
+            for (int k = 0; k < MAXBP; ++k)
+                if (tid + (k << 8) < nbp) *reinterpret_cast<u32x4*>(sB + lds_lane + k * (RPP * 64)) = rb[k];
             __syncthreads();
             if (c + 1 < p.nchunk) load_chunk(c + 1);
             compute_chunk();
