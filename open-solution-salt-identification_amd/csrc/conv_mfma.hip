@@ -836,18 +836,47 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradKP p) {
     };
 
     if (PIPE && nq <= MAXQ * 256) {
-        // software pipeline: next tile's global loads fly while the matrix cores work on the current one
+        // software pipeline: next tile's global loads fly while the matrix cores work on the current one.
+        // Per piece only tile-invariant lane constants are kept (packed coordinates for the bounds test, a 32-bit element offset
+        // relative to the tile); per tile the origin is a handful of uniform values - no per-piece 64-bit index arithmetic.
         unsigned dp[MAXP], dq[MAXQ];
+        int offP[MAXP], offQ[MAXQ];
+        const int rowP = p.PW * p.p_cs, rowQ = p.QW * p.q_cs;
 #pragma unroll
-        for (int k = 0; k < MAXP; ++k) dp[k] = descP(tid + (k << 8));
+        for (int k = 0; k < MAXP; ++k) {
+            dp[k] = descP(tid + (k << 8));
+            const int bl = (int)(dp[k] >> 16), ty = (int)((dp[k] >> 8) & 255u), tx = (int)(dp[k] & 255u);
+            offP[k] = (bl * p.PH + ty) * rowP + tx * p.p_cs + chP;
+        }
 #pragma unroll
-        for (int k = 0; k < MAXQ; ++k) dq[k] = descQ(tid + (k << 8));
+        for (int k = 0; k < MAXQ; ++k) {
+            dq[k] = descQ(tid + (k << 8));
+            offQ[k] = (int)(dq[k] >> 16) * p.QH * rowQ + chQ;                 // image part only: rows / columns may be clamped
+        }
         u32x4 rp[MAXP], rq[MAXQ];
         auto load_tile = [&](const TileC& c) {
+            const int limB = p.B - c.tbi * p.nb, limY = p.PH - (c.tyi << p.th_log2), limX = p.PW - (c.txi << p.tw_log2);
+            const T* baseP = Pg + (((int64_t)c.tbi * p.nb * p.PH + (c.tyi << p.th_log2)) * p.PW + (c.txi << p.tw_log2)) * p.p_cs;
+            const T* baseQ = Qg + (int64_t)c.tbi * p.nb * p.QH * rowQ;
+            const int iy0 = (c.tyi << p.th_log2) * p.q_step + p.min_dy, ix0 = (c.txi << p.tw_log2) * p.q_step + p.min_dx;
 #pragma unroll
-            for (int k = 0; k < MAXP; ++k) rp[k] = fetchP(c, dp[k]);
+            for (int k = 0; k < MAXP; ++k) {
+                rp[k] = u32x4{0u, 0u, 0u, 0u};
+                const unsigned d = dp[k];
+                if (d != 0xffffffffu && (int)(d >> 16) < limB && (int)((d >> 8) & 255u) < limY && (int)(d & 255u) < limX)
+                    rp[k] = load_piece<T>(baseP, offP[k], chP, p.Ca, p_vec);
+            }
 #pragma unroll
-            for (int k = 0; k < MAXQ; ++k) rq[k] = fetchQ(c, dq[k]);
+            for (int k = 0; k < MAXQ; ++k) {
+                rq[k] = u32x4{0u, 0u, 0u, 0u};
+                const unsigned d = dq[k];
+                if (d == 0xffffffffu) continue;
+                int iy = iy0 + (int)((d >> 8) & 255u), ix = ix0 + (int)(d & 255u);
+                bool valid = (int)(d >> 16) < limB;
+                if (p.pad_mode) { iy = min(max(iy, 0), p.QH - 1); ix = min(max(ix, 0), p.QW - 1); }
+                else valid = valid && (unsigned)iy < (unsigned)p.QH && (unsigned)ix < (unsigned)p.QW;
+                if (valid) rq[k] = load_piece<T>(baseQ, offQ[k] + iy * rowQ + ix * p.q_cs, chQ, p.Cb, q_vec);
+            }
         };
         TileC cur = decode(split);
         if (split < p.ntiles) load_tile(cur);
