@@ -35,7 +35,35 @@ __global__ void affine_act_kernel(salt_view y, const float* scale, const float* 
     constexpr int N = Unit<T, VEC>::N;
     const int cpv = y.C / N;
     const int64_t units = (int64_t)y.B * y.H * y.W * cpv;
-    for (int64_t u = blockIdx.x * 256LL + threadIdx.x; u < units; u += gridDim.x * 256LL) {
+    const int64_t stride = gridDim.x * 256LL;
+    if (stride % cpv == 0) {
+        // the thread's channel piece is the same in every iteration: per-channel parameters live in registers, two units in flight
+        const int64_t u0 = blockIdx.x * 256LL + threadIdx.x;
+        const int c0 = (int)(u0 % cpv) * N;
+        float sc[N], sh[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) { sc[j] = scale ? scale[c0 + j] : 1.f; sh[j] = scale ? shift[c0 + j] : 0.f; }
+        for (int64_t u = u0; u < units; u += 2 * stride) {
+            const int64_t pixA = u / cpv, uB = u + stride;
+            const bool hasB = uB < units;
+            const int64_t pixB = hasB ? uB / cpv : pixA;
+            float fA[N], fB[N], rA[N], rB[N];
+            Unit<T, VEC>::ld((const T*)y.p + pixA * y.cs + c0, fA);
+            Unit<T, VEC>::ld((const T*)y.p + pixB * y.cs + c0, fB);
+            if (res.p) { Unit<T, VEC>::ld((const T*)res.p + pixA * res.cs + c0, rA); Unit<T, VEC>::ld((const T*)res.p + pixB * res.cs + c0, rB); }
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                float va = fA[j] * sc[j] + sh[j], vb = fB[j] * sc[j] + sh[j];
+                if (res.p) { va += rA[j]; vb += rB[j]; }
+                if (relu) { va = fmaxf(va, 0.f); vb = fmaxf(vb, 0.f); }
+                fA[j] = va; fB[j] = vb;
+            }
+            Unit<T, VEC>::st((T*)a.p + pixA * a.cs + c0, fA);
+            if (hasB) Unit<T, VEC>::st((T*)a.p + pixB * a.cs + c0, fB);
+        }
+        return;
+    }
+    for (int64_t u = blockIdx.x * 256LL + threadIdx.x; u < units; u += stride) {
         const int64_t pix = u / cpv; const int c0 = (int)(u - pix * cpv) * N;
         float f[N], r[N];
         Unit<T, VEC>::ld((const T*)y.p + pix * y.cs + c0, f);
@@ -244,6 +272,54 @@ __global__ void bn_bwd_apply_kernel(salt_view da, salt_view a, salt_view y, int 
     constexpr int N = Unit<T, VEC>::N;
     const int C = y.C, cpv = C / N;
     const int64_t units = (int64_t)y.B * y.H * y.W * cpv;
+    {
+        const int64_t stride_ = gridDim.x * 256LL;
+        if (stride_ % cpv == 0) {
+            // the thread's channel piece is loop invariant: the seven per-channel parameters are read once, not per unit
+            const int64_t u0 = blockIdx.x * 256LL + threadIdx.x;
+            const int c0 = (int)(u0 % cpv) * N;
+            const bool from_y = relu && a.p == nullptr;
+            float mu[N], is[N], k0[N], k1[N], k2[N], sc[N], sh[N], ga[N], be[N];
+            const float* gptr = from_y ? gamma : mean;             // valid addresses either way: every load below is unconditional,
+            const float* bptr = from_y ? beta : mean;              // so all of them are in flight together (one latency, not N)
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                mu[j] = mean[c0 + j]; is[j] = invstd[c0 + j];
+                k0[j] = coef[c0 + j]; k1[j] = coef[C + c0 + j]; k2[j] = coef[2 * C + c0 + j];
+                ga[j] = gptr[c0 + j]; be[j] = bptr[c0 + j];
+            }
+#pragma unroll
+            for (int j = 0; j < N; ++j) { sc[j] = ga[j] * is[j]; sh[j] = be[j] - mu[j] * sc[j]; }
+            for (int64_t u = u0; u < units; u += stride_) {
+                const int64_t pix = u / cpv;
+                float g[N], yy[N], o[N], aa[N];
+                Unit<T, VEC>::ld((const T*)da.p + pix * da.cs + c0, g);
+                Unit<T, VEC>::ld((const T*)y.p + pix * y.cs + c0, yy);
+#pragma unroll
+                for (int j = 0; j < N; ++j) aa[j] = 1.f;
+                if (relu && !from_y) Unit<T, VEC>::ld((const T*)a.p + pix * a.cs + c0, aa);
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const float pre = from_y ? yy[j] * sc[j] + sh[j] : aa[j];
+                    const float gg = (!relu || pre > 0.f) ? g[j] : 0.f;
+                    g[j] = gg;
+                    const float xh = (yy[j] - mu[j]) * is[j];
+                    o[j] = k0[j] * (gg - k1[j] - xh * k2[j]);
+                }
+                Unit<T, VEC>::st((T*)dy.p + pix * dy.cs + c0, o);
+                if (dres.p) {
+                    if (acc_dres) {
+                        float old[N];
+                        Unit<T, VEC>::ld((const T*)dres.p + pix * dres.cs + c0, old);
+#pragma unroll
+                        for (int j = 0; j < N; ++j) g[j] += old[j];
+                    }
+                    Unit<T, VEC>::st((T*)dres.p + pix * dres.cs + c0, g);
+                }
+            }
+            return;
+        }
+    }
     for (int64_t u = blockIdx.x * 256LL + threadIdx.x; u < units; u += gridDim.x * 256LL) {
         const int64_t pix = u / cpv; const int c0 = (int)(u - pix * cpv) * N;
         float g[N], yy[N], o[N], msk[N];
