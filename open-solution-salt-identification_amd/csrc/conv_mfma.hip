@@ -653,6 +653,22 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const salt_pack_conv_
     const int64_t total = (int64_t)nchunk * a.ntaps * N * KCE;
     const int64_t base = (int64_t)(blockIdx.x - job_block0[lo]) * PACK_EPB;
     T* out = reinterpret_cast<T*>(a.wp);
+    if (!a.transpose) {
+        // forward packs: thread = one (output channel n, input channel ch) pair, lanes along ch.  The KH*KW weights of a pair are
+        // contiguous (neighbouring lanes read neighbouring 36-byte blocks: coalesced), and for every tap the lanes of a chunk write
+        // one contiguous 64-byte packed row.
+        const int Cp = nchunk * KCE;
+        const int64_t pi = (int64_t)(blockIdx.x - job_block0[lo]) * 256 + threadIdx.x;
+        if (pi >= (int64_t)N * Cp) return;
+        const int n = (int)(pi / Cp), ch = (int)(pi - (int64_t)n * Cp);
+        const int chunk = ch / KCE, kc = ch - chunk * KCE;
+        const float* src = a.w + ((int64_t)n * a.D1 + ch) * a.KH * a.KW;
+        for (int t = 0; t < a.ntaps; ++t) {
+            const float v = ch < C ? src[a.tap_kh[t] * a.KW + a.tap_kw[t]] : 0.f;
+            Elem<T>::st(out + (((int64_t)chunk * a.ntaps + t) * N + n) * KCE + kc, v);
+        }
+        return;
+    }
     for (int e = threadIdx.x; e < PACK_EPB; e += 256) {
         const int64_t i = base + e;
         if (i >= total) break;
@@ -1044,6 +1060,7 @@ extern "C" int salt_pack_job_blocks(const salt_pack_conv_weight_args* a) {
     if (!a) return -1;
     const int KCE = a->dtype == SALT_F32 ? 16 : 32;
     const int N = a->transpose ? a->D1 : a->D0, C = a->transpose ? a->D0 : a->D1;
+    if (!a->transpose) return (int)(((int64_t)N * cdiv(C, KCE) * KCE + 255) / 256);      // one thread per (n, padded channel) pair
     const int64_t total = (int64_t)cdiv(C, KCE) * a->ntaps * N * KCE;
     return (int)((total + PACK_EPB - 1) / PACK_EPB);
 }
