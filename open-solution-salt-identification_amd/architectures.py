@@ -22,7 +22,6 @@ import torch
 from torch import nn
 
 from ._abi import SaltError
-from .engine import Act, Buffer
 from .runtime import Engine
 
 

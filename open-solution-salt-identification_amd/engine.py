@@ -13,12 +13,10 @@ PyTorch is used for device memory (tensors), streams and nothing else on this pa
 """
 import ctypes
 import os
-import math
 
 import numpy as np
 import torch
 
-from . import _abi
 from ._abi import OP_FUNCS, STRUCTS, SaltError, check, fill, lib
 
 DT_CODE = {'f32': 0, 'bf16': 1}

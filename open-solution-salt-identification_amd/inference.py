@@ -19,7 +19,7 @@ import itertools
 import numpy as np
 import torch
 
-from ._abi import OP_FUNCS, SaltError, check, fill, lib
+from ._abi import OP_FUNCS, SaltError, check, fill
 
 IOUT_THRESHOLDS = (0.5, 0.55, 0.6, 0.65, 0.7, 0.75, 0.8, 0.85, 0.9, 0.95)        # metrics.py:37-50
 

@@ -9,7 +9,6 @@ import ctypes
 
 import torch
 
-from . import _abi
 from ._abi import SaltError, STRUCTS, fill, lib, check
 
 _ws = {}

@@ -5,8 +5,6 @@ Mirrors ``optim.Adam(weight_regularization(model, regularize, weight_decay_conv2
 biases included), classic Adam (not AdamW), torch defaults beta=(0.9,0.999), eps=1e-8.  The surface the
 reference's callbacks touch is kept: ``param_groups`` (lr is read AND written by the schedulers,
 callbacks.py:262-275), ``state_dict()``, ``zero_grad()``, ``step()``."""
-import ctypes
-
 import torch
 
 from ._abi import SaltError

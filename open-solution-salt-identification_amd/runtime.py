@@ -15,11 +15,10 @@ import ctypes
 import os
 
 import torch
-from torch import nn
 
 from . import _abi
 from ._abi import SaltError, lib
-from .engine import Graph, Program, Scratch, DT_CODE, TORCH_DT
+from .engine import Graph, Program, DT_CODE, TORCH_DT
 
 
 def _require_gpu(device):
