@@ -58,6 +58,10 @@ template <> __device__ __forceinline__ u32x4 pack16<bf16_t>(const float* f) {
 
 // ---- host-side helpers
 void salt_set_error(const char* fmt, ...);
+// Fork hand-off (runtime.hip): when the two-stream executor is about to fork the side stream right after a main-stream
+// entry it parks an event here; an entry whose LAST launch can carry a stop event (hipExtLaunchKernelGGL) takes it, so the
+// kernel's own completion signal orders the side stream and no marker packet is queued behind the kernel.
+hipEvent_t salt_take_fork_event();
 #define SALT_FAIL(code, ...) do { salt_set_error(__VA_ARGS__); return (code); } while (0)
 #define SALT_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { \
     salt_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_)); return (int)e_; } } while (0)

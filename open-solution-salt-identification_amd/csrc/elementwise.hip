@@ -4,6 +4,7 @@
 // pixel, so a wave reads whole 128-B+ lines), fp32 math, deterministic two-level reductions (no atomics).
 // Reference anchors are listed per entry point in include/saltnet.h.
 #include "common.h"
+#include <hip/hip_ext.h>
 
 namespace {
 
@@ -28,6 +29,13 @@ inline int ew_blocks(int64_t units) { int64_t b = (units + 255) / 256; return (i
 #define EW_LAUNCH(KERN, T, allvec, units, stream, ...) \
     do { if (allvec) hipLaunchKernelGGL((KERN<T, true>), dim3(ew_blocks(units)), dim3(256), 0, stream, __VA_ARGS__); \
          else hipLaunchKernelGGL((KERN<T, false>), dim3(ew_blocks(units)), dim3(256), 0, stream, __VA_ARGS__); } while (0)
+
+// same, with the launch's completion signal bound to ``ev`` when it is non-null (fork hand-off, see common.h)
+#define EW_LAUNCH_EV(KERN, T, allvec, units, stream, ev, ...) \
+    do { hipEvent_t ev_ = (ev); \
+         if (!ev_) { EW_LAUNCH(KERN, T, allvec, units, stream, __VA_ARGS__); } \
+         else if (allvec) hipExtLaunchKernelGGL((KERN<T, true>), dim3(ew_blocks(units)), dim3(256), 0, stream, nullptr, ev_, 0, __VA_ARGS__); \
+         else hipExtLaunchKernelGGL((KERN<T, false>), dim3(ew_blocks(units)), dim3(256), 0, stream, nullptr, ev_, 0, __VA_ARGS__); } while (0)
 
 // ---------------------------------------------------------------- affine + act (+ residual)
 template <typename T, bool VEC>
@@ -757,7 +765,7 @@ extern "C" int salt_bn_bwd(const salt_bn_bwd_args* a, void* stream) {
             SALT_CHECK_LAUNCH();
         }
         const int64_t units = view_pixels(a->y) * cpv;
-        EW_LAUNCH(bn_bwd_apply_kernel, T, v, units, st, a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->gamma, a->beta, a->coef, a->dy, a->dres, a->accumulate_dres);
+        EW_LAUNCH_EV(bn_bwd_apply_kernel, T, v, units, st, salt_take_fork_event(), a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->gamma, a->beta, a->coef, a->dy, a->dres, a->accumulate_dres);
     })
     SALT_CHECK_LAUNCH();
     return SALT_OK;

@@ -6,6 +6,7 @@
 // captured into a hipGraph so that a launch-bound step costs one graph launch.
 #include <stdarg.h>
 #include <string.h>
+#include <stdlib.h>
 #include "common.h"
 
 static thread_local char g_err[512] = "";
@@ -79,7 +80,11 @@ struct EventPool {
     }
 };
 thread_local EventPool g_events;
+thread_local hipEvent_t g_fork_event = nullptr;
+const bool g_fork_handoff = !getenv("SALT_NO_FORK_HANDOFF");
 }  // namespace
+
+hipEvent_t salt_take_fork_event() { hipEvent_t e = g_fork_event; g_fork_event = nullptr; return e; }
 
 extern "C" int salt_program_run_streams(const salt_program_entry* e, int begin, int end, void* main_stream, void* side_stream) {
     return salt_program_run_streams_ex(e, begin, end, main_stream, side_stream, 1);
@@ -103,14 +108,20 @@ extern "C" int salt_program_run_streams_ex(const salt_program_entry* e, int begi
             (void)hipStreamWaitEvent(ss, g_events.ev[0], 0);
             main_dirty = false;
         }
+        const bool handoff = g_fork_handoff && !side && i + 1 < end && e[i + 1].stream == 1;
+        if (handoff) g_fork_event = g_events.ev[0];        // the entry may attach it to its last launch as the stop event
         const int rc = e[i].fn(e[i].args, side ? side_stream : main_stream);
+        const bool taken = handoff && g_fork_event == nullptr;
+        g_fork_event = nullptr;
         if (rc) {
             char prev[400];
             strncpy(prev, g_err, sizeof(prev) - 1); prev[sizeof(prev) - 1] = 0;
             salt_set_error("program entry %d failed (%d): %s", i, rc, prev);
             return rc;
         }
-        if (side) side_used = true; else main_dirty = true;
+        if (side) side_used = true;
+        else if (taken) { (void)hipStreamWaitEvent(ss, g_events.ev[0], 0); main_dirty = false; }
+        else main_dirty = true;
     }
     if (side_used && join_at_end) {
         (void)hipEventRecord(g_events.ev[1], ss);
