@@ -934,6 +934,233 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradKP p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------ weight gradient, fast path
+// Same decomposition and partial-slab format as conv_wgrad_kernel, for the shapes that dominate training: bf16, 3x3 (NT taps in
+// one launch), KS*16-pixel K tiles, 16-byte aligned views whose channel counts are multiples of 8, halo of at most MAXQ*256
+// pieces (the host checks all of it).  A weight-gradient workgroup is alone on its CU (144 accumulator registers per lane), so
+// nothing hides latency unless the instruction stream does it itself:
+//   * the k-step loop is fully unrolled and software pipelined: the transposed LDS reads of k-step j+1 and the global loads of
+//     the NEXT pixel tile are issued between the MFMAs of k-step j (sched_group_barrier pins the interleave);
+//   * the loader is branch free: a masked-out piece loads 16 zero bytes from g_zero_piece instead of zero-initialising its
+//     destination registers (which made the compiler wait for the loads already in flight) - per piece a few VALU instructions;
+//   * the MFMA operands are swapped (D^T): a lane then owns 4 consecutive b-channels of one a-row, the slab is written with
+//     16-byte stores instead of 4-byte ones.
+__device__ __attribute__((aligned(16))) unsigned int g_zero_piece[4] = {0u, 0u, 0u, 0u};
+
+// ROW16: every k-step is one 16-pixel tile row (tw = 16, th = KS, one image per tile, 18-pixel halo rows, unit step): the halo
+// address of a fragment read is a per-tap lane constant plus a compile-time multiple of the halo row - no address arithmetic.
+template <int NT, int KS, bool PAD, bool ROW16>
+__global__ __launch_bounds__(256) void conv_wgrad_fast_kernel(WgradKP p) {
+    static_assert(!ROW16 || NT == 9, "ROW16 shares pixel runs between the three taps of a 3x3 kernel row");
+    typedef bf16_t T;
+    constexpr int PPR = 8, ROWB = 192, BMP = KS * 16;
+    constexpr int MAXP = BMP * PPR / 256, MAXQ = 10, NPIECE = MAXP + MAXQ;
+    constexpr int LSTEPS = KS / 2;                               // the next tile's loads are issued during the first k-steps
+    constexpr int LPS = (NPIECE + LSTEPS - 1) / LSTEPS;
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sP = smem;
+    unsigned char* sQ = smem + BMP * ROWB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wa = wave >> 1, wb = wave & 1;
+    const int blk = blockIdx.x;
+    const int ab = blk % p.a_blocks;
+    const int bb = (blk / p.a_blocks) % p.b_blocks;
+    const int split = blk / (p.a_blocks * p.b_blocks);
+    const int a0 = ab * 64, c0 = bb * 64;
+    const int hhw = p.hh * p.hw, phalo = p.nb * hhw;
+    const T* Pg = reinterpret_cast<const T*>(p.P);
+    const T* Qg = reinterpret_cast<const T*>(p.Q);
+    const T* zp = reinterpret_cast<const T*>(g_zero_piece);
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // ---- tile walk without divisions (see conv_wgrad_kernel)
+    struct TileC { int tbi, tyi, txi; };
+    auto decode = [&](int tile) { TileC c; c.txi = tile % p.tiles_x; const int tt = tile / p.tiles_x; c.tyi = tt % p.tiles_y; c.tbi = tt / p.tiles_y; return c; };
+    const TileC tstep = decode(p.nsplit);
+    auto advance = [&](TileC& c) {
+        c.txi += tstep.txi; if (c.txi >= p.tiles_x) { c.txi -= p.tiles_x; ++c.tyi; }
+        c.tyi += tstep.tyi; if (c.tyi >= p.tiles_y) { c.tyi -= p.tiles_y; ++c.tbi; }
+        c.tbi += tstep.tbi;
+    };
+
+    // ---- tile-invariant piece constants.  Piece q = tid + 256 k is 16 bytes (8 channels) of pixel row q / 8.
+    const int pcx = tid % PPR;
+    const int chP = a0 + pcx * 8, chQ = c0 + pcx * 8;
+    const int np = BMP * PPR, nq = phalo * PPR;
+    const int rowP = p.PW * p.p_cs, rowQ = p.QW * p.q_cs;
+    int offP[MAXP], pby[MAXP], pxx[MAXP];                          // element offset in the tile, (image << 8 | row), column
+    int offQ[MAXQ], hyq[MAXQ], hxq[MAXQ], blq[MAXQ];
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+        const int q = tid + (k << 8), m = q / PPR;
+        const int tx = m & ((1 << p.tw_log2) - 1), ty = (m >> p.tw_log2) & ((1 << p.th_log2) - 1), bl = m >> (p.tw_log2 + p.th_log2);
+        const bool ok = q < np && chP < p.Ca;
+        offP[k] = (bl * p.PH + ty) * rowP + tx * p.p_cs + chP;
+        pby[k] = ok ? bl : (1 << 20); pxx[k] = tx | (ty << 16);
+    }
+#pragma unroll
+    for (int k = 0; k < MAXQ; ++k) {
+        const int q = tid + (k << 8), pix = q / PPR;
+        const int bl = pix / hhw, r = pix - bl * hhw, hy = r / p.hw, hx = r - hy * p.hw;
+        const bool ok = q < nq && chQ < p.Cb;
+        blq[k] = ok ? bl : (1 << 20);                                // fails "image < limB" for every tile
+        hyq[k] = hy; hxq[k] = hx;
+        offQ[k] = bl * p.QH * rowQ + chQ + (PAD ? 0 : hy * rowQ + hx * p.q_cs);
+    }
+    u32x4 rp[MAXP], rq[MAXQ];
+    struct TileCtx { const T* baseP; const T* baseQ; int iy0, ix0, limB, limY, limX; };
+    auto make_ctx = [&](const TileC& c, bool live) {
+        TileCtx x;
+        x.limB = live ? p.B - c.tbi * p.nb : 0;                      // no next tile: every piece is masked out
+        x.limY = p.PH - (c.tyi << p.th_log2); x.limX = p.PW - (c.txi << p.tw_log2);
+        x.baseP = Pg + (((int64_t)c.tbi * p.nb * p.PH + (c.tyi << p.th_log2)) * p.PW + (c.txi << p.tw_log2)) * p.p_cs;
+        x.iy0 = (c.tyi << p.th_log2) * p.q_step + p.min_dy; x.ix0 = (c.txi << p.tw_log2) * p.q_step + p.min_dx;
+        x.baseQ = Qg + (int64_t)c.tbi * p.nb * p.QH * rowQ;
+        if (!PAD) x.baseQ += (int64_t)x.iy0 * rowQ + (int64_t)x.ix0 * p.q_cs;     // may point in front of the image: in-range pieces only
+        return x;
+    };
+    auto issue_piece = [&](int K, const TileCtx& x) {                // K is a constant after unrolling
+        if (K < MAXP) {
+            const int k = K;
+            const bool ok = pby[k] < x.limB && (pxx[k] >> 16) < x.limY && (pxx[k] & 0xffff) < x.limX;
+            rp[k] = *reinterpret_cast<const u32x4*>(ok ? x.baseP + offP[k] : zp);
+        } else {
+            const int k = K - MAXP;
+            if (!PAD) {
+                const bool ok = (unsigned)(x.iy0 + hyq[k]) < (unsigned)p.QH && (unsigned)(x.ix0 + hxq[k]) < (unsigned)p.QW && blq[k] < x.limB;
+                rq[k] = *reinterpret_cast<const u32x4*>(ok ? x.baseQ + offQ[k] : zp);
+            } else {
+                const int iy = min(max(x.iy0 + hyq[k], 0), p.QH - 1), ix = min(max(x.ix0 + hxq[k], 0), p.QW - 1);
+                rq[k] = *reinterpret_cast<const u32x4*>(blq[k] < x.limB ? x.baseQ + (offQ[k] + iy * rowQ + ix * p.q_cs) : zp);
+            }
+        }
+    };
+
+    // ---- fragment addressing: ds_read_b64_tr_b16 transposes a [4 pixel][16 channel] block per 16-lane group (conv_wgrad_kernel)
+    const int khalf = lane >> 5, g16 = (lane >> 4) & 1, i16 = lane & 15, prow = i16 >> 2, pcol = (i16 & 3) * 4;
+    const int pa_base = (khalf * 8 + prow) * ROWB + (wa * 32 + g16 * 16 + pcol) * 2;     // + (16 j + 4 h) rows: an immediate
+    int qaddr[ROW16 ? 2 : KS * 2];                                    // halo-row byte address of pixel 16 j + 8 khalf + 4 h + prow
+#pragma unroll
+    for (int i = 0; i < (ROW16 ? 2 : KS * 2); ++i) {
+        const int m = (i >> 1) * 16 + khalf * 8 + (i & 1) * 4 + prow;
+        const int tx = m & ((1 << p.tw_log2) - 1), ty = (m >> p.tw_log2) & ((1 << p.th_log2) - 1), bl = m >> (p.tw_log2 + p.th_log2);
+        qaddr[i] = (bl * hhw + ty * p.q_step * p.hw + tx * p.q_step) * ROWB + (wb * 32 + g16 * 16 + pcol) * 2;
+    }
+    int tob[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) tob[t] = p.tap_off[t] * ROWB;
+    // ROW16: the three taps of a kernel row read overlapping pixel runs, so one run of 12 pixels (three transposed quads per
+    // lane) serves all three: tap dx is the run shifted by dx pixels = dx 16-bit elements (dx = 1: four v_alignbit, dx = 2: a
+    // register offset).  11 LDS reads per k-step instead of 20 - the LDS return path, not the MFMA, bounds this kernel.
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    struct Frag { s16x4 alo, ahi, blo[ROW16 ? 1 : NT], bhi[ROW16 ? 1 : NT]; u32x2 q[ROW16 ? 3 : 1][3]; };
+    int tq[3];
+    if (ROW16) {
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) tq[dy] = (khalf * 8 + prow) * ROWB + (wb * 32 + g16 * 16 + pcol) * 2 + dy * (18 * ROWB);
+    }
+    auto read_frags = [&](int j, Frag& fr) {
+        fr.alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sP + pa_base + (j * 16) * ROWB));
+        fr.ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sP + pa_base + (j * 16 + 4) * ROWB));
+        if constexpr (ROW16) {
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int u = 0; u < 3; ++u)
+                    fr.q[dy][u] = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sQ + tq[dy] + (j * 18 + u * 4) * ROWB)));
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                fr.blo[t] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sQ + qaddr[2 * j] + tob[t]));
+                fr.bhi[t] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sQ + qaddr[2 * j + 1] + tob[t]));
+            }
+        }
+    };
+    auto b_operand = [&](const Frag& fr, int t) -> bf16x8 {
+        if constexpr (ROW16) {
+            const int dy = t / 3, dx = t - dy * 3;
+            const unsigned w0 = fr.q[dy][0].x, w1 = fr.q[dy][0].y, w2 = fr.q[dy][1].x, w3 = fr.q[dy][1].y, w4 = fr.q[dy][2].x;
+            u32x4 v;
+            if (dx == 0) v = u32x4{w0, w1, w2, w3};
+            else if (dx == 1) v = u32x4{__builtin_amdgcn_alignbit(w1, w0, 16), __builtin_amdgcn_alignbit(w2, w1, 16),
+                                        __builtin_amdgcn_alignbit(w3, w2, 16), __builtin_amdgcn_alignbit(w4, w3, 16)};
+            else v = u32x4{w1, w2, w3, w4};
+            return __builtin_bit_cast(bf16x8, v);
+        } else {
+            const s16x8 bv = {fr.blo[t][0], fr.blo[t][1], fr.blo[t][2], fr.blo[t][3], fr.bhi[t][0], fr.bhi[t][1], fr.bhi[t][2], fr.bhi[t][3]};
+            return __builtin_bit_cast(bf16x8, bv);
+        }
+    };
+
+    TileC cur = decode(split);
+    {
+        const TileCtx x = make_ctx(cur, split < p.ntiles);
+#pragma unroll
+        for (int K = 0; K < NPIECE; ++K) issue_piece(K, x);
+    }
+    Frag f0, f1;
+    for (int tile = split; tile < p.ntiles; tile += p.nsplit) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) { const int q = tid + (k << 8); if (q < np) *reinterpret_cast<u32x4*>(sP + (q / PPR) * ROWB + pcx * 16) = rp[k]; }
+#pragma unroll
+        for (int k = 0; k < MAXQ; ++k) { const int q = tid + (k << 8); if (q < nq) *reinterpret_cast<u32x4*>(sQ + (q / PPR) * ROWB + pcx * 16) = rq[k]; }
+        __syncthreads();
+        advance(cur);
+        const TileCtx x = make_ctx(cur, tile + p.nsplit < p.ntiles);
+        read_frags(0, f0);
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            Frag& fc = (j & 1) ? f1 : f0;
+            Frag& fn = (j & 1) ? f0 : f1;
+            if (j + 1 < KS) read_frags(j + 1, fn);
+            int nld = 0;
+            if (j < LSTEPS) {
+#pragma unroll
+                for (int u = 0; u < LPS; ++u)
+                    if (j * LPS + u < NPIECE) { issue_piece(j * LPS + u, x); ++nld; }
+            }
+            const s16x8 av = {fc.alo[0], fc.alo[1], fc.alo[2], fc.alo[3], fc.ahi[0], fc.ahi[1], fc.ahi[2], fc.ahi[3]};
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const bf16x8 bv = b_operand(fc, t);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv, __builtin_bit_cast(bf16x8, av), acc[t], 0, 0, 0);
+            }
+            if (j + 1 < KS) {                                        // pin: 2 LDS reads (+ a global load) behind every MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, ROW16 ? 1 : 2, 0);
+                    if (t < nld) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+            }
+        }
+    }
+    // ---- partial slab partials[split][t][a][b]: lane = a-row, 4 consecutive registers = 4 consecutive b
+    const int l31 = lane & 31;
+    const int a = a0 + wa * 32 + l31;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (t < p.ntaps && a < p.Ca) {
+            float* row = p.partials + (((int64_t)split * p.ntaps + t) * p.Ca + a) * p.Cb;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int b = c0 + wb * 32 + 8 * g + 4 * khalf;
+                if (b < p.Cb) *reinterpret_cast<f32x4*>(row + b) = f32x4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+            }
+        }
+    }
+}
+
 int wgrad_plan(const salt_conv_wgrad_args* a, WgradKP* k, int* nsplit_out) {
     if (!a || !view_ok(a->p) || !view_ok(a->q)) SALT_FAIL(SALT_E_BADARG, "wgrad: bad view");
     if (a->ntaps < 1 || a->ntaps > 9) SALT_FAIL(SALT_E_BADARG, "wgrad: ntaps %d (max 9 per launch)", a->ntaps);
@@ -1087,6 +1314,24 @@ static int launch_wgrad(const WgradKP& k, hipStream_t st) {
     const size_t lds = (size_t)(k.bmp + k.nb * k.hh * k.hw) * ROWB;
     if (lds > 160 * 1024) SALT_FAIL(SALT_E_LDS, "wgrad: needs %zu bytes of LDS", lds);
     const dim3 grid((unsigned)(k.a_blocks * k.b_blocks * k.nsplit));
+    if constexpr (sizeof(T) == 2) {
+        // fast path: whole aligned 16-byte pieces, 3x3, 128-pixel K tiles (conv_wgrad_fast_kernel)
+        static const bool generic = getenv("SALT_WGRAD_GENERIC") != nullptr;
+        const bool fast = !generic && k.ntaps == 9 && k.bmp == 128 && k.p_cs % 8 == 0 && k.q_cs % 8 == 0 && k.Ca % 8 == 0 && k.Cb % 8 == 0 &&
+                          ((reinterpret_cast<uintptr_t>(k.P) | reinterpret_cast<uintptr_t>(k.Q) | reinterpret_cast<uintptr_t>(k.partials)) & 15) == 0 &&
+                          k.nb * k.hh * k.hw * 8 <= 10 * 256;
+        if (fast) {
+            bool row16 = k.tw_log2 == 4 && k.th_log2 == 3 && k.nb == 1 && k.q_step == 1 && k.hw == 18;
+            for (int t = 0; t < 9; ++t) row16 = row16 && k.tap_off[t] == (t / 3) * 18 + t % 3;       // raster tap order
+            auto kern = k.pad_mode ? (row16 ? conv_wgrad_fast_kernel<9, 8, true, true> : conv_wgrad_fast_kernel<9, 8, true, false>)
+                                   : (row16 ? conv_wgrad_fast_kernel<9, 8, false, true> : conv_wgrad_fast_kernel<9, 8, false, false>);
+            if (lds > 64 * 1024) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) SALT_FAIL((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e)); }
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, k);
+            SALT_CHECK_LAUNCH();
+            return SALT_OK;
+        }
+    }
 #define SALT_WG(NT) { auto kern = conv_wgrad_kernel<T, NT>; \
         if (lds > 64 * 1024) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             if (e != hipSuccess) SALT_FAIL((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e)); } \
