@@ -365,15 +365,14 @@ __global__ __launch_bounds__(256) void head1x1_bwd_vec_kernel(salt_view x, const
             for (int j = 0; j < N; ++j) sm[((row * cpv + cv) * N + j) * 4 + o] = gw[o][j];
     }
     __syncthreads();
-    if (row == 0) {
-#pragma unroll
-        for (int j = 0; j < N; ++j)
-#pragma unroll
-            for (int o = 0; o < 4; ++o) if (o < Cout) {
-                float t = 0.f;
-                for (int r = 0; r < R; ++r) t += sm[((r * cpv + cv) * N + j) * 4 + o];
-                partials[(int64_t)blockIdx.x * PW + o * (C + 1) + c0 + j] = t;
-            }
+    // cross-row sums, one thread per (channel, output) pair (rows in ascending order)
+    for (int e = threadIdx.x; e < C * 4; e += 256) {
+        const int o = e & 3, c = e >> 2;
+        if (o < Cout) {
+            float t = 0.f;
+            for (int r = 0; r < R; ++r) t += sm[r * C * 4 + e];
+            partials[(int64_t)blockIdx.x * PW + o * (C + 1) + c] = t;
+        }
     }
     __syncthreads();
     if (row < R && cv == 0) {

@@ -228,14 +228,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(salt_view da, salt_v
             for (int j = 0; j < N; ++j) { sm[((row * cvn + (cv - cv0)) * N + j) * 2] = s1[j]; sm[((row * cvn + (cv - cv0)) * N + j) * 2 + 1] = s2[j]; }
         }
         __syncthreads();
-        if (row == 0) {
-#pragma unroll
-            for (int j = 0; j < N; ++j) {
-                float t1 = 0.f, t2 = 0.f;
-                for (int r = 0; r < R; ++r) { t1 += sm[((r * cvn + (cv - cv0)) * N + j) * 2]; t2 += sm[((r * cvn + (cv - cv0)) * N + j) * 2 + 1]; }
-                partials[((int64_t)blockIdx.x * 2 + 0) * C + cv * N + j] = t1;
-                partials[((int64_t)blockIdx.x * 2 + 1) * C + cv * N + j] = t2;
-            }
+        // cross-row sums: one thread per (statistic, channel) instead of row 0 walking all of them; rows are added in
+        // ascending order exactly as before
+        const int E = cvn * N;
+        for (int e = threadIdx.x; e < 2 * E; e += 256) {
+            const int st = e >= E ? 1 : 0, cl = e - st * E;
+            float t = 0.f;
+            for (int r = 0; r < R; ++r) t += sm[(r * E + cl) * 2 + st];
+            partials[((int64_t)blockIdx.x * 2 + st) * C + cv0 * N + cl] = t;
         }
         __syncthreads();
     }

@@ -36,13 +36,11 @@ __global__ __launch_bounds__(256) void gap_partial_kernel(salt_view x, float* pa
 #pragma unroll
     for (int j = 0; j < N; ++j) sm[(row * cpv + cv) * N + j] = s[j];
     __syncthreads();
-    if (row == 0) {
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-            float t = 0.f;
-            for (int r = 0; r < R; ++r) t += sm[(r * cpv + cv) * N + j];
-            partials[((int64_t)b * nparts + part) * C + cv * N + j] = t;
-        }
+    // cross-row sums, one thread per channel (rows in ascending order)
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float t = 0.f;
+        for (int r = 0; r < R; ++r) t += sm[r * C + c];
+        partials[((int64_t)b * nparts + part) * C + c] = t;
     }
 }
 
@@ -158,14 +156,13 @@ __global__ __launch_bounds__(256) void scse_bwd1_kernel(salt_view x, salt_view y
     if (cv == 0) sb[row] = s_bs;
     __syncthreads();
     float* out = partials + ((int64_t)b * nparts + part) * (2 * C + 1);
-    if (row == 0) {
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-            float t1 = 0.f, t2 = 0.f;
-            for (int r = 0; r < R; ++r) { t1 += sg[(r * cpv + cv) * N + j]; t2 += sw[(r * cpv + cv) * N + j]; }
-            out[cv * N + j] = t1; out[C + cv * N + j] = t2;
-        }
-        if (cv == 0) { float t = 0.f; for (int r = 0; r < R; ++r) t += sb[r]; out[2 * C] = t; }
+    // cross-row sums, one thread per output (rows in ascending order)
+    for (int e = threadIdx.x; e < 2 * C + 1; e += 256) {
+        float t = 0.f;
+        if (e < C) { for (int r = 0; r < R; ++r) t += sg[r * C + e]; }
+        else if (e < 2 * C) { for (int r = 0; r < R; ++r) t += sw[r * C + e - C]; }
+        else { for (int r = 0; r < R; ++r) t += sb[r]; }
+        out[e] = t;
     }
 }
 
