@@ -5,6 +5,7 @@
 // Reference anchors are listed per entry point in include/saltnet.h.
 #include "common.h"
 #include <hip/hip_ext.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -24,7 +25,10 @@ template <typename T, bool VEC> struct Unit {
 inline bool vec_ok(const salt_view& v, int ve) {
     return v.p == nullptr || ((v.C % ve) == 0 && (v.cs % ve) == 0 && (reinterpret_cast<uintptr_t>(v.p) & 15) == 0);
 }
-inline int ew_blocks(int64_t units) { int64_t b = (units + 255) / 256; return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b)); }
+inline int ew_blocks(int64_t units) {
+    static const int64_t cap = getenv("SALT_EW_BLOCKS") ? atoi(getenv("SALT_EW_BLOCKS")) : 1024;
+    int64_t b = (units + 255) / 256; return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
 
 #define EW_LAUNCH(KERN, T, allvec, units, stream, ...) \
     do { if (allvec) hipLaunchKernelGGL((KERN<T, true>), dim3(ew_blocks(units)), dim3(256), 0, stream, __VA_ARGS__); \
@@ -92,8 +96,8 @@ __global__ void affine_act_kernel(salt_view y, const float* scale, const float* 
 // Partials are (sum, M2 about the partial's own mean, count), one per convolution workgroup.  Merging uses the exact identity
 //   mean = S/N,  M2 = sum_k [ M2_k + n_k (mean_k - mean)^2 ]
 // The kernel is latency-bound (a few hundred KB at most), so the layout maximises loads in flight: 256 threads = ROWS part-rows x
-// (256/ROWS) channels, ROWS in {4, 16, 64} picked so that a thread holds <= 16 partials in registers (one batch, no re-read in the
-// second pass) for every layer of the networks here; more partials loop over batches and re-read in pass two.
+// (256/ROWS) channels; a thread holds <= 16 partials in registers (one batch, no re-read in the second pass) up to ROWS*16
+// partials, more loop over batches and re-read in pass two.  ROWS = 64 is used for every layer (bn_rows_for).
 template <int ROWS>
 __global__ __launch_bounds__(256) void bn_finalize_kernel(salt_bn_finalize_args a) {
     constexpr int CPB = 256 / ROWS, U = 16;
@@ -157,7 +161,13 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(salt_bn_finalize_args 
     }
 }
 
-inline int bn_rows_for(int nparts) { return nparts <= 64 ? 4 : (nparts <= 256 ? 16 : 64); }
+// 64 part-rows x 4 channels for every layer: these kernels are pure latency (a few hundred KB), and the widest split - most
+// workgroups, fewest loads per thread - measured fastest on the whole step (7.50 vs 7.72 ms against the size-dependent choice).
+inline int bn_rows_for(int nparts) {
+    static const int force = getenv("SALT_BN_ROWS") ? atoi(getenv("SALT_BN_ROWS")) : 64;
+    (void)nparts;
+    return force;
+}
 
 __global__ void bn_fold_kernel(salt_bn_fold_args a) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
