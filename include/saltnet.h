@@ -97,6 +97,19 @@ typedef struct {
     int fold_bottom;
     int fold_left;
     int fold_right;
+    /* BatchNorm-backward sums fused into a data-gradient launch (the launch that completes g = dL/da of a = relu?(bn(yc)), yc the
+     * producer convolution's output): each workgroup also reduces, over its pixel tile and per channel, sum(g m) and
+     * sum(g m xhat) with m = [yc*scale + shift > 0] (or 1 without ReLU), xhat = (yc - mean) invstd, of the value it STORES, into
+     * bnb_partials[tile][2][Cout], tile < salt_conv_stats_parts(args).  salt_bn_bwd then runs with partials_ready = 1 and skips
+     * its own reduction pass over g and yc.  bnb_partials == NULL: off.  Needs out_step 1 on the full grid, no strip, no stats,
+     * 16-byte aligned views with Cout a multiple of 8 (bf16) / 4 (f32). */
+    salt_view bnb_y;          /* yc, same shape as y */
+    const float* bnb_mean;
+    const float* bnb_invstd;
+    const float* bnb_gamma;
+    const float* bnb_beta;
+    float* bnb_partials;
+    int bnb_relu;
 } salt_conv_args;
 int salt_conv(const salt_conv_args*, void* stream);
 /* number of stats partials a launch with these args writes (host sizes the workspace with it) */
@@ -342,6 +355,7 @@ typedef struct {              /* backward of a = relu?(bn(y) (+res)) in train mo
     salt_view dy;             /* out: grad wrt y */
     salt_view dres;           /* out: grad wrt residual (masked da); dres.p == NULL: none */
     int accumulate_dres;
+    int partials_ready;       /* 1: `partials` ([nparts][2][C], any nparts >= 1) was filled by the producer of da (salt_conv_args.bnb_*) */
 } salt_bn_bwd_args;
 int salt_bn_bwd(const salt_bn_bwd_args*, void* stream);
 int salt_bn_bwd_parts(const salt_bn_bwd_args*);

@@ -40,6 +40,9 @@ struct ConvKP {
     unsigned hhw_magic, hw_magic;                                                // x / d == umulhi(x, 2^32 / d + 1) for x * d < 2^32
     int m_tiles, n_tiles;
     int vt;                          // virtual taps of a 1x1 convolution: vt channel chunks staged per barrier round (1 = off)
+    // BatchNorm-backward sums of the stored tile (saltnet.h, salt_conv_args.bnb_*); bnb_partials == nullptr: off
+    const void* bnb_y; int bnb_cs, bnb_relu;
+    const float* bnb_mean; const float* bnb_invstd; const float* bnb_gamma; const float* bnb_beta; float* bnb_partials;
 };
 
 template <typename T> struct Mma;
@@ -395,6 +398,20 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
     {
         T* yg = reinterpret_cast<T*>(p.y);
         const bool y_vec = ((p.y_cs % VE) == 0) && ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0);
+        // BatchNorm-backward sums of the stored values: a thread's channel piece (tid % PPO) is the same for all of its pixels
+        const bool bnb = p.bnb_partials != nullptr;
+        float b1[VE], b2[VE], bmu[VE], bis[VE], bsc[VE], bsh[VE];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) { b1[e] = 0.f; b2[e] = 0.f; bmu[e] = 0.f; bis[e] = 0.f; bsc[e] = 0.f; bsh[e] = 0.f; }
+        if (bnb) {
+            const int nb0 = n0 + (tid % PPO) * VE;
+#pragma unroll
+            for (int e = 0; e < VE; ++e)
+                if (nb0 + e < p.Cout) {
+                    bmu[e] = p.bnb_mean[nb0 + e]; bis[e] = p.bnb_invstd[nb0 + e];
+                    bsc[e] = p.bnb_gamma[nb0 + e] * bis[e]; bsh[e] = p.bnb_beta[nb0 + e] - bmu[e] * bsc[e];
+                }
+        }
         for (int q = tid; q < BM * PPO; q += 256) {
             const int m = q / PPO, pc = q - m * PPO;
             const int tx = m & ((1 << p.tw_log2) - 1);
@@ -419,15 +436,25 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
             }
             const u32x4 v = *reinterpret_cast<const u32x4*>(sO + m * PITCH + pc * VE);
             if (dvec && n + VE <= p.Cout) {
+                u32x4 stored = v;
                 if (accum) {
                     float f[VE], o[VE];
                     unpack16<T>(v, f);
                     unpack16<T>(*reinterpret_cast<const u32x4*>(dst), o);
 #pragma unroll
                     for (int e = 0; e < VE; ++e) f[e] += o[e];
-                    *reinterpret_cast<u32x4*>(dst) = pack16<T>(f);
-                } else {
-                    *reinterpret_cast<u32x4*>(dst) = v;
+                    stored = pack16<T>(f);
+                }
+                *reinterpret_cast<u32x4*>(dst) = stored;
+                if (bnb) {                                         // host: bnb implies whole aligned pieces, out_step 1, no strip
+                    float g[VE], yc[VE];
+                    unpack16<T>(stored, g);
+                    unpack16<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.bnb_y) + (((int64_t)b * p.OHf + oy) * p.OWf + ox) * p.bnb_cs + n), yc);
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) {
+                        const float gg = (!p.bnb_relu || yc[e] * bsc[e] + bsh[e] > 0.f) ? g[e] : 0.f;
+                        b1[e] += gg; b2[e] += gg * (yc[e] - bmu[e]) * bis[e];
+                    }
                 }
             } else {
                 float f[VE];
@@ -435,6 +462,21 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
 #pragma unroll
                 for (int e = 0; e < VE; ++e)
                     if (n + e < p.Cout) Elem<T>::st(dst + e, accum ? f[e] + Elem<T>::ld(dst + e) : f[e]);
+            }
+        }
+        if (bnb) {
+            // cross-row sums: 256/PPO rows of BN channels x 2 statistics through LDS, rows added in ascending order
+            float* sR = reinterpret_cast<float*>(smem);
+            const int row = tid / PPO, cl0 = (tid % PPO) * VE;
+            __syncthreads();                                       // the output tile in LDS has been stored
+#pragma unroll
+            for (int e = 0; e < VE; ++e) { sR[(row * BN + cl0 + e) * 2] = b1[e]; sR[(row * BN + cl0 + e) * 2 + 1] = b2[e]; }
+            __syncthreads();
+            for (int e = tid; e < 2 * BN; e += 256) {
+                const int st = e >= BN ? 1 : 0, cl = e - st * BN;
+                float t = 0.f;
+                for (int r = 0; r < 256 / PPO; ++r) t += sR[(r * BN + cl) * 2 + st];
+                if (n0 + cl < p.Cout) p.bnb_partials[((int64_t)m_tile * 2 + st) * p.Cout + n0 + cl] = t;
             }
         }
     }
@@ -578,6 +620,20 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
         if (out_bytes > pl->lds) pl->lds = out_bytes;
     }
     pl->parts = tiles_b * k.tiles_y * k.tiles_x;
+    k.bnb_partials = a->bnb_partials; k.bnb_y = a->bnb_y.p; k.bnb_cs = a->bnb_y.cs; k.bnb_relu = a->bnb_relu;
+    k.bnb_mean = a->bnb_mean; k.bnb_invstd = a->bnb_invstd; k.bnb_gamma = a->bnb_gamma; k.bnb_beta = a->bnb_beta;
+    if (a->bnb_partials) {
+        const int ve = a->dtype == SALT_F32 ? 4 : 8;
+        if (a->strip || a->stats || a->out_step != 1 || a->out_oy || a->out_ox || a->OH != a->y.H || a->OW != a->y.W)
+            SALT_FAIL(SALT_E_BADARG, "conv: BatchNorm-backward sums need a plain full-grid launch");
+        if (!view_ok(a->bnb_y) || a->bnb_y.B != a->y.B || a->bnb_y.H != a->y.H || a->bnb_y.W != a->y.W || a->bnb_y.C != a->y.C)
+            SALT_FAIL(SALT_E_BADARG, "conv: bnb_y shape");
+        if (!a->bnb_mean || !a->bnb_invstd || !a->bnb_gamma || !a->bnb_beta) SALT_FAIL(SALT_E_BADARG, "conv: bnb parameters missing");
+        if (Cout % ve || a->y.cs % ve || a->bnb_y.cs % ve || ((reinterpret_cast<uintptr_t>(a->y.p) | reinterpret_cast<uintptr_t>(a->bnb_y.p)) & 15))
+            SALT_FAIL(SALT_E_BADARG, "conv: BatchNorm-backward sums need 16-byte aligned whole channel pieces");
+        const size_t red_bytes = (size_t)(256 / (BN / ve)) * BN * 2 * sizeof(float);
+        if (red_bytes > pl->lds) pl->lds = red_bytes;
+    }
     if (pl->lds > 160 * 1024) SALT_FAIL(SALT_E_LDS, "conv: needs %zu bytes of LDS", pl->lds);
     return SALT_OK;
 }

@@ -34,6 +34,10 @@ inline int ew_blocks(int64_t units) {
     do { if (allvec) hipLaunchKernelGGL((KERN<T, true>), dim3(ew_blocks(units)), dim3(256), 0, stream, __VA_ARGS__); \
          else hipLaunchKernelGGL((KERN<T, false>), dim3(ew_blocks(units)), dim3(256), 0, stream, __VA_ARGS__); } while (0)
 
+#define EW_LAUNCH_U(KERN, T, allvec, UU, units, stream, ...) \
+    do { if (allvec) hipLaunchKernelGGL((KERN<T, true, UU>), dim3(ew_blocks(units)), dim3(256), 0, stream, __VA_ARGS__); \
+         else hipLaunchKernelGGL((KERN<T, false, UU>), dim3(ew_blocks(units)), dim3(256), 0, stream, __VA_ARGS__); } while (0)
+
 // same, with the launch's completion signal bound to ``ev`` when it is non-null (fork hand-off, see common.h)
 #define EW_LAUNCH_EV(KERN, T, allvec, units, stream, ev, ...) \
     do { hipEvent_t ev_ = (ev); \
@@ -42,36 +46,40 @@ inline int ew_blocks(int64_t units) {
          else hipExtLaunchKernelGGL((KERN<T, false>), dim3(ew_blocks(units)), dim3(256), 0, stream, nullptr, ev_, 0, __VA_ARGS__); } while (0)
 
 // ---------------------------------------------------------------- affine + act (+ residual)
-template <typename T, bool VEC>
+template <typename T, bool VEC, int U = 2>
 __global__ void affine_act_kernel(salt_view y, const float* scale, const float* shift, salt_view res, int relu, salt_view a) {
     constexpr int N = Unit<T, VEC>::N;
     const int cpv = y.C / N;
     const int64_t units = (int64_t)y.B * y.H * y.W * cpv;
     const int64_t stride = gridDim.x * 256LL;
     if (stride % cpv == 0) {
-        // the thread's channel piece is the same in every iteration: per-channel parameters live in registers, two units in flight
+        // the thread's channel piece is the same in every iteration: per-channel parameters live in registers, U units in flight
         const int64_t u0 = blockIdx.x * 256LL + threadIdx.x;
         const int c0 = (int)(u0 % cpv) * N;
         float sc[N], sh[N];
 #pragma unroll
         for (int j = 0; j < N; ++j) { sc[j] = scale ? scale[c0 + j] : 1.f; sh[j] = scale ? shift[c0 + j] : 0.f; }
-        for (int64_t u = u0; u < units; u += 2 * stride) {
-            const int64_t pixA = u / cpv, uB = u + stride;
-            const bool hasB = uB < units;
-            const int64_t pixB = hasB ? uB / cpv : pixA;
-            float fA[N], fB[N], rA[N], rB[N];
-            Unit<T, VEC>::ld((const T*)y.p + pixA * y.cs + c0, fA);
-            Unit<T, VEC>::ld((const T*)y.p + pixB * y.cs + c0, fB);
-            if (res.p) { Unit<T, VEC>::ld((const T*)res.p + pixA * res.cs + c0, rA); Unit<T, VEC>::ld((const T*)res.p + pixB * res.cs + c0, rB); }
+        for (int64_t u = u0; u < units; u += U * stride) {
+            float f[U][N], r[U][N];
+            int64_t pix[U];
 #pragma unroll
-            for (int j = 0; j < N; ++j) {
-                float va = fA[j] * sc[j] + sh[j], vb = fB[j] * sc[j] + sh[j];
-                if (res.p) { va += rA[j]; vb += rB[j]; }
-                if (relu) { va = fmaxf(va, 0.f); vb = fmaxf(vb, 0.f); }
-                fA[j] = va; fB[j] = vb;
+            for (int i = 0; i < U; ++i) {
+                const int64_t ui = u + i * stride;
+                pix[i] = (ui < units ? ui : u) / cpv;                 // past the end: re-read the first unit, never stored
+                Unit<T, VEC>::ld((const T*)y.p + pix[i] * y.cs + c0, f[i]);
+                if (res.p) Unit<T, VEC>::ld((const T*)res.p + pix[i] * res.cs + c0, r[i]);
             }
-            Unit<T, VEC>::st((T*)a.p + pixA * a.cs + c0, fA);
-            if (hasB) Unit<T, VEC>::st((T*)a.p + pixB * a.cs + c0, fB);
+#pragma unroll
+            for (int i = 0; i < U; ++i) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    float v = f[i][j] * sc[j] + sh[j];
+                    if (res.p) v += r[i][j];
+                    if (relu) v = fmaxf(v, 0.f);
+                    f[i][j] = v;
+                }
+                if (i == 0 || u + i * stride < units) Unit<T, VEC>::st((T*)a.p + pix[i] * a.cs + c0, f[i]);
+            }
         }
         return;
     }
@@ -700,7 +708,7 @@ extern "C" int salt_affine_act(const salt_affine_act_args* a, void* stream) {
         const int ve = Elem<T>::VE;
         const bool v = vec_ok(a->y, ve) && vec_ok(a->a, ve) && vec_ok(a->res, ve);
         const int64_t units = view_pixels(a->y) * (a->y.C / (v ? ve : 1));
-        EW_LAUNCH(affine_act_kernel, T, v, units, (hipStream_t)stream, a->y, a->scale, a->shift, a->res, a->relu, a->a);
+        EW_LAUNCH_U(affine_act_kernel, T, v, 2, units, (hipStream_t)stream, a->y, a->scale, a->shift, a->res, a->relu, a->a);
     })
     SALT_CHECK_LAUNCH();
     return SALT_OK;
@@ -752,8 +760,11 @@ extern "C" int salt_bn_bwd(const salt_bn_bwd_args* a, void* stream) {
     if (a->dres.p && !same_shape(a->dres, a->y)) SALT_FAIL(SALT_E_BADARG, "bn_bwd: dres shape");
     if (!a->mean || !a->invstd || !a->gamma || !a->partials || !a->coef) SALT_FAIL(SALT_E_BADARG, "bn_bwd: missing buffers");
     int64_t per = 0;
-    const int nparts = bn_bwd_nparts(a, &per);
-    if (a->nparts != nparts) SALT_FAIL(SALT_E_BADARG, "bn_bwd: nparts %d, expected %d", a->nparts, nparts);
+    int nparts = bn_bwd_nparts(a, &per);
+    if (a->partials_ready) {                                // the producer of da reduced already (salt_conv_args.bnb_*)
+        if (a->nparts < 1 || a->dres.p || (a->relu && a->a.p)) SALT_FAIL(SALT_E_BADARG, "bn_bwd: partials_ready needs nparts >= 1, no residual, mask from y");
+        nparts = a->nparts;
+    } else if (a->nparts != nparts) SALT_FAIL(SALT_E_BADARG, "bn_bwd: nparts %d, expected %d", a->nparts, nparts);
     hipStream_t st = (hipStream_t)stream;
     const int C = a->y.C;
     SALT_DISPATCH_DTYPE(a->dtype, T, {
@@ -763,9 +774,11 @@ extern "C" int salt_bn_bwd(const salt_bn_bwd_args* a, void* stream) {
         const int cpv = C / N;
         const int cvn = cpv < 256 ? cpv : 256;
         const size_t lds = (size_t)(256 / cvn) * cvn * N * 2 * sizeof(float);
-        if (v) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), dim3(nparts), dim3(256), lds, st, a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->gamma, a->beta, a->partials, per);
-        else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), dim3(nparts), dim3(256), lds, st, a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->gamma, a->beta, a->partials, per);
-        SALT_CHECK_LAUNCH();
+        if (!a->partials_ready) {
+            if (v) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), dim3(nparts), dim3(256), lds, st, a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->gamma, a->beta, a->partials, per);
+            else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), dim3(nparts), dim3(256), lds, st, a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->gamma, a->beta, a->partials, per);
+            SALT_CHECK_LAUNCH();
+        }
         {
             const int rows = bn_rows_for(nparts);
             const double M = (double)view_pixels(a->y);

@@ -69,6 +69,16 @@ class Program:
         self.ops.append((opname, fn, s))
         return s
 
+    def set_fields(self, s, **fields):
+        """Set more fields of an argument struct that ``add`` returned (same conventions: Scratch values are patched at finalize)."""
+        plain = {}
+        for k, v in fields.items():
+            if isinstance(v, Scratch):
+                self.patches.append((s, (k,), v))
+            else:
+                plain[k] = v
+        fill(s, **plain)
+
     def mark(self, label):
         self.marks[label] = len(self.ops)
 
@@ -170,6 +180,7 @@ class Buffer:
         self.t = graph.alloc((B, H, W, self.Ct), graph.tdtype)
         self.grad_t = None
         self.grad_init = np.zeros(self.Ct, dtype=bool)
+        self.grad_writers = []         # one entry per gradient writer in backward-program order: [c0, C, conv-args struct | None]
 
     def grad(self):
         if self.grad_t is None:
@@ -206,6 +217,7 @@ class Act:
     def grad_state(self):
         """-> accumulate flag for the next writer of this slice's gradient; marks it initialised."""
         st = self.buf.grad_init[self.c0:self.c0 + self.C]
+        self.buf.grad_writers.append([self.c0, self.C, None])
         if st.all():
             return 1
         if st.any():
@@ -387,11 +399,25 @@ class Graph:
             dres = res.gview()
         acc_y = y.grad_state()
         assert acc_y == 0, 'conv output gradient has a single producer'
+        partials, ready = Scratch('bn_bwd', nparts * 2 * C * 4), 0
+        wr = out.buf.grad_writers
+        if (res is None and len(wr) == 1 and wr[0][2] is not None and (wr[0][0], wr[0][1]) == (out.c0, out.C) and C % self.ve == 0
+                and not os.environ.get('SALT_NO_BNB_FUSE')):
+            # dL/d(out) has exactly one writer, a plain data-gradient launch: its epilogue also reduces this layer's BatchNorm-backward
+            # sums over its pixel tiles (salt_conv_args.bnb_*), and bn_bwd skips its own pass over da and y
+            s = wr[0][2]
+            nparts = lib.salt_conv_stats_parts(ctypes.byref(s))
+            if nparts < 1:
+                raise SaltError('conv plan failed: ' + lib.salt_last_error().decode())
+            self._n_bnb = getattr(self, '_n_bnb', 0) + 1
+            partials, ready = Scratch('bnb%d' % self._n_bnb, nparts * 2 * C * 4), 1
+            self.bwd.set_fields(s, bnb_y=y.view(), bnb_mean=w['mean'].data_ptr(), bnb_invstd=w['invstd'].data_ptr(), bnb_gamma=bn.weight.data_ptr(),
+                                bnb_beta=bn.bias.data_ptr(), bnb_partials=partials, bnb_relu=int(relu))
         # without a residual a = relu(y*scale + shift): the kernel recomputes the mask from y and never reads `a`
         self.bwd.add('bn_bwd', dtype=self.dt, da=out.gview(), a=out.view() if (relu and res is not None) else null_view(), y=y.view(), relu=int(relu),
                      mean=w['mean'].data_ptr(), invstd=w['invstd'].data_ptr(), gamma=bn.weight.data_ptr(), beta=bn.bias.data_ptr(),
-                     partials=Scratch('bn_bwd', nparts * 2 * C * 4), nparts=nparts, dgamma=gw, dbeta=gb, accumulate_param_grads=0,
-                     coef=coef.data_ptr(), dy=y.gview(), dres=dres, accumulate_dres=acc_res)
+                     partials=partials, nparts=nparts, dgamma=gw, dbeta=gb, accumulate_param_grads=0,
+                     coef=coef.data_ptr(), dy=y.gview(), dres=dres, accumulate_dres=acc_res, partials_ready=ready)
 
     # ------------------------------------------------------------------ dense convolution (+BN +ReLU +residual)
     def conv(self, x, conv, bn=None, relu=False, res=None, out=None, replicate=False, name=''):
@@ -516,7 +542,8 @@ class Graph:
         acc = x.grad_state()
         if stride == 1:
             td = [(-t[2], -t[3]) for t in taps]
-            self._conv_launch(self.bwd, dy.gview(), pk.data_ptr(), td, 1, 0, x.gview(), x.H, x.W, accumulate=acc, stream=self._bwd_pack_tag())
+            s = self._conv_launch(self.bwd, dy.gview(), pk.data_ptr(), td, 1, 0, x.gview(), x.H, x.W, accumulate=acc, stream=self._bwd_pack_tag())
+            x.buf.grad_writers[-1][2] = s          # a plain full-grid launch: can carry the BatchNorm-backward sums of x's producer
             return
         # stride 2: one launch per output parity phase (a transposed convolution)
         phases = []
