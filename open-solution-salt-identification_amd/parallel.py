@@ -12,7 +12,8 @@ step, and because gradients live in one flat buffer the all-reduce works on cont
     bucket's all-reduce is issued on a side stream, overlapping RCCL with the remaining backward kernels;
   * xGMI is a point-to-point mesh (7 links x ~153 GB/s per GPU): RCCL's direct reduce-scatter/all-gather
     uses all links at once when the payload is large, so buckets are few and big (default 32 MB) rather
-    than NCCL/NVSwitch-style 25 MB-by-habit; the 120.7 MB ResNet34 U-Net gradient is 4 collectives;
+    than NCCL/NVSwitch-style 25 MB-by-habit; the 120.7 MB ResNet34 U-Net gradient is 5 collectives, the last
+    of them (stem + first encoder stage, final only when backward ends and therefore not overlapped) <= 4 MB;
   * the 1/world average is folded into Adam's gradient scale (no extra pass).
 
 CPU (gloo) is supported for the bucket planner / reducer so the N>1 logic is testable without GPUs.
@@ -23,29 +24,33 @@ import torch
 import torch.distributed as dist
 
 DEFAULT_BUCKET_BYTES = 32 << 20
+DEFAULT_TAIL_BYTES = 4 << 20
 
 
-def plan_buckets(ready, total, bucket_bytes=DEFAULT_BUCKET_BYTES):
+def plan_buckets(ready, total, bucket_bytes=DEFAULT_BUCKET_BYTES, tail_bytes=DEFAULT_TAIL_BYTES):
     """ready: list of (offset, numel, ready_index) per parameter (offsets ascending in forward order; ready_index =
     backward-program position after which that gradient is final).  Returns buckets in issue order:
-    [(lo, hi, ready_index)] covering [0,total) with hi-lo*4 >= bucket_bytes except possibly the last."""
+    [(lo, hi, ready_index)] covering [0,total); every bucket but the remainder holds >= bucket_bytes.  The remainder (the first
+    layers of the encoder: their gradients are final only when backward ends, so their collective is the one left exposed)
+    is split once more so that the very last collective moves at most ``tail_bytes``."""
     items = sorted(ready, key=lambda r: r[0])
-    buckets = []
+    cuts = []                                    # lower bounds of the buckets, descending
     hi = total
-    cur_ready = 0
-    for off, n, ridx in reversed(items):
-        cur_ready = max(cur_ready, ridx)
+    for off, n, _ in reversed(items):
         if (hi - off) * 4 >= bucket_bytes:
-            buckets.append((off, hi, cur_ready))
+            cuts.append(off)
             hi = off
-            cur_ready = 0
     if hi > 0:
-        buckets.append((0, hi, max(cur_ready, max((r[2] for r in items), default=0))))
-    # ready indices must be non-decreasing in issue order
-    out, m = [], 0
-    for lo, h, r in buckets:
-        m = max(m, r)
-        out.append((lo, h, m))
+        if tail_bytes and hi * 4 > tail_bytes:
+            split = max((off for off, _, _ in items if 0 < off < hi and off * 4 <= tail_bytes), default=0)
+            if split > 0:
+                cuts.append(split)
+        cuts.append(0)
+    out, hi, m = [], total, 0
+    for lo in cuts:
+        m = max([m] + [r for off, _, r in items if lo <= off < hi])      # ready indices are non-decreasing in issue order
+        out.append((lo, hi, m))
+        hi = lo
     return out
 
 

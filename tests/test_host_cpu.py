@@ -97,6 +97,12 @@ def test_bucket_planner_covers_flat_buffer_in_reverse_order():
         assert lo == hi2 and r2 >= r                     # contiguous, issued in readiness order
     assert sum(hi - lo for lo, hi, _ in b) == off
     assert [shard_batch(10, r, 4) for r in range(4)] == [slice(0, 3), slice(3, 6), slice(6, 9), slice(9, 10)]
+    # the collective that is issued last (the first parameters: final only when backward ends) is kept small
+    t = plan_buckets(ready, off, bucket_bytes=32 << 20, tail_bytes=1 << 20)
+    assert t[-1][0] == 0 and t[-1][1] * 4 <= 1 << 20 and t[-1][1] > 0
+    assert sum(hi - lo for lo, hi, _ in t) == off and all(a[0] == b2[1] for a, b2 in zip(t, t[1:]))
+    assert all(r2 >= r for (_, _, r), (_, _, r2) in zip(t, t[1:]))
+    assert plan_buckets(ready, off, bucket_bytes=8 << 20, tail_bytes=0) == plan_buckets(ready, off, bucket_bytes=8 << 20, tail_bytes=1 << 40)
 
 
 _WORKER = r'''
