@@ -226,3 +226,62 @@ def test_first_layer_conv_vs_torch():
         off, n = eng.grad_range(conv.weight)
         assert_close(eng.grads[off:off + n].view(conv.weight.shape).cpu(), rc.weight.grad, 3e-3, 'conv_first wgrad')
         assert_close(bn.running_var.cpu(), rb.running_var, 1e-4, 'running_var')
+
+
+@pytest.mark.parametrize('case', [(2, 16, 20, 24, 24), (1, 64, 16, 16, 64), (3, 32, 8, 8, 40), (2, 24, 33, 19, 16)])
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('replicate', [True, False])
+def test_two_conv_bn_relu_layers_vs_torch(case, dtype, replicate):
+    """Two stacked 3x3 conv + BN + ReLU layers against torch CPU fp32: forward, data gradient, weight and BN gradients.
+    replicate: the reference's replicate top/right padding (architectures/base.py:21-27) - fold-mode data gradient and the
+    pipelined weight-gradient kernel's clamp loader on ragged tiles.  Zero padding: the second layer's data gradient is the only
+    writer of dL/d(first activation), so its epilogue must also produce the first layer's BatchNorm-backward sums
+    (salt_conv_args.bnb_*; checked on the emitted program)."""
+    from gpu_harness import BlockRun
+    from torch import nn
+    B, Cin, H, W, Cmid = case
+    Cout = Cmid + 8
+    c1, b1, c2, b2 = nn.Conv2d(Cin, Cmid, 3, 1, 0, bias=False), nn.BatchNorm2d(Cmid), nn.Conv2d(Cmid, Cout, 3, 1, 0, bias=False), nn.BatchNorm2d(Cout)
+    mod = nn.Sequential(c1, b1, c2, b2)
+    with torch.no_grad():
+        c1.weight.copy_(_rand(c1.weight.shape, 11, (2.0 / (Cin * 9)) ** 0.5)); c2.weight.copy_(_rand(c2.weight.shape, 12, (2.0 / (Cmid * 9)) ** 0.5))
+        for i, b in enumerate((b1, b2)):
+            b.weight.copy_(1 + 0.1 * _rand(b.weight.shape, 13 + i)); b.bias.copy_(0.1 * _rand(b.bias.shape, 15 + i))
+    x = _rand((B, Cin, H, W), 17)
+    if dtype == 'bf16':
+        x = x.bfloat16().float()
+    ref = nn.Sequential(nn.Conv2d(Cin, Cmid, 3, 1, 0, bias=False), nn.BatchNorm2d(Cmid), nn.Conv2d(Cmid, Cout, 3, 1, 0, bias=False), nn.BatchNorm2d(Cout))
+    ref.load_state_dict({k: v.clone() for k, v in mod.state_dict().items()})
+    if dtype == 'bf16':
+        with torch.no_grad():
+            ref[0].weight.copy_(ref[0].weight.bfloat16().float()); ref[2].weight.copy_(ref[2].weight.bfloat16().float())
+
+    if not replicate:
+        c1.padding = c2.padding = (1, 1)
+
+    def emit(g, a):
+        h = g.conv(a, c1, b1, relu=True, replicate=replicate)
+        return g.conv(h, c2, b2, relu=True, replicate=replicate)
+
+    mod.train()
+    run = BlockRun(mod, [x], emit, train=True, dtype=dtype)
+    y = run.forward()
+    xr = x.clone().requires_grad_(True)
+    pad = (lambda t: F.pad(t, (0, 2, 2, 0), mode='replicate')) if replicate else (lambda t: F.pad(t, (1, 1, 1, 1)))   # l, r, t, b
+    hr = F.relu(ref[1](ref[0](pad(xr))))
+    yr = F.relu(ref[3](ref[2](pad(hr))))
+    tol = TOL32 if dtype == 'f32' else TOLBF
+    assert_close(y, yr, tol * (1 if dtype == 'f32' else 2), 'y')
+    gy = _rand(tuple(yr.shape), 18)
+    yr.backward(gy)
+    gx, grads = run.backward(gy.to('cuda:0'))
+    ready = [int(st.partials_ready) for name, _, st in run.g.bwd.ops if name == 'bn_bwd']
+    fusable = (not replicate) and Cmid % (4 if dtype == 'f32' else 8) == 0
+    assert ready == [0, 1 if fusable else 0], ready                  # backward order: layer 2, then layer 1
+    pairs = [('dgrad', gx[0], xr.grad)] + [(k, grads[k], dict(ref.named_parameters())[k].grad) for k in grads]
+    for name, got, want in pairs:
+        if dtype == 'f32':
+            assert_close(got, want, tol * 4, name)
+        else:
+            l2 = float((got.double() - want.double()).norm() / want.double().norm())
+            assert l2 <= 2 * tol, '%s: rel-L2 %.3e' % (name, l2)
