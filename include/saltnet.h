@@ -99,11 +99,12 @@ typedef struct {
     int fold_right;
     /* BatchNorm-backward sums fused into a data-gradient launch (the launch that completes g = dL/da of a = relu?(bn(yc)), yc the
      * producer convolution's output): each workgroup also reduces, over its pixel tile and per channel, sum(g m) and
-     * sum(g m xhat) with m = [yc*scale + shift > 0] (or 1 without ReLU), xhat = (yc - mean) invstd, of the value it STORES, into
+     * sum(g m xhat) with m = [yc*scale + shift > 0] (or [a > 0] / 1, see bnb_a / bnb_relu), xhat = (yc - mean) invstd, of the value it STORES, into
      * bnb_partials[tile][2][Cout], tile < salt_conv_stats_parts(args).  salt_bn_bwd then runs with partials_ready = 1 and skips
      * its own reduction pass over g and yc.  bnb_partials == NULL: off.  Needs out_step 1 on the full grid, no strip, no stats,
      * 16-byte aligned views with Cout a multiple of 8 (bf16) / 4 (f32). */
     salt_view bnb_y;          /* yc, same shape as y */
+    salt_view bnb_a;          /* residual layers, a = relu(bn(yc) + res): the forward output the mask comes from (m = [a > 0]); p == NULL: mask from yc */
     const float* bnb_mean;
     const float* bnb_invstd;
     const float* bnb_gamma;

@@ -41,7 +41,7 @@ struct ConvKP {
     int m_tiles, n_tiles;
     int vt;                          // virtual taps of a 1x1 convolution: vt channel chunks staged per barrier round (1 = off)
     // BatchNorm-backward sums of the stored tile (saltnet.h, salt_conv_args.bnb_*); bnb_partials == nullptr: off
-    const void* bnb_y; int bnb_cs, bnb_relu;
+    const void* bnb_y; const void* bnb_a; int bnb_cs, bnb_acs, bnb_relu;
     const float* bnb_mean; const float* bnb_invstd; const float* bnb_gamma; const float* bnb_beta; float* bnb_partials;
 };
 
@@ -450,10 +450,20 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
                     float g[VE], yc[VE];
                     unpack16<T>(stored, g);
                     unpack16<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.bnb_y) + (((int64_t)b * p.OHf + oy) * p.OWf + ox) * p.bnb_cs + n), yc);
+                    if (p.bnb_a) {                                 // residual layer: the mask is the sign of the forward output
+                        float av[VE];
+                        unpack16<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.bnb_a) + (((int64_t)b * p.OHf + oy) * p.OWf + ox) * p.bnb_acs + n), av);
 #pragma unroll
-                    for (int e = 0; e < VE; ++e) {
-                        const float gg = (!p.bnb_relu || yc[e] * bsc[e] + bsh[e] > 0.f) ? g[e] : 0.f;
-                        b1[e] += gg; b2[e] += gg * (yc[e] - bmu[e]) * bis[e];
+                        for (int e = 0; e < VE; ++e) {
+                            const float gg = (!p.bnb_relu || av[e] > 0.f) ? g[e] : 0.f;
+                            b1[e] += gg; b2[e] += gg * (yc[e] - bmu[e]) * bis[e];
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < VE; ++e) {
+                            const float gg = (!p.bnb_relu || yc[e] * bsc[e] + bsh[e] > 0.f) ? g[e] : 0.f;
+                            b1[e] += gg; b2[e] += gg * (yc[e] - bmu[e]) * bis[e];
+                        }
                     }
                 }
             } else {
@@ -621,6 +631,7 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
     }
     pl->parts = tiles_b * k.tiles_y * k.tiles_x;
     k.bnb_partials = a->bnb_partials; k.bnb_y = a->bnb_y.p; k.bnb_cs = a->bnb_y.cs; k.bnb_relu = a->bnb_relu;
+    k.bnb_a = a->bnb_a.p; k.bnb_acs = a->bnb_a.cs;
     k.bnb_mean = a->bnb_mean; k.bnb_invstd = a->bnb_invstd; k.bnb_gamma = a->bnb_gamma; k.bnb_beta = a->bnb_beta;
     if (a->bnb_partials) {
         const int ve = a->dtype == SALT_F32 ? 4 : 8;
@@ -629,6 +640,9 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
         if (!view_ok(a->bnb_y) || a->bnb_y.B != a->y.B || a->bnb_y.H != a->y.H || a->bnb_y.W != a->y.W || a->bnb_y.C != a->y.C)
             SALT_FAIL(SALT_E_BADARG, "conv: bnb_y shape");
         if (!a->bnb_mean || !a->bnb_invstd || !a->bnb_gamma || !a->bnb_beta) SALT_FAIL(SALT_E_BADARG, "conv: bnb parameters missing");
+        if (a->bnb_a.p && (!view_ok(a->bnb_a) || a->bnb_a.B != a->y.B || a->bnb_a.H != a->y.H || a->bnb_a.W != a->y.W || a->bnb_a.C != a->y.C ||
+                           a->bnb_a.cs % ve || (reinterpret_cast<uintptr_t>(a->bnb_a.p) & 15)))
+            SALT_FAIL(SALT_E_BADARG, "conv: bnb_a shape / alignment");
         if (Cout % ve || a->y.cs % ve || a->bnb_y.cs % ve || ((reinterpret_cast<uintptr_t>(a->y.p) | reinterpret_cast<uintptr_t>(a->bnb_y.p)) & 15))
             SALT_FAIL(SALT_E_BADARG, "conv: BatchNorm-backward sums need 16-byte aligned whole channel pieces");
         const size_t red_bytes = (size_t)(256 / (BN / ve)) * BN * 2 * sizeof(float);

@@ -762,7 +762,7 @@ extern "C" int salt_bn_bwd(const salt_bn_bwd_args* a, void* stream) {
     int64_t per = 0;
     int nparts = bn_bwd_nparts(a, &per);
     if (a->partials_ready) {                                // the producer of da reduced already (salt_conv_args.bnb_*)
-        if (a->nparts < 1 || a->dres.p || (a->relu && a->a.p)) SALT_FAIL(SALT_E_BADARG, "bn_bwd: partials_ready needs nparts >= 1, no residual, mask from y");
+        if (a->nparts < 1) SALT_FAIL(SALT_E_BADARG, "bn_bwd: partials_ready needs nparts >= 1");
         nparts = a->nparts;
     } else if (a->nparts != nparts) SALT_FAIL(SALT_E_BADARG, "bn_bwd: nparts %d, expected %d", a->nparts, nparts);
     hipStream_t st = (hipStream_t)stream;

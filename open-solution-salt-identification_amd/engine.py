@@ -401,18 +401,20 @@ class Graph:
         assert acc_y == 0, 'conv output gradient has a single producer'
         partials, ready = Scratch('bn_bwd', nparts * 2 * C * 4), 0
         wr = out.buf.grad_writers
-        if (res is None and len(wr) == 1 and wr[0][2] is not None and (wr[0][0], wr[0][1]) == (out.c0, out.C) and C % self.ve == 0
-                and not os.environ.get('SALT_NO_BNB_FUSE')):
-            # dL/d(out) has exactly one writer, a plain data-gradient launch: its epilogue also reduces this layer's BatchNorm-backward
-            # sums over its pixel tiles (salt_conv_args.bnb_*), and bn_bwd skips its own pass over da and y
-            s = wr[0][2]
+        if (wr and wr[-1][2] is not None and all((w_[0], w_[1]) == (out.c0, out.C) for w_ in wr) and C % self.ve == 0
+                and (res is None or not os.environ.get('SALT_NO_BNB_RES')) and not os.environ.get('SALT_NO_BNB_FUSE')):
+            # the LAST writer of dL/d(out) is a plain data-gradient launch (it completes the gradient: earlier writers of the same
+            # slice were accumulated): its epilogue also reduces this layer's BatchNorm-backward sums over its pixel tiles
+            # (salt_conv_args.bnb_*), and bn_bwd skips its own pass over da and y.  With a residual the mask comes from `out`.
+            s = wr[-1][2]
             nparts = lib.salt_conv_stats_parts(ctypes.byref(s))
             if nparts < 1:
                 raise SaltError('conv plan failed: ' + lib.salt_last_error().decode())
             self._n_bnb = getattr(self, '_n_bnb', 0) + 1
             partials, ready = Scratch('bnb%d' % self._n_bnb, nparts * 2 * C * 4), 1
             self.bwd.set_fields(s, bnb_y=y.view(), bnb_mean=w['mean'].data_ptr(), bnb_invstd=w['invstd'].data_ptr(), bnb_gamma=bn.weight.data_ptr(),
-                                bnb_beta=bn.bias.data_ptr(), bnb_partials=partials, bnb_relu=int(relu))
+                                bnb_beta=bn.bias.data_ptr(), bnb_partials=partials, bnb_relu=int(relu),
+                                bnb_a=out.view() if (relu and res is not None) else null_view())
         # without a residual a = relu(y*scale + shift): the kernel recomputes the mask from y and never reads `a`
         self.bwd.add('bn_bwd', dtype=self.dt, da=out.gview(), a=out.view() if (relu and res is not None) else null_view(), y=y.view(), relu=int(relu),
                      mean=w['mean'].data_ptr(), invstd=w['invstd'].data_ptr(), gamma=bn.weight.data_ptr(), beta=bn.bias.data_ptr(),
