@@ -1231,6 +1231,198 @@ __global__ __launch_bounds__(256) void conv_wgrad_fast_kernel(WgradKP p) {
     }
 }
 
+// 8-wave variant of the ROW16 fast path: the same workgroup tile and LDS layout, but two waves per SIMD - waves 0-3 accumulate
+// taps 0-4, waves 4-7 taps 5-8 (80 / 64 accumulator registers per lane instead of 144) - so that one wave's VMEM / LDS issue
+// stalls (a global_load_dwordx4 costs ~115 cycles of issue time) overlap with the other wave's MFMAs.  Each half reads the pixel
+// runs of the two kernel rows its taps touch (8 LDS reads per k-step) and moves half of the tile pieces.
+template <bool PAD>
+__global__ __launch_bounds__(512) void conv_wgrad_fast8_kernel(WgradKP p) {
+    typedef bf16_t T;
+    constexpr int KS = 8, NTH = 512, PPR = 8, ROWB = 192, BMP = KS * 16, NTA = 5;
+    constexpr int MAXP = BMP * PPR / NTH, MAXQ = 5, NPIECE = MAXP + MAXQ;
+    constexpr int LSTEPS = KS / 2, LPS = (NPIECE + LSTEPS - 1) / LSTEPS;
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sP = smem;
+    unsigned char* sQ = smem + BMP * ROWB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = wave >> 2, wa = (wave >> 1) & 1, wb = wave & 1;
+    const int blk = blockIdx.x;
+    const int ab = blk % p.a_blocks;
+    const int bb = (blk / p.a_blocks) % p.b_blocks;
+    const int split = blk / (p.a_blocks * p.b_blocks);
+    const int a0 = ab * 64, c0 = bb * 64;
+    const int hhw = p.hh * p.hw, phalo = p.nb * hhw;
+    const T* Pg = reinterpret_cast<const T*>(p.P);
+    const T* Qg = reinterpret_cast<const T*>(p.Q);
+    const T* zp = reinterpret_cast<const T*>(g_zero_piece);
+
+    f32x16 acc[NTA];
+#pragma unroll
+    for (int t = 0; t < NTA; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    struct TileC { int tbi, tyi, txi; };
+    auto decode = [&](int tile) { TileC c; c.txi = tile % p.tiles_x; const int tt = tile / p.tiles_x; c.tyi = tt % p.tiles_y; c.tbi = tt / p.tiles_y; return c; };
+    const TileC tstep = decode(p.nsplit);
+    auto advance = [&](TileC& c) {
+        c.txi += tstep.txi; if (c.txi >= p.tiles_x) { c.txi -= p.tiles_x; ++c.tyi; }
+        c.tyi += tstep.tyi; if (c.tyi >= p.tiles_y) { c.tyi -= p.tiles_y; ++c.tbi; }
+        c.tbi += tstep.tbi;
+    };
+
+    // ---- tile-invariant piece constants.  Piece q = tid + 512 k is 16 bytes (8 channels) of pixel row q / 8.
+    const int pcx = tid % PPR;
+    const int chP = a0 + pcx * 8, chQ = c0 + pcx * 8;
+    const int np = BMP * PPR, nq = phalo * PPR;
+    const int rowP = p.PW * p.p_cs, rowQ = p.QW * p.q_cs;
+    int offP[MAXP], pby[MAXP], pxx[MAXP];
+    int offQ[MAXQ], hyq[MAXQ], hxq[MAXQ], blq[MAXQ];
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+        const int q = tid + k * NTH, m = q / PPR;
+        const int tx = m & ((1 << p.tw_log2) - 1), ty = (m >> p.tw_log2) & ((1 << p.th_log2) - 1), bl = m >> (p.tw_log2 + p.th_log2);
+        const bool ok = q < np && chP < p.Ca;
+        offP[k] = (bl * p.PH + ty) * rowP + tx * p.p_cs + chP;
+        pby[k] = ok ? bl : (1 << 20); pxx[k] = tx | (ty << 16);
+    }
+#pragma unroll
+    for (int k = 0; k < MAXQ; ++k) {
+        const int q = tid + k * NTH, pix = q / PPR;
+        const int bl = pix / hhw, r = pix - bl * hhw, hy = r / p.hw, hx = r - hy * p.hw;
+        const bool ok = q < nq && chQ < p.Cb;
+        blq[k] = ok ? bl : (1 << 20);
+        hyq[k] = hy; hxq[k] = hx;
+        offQ[k] = bl * p.QH * rowQ + chQ + (PAD ? 0 : hy * rowQ + hx * p.q_cs);
+    }
+    u32x4 rp[MAXP], rq[MAXQ];
+    struct TileCtx { const T* baseP; const T* baseQ; int iy0, ix0, limB, limY, limX; };
+    auto make_ctx = [&](const TileC& c, bool live) {
+        TileCtx x;
+        x.limB = live ? p.B - c.tbi * p.nb : 0;
+        x.limY = p.PH - (c.tyi << p.th_log2); x.limX = p.PW - (c.txi << p.tw_log2);
+        x.baseP = Pg + (((int64_t)c.tbi * p.nb * p.PH + (c.tyi << p.th_log2)) * p.PW + (c.txi << p.tw_log2)) * p.p_cs;
+        x.iy0 = (c.tyi << p.th_log2) * p.q_step + p.min_dy; x.ix0 = (c.txi << p.tw_log2) * p.q_step + p.min_dx;
+        x.baseQ = Qg + (int64_t)c.tbi * p.nb * p.QH * rowQ;
+        if (!PAD) x.baseQ += (int64_t)x.iy0 * rowQ + (int64_t)x.ix0 * p.q_cs;
+        return x;
+    };
+    auto issue_piece = [&](int K, const TileCtx& x) {
+        if (K < MAXP) {
+            const int k = K;
+            const bool ok = pby[k] < x.limB && (pxx[k] >> 16) < x.limY && (pxx[k] & 0xffff) < x.limX;
+            rp[k] = *reinterpret_cast<const u32x4*>(ok ? x.baseP + offP[k] : zp);
+        } else {
+            const int k = K - MAXP;
+            if (!PAD) {
+                const bool ok = (unsigned)(x.iy0 + hyq[k]) < (unsigned)p.QH && (unsigned)(x.ix0 + hxq[k]) < (unsigned)p.QW && blq[k] < x.limB;
+                rq[k] = *reinterpret_cast<const u32x4*>(ok ? x.baseQ + offQ[k] : zp);
+            } else {
+                const int iy = min(max(x.iy0 + hyq[k], 0), p.QH - 1), ix = min(max(x.ix0 + hxq[k], 0), p.QW - 1);
+                rq[k] = *reinterpret_cast<const u32x4*>(blq[k] < x.limB ? x.baseQ + (offQ[k] + iy * rowQ + ix * p.q_cs) : zp);
+            }
+        }
+    };
+
+    // ---- fragment addressing (conv_wgrad_fast_kernel, ROW16): this wave half reads kernel rows grp and grp + 1
+    const int khalf = lane >> 5, g16 = (lane >> 4) & 1, i16 = lane & 15, prow = i16 >> 2, pcol = (i16 & 3) * 4;
+    const int pa_base = (khalf * 8 + prow) * ROWB + (wa * 32 + g16 * 16 + pcol) * 2;
+    int tq[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) tq[i] = (khalf * 8 + prow) * ROWB + (wb * 32 + g16 * 16 + pcol) * 2 + (grp + i) * (18 * ROWB);
+    struct Frag { s16x4 alo, ahi; u32x2 q[2][3]; };
+    auto read_frags = [&](int j, Frag& fr) {
+        fr.alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sP + pa_base + (j * 16) * ROWB));
+        fr.ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sP + pa_base + (j * 16 + 4) * ROWB));
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+                fr.q[i][u] = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(sQ + tq[i] + (j * 18 + u * 4) * ROWB)));
+    };
+    auto b_operand = [&](const Frag& fr, int row, int dx) -> bf16x8 {       // row, dx constants after unrolling
+        const unsigned w0 = fr.q[row][0].x, w1 = fr.q[row][0].y, w2 = fr.q[row][1].x, w3 = fr.q[row][1].y, w4 = fr.q[row][2].x;
+        u32x4 v;
+        if (dx == 0) v = u32x4{w0, w1, w2, w3};
+        else if (dx == 1) v = u32x4{__builtin_amdgcn_alignbit(w1, w0, 16), __builtin_amdgcn_alignbit(w2, w1, 16),
+                                    __builtin_amdgcn_alignbit(w3, w2, 16), __builtin_amdgcn_alignbit(w4, w3, 16)};
+        else v = u32x4{w1, w2, w3, w4};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    Frag f0, f1;
+    // the k-steps of one tile for wave half G (taps 5 G ... 5 G + CNT - 1): static register indices need G at compile time
+    auto ksteps = [&](auto gc, const TileCtx& x) {
+        constexpr int G = decltype(gc)::value, CNT = G ? 4 : 5;
+        read_frags(0, f0);
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            Frag& fc = (j & 1) ? f1 : f0;
+            Frag& fn = (j & 1) ? f0 : f1;
+            if (j + 1 < KS) read_frags(j + 1, fn);
+            int nld = 0;
+            if (j < LSTEPS) {
+#pragma unroll
+                for (int u = 0; u < LPS; ++u)
+                    if (j * LPS + u < NPIECE) { issue_piece(j * LPS + u, x); ++nld; }
+            }
+            const s16x8 av = {fc.alo[0], fc.alo[1], fc.alo[2], fc.alo[3], fc.ahi[0], fc.ahi[1], fc.ahi[2], fc.ahi[3]};
+#pragma unroll
+            for (int tl = 0; tl < CNT; ++tl) {
+                const int t = G * 5 + tl;
+                acc[tl] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_operand(fc, t / 3 - G, t % 3), __builtin_bit_cast(bf16x8, av), acc[tl], 0, 0, 0);
+            }
+            if (j + 1 < KS) {                                        // pin: the 8 LDS reads (+ the global loads) between the MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+                for (int tl = 0; tl < CNT; ++tl) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (tl < 6 - CNT) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    else __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (tl < nld) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+            }
+        }
+    };
+
+    TileC cur = decode(split);
+    {
+        const TileCtx x = make_ctx(cur, split < p.ntiles);
+#pragma unroll
+        for (int K = 0; K < NPIECE; ++K) issue_piece(K, x);
+    }
+    for (int tile = split; tile < p.ntiles; tile += p.nsplit) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) { const int q = tid + k * NTH; if (q < np) *reinterpret_cast<u32x4*>(sP + (q / PPR) * ROWB + pcx * 16) = rp[k]; }
+#pragma unroll
+        for (int k = 0; k < MAXQ; ++k) { const int q = tid + k * NTH; if (q < nq) *reinterpret_cast<u32x4*>(sQ + (q / PPR) * ROWB + pcx * 16) = rq[k]; }
+        __syncthreads();
+        advance(cur);
+        const TileCtx x = make_ctx(cur, tile + p.nsplit < p.ntiles);
+        if (grp == 0) ksteps(std::integral_constant<int, 0>{}, x);     // wave-uniform: no barrier inside
+        else ksteps(std::integral_constant<int, 1>{}, x);
+    }
+    // ---- partial slab partials[split][t][a][b]: lane = a-row, 4 consecutive registers = 4 consecutive b
+    const int l31 = lane & 31;
+    const int a = a0 + wa * 32 + l31;
+    const int cnt = grp ? 4 : 5;
+#pragma unroll
+    for (int tl = 0; tl < NTA; ++tl) {
+        if (tl < cnt && a < p.Ca) {
+            float* row = p.partials + (((int64_t)split * p.ntaps + grp * 5 + tl) * p.Ca + a) * p.Cb;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int b = c0 + wb * 32 + 8 * g + 4 * khalf;
+                if (b < p.Cb) *reinterpret_cast<f32x4*>(row + b) = f32x4{acc[tl][4 * g], acc[tl][4 * g + 1], acc[tl][4 * g + 2], acc[tl][4 * g + 3]};
+            }
+        }
+    }
+}
+
 int wgrad_plan(const salt_conv_wgrad_args* a, WgradKP* k, int* nsplit_out) {
     if (!a || !view_ok(a->p) || !view_ok(a->q)) SALT_FAIL(SALT_E_BADARG, "wgrad: bad view");
     if (a->ntaps < 1 || a->ntaps > 9) SALT_FAIL(SALT_E_BADARG, "wgrad: ntaps %d (max 9 per launch)", a->ntaps);
@@ -1393,6 +1585,15 @@ static int launch_wgrad(const WgradKP& k, hipStream_t st) {
         if (fast) {
             bool row16 = k.tw_log2 == 4 && k.th_log2 == 3 && k.nb == 1 && k.q_step == 1 && k.hw == 18;
             for (int t = 0; t < 9; ++t) row16 = row16 && k.tap_off[t] == (t / 3) * 18 + t % 3;       // raster tap order
+            static const bool four_waves = getenv("SALT_WGRAD_W4") != nullptr;
+            if (row16 && !four_waves) {
+                auto kern8 = k.pad_mode ? conv_wgrad_fast8_kernel<true> : conv_wgrad_fast8_kernel<false>;
+                if (lds > 64 * 1024) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern8), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    if (e != hipSuccess) SALT_FAIL((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e)); }
+                hipLaunchKernelGGL(kern8, grid, dim3(512), lds, st, k);
+                SALT_CHECK_LAUNCH();
+                return SALT_OK;
+            }
             auto kern = k.pad_mode ? (row16 ? conv_wgrad_fast_kernel<9, 8, true, true> : conv_wgrad_fast_kernel<9, 8, true, false>)
                                    : (row16 ? conv_wgrad_fast_kernel<9, 8, false, true> : conv_wgrad_fast_kernel<9, 8, false, false>);
             if (lds > 64 * 1024) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
