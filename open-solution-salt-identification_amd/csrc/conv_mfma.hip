@@ -77,13 +77,21 @@ __device__ __forceinline__ int swz_addr(int row, int slot) {        // 64-byte r
     return row * 64 + (((slot ^ (row >> 2)) & 3) << 4);
 }
 
+// 16 zero bytes in device memory: a masked-out piece of a branch-free loader reads them instead of zero-initialising its
+// destination registers under a branch (see conv_wgrad_fast_kernel)
+__device__ __attribute__((aligned(16))) unsigned int g_zero_piece[4] = {0u, 0u, 0u, 0u};
+
 constexpr int MAXA = 9;     // halo pieces per thread: P_halo*4 <= 9*256 (6*256 for the 256-pixel tile: keeps its prefetch registers in budget)
 constexpr int maxa_for(int bm) { return bm >= 256 ? 6 : MAXA; }
 
 // NT > 0: tap count known at compile time (9 for every 3x3): the tap loop is fully unrolled so the compiler keeps the tap
 // offsets in SGPRs, folds the weight-row offsets into ds_read immediates and hoists the next taps' fragment reads above the
 // current MFMAs (the runtime-loop form serialised s_load -> address VALU -> ds_read -> MFMA per tap).
-template <typename T, int MI, int NI, int WM, int WN, int NT>
+// MAXA_T > 0 selects the INTERLEAVED loader (host: aligned input view, Cin a multiple of the 16-byte piece, halo <= MAXA_T pieces
+// per thread): the global loads of chunk c+1 are not issued in one burst after the barrier - where the 8-12 waves of a CU queue up
+// behind its 64 B/clk address path and nobody feeds the matrix cores (in-kernel clocks on 256->256 @32x32: 0.98 us of load issue
+// per 0.94 us of MFMAs) - but one piece per (tap, k-step) stage between the MFMAs, branch-free (masked pieces read g_zero_piece).
+template <typename T, int MI, int NI, int WM, int WN, int NT, int MAXA_T = 0>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
     constexpr int BN = 32 * NI * WN;
     constexpr int KCE = 64 / (int)sizeof(T);
@@ -115,7 +123,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
     const bool x_vec = ((p.x_cs % VE) == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
 
     // ---- per-thread halo staging pieces (fixed for the whole chunk loop); offsets are relative to image b0 (fit 32 bits)
-    constexpr int MAXA = maxa_for(32 * MI * WM);
+    constexpr bool ILV = MAXA_T > 0;
+    static_assert(!ILV || NT > 0, "the interleaved loader rides on the unrolled tap pipeline");
+    constexpr int MAXA = ILV ? MAXA_T : maxa_for(32 * MI * WM);
     const T* xg0 = xg + (int64_t)b0 * p.H * p.W * p.x_cs;
     int a_goff[MAXA];
     // A 1x1 convolution stages vt consecutive channel chunks per round as "virtual taps": LDS row = vtap * phalo + pixel, the packed
@@ -224,7 +234,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
 #pragma unroll
             for (int j = 0; j < NI; ++j) Mma<T>::step(f.a[i], f.b[j], acc[i][j]);
     };
-    auto compute_chunk = [&]() {
+    // hook(s): extra work of stage s (the interleaved loader's global loads), nvm = how many VMEM instructions that is
+    auto compute_chunk = [&](auto&& hook, auto nvm_c) {
+        constexpr int NVM = decltype(nvm_c)::value;
         if constexpr (NT > 0) {
             Frag f0, f1;
             load_frag(0, f0);
@@ -232,18 +244,24 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
 #pragma unroll
             for (int s = 0; s < 2 * NT; s += 2) {
                 load_frag(s + 1, f1);
+                hook(s);
                 mma_frag(f0);
                 __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);     // DS reads of stage s+1 ...
+                if (NVM > 0) __builtin_amdgcn_sched_group_barrier(0x020, NVM, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, MI * NI, 0);     // ... then the MFMAs of stage s
                 if (s + 2 < 2 * NT) load_frag(s + 2, f0);
+                hook(s + 1);
                 mma_frag(f1);
                 if (s + 2 < 2 * NT) __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
+                if (NVM > 0) __builtin_amdgcn_sched_group_barrier(0x020, NVM, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, MI * NI, 0);
             }
         } else {
             for (int t = 0; t < p.ntaps; ++t) tap_mma(t, p.tap_off[t]);
         }
     };
+    auto no_hook = [](int) {};
+    const std::integral_constant<int, 0> no_vm{};
 
     if (NT > 0 || p.ntaps <= 9) {
         // Software pipeline: the global loads of chunk c+1 are issued right after the barrier that releases the MFMA
@@ -285,7 +303,28 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
                 if (tid + (k << 8) < nbp && b_ok(k)) rb[k] = *reinterpret_cast<const u32x4*>(wc + b_uniform(k) + b_lane_off);
             }
         };
-        load_chunk(0);
+        // interleaved loader: piece i < MAXA is halo piece i, the rest are weight pieces; branch-free (masked: the zero piece)
+        constexpr int NPC = MAXA + MAXBP, PPS = NT > 0 ? (NPC + 2 * NT - 1) / (2 * NT) : 1;
+        const T* zp = reinterpret_cast<const T*>(g_zero_piece);
+        auto issue_piece = [&](int i, int c, bool live) {          // i is a constant after unrolling
+            if (i < MAXA) {
+                const int k = i;
+                const int ch_base = c * KCE * p.vt;
+                const bool ok = live && k < npa && a_goff[k] >= 0 && ch_base + (tid & 3) * VE < p.Cin;
+                ra[k] = *reinterpret_cast<const u32x4*>(ok ? xg0 + (a_goff[k] + ch_base) : zp);
+            } else {
+                const int k = i - MAXA;
+                const T* wc = wg + (int64_t)c * p.ntaps * p.Cout * KCE;
+                const bool ok = live && tid + (k << 8) < nbp && b_ok(k);
+                rb[k] = *reinterpret_cast<const u32x4*>(ok ? wc + b_uniform(k) + b_lane_off : zp);
+            }
+        };
+        if constexpr (ILV) {
+#pragma unroll
+            for (int i = 0; i < NPC; ++i) issue_piece(i, 0, true);
+        } else {
+            load_chunk(0);
+        }
         for (int c = 0; c < p.nchunk; ++c) {
             __syncthreads();                    // fragment reads of chunk c-1 are done
 #pragma unroll
@@ -295,8 +334,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
             for (int k = 0; k < MAXBP; ++k)
                 if (tid + (k << 8) < nbp) *reinterpret_cast<u32x4*>(sB + lds_lane + k * (RPP * 64)) = rb[k];
             __syncthreads();
-            if (c + 1 < p.nchunk) load_chunk(c + 1);
-            compute_chunk();
+            if constexpr (ILV) {
+                const bool live = c + 1 < p.nchunk;
+                compute_chunk([&](int st) {
+#pragma unroll
+                    for (int u = 0; u < PPS; ++u)
+                        if (st * PPS + u < NPC) issue_piece(st * PPS + u, c + 1, live);
+                }, std::integral_constant<int, PPS>{});
+            } else {
+                if (c + 1 < p.nchunk) load_chunk(c + 1);
+                compute_chunk(no_hook, no_vm);
+            }
         }
     } else {
         for (int c = 0; c < p.nchunk; ++c) {
@@ -321,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
                 *reinterpret_cast<u32x4*>(sB + swz_addr(row, q & 3)) = v;
             }
             __syncthreads();
-            compute_chunk();
+            compute_chunk(no_hook, no_vm);
         }
     }
 
@@ -652,9 +700,9 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
     return SALT_OK;
 }
 
-template <typename T, int MI, int NI, int WM, int WN, int NT>
+template <typename T, int MI, int NI, int WM, int WN, int NT, int MAXA_T = 0>
 int launch_cfg_nt(const Plan& pl, hipStream_t st) {
-    auto kern = conv_mfma_kernel<T, MI, NI, WM, WN, NT>;
+    auto kern = conv_mfma_kernel<T, MI, NI, WM, WN, NT, MAXA_T>;
     static bool attr_set = false;
     if (pl.lds > 64 * 1024 && !attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -668,6 +716,20 @@ int launch_cfg_nt(const Plan& pl, hipStream_t st) {
 
 template <typename T, int MI, int NI, int WM, int WN>
 int launch_cfg(const Plan& pl, hipStream_t st) {
+    if constexpr (sizeof(T) == 2 && MI * WM != 2) {                       // bf16, 128- and 256-pixel tiles: interleaved loader
+        static const bool ilv_off = getenv("SALT_CONV_NO_ILV") != nullptr;
+        const ConvKP& k = pl.kp;
+        const int npa = (k.nb * k.hh * k.hw * k.vt * 4 + 255) >> 8;
+        const bool ok = !ilv_off && k.x_cs % 8 == 0 && k.Cin % 8 == 0 && (reinterpret_cast<uintptr_t>(k.x) & 15) == 0;
+        if (ok && k.ntaps == 9) {
+            if constexpr (MI * WM == 8) { if (npa <= 6) return launch_cfg_nt<T, MI, NI, WM, WN, 9, 6>(pl, st); }
+            else {
+                if (npa <= 3) return launch_cfg_nt<T, MI, NI, WM, WN, 9, 3>(pl, st);
+                return launch_cfg_nt<T, MI, NI, WM, WN, 9, 9>(pl, st);
+            }
+        }
+        if constexpr (MI * WM != 8) { if (ok && k.ntaps == 4) return launch_cfg_nt<T, MI, NI, WM, WN, 4, 9>(pl, st); }
+    }
     if (pl.kp.ntaps == 9) return launch_cfg_nt<T, MI, NI, WM, WN, 9>(pl, st);
     if (pl.kp.ntaps == 4) return launch_cfg_nt<T, MI, NI, WM, WN, 4>(pl, st);      // 1x1 with 4 virtual taps, ConvT k4 output phases
     return launch_cfg_nt<T, MI, NI, WM, WN, 0>(pl, st);
@@ -1015,7 +1077,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradKP p) {
 //     destination registers (which made the compiler wait for the loads already in flight) - per piece a few VALU instructions;
 //   * the MFMA operands are swapped (D^T): a lane then owns 4 consecutive b-channels of one a-row, the slab is written with
 //     16-byte stores instead of 4-byte ones.
-__device__ __attribute__((aligned(16))) unsigned int g_zero_piece[4] = {0u, 0u, 0u, 0u};
 
 // ROW16: every k-step is one 16-pixel tile row (tw = 16, th = KS, one image per tile, 18-pixel halo rows, unit step): the halo
 // address of a fragment read is a per-tap lane constant plus a compile-time multiple of the halo row - no address arithmetic.
