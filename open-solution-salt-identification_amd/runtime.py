@@ -232,14 +232,17 @@ class Engine:
         self._pack_batched, self._pack_batched_bwd = fwd, bwd
         self._pack_batched_n = len(self._pack_ops)
 
-    def refresh(self, train):
+    def refresh(self, train, defer_bwd=False):
+        """Bring the packed weight copies (and, in eval mode, the folded BN constants) up to date.  ``defer_bwd``: leave the
+        data-gradient packs to a later ``refresh(True)`` (Engine.forward issues them after the forward program, so that they run under
+        the loss kernel - 32 workgroups on an otherwise idle GPU - instead of competing with the first forward layers)."""
         if getattr(self, '_pack_batched_n', -1) != len(self._pack_ops):
             self._build_pack_batch()
             self._packed_version = self._packed_bwd_version = -1
         if self._packed_version != self.wver:
             self._pack_batched.run()
             self._packed_version = self.wver
-        if train and self._packed_bwd_version != self.wver and len(self._pack_batched_bwd):
+        if train and not defer_bwd and self._packed_bwd_version != self.wver and len(self._pack_batched_bwd):
             # ordered after the optimizer step on the main stream; the backward program's first data-gradient joins (engine.py)
             if os.environ.get('SALT_PACK_BWD_MAIN'):                 # A/B: everything on the main stream
                 self._pack_batched_bwd.run()
@@ -262,8 +265,11 @@ class Engine:
         _require_gpu(x.device)
         net = self.net(x.shape, train)
         net.x.copy_(x)
-        self.refresh(train)
+        late = train and not os.environ.get('SALT_PACK_BWD_EARLY')
+        self.refresh(train, defer_bwd=late)
         net.fwd.run(side=None if os.environ.get('SALT_NO_FWD_SIDE') else self.side_stream)
+        if late:
+            self.refresh(True)                               # data-gradient packs: behind the forward pass, under the loss
         if train:
             self.touch(weights=False, stats=True)            # BN running statistics moved
         return net
