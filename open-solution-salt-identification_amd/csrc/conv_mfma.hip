@@ -1557,6 +1557,24 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(ReduceKP p) {
     *dst = p.accumulate ? (*dst + s) : s;
 }
 
+// nsplit <= 8 (every 3x3 layer of the networks here): one thread per element with all split loads in flight, no LDS round trip;
+// same summation order as wgrad_reduce_kernel for nsplit <= 8: (((v0 + v4) + (v1 + v5)) + (v2 + v6)) + (v3 + v7)
+__global__ __launch_bounds__(256) void wgrad_reduce8_kernel(ReduceKP p) {
+    const int64_t slab = (int64_t)p.ntaps * p.Ca * p.Cb;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= slab) return;
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = k < p.nsplit ? p.partials[k * slab + i] : 0.f;
+    const float s = (((v[0] + v[4]) + (v[1] + v[5])) + (v[2] + v[6])) + (v[3] + v[7]);
+    const int b = (int)(i % p.Cb);
+    int64_t r = i / p.Cb;
+    const int a = (int)(r % p.Ca);
+    const int t = (int)(r / p.Ca);
+    float* dst = p.grad + (((int64_t)a * p.Cb + b) * p.KH + p.tap_kh[t]) * p.KW + p.tap_kw[t];
+    *dst = p.accumulate ? (*dst + s) : s;
+}
+
 }  // namespace
 
 extern "C" int salt_conv(const salt_conv_args* a, void* stream) {
@@ -1695,7 +1713,9 @@ extern "C" int salt_wgrad_reduce(const salt_wgrad_reduce_args* a, void* stream) 
     p.KH = a->KH; p.KW = a->KW; p.accumulate = a->accumulate;
     for (int t = 0; t < a->ntaps; ++t) { p.tap_kh[t] = a->tap_kh[t]; p.tap_kw[t] = a->tap_kw[t]; }
     const int64_t slab = (int64_t)a->ntaps * a->Ca * a->Cb;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((slab + 63) / 64)), dim3(256), 0, (hipStream_t)stream, p);
+    static const bool rows_reduce = getenv("SALT_WGRAD_REDUCE_ROWS") != nullptr;
+    if (!rows_reduce && a->nsplit <= 8) hipLaunchKernelGGL(wgrad_reduce8_kernel, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((slab + 63) / 64)), dim3(256), 0, (hipStream_t)stream, p);
     SALT_CHECK_LAUNCH();
     return SALT_OK;
 }
