@@ -1484,6 +1484,166 @@ __global__ __launch_bounds__(512) void conv_wgrad_fast8_kernel(WgradKP p) {
     }
 }
 
+// fp32 version of the ROW16 fast path (exact fp32: v_mfma_f32_32x32x2_f32, two pixels per k-step, 64 k-steps per 128-pixel tile).
+// LDS rows are 64 channels x 4 B; a fragment read is one dword per lane (lanes = consecutive channels: conflict free) at a per-tap
+// lane constant plus a compile-time offset of the k-step, so the unrolled loop has no address arithmetic; the branch-free loader and
+// the 16-byte slab stores are those of conv_wgrad_fast_kernel.  The generic kernel spent ~34 us per tile here, most of it on one
+// global load in flight at a time.
+template <bool PAD>
+__global__ __launch_bounds__(256) void conv_wgrad_fast32_kernel(WgradKP p) {
+    typedef float T;
+    constexpr int NT = 9, KS = 64, PPR = 16, ROWB = 256, BMP = 128;
+    constexpr int MAXP = BMP * PPR / 256, MAXQ = 12, NPIECE = MAXP + MAXQ;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sP = smem;
+    unsigned char* sQ = smem + BMP * ROWB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wa = wave >> 1, wb = wave & 1;
+    const int blk = blockIdx.x;
+    const int ab = blk % p.a_blocks;
+    const int bb = (blk / p.a_blocks) % p.b_blocks;
+    const int split = blk / (p.a_blocks * p.b_blocks);
+    const int a0 = ab * 64, c0 = bb * 64;
+    const int hhw = p.hh * p.hw, phalo = p.nb * hhw;
+    const T* Pg = reinterpret_cast<const T*>(p.P);
+    const T* Qg = reinterpret_cast<const T*>(p.Q);
+    const T* zp = reinterpret_cast<const T*>(g_zero_piece);
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    struct TileC { int tbi, tyi, txi; };
+    auto decode = [&](int tile) { TileC c; c.txi = tile % p.tiles_x; const int tt = tile / p.tiles_x; c.tyi = tt % p.tiles_y; c.tbi = tt / p.tiles_y; return c; };
+    const TileC tstep = decode(p.nsplit);
+    auto advance = [&](TileC& c) {
+        c.txi += tstep.txi; if (c.txi >= p.tiles_x) { c.txi -= p.tiles_x; ++c.tyi; }
+        c.tyi += tstep.tyi; if (c.tyi >= p.tiles_y) { c.tyi -= p.tiles_y; ++c.tbi; }
+        c.tbi += tstep.tbi;
+    };
+
+    // ---- tile-invariant piece constants.  Piece q = tid + 256 k is 16 bytes (4 channels) of pixel row q / 16.
+    const int pcx = tid % PPR;
+    const int chP = a0 + pcx * 4, chQ = c0 + pcx * 4;
+    const int np = BMP * PPR, nq = phalo * PPR;
+    const int rowP = p.PW * p.p_cs, rowQ = p.QW * p.q_cs;
+    int offP[MAXP], offQ[MAXQ];
+    unsigned dp[MAXP], dq[MAXQ];                                      // packed (image << 16 | row << 8 | column); 0xffffffff: no piece
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+        const int q = tid + (k << 8), m = q / PPR;
+        const int tx = m & 15, ty = (m >> 4) & 7, bl = m >> 7;
+        const bool ok = q < np && chP < p.Ca;
+        offP[k] = (bl * p.PH + ty) * rowP + tx * p.p_cs + chP;
+        dp[k] = ok ? (unsigned)((bl << 16) | (ty << 8) | tx) : 0xffffffffu;
+    }
+#pragma unroll
+    for (int k = 0; k < MAXQ; ++k) {
+        const int q = tid + (k << 8), pix = q / PPR;
+        const int bl = pix / hhw, r = pix - bl * hhw, hy = r / p.hw, hx = r - hy * p.hw;
+        const bool ok = q < nq && chQ < p.Cb;
+        dq[k] = ok ? (unsigned)((bl << 16) | (hy << 8) | hx) : 0xffffffffu;
+        offQ[k] = bl * p.QH * rowQ + chQ + (PAD ? 0 : hy * rowQ + hx * p.q_cs);
+    }
+    u32x4 rp[MAXP], rq[MAXQ];
+    struct TileCtx { const T* baseP; const T* baseQ; int iy0, ix0, limB, limY, limX; };
+    auto make_ctx = [&](const TileC& c, bool live) {
+        TileCtx x;
+        x.limB = live ? p.B - c.tbi * p.nb : 0;
+        x.limY = p.PH - (c.tyi << p.th_log2); x.limX = p.PW - (c.txi << p.tw_log2);
+        x.baseP = Pg + (((int64_t)c.tbi * p.nb * p.PH + (c.tyi << p.th_log2)) * p.PW + (c.txi << p.tw_log2)) * p.p_cs;
+        x.iy0 = (c.tyi << p.th_log2) * p.q_step + p.min_dy; x.ix0 = (c.txi << p.tw_log2) * p.q_step + p.min_dx;
+        x.baseQ = Qg + (int64_t)c.tbi * p.nb * p.QH * rowQ;
+        if (!PAD) x.baseQ += (int64_t)x.iy0 * rowQ + (int64_t)x.ix0 * p.q_cs;
+        return x;
+    };
+    auto issue_piece = [&](int K, const TileCtx& x) {
+        if (K < MAXP) {
+            const int k = K;
+            const unsigned d = dp[k];
+            const bool ok = (int)(d >> 16) < x.limB && (int)((d >> 8) & 255u) < x.limY && (int)(d & 255u) < x.limX;    // no piece: image 65535
+            rp[k] = *reinterpret_cast<const u32x4*>(ok ? x.baseP + offP[k] : zp);
+        } else {
+            const int k = K - MAXP;
+            const unsigned d = dq[k];
+            const int bl = (int)(d >> 16), hy = (int)((d >> 8) & 255u), hx = (int)(d & 255u);
+            if (!PAD) {
+                const bool ok = (unsigned)(x.iy0 + hy) < (unsigned)p.QH && (unsigned)(x.ix0 + hx) < (unsigned)p.QW && bl < x.limB;
+                rq[k] = *reinterpret_cast<const u32x4*>(ok ? x.baseQ + offQ[k] : zp);
+            } else {
+                const int iy = min(max(x.iy0 + hy, 0), p.QH - 1), ix = min(max(x.ix0 + hx, 0), p.QW - 1);
+                rq[k] = *reinterpret_cast<const u32x4*>(bl < x.limB ? x.baseQ + (offQ[k] + iy * rowQ + ix * p.q_cs) : zp);
+            }
+        }
+    };
+
+    // ---- fragment addressing: k-step j covers pixels 2 j + khalf = (row j >> 3, column (2 j & 15) + khalf) of the 8 x 16 tile
+    const int khalf = lane >> 5, l31 = lane & 31;
+    const int pa_lane = khalf * ROWB + (wa * 32 + l31) * 4;            // + 2 j rows: an immediate
+    int qt[NT];                                                        // per-tap lane constant; + ((j >> 3) * 18 + (2 j & 15)) rows: an immediate
+#pragma unroll
+    for (int t = 0; t < NT; ++t) qt[t] = (khalf + p.tap_off[t]) * ROWB + (wb * 32 + l31) * 4;
+    struct Frag { float a, b[NT]; };
+    auto read_frags = [&](int j, Frag& fr) {
+        fr.a = *reinterpret_cast<const float*>(sP + pa_lane + (2 * j) * ROWB);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) fr.b[t] = *reinterpret_cast<const float*>(sQ + qt[t] + ((j >> 3) * 18 + ((2 * j) & 15)) * ROWB);
+    };
+
+    TileC cur = decode(split);
+    {
+        const TileCtx x = make_ctx(cur, split < p.ntiles);
+#pragma unroll
+        for (int K = 0; K < NPIECE; ++K) issue_piece(K, x);
+    }
+    Frag f0, f1;
+    for (int tile = split; tile < p.ntiles; tile += p.nsplit) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) { const int q = tid + (k << 8); if (q < np) *reinterpret_cast<u32x4*>(sP + (q / PPR) * ROWB + pcx * 16) = rp[k]; }
+#pragma unroll
+        for (int k = 0; k < MAXQ; ++k) { const int q = tid + (k << 8); if (q < nq) *reinterpret_cast<u32x4*>(sQ + (q / PPR) * ROWB + pcx * 16) = rq[k]; }
+        __syncthreads();
+        advance(cur);
+        const TileCtx x = make_ctx(cur, tile + p.nsplit < p.ntiles);
+        read_frags(0, f0);
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            Frag& fc = (j & 1) ? f1 : f0;
+            Frag& fn = (j & 1) ? f0 : f1;
+            if (j + 1 < KS) read_frags(j + 1, fn);
+            const bool ld = (j % 3 == 0) && (j / 3 < NPIECE);         // the next tile's 20 pieces: one every third k-step
+            if (ld) issue_piece(j / 3, x);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fc.b[t], fc.a, acc[t], 0, 0, 0);
+            if (j + 1 < KS) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (ld && t == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                }
+            }
+        }
+    }
+    // ---- partial slab partials[split][t][a][b]: lane = a-row, 4 consecutive registers = 4 consecutive b
+    const int a = a0 + wa * 32 + l31;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (t < p.ntaps && a < p.Ca) {
+            float* row = p.partials + (((int64_t)split * p.ntaps + t) * p.Ca + a) * p.Cb;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int b = c0 + wb * 32 + 8 * g + 4 * khalf;
+                if (b < p.Cb) *reinterpret_cast<f32x4*>(row + b) = f32x4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+            }
+        }
+    }
+}
+
 int wgrad_plan(const salt_conv_wgrad_args* a, WgradKP* k, int* nsplit_out) {
     if (!a || !view_ok(a->p) || !view_ok(a->q)) SALT_FAIL(SALT_E_BADARG, "wgrad: bad view");
     if (a->ntaps < 1 || a->ntaps > 9) SALT_FAIL(SALT_E_BADARG, "wgrad: ntaps %d (max 9 per launch)", a->ntaps);
@@ -1675,6 +1835,21 @@ static int launch_wgrad(const WgradKP& k, hipStream_t st) {
             }
             auto kern = k.pad_mode ? (row16 ? conv_wgrad_fast_kernel<9, 8, true, true> : conv_wgrad_fast_kernel<9, 8, true, false>)
                                    : (row16 ? conv_wgrad_fast_kernel<9, 8, false, true> : conv_wgrad_fast_kernel<9, 8, false, false>);
+            if (lds > 64 * 1024) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) SALT_FAIL((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e)); }
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, k);
+            SALT_CHECK_LAUNCH();
+            return SALT_OK;
+        }
+    }
+    if constexpr (sizeof(T) == 4) {
+        static const bool generic = getenv("SALT_WGRAD_GENERIC") != nullptr;
+        bool fast = !generic && k.ntaps == 9 && k.bmp == 128 && k.p_cs % 4 == 0 && k.q_cs % 4 == 0 && k.Ca % 4 == 0 && k.Cb % 4 == 0 &&
+                    ((reinterpret_cast<uintptr_t>(k.P) | reinterpret_cast<uintptr_t>(k.Q) | reinterpret_cast<uintptr_t>(k.partials)) & 15) == 0 &&
+                    k.tw_log2 == 4 && k.th_log2 == 3 && k.nb == 1 && k.q_step == 1 && k.hw == 18 && k.hh == 10;
+        for (int t = 0; t < 9 && fast; ++t) fast = k.tap_off[t] == (t / 3) * 18 + t % 3;
+        if (fast) {
+            auto kern = k.pad_mode ? conv_wgrad_fast32_kernel<true> : conv_wgrad_fast32_kernel<false>;
             if (lds > 64 * 1024) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 if (e != hipSuccess) SALT_FAIL((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e)); }
             hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, k);
