@@ -182,6 +182,22 @@ __global__ void partial_sum_kernel(const float* partials, int nparts, int64_t n,
     }
 }
 
+// many partials, few outputs (the first-layer weight gradient: 2048 partials of 144 values): one workgroup per output, thread t
+// adds parts t, t + 256, ... in ascending order, then a fixed-order tree over the 256 threads
+__global__ __launch_bounds__(256) void partial_sum_wide_kernel(const float* partials, int nparts, int64_t n, float* out, int accumulate) {
+    __shared__ float sm[256];
+    const int64_t i = blockIdx.x;
+    float s = 0.f;
+    for (int k = threadIdx.x; k < nparts; k += 256) s += partials[(int64_t)k * n + i];
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[i] = accumulate ? out[i] + sm[0] : sm[0];
+}
+
 // ---------------------------------------------------------------- 1x1 head, Cout <= 4
 template <typename T>
 __global__ void head1x1_kernel(salt_view x, const float* w, const float* bias, int Cout, float* y_nchw, salt_view y) {
@@ -542,7 +558,8 @@ extern "C" int salt_conv_first_wgrad(const salt_conv_first_wgrad_args* a, void* 
     })
     SALT_CHECK_LAUNCH();
     const int64_t n = (int64_t)Cout * KKC;
-    hipLaunchKernelGGL(partial_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a->partials, nparts, n, a->grad, a->accumulate);
+    if (nparts >= 64 && n <= 4096) hipLaunchKernelGGL(partial_sum_wide_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, a->partials, nparts, n, a->grad, a->accumulate);
+    else hipLaunchKernelGGL(partial_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a->partials, nparts, n, a->grad, a->accumulate);
     SALT_CHECK_LAUNCH();
     return SALT_OK;
 }
