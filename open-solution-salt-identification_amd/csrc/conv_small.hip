@@ -125,7 +125,9 @@ struct FirstWgKP {
     int B, Cin, H, W, K, stride, pad, OH, OW, Cout, dy_cs, tiles_y, tiles_x, halo, groups, per;
 };
 
-template <typename T>
+// PER: compile-time bound of the taps a thread accumulates (p.per <= PER): with the runtime bound alone the pixel loop carried
+// MAXKK predicated multiply-adds per pixel even for a 3x3 single-channel layer that needs one
+template <typename T, int PER>
 __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstWgKP p) {
     extern __shared__ __attribute__((aligned(16))) float smf[];
     const int KKC = p.K * p.K * p.Cin;
@@ -150,10 +152,10 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstWgKP p) {
     __syncthreads();
     const int co = tid % p.Cout, grp = tid / p.Cout;
     if (grp >= p.groups) return;
-    float acc[MAXKK];
-    int koff[MAXKK];
+    float acc[PER];
+    int koff[PER];
 #pragma unroll
-    for (int j = 0; j < MAXKK; ++j) {
+    for (int j = 0; j < PER; ++j) {
         acc[j] = 0.f;
         const int kk = grp + j * p.groups;
         int off = 0;
@@ -164,11 +166,11 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstWgKP p) {
         const float g = s_dy[px * p.Cout + co];
         const int base = ((px >> 4) * p.stride) * p.halo + (px & 15) * p.stride;
 #pragma unroll
-        for (int j = 0; j < MAXKK; ++j)
+        for (int j = 0; j < PER; ++j)
             if (j < p.per) acc[j] += g * s_in[base + koff[j]];
     }
 #pragma unroll
-    for (int j = 0; j < MAXKK; ++j) {
+    for (int j = 0; j < PER; ++j) {
         const int kk = grp + j * p.groups;
         if (j < p.per && kk < KKC) p.partials[(int64_t)blockIdx.x * p.Cout * KKC + (int64_t)co * KKC + kk] = acc[j];
     }
@@ -552,7 +554,8 @@ extern "C" int salt_conv_first_wgrad(const salt_conv_first_wgrad_args* a, void* 
     const size_t lds = sizeof(float) * ((size_t)p.Cin * p.halo * p.halo + (size_t)256 * Cout);
     if (lds > 160 * 1024) SALT_FAIL(SALT_E_LDS, "conv_first_wgrad: needs %zu bytes of LDS", lds);
     SALT_DISPATCH_DTYPE(a->dtype, T, {
-        auto kern = conv_first_wgrad_kernel<T>;
+        auto kern = p.per <= 1 ? conv_first_wgrad_kernel<T, 1> : p.per <= 4 ? conv_first_wgrad_kernel<T, 4> : p.per <= 12 ? conv_first_wgrad_kernel<T, 12>
+                                                                                                                 : conv_first_wgrad_kernel<T, MAXKK>;
         if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL(kern, dim3(nparts), dim3(256), lds, (hipStream_t)stream, p);
     })
