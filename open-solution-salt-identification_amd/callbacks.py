@@ -78,7 +78,16 @@ class Callback:
         if self.transformer is None:
             raise RuntimeError('callback is not attached to a transformer (set_params was not called)')
         if self.epoch_id not in self.transformer.validation_loss:
-            self.transformer.validation_loss[self.epoch_id] = self.transformer.score_validation(self.validation_datagen)
+            val = self.transformer.score_validation(self.validation_datagen)
+            dp = getattr(self.transformer, 'dp', None)
+            if dp is not None and dp.world > 1:
+                # one process per GPU: every rank's scheduler / checkpoint / early-stopping callbacks must see the SAME score
+                # (rank 0's, the replica whose weights are persisted) or the replicas drift apart / dead-lock
+                keys = sorted(val)
+                nums = dp.broadcast_scalars([_scalar(val[k]) for k in keys] + [float(getattr(self.transformer, 'best_threshold', 0.5))])
+                val = {k: torch.tensor([v], dtype=torch.float32) for k, v in zip(keys, nums)}
+                self.transformer.best_threshold = nums[-1]
+            self.transformer.validation_loss[self.epoch_id] = val
         return self.transformer.validation_loss[self.epoch_id]
 
 

@@ -75,10 +75,27 @@ def tta_mean(logits, variants, batch):
     return prob
 
 
-def predict_tta(net, X, flip_ud=True, flip_lr=True, variants_per_pass=None):
-    """Probabilities [B, C, H, W] of an eval-mode HipNetwork averaged over the flip variants (C4: 4 flips).
+def _flip_input(X, ud, lr, depth_channels):
+    """One TTA variant of a preprocessed batch.  The reference flips the RAW tile and only then normalises and adds the depth channels
+    (loaders.py:401-423 -> 603-612, utils.py:494-500), so channel 1 (the row ramp) is NOT flipped and channel 2 is
+    flipped(gray) * ramp; flipping all three channels of the network input would hand the network an inverted ramp."""
+    if not (ud or lr):
+        return X
+    Y = flip(X, ud, lr)
+    if depth_channels and ud and X.shape[1] == 3:
+        Y[:, 1] = X[:, 1]
+        Y[:, 2] = Y[:, 0] * X[:, 1]
+    return Y
 
-    The variants are forwarded ``variants_per_pass`` at a time as one larger batch (default: all of them)."""
+
+def predict_tta(net, X, flip_ud=False, flip_lr=True, variants_per_pass=None, depth_channels=True, method='mean'):
+    """Probabilities [B, C, H, W] of an eval-mode HipNetwork aggregated over the flip variants (reference default main.py:282-285:
+    left-right only; BASELINE C4's "4-flip" is flip_ud=True, flip_lr=True).  ``depth_channels``: the input is the reference's
+    3-channel [gray, depth ramp, gray*ramp] batch (see _flip_input).  ``method``: 'mean' (default, neptune.yaml:80; one fused kernel)
+    or 'max' / 'min' / 'gmean' (loaders.py:727-735).
+
+    The variants are forwarded ``variants_per_pass`` at a time as one larger batch (default: all of them).  For bit-faithful
+    handling of the asymmetric 13/14 edge pad use :func:`predict_tta_tiles`, which flips the raw tiles like the reference."""
     if net.training:
         raise SaltError('predict_tta: call net.eval() first')
     X = _f32c(X)
@@ -88,10 +105,68 @@ def predict_tta(net, X, flip_ud=True, flip_lr=True, variants_per_pass=None):
     outs = []
     with torch.no_grad():
         for i in range(0, len(variants), per):
-            xs = [X if not (ud or lr) else flip(X, ud, lr) for ud, lr in variants[i:i + per]]
+            xs = [_flip_input(X, ud, lr, depth_channels) for ud, lr in variants[i:i + per]]
             outs.append(net(torch.cat(xs, 0) if len(xs) > 1 else xs[0]).float())
     logits = torch.cat(outs, 0) if len(outs) > 1 else outs[0]
-    return tta_mean(logits, variants, B)
+    return _aggregate(logits, variants, B, method)
+
+
+def _aggregate(logits, variants, B, method):
+    if method == 'mean':
+        return tta_mean(logits, variants, B)
+    if method not in ('max', 'min', 'gmean'):
+        raise SaltError('TTA aggregation %r (mean | max | min | gmean, loaders.py:727-735)' % (method,))
+    V = len(variants)
+    probs = []
+    for v, (ud, lr) in enumerate(variants):             # sigmoid + inverse flip of ONE variant = tta_mean over a single variant
+        probs.append(tta_mean(logits[v * B:(v + 1) * B], [(ud, lr)], B))
+    st = torch.stack(probs, 0)
+    if method == 'max':
+        return st.max(0).values
+    if method == 'min':
+        return st.min(0).values
+    return torch.exp(torch.log(st).mean(0))            # scipy.stats.gmean
+
+
+def predict_tta_tiles(net, preprocessor, images, flip_ud=False, flip_lr=True, rotation=False, method='mean'):
+    """TTA exactly in the reference's order of operations: transform the RAW [B,h,w] tiles (augmentation.py:143-153: flipud, fliplr,
+    rot90), preprocess every variant (inference pad + Normalize + AddDepthChannels), forward, inverse-transform the probability
+    maps (augmentation.py:156-163) and aggregate (loaders.py:722-760).  ``rotation`` needs square tiles."""
+    if net.training:
+        raise SaltError('predict_tta_tiles: call net.eval() first')
+    if not images.is_cuda:
+        raise SaltError('predict_tta_tiles: tensors must live on the GPU (there is no CPU path)')
+    B = images.shape[0]
+    specs = [(False, False, 0)]
+    for ud, lr, k in itertools.product([True, False] if flip_ud else [False], [True, False] if flip_lr else [False],
+                                       [0, 1, 2, 3] if rotation else [0]):
+        if ud or lr or k:
+            specs.append((ud, lr, k))
+    probs = []
+    with torch.no_grad():
+        for ud, lr, k in specs:
+            t = images
+            if ud:
+                t = torch.flip(t, dims=(1,))
+            if lr:
+                t = torch.flip(t, dims=(2,))
+            if k:
+                t = torch.rot90(t, k, dims=(1, 2))
+            x, _ = preprocessor(t.contiguous())
+            p = tta_mean(net(x).float(), [(False, False)], B)          # sigmoid of this variant
+            if k:
+                p = torch.rot90(p, -k, dims=(2, 3))
+            probs.append(flip(p, ud, lr) if (ud or lr) else p)           # inverse: rot90(-k), then fliplr, then flipud (they commute)
+    st = torch.stack(probs, 0)
+    if method == 'mean':
+        return st.mean(0)
+    if method == 'max':
+        return st.max(0).values
+    if method == 'min':
+        return st.min(0).values
+    if method == 'gmean':
+        return torch.exp(torch.log(st).mean(0))
+    raise SaltError('TTA aggregation %r (mean | max | min | gmean, loaders.py:727-735)' % (method,))
 
 
 # ----------------------------------------------------------------------------- post-processing

@@ -36,8 +36,11 @@ def native_loss(logits, target, kind, want_grad=True, loss_scale=1.0):
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     if kind == 'lovasz':
         P = C * H * W
-        wk = _workspace(('k', dev), 2 * B * P, torch.int32, dev)
-        wv = _workspace(('v', dev), 2 * B * P, torch.int32, dev)
+        # sort scratch is cached per (device, stream): kernels of ONE stream run in order, so two losses may share it; losses
+        # enqueued on different streams (two models on one device) get their own
+        sid = torch.cuda.current_stream().cuda_stream
+        wk = _workspace(('k', dev, sid), 2 * B * P, torch.int32, dev)
+        wv = _workspace(('v', dev, sid), 2 * B * P, torch.int32, dev)
         lpi = torch.empty(B, dtype=torch.float32, device=dev)
         a = STRUCTS['salt_lovasz_args']()
         fill(a, logits=logits.data_ptr(), target=target.data_ptr(), B=B, P=P, ws_keys=wk.data_ptr(), ws_vals=wv.data_ptr(),

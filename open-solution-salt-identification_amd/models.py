@@ -80,7 +80,11 @@ class Model:
 
     def persist(self, filepath):
         """Reference checkpoints are written through nn.DataParallel, so every key carries a 'module.' prefix
-        (models.py:199-204, callbacks.py:776-792); keep that format."""
+        (models.py:199-204, callbacks.py:776-792); keep that format.  One process per GPU: only rank 0 writes (the replicas are
+        identical up to their per-rank BatchNorm running statistics, and DataParallel keeps device 0's as well)."""
+        dp = getattr(self, 'dp', None)
+        if dp is not None and dp.rank != 0:
+            return
         self.model.eval()
         sd = {'module.' + k: v.detach().cpu() for k, v in self.model.state_dict().items()}
         torch.save(sd, filepath)
@@ -135,7 +139,7 @@ class SegmentationModel(Model):
                 if batch_id == steps:
                     break
             self.callbacks.on_epoch_end()
-            if self.callbacks.training_break():
+            if self.dp.any_rank(self.callbacks.training_break()):       # every rank leaves the loop in the same epoch
                 break
         self.callbacks.on_train_end()
         return self
@@ -163,7 +167,7 @@ class SegmentationModel(Model):
             outputs_batch = self.model(X)
             batch_loss = loss_function(outputs_batch, target) * weight
             batch_loss.backward()
-            self.dp.allreduce_gradients(self.model.engine())
+            self.dp.allreduce_gradients(self.model.engine(), self.optimizer)   # SUM over ranks; Adam's grad_scale carries 1/world
         self.optimizer.step()
         return {'sum': batch_loss}
 

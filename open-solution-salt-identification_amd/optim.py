@@ -43,10 +43,18 @@ class FusedAdam(torch.optim.Optimizer):
         eng = self.model.engine()
         if self._eng is eng:
             return
+        old = (self.exp_avg, self.exp_avg_sq) if self._eng is not None else None
         self._eng = eng
         dev = eng.device
-        self.exp_avg = torch.zeros_like(eng.flat)
-        self.exp_avg_sq = torch.zeros_like(eng.flat)
+        if old is not None and old[0].numel() == eng.flat.numel():
+            # the model's engine was rebuilt (.to() / .float() / set_compute_dtype drop it): the flat layout is the same, so the Adam
+            # moments and the bias-correction counter carry over instead of being silently reset
+            self.exp_avg, self.exp_avg_sq = old[0].to(dev).clone(), old[1].to(dev).clone()
+        else:
+            if old is not None:
+                self.steps = 0                       # different parameter set: moments AND bias correction restart together
+            self.exp_avg = torch.zeros_like(eng.flat)
+            self.exp_avg_sq = torch.zeros_like(eng.flat)
         self.hyper = torch.zeros(8, dtype=torch.float32, device=dev)
         self.step_t = torch.full((1,), self.steps, dtype=torch.int64, device=dev)
         self._host_hyper = None
@@ -80,6 +88,8 @@ class FusedAdam(torch.optim.Optimizer):
         g = {k: v for k, v in self.param_groups[0].items() if k != 'params'}
         g['params'] = list(range(len(self.param_groups[0]['params'])))
         st = {}
+        if self._eng is None and self.model is not None and getattr(self.model, '_engine', None) is not None:
+            self._bind()                             # zero moments before the first step, like torch's Adam after initialisation
         if self._eng is not None:
             st = {'step': self.steps, 'exp_avg': self.exp_avg.detach().cpu(), 'exp_avg_sq': self.exp_avg_sq.detach().cpu()}
         return {'state': st, 'param_groups': [g]}

@@ -65,6 +65,8 @@ class DataParallel:
         self.rank, self.world, self.bucket_bytes = rank, world, bucket_bytes
         self._comm_stream = None
         self._plans = {}
+        self.measure = False            # bench.py: record an event pair around the final wait for the collectives
+        self.exposed_events = []
 
     @classmethod
     def from_env(cls):
@@ -96,23 +98,65 @@ class DataParallel:
     # ------------------------------------------------------------------ flat-buffer reducer (device agnostic)
     def allreduce_flat(self, flat, buckets):
         """Sum-reduce contiguous ranges of ``flat`` in place (the 1/world factor is applied by the optimizer)."""
-        if self.world == 1 and not (os.environ.get('SALT_FORCE_DP_PATH') and dist.is_initialized()):
+        if not self._active():
             return
-        works = [dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True) for lo, hi, _ in buckets]
+        works = [self._all_reduce(flat[lo:hi]) for lo, hi, _ in buckets]
         for w in works:
-            w.wait()
+            if w is not None:
+                w.wait()
 
-    def allreduce_gradients(self, eng):
-        if self.world == 1 and not (os.environ.get('SALT_FORCE_DP_PATH') and dist.is_initialized()):
+    def _active(self):
+        return self.world > 1 or bool(os.environ.get('SALT_FORCE_DP_PATH') and dist.is_initialized())
+
+    def _all_reduce(self, t):
+        """SUM all-reduce of one contiguous gradient range on the current stream (async work handle).  Tests substitute the
+        collective (e.g. x2 = the sum over two ranks that hold the same batch) to exercise the plan without a second GPU."""
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+
+    def allreduce_gradients(self, eng, optimizer=None):
+        """Autograd-bridge branch of _fit_loop: one SUM all-reduce of the whole flat gradient buffer after backward; the 1/world
+        of the average goes into the optimizer's gradient scale exactly as in :meth:`backward`."""
+        if optimizer is not None:
+            optimizer.grad_scale = 1.0 / self.world
+        if not self._active():
             return
         self.allreduce_flat(eng.grads, [(0, eng.n_live, 0)])
+
+    # ------------------------------------------------------------------ rank-consistent trainer decisions
+    def any_rank(self, flag):
+        """True on every rank when ``flag`` is true on at least one (early stopping must end fit() everywhere in the same epoch,
+        otherwise the remaining ranks block in the next all-reduce)."""
+        if self.world == 1 or not dist.is_initialized():
+            return bool(flag)
+        dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+        t = torch.tensor([1.0 if flag else 0.0], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return bool(t.item() > 0)
+
+    def broadcast_scalars(self, values, src=0):
+        """Replace a list of python floats by rank ``src``'s (validation scores: the callbacks of every rank must decide on the
+        same numbers - BatchNorm running statistics are per rank, so the per-rank scores differ slightly)."""
+        if self.world == 1 or not dist.is_initialized():
+            return [float(v) for v in values]
+        dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=dev)
+        dist.broadcast(t, src=src)
+        return [float(v) for v in t.cpu()]
+
+    def exposed_allreduce_ms(self):
+        """Mean milliseconds per step the compute stream spent waiting for the collectives after backward finished (measure=True)."""
+        if not self.exposed_events:
+            return None
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in self.exposed_events]
+        return sum(ms) / len(ms)
 
     # ------------------------------------------------------------------ overlapped backward
     def backward(self, eng, net, optimizer=None):
         """Run net.bwd; with world > 1 run it in bucket segments with the all-reduce on a side stream."""
         if optimizer is not None:
             optimizer.grad_scale = 1.0 / self.world
-        if self.world == 1 and not (os.environ.get('SALT_FORCE_DP_PATH') and dist.is_initialized()):
+        if not self._active():
             net.bwd.run(side=eng.side_stream)
             return
         key = id(net)
@@ -137,8 +181,16 @@ class DataParallel:
             with torch.cuda.stream(comm):
                 comm.wait_event(ev)
                 comm.wait_event(ev_side)
-                works.append(dist.all_reduce(eng.grads[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+                works.append(self._all_reduce(eng.grads[lo:hi]))
         if pos < n_ops:
             net.bwd.run(begin=pos, end=n_ops, side=eng.side_stream)
+        if self.measure:        # exposed communication = what the compute stream waits for after its last backward kernel
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(cur)
         for w in works:
-            w.wait()            # the compute stream waits for RCCL before Adam reads the gradients
+            if w is not None:
+                w.wait()        # the compute stream waits for RCCL before Adam reads the gradients
+        cur.wait_stream(comm)   # (also orders a substituted collective that returned no work handle)
+        if self.measure:
+            e1.record(cur)
+            self.exposed_events.append((e0, e1))

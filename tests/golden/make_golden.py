@@ -184,7 +184,7 @@ def main():
             'ternaus_resnet101_deconv': lambda: um.UNetResNet(101, 2, dropout_2d=0.0, pretrained=False, is_deconv=True)}
     only = [a for a in sys.argv[1:] if a.startswith('F8_')]
     for tag, make in nets.items():
-        if only and 'F8_' + tag not in only:
+        if ONLY and 'F8_' + tag not in ONLY:
             continue
         net = make()
         canon = canonical_fn(net)
@@ -229,6 +229,30 @@ def main():
                   or n.endswith('dec1.conv2.conv.weight') or n.endswith('encoder.conv1.weight')][:4]:
             out['fullgrad:' + k] = named[k].grad
         save('F8_' + tag, **out)
+
+    # ---- F11: the deep (Bottleneck) networks once more in float64 - the same reference modules, `.double()` - so that the tests can
+    # EARN their gradient tolerances: |HIP - f64| is compared with |reference fp32 - f64| instead of with a chosen constant
+    for tag in ('unet_resnet152_hyper', 'ternaus_resnet101_deconv'):
+        if ONLY and 'F11_' + tag + '_f64' not in ONLY:
+            continue
+        net = nets[tag]()
+        CF.fill_module(net, canonical=canonical_fn(net))
+        net.double().train()
+        o = net(X.double())
+        loss = models.lovasz_loss(o, T.double()) * 1.0
+        loss.backward()
+        out = OrderedDict(train_logits64=o.detach(), train_loss64=loss.detach())
+        names, gnorm = [], []
+        for k, p in net.named_parameters():
+            names.append(k)
+            gnorm.append(float(p.grad.norm()) if p.grad is not None else 0.0)
+        out['param_names'] = np.array(names)
+        out['grad_norm64'] = np.array(gnorm)
+        named = dict(net.named_parameters())
+        for k in [n for n in names if n.endswith('final.1.weight') or n.endswith('final.weight')
+                  or n.endswith('dec1.conv2.conv.weight') or n.endswith('encoder.conv1.weight')][:4]:
+            out['fullgrad64:' + k] = named[k].grad
+        save('F11_' + tag + '_f64', **out)
 
     # ---- F9 / F10: numpy helpers pulled from files that cannot be imported (executed unmodified)
     ns = {'np': np}

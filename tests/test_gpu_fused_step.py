@@ -1,0 +1,271 @@
+"""Parity of the SHIPPED training entry point: ``SegmentationModel._fit_loop`` -> ``_fused_step`` (forward program, native loss
+writing dlogits in place, ``dp.backward`` in bucket segments, fused Adam with its gradient scale) against the goldens the
+reference produced (common_blocks/models.py:105-136 executed on the reference's own modules) and against the oracle.
+
+The autograd-bridge tests (test_gpu_models.py) drive ``net(x) -> loss.backward() -> opt.step()``; bench.py times THIS path."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden, T, assert_close
+import closed_form as CF
+from test_gpu_models import _fill_closed_form, _grad_report
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _segmentation_model(architecture, loss='lovasz', dtype='f32', lr=1e-4):
+    from salt_amd.models import SegmentationModel
+    arch = {'model_params': {'architecture': architecture, 'out_channels': 2, 'activation': 'sigmoid', 'loss': loss, 'compute_dtype': dtype},
+            'optimizer_params': {'lr': lr}, 'regularizer_params': {'regularize': True, 'weight_decay_conv2d': 1e-4}}
+    m = SegmentationModel(arch, {'epochs': 1}, {})
+    return m
+
+
+@pytest.mark.parametrize('tag,architecture', [('unet_resnet34_hyper', 'UNetResNet'), ('ternaus_resnet34_deconv', 'TernausUNetResNet')])
+def test_fit_loop_fused_step_matches_reference_golden(tag, architecture):
+    """models.py:105-136 through the fused path, Lovasz hinge: loss, every per-tensor gradient norm, selected full gradients,
+    post-Adam weight norms and BatchNorm running-statistics sums exactly as test_one_training_step_matches_reference asserts
+    them for the autograd-bridge path."""
+    fx = golden('F8_' + tag)
+    m = _segmentation_model(architecture)
+    _fill_closed_form(m.model)
+    m._to_device()
+    m.model.train()
+    net = m.model
+    metrics = m._fit_loop([T(fx['x']), T(fx['t'])])
+    torch.cuda.synchronize()
+    loss, ref = float(metrics['sum']), float(fx['train_loss'])
+    assert abs(loss - ref) < 2e-3 * max(1.0, abs(ref)), (loss, ref)
+    eng = net.engine()
+    cnet = eng.net(tuple(fx['x'].shape), True)
+    assert_close(cnet.logits.cpu(), fx['train_logits'], 2e-3, 'train logits')
+    names = fx['param_names'].tolist()
+    idx = {n: i for i, n in enumerate(names)}
+    dead = set(net.dead_parameter_names())
+    own = dict(net.named_parameters())
+    checked, worst = 0, (0.0, '')
+    for k, p in own.items():
+        i = idx[k]
+        has = bool(fx['param_has_grad'][i])
+        assert has == (k not in dead), k
+        if has and fx['grad_norm'][i] > 1e-4:
+            off, n = eng.grad_range(p)
+            gn = float(eng.grads[off:off + n].double().norm())        # Adam reads the gradients, it does not modify them
+            worst = max(worst, (abs(gn - fx['grad_norm'][i]) / fx['grad_norm'][i], k))
+            checked += 1
+    assert checked > 100 and worst[0] < 1e-2, (checked, worst)
+    for k in fx:
+        if k.startswith('fullgrad:'):
+            p = own[k[9:]]
+            off, n = eng.grad_range(p)
+            assert_close(eng.grads[off:off + n].view(p.shape).cpu(), fx[k], 2e-2, k)
+    for k, p in own.items():
+        i = idx[k]
+        if fx['param_has_grad'][i] and fx['grad_norm'][i] > 1e-4:
+            pn = float(p.detach().double().norm())
+            assert abs(pn - fx['post_norm'][i]) <= 1e-4 * max(fx['post_norm'][i], 1e-3), (k, pn, fx['post_norm'][i])
+    sd = net.state_dict()
+    for k, s in zip(fx['bn_keys'].tolist(), fx['bn_sum'].tolist()):
+        assert abs(float(sd[k].double().sum()) - s) <= 1e-3 * max(1.0, abs(s)), k
+
+
+@pytest.mark.parametrize('loss', ['lovasz', 'bce_dice'])
+def test_fit_loop_fused_step_matches_oracle_step(loss):
+    """One fused step of the hypercolumn ResNet34 U-Net from default initialisation vs the oracle's step (forward, loss, backward,
+    Adam + L2): loss value, every parameter gradient (relative L2 / cosine), and the updated weights."""
+    from oracle import nets as ON, specs as OS, losses as OL
+    torch.manual_seed(5)
+    m = _segmentation_model('UNetResNet', loss)
+    spec = OS.SPECS['UNetResNet'](with_fc=True)
+    sd = OS.init_state(spec, seed=7)
+    m.model.load_state_dict({k: sd[k] for k in m.model.state_dict() if k in sd}, strict=False)
+    sd = {k: v.detach().clone() for k, v in m.model.state_dict().items() if k in spec}
+    x = CF.input_for('r34', (4, 3, 64, 64))
+    t = CF.mask_for('r34', (4, 64, 64))
+    m._to_device()
+    m.model.train()
+    dead = set(m.model.dead_parameter_names())
+    keys = [k for k in OS.trainable_keys(spec) if k not in dead]
+    for k in keys:
+        sd[k].requires_grad_(True)
+    out_r = ON.unet_resnet(sd, x, True)
+    loss_r = OL.LOSSES[loss](out_r, t)
+    loss_r.backward()
+    metrics = m._fit_loop([x, t])
+    torch.cuda.synchronize()
+    assert abs(float(metrics['sum']) - float(loss_r)) < 1e-4 * max(1.0, abs(float(loss_r)))
+    # Lovasz: g_k = J_k - J_(k-1) carries ~1e-3 relative fp32 cancellation noise in torch itself (test_gpu_models.py)
+    worst, cos, n = _grad_report(m.model, {k: sd[k].grad for k in keys})
+    assert n > 120 and worst[0] < 5e-2 and cos > 0.9999, (worst, cos, n)
+    # the oracle's Adam + L2 step on the oracle's gradients vs the fused Adam kernel on the HIP gradients
+    params = [sd[k] for k in keys]
+    before = [p.detach().clone() for p in params]
+    with torch.no_grad():
+        OL.adam_l2_step([p.data for p in params], [p.grad for p in params], [torch.zeros_like(p) for p in params],
+                        [torch.zeros_like(p) for p in params], 1)
+    own = dict(m.model.named_parameters())
+    moved = 0
+    for k, p0, p1 in zip(keys, before, params):
+        mine = own[k].detach().cpu()
+        step_ref, step_mine = (p1.detach() - p0), (mine - p0)
+        # first Adam step: |delta| = lr * g / (|g| + eps) -> +-1e-4 wherever the gradient is not tiny; compare the updates themselves
+        big = sd[k].grad.abs() > 1e-6
+        if int(big.sum()) == 0:
+            continue
+        moved += 1
+        agree = float(((step_ref - step_mine).abs()[big] < 2e-5).float().mean())
+        assert agree > 0.98, (k, agree)
+    assert moved > 100
+
+
+class _TwoIdenticalRanks:
+    """DataParallel stand-in for ONE GPU: world = 2 with both ranks holding the same minibatch, i.e. the SUM all-reduce of a bucket
+    is exactly 2 x the local gradient (a power of two: exact in fp32).  Everything else - the bucket plan, segmented backward,
+    the communication stream's event ordering, grad_scale = 1/2 folded into Adam - is the production code."""
+
+    @staticmethod
+    def make():
+        from salt_amd import parallel
+
+        class Two(parallel.DataParallel):
+            def _all_reduce(self, t):
+                t.mul_(2.0)
+                return None
+        return Two(rank=0, world=2, bucket_bytes=8 << 20)
+
+
+@pytest.mark.parametrize('branch', ['fused', 'bridge'])
+def test_grad_scale_half_on_doubled_gradients_equals_plain_step(branch):
+    """world = 2 semantics on one GPU: gradients are summed over two identical ranks and Adam applies grad_scale = 0.5; three steps
+    must reproduce the plain single-rank steps BIT FOR BIT (scaling by 2 and by 1/2 is exact).  'bridge' = a loss without
+    ``native_kind`` (models.py autograd branch), whose all-reduce used to leave grad_scale at 1."""
+    from salt_amd import losses
+    results = {}
+    for mode in ('plain', 'two'):
+        torch.manual_seed(11)
+        m = _segmentation_model('UNetResNet', 'lovasz', dtype='bf16', lr=1e-3)
+        if branch == 'bridge':
+            m.loss_function = [('mask', lambda o, t: losses.lovasz_loss(o, t), 1.0)]
+        if mode == 'two':
+            m.dp = _TwoIdenticalRanks.make()
+        m._to_device()
+        m.model.train()
+        g = torch.Generator().manual_seed(5)
+        X = torch.randn(4, 3, 128, 128, generator=g)
+        M = (torch.rand(4, 1, 128, 128, generator=g) > 0.6).float()
+        Tt = torch.cat([1 - M, M], 1)
+        ls = [float(m._fit_loop([X, Tt])['sum']) for _ in range(3)]
+        torch.cuda.synchronize()
+        eng = m.model.engine()
+        results[mode] = (ls, eng.flat.clone(), eng.grads.clone(), m.optimizer.grad_scale,
+                         len(list(m.dp._plans.values())[0]) if (mode == 'two' and branch == 'fused') else 0)
+    assert results['plain'][3] == 1.0 and results['two'][3] == 0.5
+    if branch == 'fused':
+        assert results['two'][4] >= 3                                   # several buckets: the segmented path really ran
+    assert results['plain'][0] == results['two'][0]
+    assert torch.equal(results['two'][2], results['plain'][2] * 2)     # the reduced (summed) gradients
+    assert torch.equal(results['plain'][1], results['two'][1])         # the weights after three steps
+
+
+def test_bf16_whole_network_vs_fp32_oracle_c2_shape():
+    """BASELINE C2's dtype and shape ([32,3,128,128], bf16 activations / MFMA inputs, fp32 accumulation, masters, statistics and
+    loss) against the fp32 oracle: eval logits, train-mode logits, loss and every parameter gradient of one fused step."""
+    from oracle import nets as ON, specs as OS, losses as OL
+    torch.manual_seed(5)
+    m = _segmentation_model('UNetResNet', 'lovasz', dtype='bf16')
+    spec = OS.SPECS['UNetResNet'](with_fc=True)
+    sd = OS.init_state(spec, seed=7)
+    m.model.load_state_dict({k: sd[k] for k in m.model.state_dict() if k in sd}, strict=False)
+    sd = {k: v.detach().clone() for k, v in m.model.state_dict().items() if k in spec}
+    x = CF.input_for('c2', (32, 3, 128, 128))
+    t = CF.mask_for('c2', (32, 128, 128))
+    m._to_device()
+    m.model.eval()
+    with torch.no_grad():
+        y = m.model(x.to(DEV)).float().cpu()
+        yr = ON.unet_resnet(sd, x, False)
+
+    def rel_l2(a, b):
+        return float((a.double() - b.double()).norm() / b.double().norm())
+    e_eval = rel_l2(y, yr)
+    # bf16 has 8 significand bits: one rounding is 2^-9 = 2e-3 relative; ~50 layers of independent roundings -> ~1.5e-2
+    assert e_eval < 3e-2, e_eval
+    agree = float(((y[:, 1] > 0) == (yr[:, 1] > 0)).float().mean())
+    assert agree > 0.995, agree                                          # the masks differ only where |logit| is within bf16 noise
+    m.model.train()
+    dead = set(m.model.dead_parameter_names())
+    keys = [k for k in OS.trainable_keys(spec) if k not in dead]
+    for k in keys:
+        sd[k].requires_grad_(True)
+    out_r = ON.unet_resnet(sd, x, True)
+    loss_r = OL.lovasz_loss(out_r, t)
+    loss_r.backward()
+    metrics = m._fit_loop([x, t])
+    torch.cuda.synchronize()
+    cnet = m.model.engine().net((32, 3, 128, 128), True)
+    e_train = rel_l2(cnet.logits.cpu(), out_r.detach())
+    assert e_train < 3e-2, e_train
+    assert abs(float(metrics['sum']) - float(loss_r)) < 1e-2 * max(1.0, abs(float(loss_r))), (float(metrics['sum']), float(loss_r))
+    worst, cos, n = _grad_report(m.model, {k: sd[k].grad for k in keys})
+    print('bf16 C2: eval logits relL2 %.3e, train logits relL2 %.3e, loss %.5f vs %.5f, grad cosine %.5f, worst tensor relL2 %.3e (%s)'
+          % (e_eval, e_train, float(metrics['sum']), float(loss_r), cos, worst[0], worst[1]))
+    assert n > 120 and cos > 0.99 and worst[0] < 0.35, (worst, cos, n)
+
+
+_RCCL_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+world = int(os.environ.get('WORLD_SIZE', '1'))
+if world > 1:
+    torch.cuda.set_device(int(os.environ['LOCAL_RANK']))
+    dist.init_process_group('nccl')
+from salt_amd import models
+arch = {'model_params': {'architecture': 'UNetResNet', 'out_channels': 2, 'activation': 'sigmoid', 'loss': 'lovasz', 'compute_dtype': 'bf16'},
+        'optimizer_params': {'lr': 1e-3}, 'regularizer_params': {'regularize': True, 'weight_decay_conv2d': 1e-4}}
+torch.manual_seed(3)
+m = models.SegmentationModel(arch, {'epochs': 1}, {})
+m.dp.bucket_bytes = 8 << 20
+m._to_device(); m.model.train()
+m.dp.broadcast_parameters(m.model)
+g = torch.Generator().manual_seed(5)
+X = torch.randn(4, 3, 128, 128, generator=g).cuda()
+M = (torch.rand(4, 1, 128, 128, generator=g) > 0.6).float()
+T = torch.cat([1 - M, M], 1).cuda()
+losses = [float(m._fit_loop([X, T])['sum']) for _ in range(3)]     # every rank trains on the SAME batch
+torch.cuda.synchronize()
+eng = m.model.engine()
+if int(os.environ.get('RANK', '0')) == 0:
+    torch.save({'losses': losses, 'flat': eng.flat.cpu(), 'grads': eng.grads.cpu(), 'world': m.dp.world, 'scale': m.optimizer.grad_scale}, sys.argv[1])
+if world > 1:
+    dist.barrier(); dist.destroy_process_group()
+'''
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs >= 2 GPUs on the node (the gpurun box exposes one)')
+def test_two_rank_rccl_fit_loop_equals_single_rank(tmp_path):
+    """Real RCCL over xGMI: torchrun 2 ranks of _fit_loop on the SAME batch -> summed gradients are exactly 2 x, grad_scale = 1/2,
+    bucketed all-reduce overlapped with backward -> weights bit-identical to the 1-rank run."""
+    script = tmp_path / 'rccl_worker.py'
+    script.write_text(_RCCL_WORKER % {'root': ROOT})
+    outs = {}
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, str(script), str(tmp_path / 'one.pt')], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    outs['one'] = torch.load(tmp_path / 'one.pt')
+    port = str(29700 + os.getpid() % 200)
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', port, str(script), str(tmp_path / 'two.pt')], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    outs['two'] = torch.load(tmp_path / 'two.pt')
+    assert outs['two']['world'] == 2 and outs['two']['scale'] == 0.5
+    assert outs['one']['losses'] == outs['two']['losses']
+    assert torch.equal(outs['two']['grads'], outs['one']['grads'] * 2)
+    assert torch.equal(outs['one']['flat'], outs['two']['flat'])

@@ -117,6 +117,31 @@ def test_one_training_step_matches_reference(tag):
     # is test_resnet34_unets_train_step_vs_oracle_default_init[UNetResNet152]
     deep = '152' in tag or '101' in tag
     assert checked > (100 if 'salt' not in tag else 30) and worst[0] < (0.15 if deep else 1e-2), (checked, worst)
+    if deep:
+        # the 15 % above is not a chosen number: the reference's OWN fp32 gradients sit that far from the same modules run in
+        # float64 (fixture F11, make_golden.py).  Measured against float64, the HIP gradients must be as good as the reference's.
+        f64 = golden('F11_' + tag + '_f64')
+        i64 = {n: i for i, n in enumerate(f64['param_names'].tolist())}
+        e_hip, e_ref = [], []
+        for k, p in own.items():
+            i = idx[k]
+            if fx['param_has_grad'][i] and fx['grad_norm'][i] > 1e-4:
+                g64 = float(f64['grad_norm64'][i64[k]])
+                off, n = eng.grad_range(p)
+                e_hip.append(abs(float(eng.grads[off:off + n].double().norm()) - g64) / g64)
+                e_ref.append(abs(float(fx['grad_norm'][i]) - g64) / g64)
+        e_hip, e_ref = np.array(e_hip), np.array(e_ref)
+        print('%s: grad-norm error vs float64: HIP max %.3e median %.3e | reference fp32 max %.3e median %.3e'
+              % (tag, e_hip.max(), np.median(e_hip), e_ref.max(), np.median(e_ref)))
+        assert e_hip.max() <= 2.5 * e_ref.max() + 1e-3 and np.median(e_hip) <= 2.5 * np.median(e_ref) + 1e-4
+        for k in f64:
+            if k.startswith('fullgrad64:'):
+                p = own[k[11:]]
+                off, n = eng.grad_range(p)
+                g64 = T(f64[k]).double()
+                l2_hip = float((eng.grads[off:off + n].view(p.shape).cpu().double() - g64).norm() / g64.norm())
+                l2_ref = float((T(fx['fullgrad:' + k[11:]]).double() - g64).norm() / g64.norm())
+                assert l2_hip <= 2.5 * l2_ref + 1e-3, (k, l2_hip, l2_ref)
     for k in fx:
         if k.startswith('fullgrad:'):
             p = own[k[9:]]
@@ -159,8 +184,13 @@ def test_vanilla_unet_matches_oracle_c1_shape():
         y = net(x.to(DEV)).cpu()
         yr = ON.vanilla_unet(sd, x, False)
     assert_close(y, yr, 1e-3, 'eval logits')
-    near = yr[:, 1].abs() > 1e-4 * float(yr.abs().max())
-    assert torch.equal((y[:, 1] > 0)[near], (yr[:, 1] > 0)[near])
+    # north_star: per-pixel masks bit-exact.  524 288 decisions; the only admissible disagreement is a pixel whose reference logit
+    # is itself within fp32 rounding of zero (|logit| < 2e-6 of the largest), and the count is reported
+    mis = (y[:, 1] > 0) != (yr[:, 1] > 0)
+    n_mis = int(mis.sum())
+    print('C1 mask: %d of %d decisions differ from the oracle' % (n_mis, mis.numel()))
+    if n_mis:
+        assert n_mis <= 2 and float(yr[:, 1][mis].abs().max()) < 2e-6 * float(yr.abs().max()), (n_mis, float(yr[:, 1][mis].abs().max()))
     net.train()
     xs, ts = x[:8], t[:8]
     from salt_amd import losses
@@ -233,6 +263,24 @@ def test_resnet34_unets_train_step_vs_oracle_default_init(arch):
     # depth 152 (train-mode BN through 150 layers): torch's own fp32 result sits at cosine 0.9975 / worst tensor 8e-2 / logits 1.1e-3
     # from its float64 result on this very input, so that is the resolution any fp32 implementation can be compared at
     assert n > (120 if 'Salt' not in arch else 30) and worst[0] < (0.3 if skw else 5e-2) and cos > (0.99 if skw else 0.9999), (worst, cos, n)
+    if skw:
+        # earn the loose depth-152 bounds: the same oracle in float64 is the yardstick - the HIP result must be as close to it as
+        # torch's fp32 result is (same input, same weights)
+        sd64 = {k: (v.detach().double().requires_grad_(v.requires_grad) if v.dtype.is_floating_point else v.clone()) for k, v in sd.items()}
+        out64 = ON.FORWARDS[arch](sd64, x.double(), True, **kw)
+        OL.mixed_dice_bce_loss(out64, t.double()).backward()
+        g64 = {k: v.grad for k, v in sd64.items() if k not in dead and v.dtype.is_floating_point and v.grad is not None}
+        w_hip, cos_hip, _ = _grad_report(net, g64)
+        flat64 = torch.cat([g64[k].reshape(-1) for k in g64 if sd[k].grad is not None])
+        flat32 = torch.cat([sd[k].grad.double().reshape(-1) for k in g64 if sd[k].grad is not None])
+        cos_ref = float((flat64 * flat32).sum() / (flat64.norm() * flat32.norm()))
+        w_ref = max(float((sd[k].grad.double() - g64[k]).norm() / g64[k].norm()) for k in g64
+                    if sd[k].grad is not None and float(g64[k].abs().max()) >= 1e-7)
+        e_log_hip = float((out.detach().cpu().double() - out64.detach()).abs().max() / out64.detach().abs().max())
+        e_log_ref = float((out_r.detach().double() - out64.detach()).abs().max() / out64.detach().abs().max())
+        print('depth 152 vs float64: HIP cosine %.5f worst %.3e logits %.3e | torch fp32 cosine %.5f worst %.3e logits %.3e'
+              % (cos_hip, w_hip[0], e_log_hip, cos_ref, w_ref, e_log_ref))
+        assert 1 - cos_hip <= 2.5 * (1 - cos_ref) + 1e-5 and w_hip[0] <= 2.5 * w_ref + 1e-3 and e_log_hip <= 2.5 * e_log_ref + 1e-5
     eng = net.engine()
     for k in ('final.1.weight', 'final.1.bias') if arch == 'UNetResNet' else ('final.weight', 'final.bias'):
         p = dict(net.named_parameters())[k]

@@ -126,6 +126,17 @@ class M(torch.nn.Module):
         super().__init__(); s.p = torch.nn.Parameter(w.clone())
 m = M(); dp.broadcast_parameters(m)
 assert float(m.p[0]) == 1.0
+# autograd-bridge branch of _fit_loop: SUM over ranks + grad_scale = 1/world on the optimizer == the average of the rank gradients
+class Eng: pass
+class Opt: grad_scale = 1.0
+eng, opt = Eng(), Opt()
+eng.grads, eng.n_live = mine.clone(), 1000
+dp.allreduce_gradients(eng, opt)
+assert opt.grad_scale == 0.5
+assert torch.allclose(eng.grads * opt.grad_scale, full.sum(0) / 2, atol=1e-5)
+# trainer decisions are rank consistent: early stopping on ONE rank ends every rank; validation scores are rank 0's
+assert dp.any_rank(dp.rank == 1) is True and dp.any_rank(False) is False
+assert dp.broadcast_scalars([0.25 + dp.rank, 7.0 * (dp.rank + 1)]) == [0.25, 7.0]
 dist.barrier(); open(os.path.join(%(out)r, 'rank%%d.ok' %% dp.rank), 'w').write('ok')
 '''
 
