@@ -90,7 +90,11 @@ typedef struct {
     /* Fold mode (data-gradient of a replicate-padded convolution, architectures/base.py:21-27): the launch computes the gradient on
      * the extended grid OH = y.H + fold_top + fold_bottom, OW = y.W + fold_left + fold_right; interior pixels go straight to y
      * (the UNPADDED tensor, (+)= per `accumulate`), the pad ring goes to `strip` ([B][salt_fold_strip_pixels][strip_cs], always
-     * overwritten) and salt_pad_fold_strip adds the ring onto the edge pixels of y.  strip == NULL: normal mode. */
+     * overwritten) and salt_pad_fold_strip adds the ring onto the edge pixels of y.
+     * strip == NULL with fold_top > 0 or fold_right > 0 (fold_bottom = fold_left = 0): FUSED fold - same extended grid, but the launch
+     * lays its tiles out so that every ring pixel shares a tile with the edge pixel it folds onto and the epilogue adds them before the
+     * store: no strip, no second pass (needs out_step 1, no stats, 16-byte aligned y with C and cs multiples of 8 (bf16) / 4 (f32)).
+     * strip == NULL and all pads 0: normal mode. */
     void* strip;
     int strip_cs;
     int fold_top;

@@ -12,7 +12,7 @@ import re
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 HEADER = os.path.join(_ROOT, 'include', 'saltnet.h')
-LIB_PATH = os.path.join(_PKG, 'libsaltnet_hip.so')
+LIB_PATH = os.environ.get('SALT_LIB') or os.path.join(_PKG, 'libsaltnet_hip.so')      # SALT_LIB: A/B a build variant (tools/build_variant.sh)
 
 _SCALARS = {
     'int': ctypes.c_int, 'float': ctypes.c_float, 'int64_t': ctypes.c_int64, 'uint32_t': ctypes.c_uint32,

@@ -37,9 +37,11 @@ struct ConvKP {
     int nchunk, a_bytes;
     int relu, accumulate, stats_part0;
     void* strip; int strip_cs, fold_top, fold_bottom, fold_left, fold_right;     // fold mode (strip != nullptr)
+    int fold_fused, ox_shift;        // fused fold (strip == nullptr, fold_top / fold_right > 0): tile columns start at -ox_shift
     unsigned hhw_magic, hw_magic;                                                // x / d == umulhi(x, 2^32 / d + 1) for x * d < 2^32
     int m_tiles, n_tiles;
     int vt;                          // virtual taps of a 1x1 convolution: vt channel chunks staged per barrier round (1 = off)
+    int nbuf;                        // conv_glds_kernel: depth of the LDS chunk ring (2 | 3)
     // BatchNorm-backward sums of the stored tile (saltnet.h, salt_conv_args.bnb_*); bnb_partials == nullptr: off
     const void* bnb_y; const void* bnb_a; int bnb_cs, bnb_acs, bnb_relu;
     const float* bnb_mean; const float* bnb_invstd; const float* bnb_gamma; const float* bnb_beta; float* bnb_partials;
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
     const int txi = tile % p.tiles_x; tile /= p.tiles_x;
     const int tyi = tile % p.tiles_y;
     const int tbi = tile / p.tiles_y;
-    const int oy0 = tyi << p.th_log2, ox0 = txi << p.tw_log2, b0 = tbi * p.nb;
+    const int oy0 = tyi << p.th_log2, ox0 = (txi << p.tw_log2) - p.ox_shift, b0 = tbi * p.nb;
     const int n0 = n_tile * BN;
     const int hhw = p.hh * p.hw;
     const int phalo = p.nb * hhw;
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
     // statistics wanted (train-mode forward only), an affine / ReLU epilogue present (eval only), tile fully inside the output grid
     const bool want_stats = p.stats != nullptr;
     const bool has_affine = p.bias || p.scale || p.shift || p.relu;
-    const bool full_tile = (b0 + p.nb <= p.B) && (oy0 + (1 << p.th_log2) <= p.OH) && (ox0 + (1 << p.tw_log2) <= p.OW);
+    const bool full_tile = (b0 + p.nb <= p.B) && (oy0 + (1 << p.th_log2) <= p.OH) && ox0 >= 0 && (ox0 + (1 << p.tw_log2) <= p.OW);
     if (want_stats) {
         if (full_tile) {
             cntf = 16.f * MI;
@@ -404,7 +406,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
                     const int tx = m & ((1 << p.tw_log2) - 1);
                     const int ty = (m >> p.tw_log2) & ((1 << p.th_log2) - 1);
                     const int bl = m >> (p.tw_log2 + p.th_log2);
-                    const bool valid = (b0 + bl < p.B) && (oy0 + ty < p.OH) && (ox0 + tx < p.OW);
+                    const bool valid = (b0 + bl < p.B) && (oy0 + ty < p.OH) && (ox0 + tx < p.OW) && (ox0 + tx >= 0);
                     if (valid) { vmask[i] |= 1u << r; cntf += 1.f; }
                 }
             }
@@ -467,10 +469,21 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
             const int bl = m >> (p.tw_log2 + p.th_log2);
             const int oy = oy0 + ty, ox = ox0 + tx, b = b0 + bl;
             const int n = n0 + pc * VE;
-            if (b >= p.B || oy >= p.OH || ox >= p.OW || n >= p.Cout) continue;
+            if (b >= p.B || oy >= p.OH || ox >= p.OW || ox < 0 || n >= p.Cout) continue;
             T* dst = yg + (((int64_t)b * p.OHf + oy * p.out_step + p.out_oy) * p.OWf + ox * p.out_step + p.out_ox) * p.y_cs + n;
             bool accum = p.accumulate != 0;
             bool dvec = y_vec;
+            int fold_rows = 0, fold_cols = 0;                      // fused fold: ring pixels above / right of this edge pixel
+            if (p.fold_fused) {
+                // replicate-pad adjoint inside the tile: the pad ring (top rows, right columns of the extended grid) is never stored;
+                // the edge pixel it folds onto sums its ring pixels from the staged tile (the tile grid is laid out so that they
+                // share a tile: rows start at 0 with th > fold_top, columns at -ox_shift)
+                const int iy = oy - p.fold_top;
+                if (iy < 0 || ox >= p.OWf) continue;
+                dst = yg + (((int64_t)b * p.OHf + iy) * p.OWf + ox) * p.y_cs + n;
+                fold_rows = iy == 0 ? p.fold_top : 0;
+                fold_cols = ox == p.OWf - 1 ? p.fold_right : 0;
+            }
             if (p.strip) {                                         // fold mode: interior -> y (unpadded), pad ring -> strip
                 const int iy = oy - p.fold_top, ix = ox - p.fold_left;
                 if (iy >= 0 && iy < p.OHf && ix >= 0 && ix < p.OWf) {
@@ -482,7 +495,19 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
                     dvec = (p.strip_cs % VE) == 0;
                 }
             }
-            const u32x4 v = *reinterpret_cast<const u32x4*>(sO + m * PITCH + pc * VE);
+            u32x4 v = *reinterpret_cast<const u32x4*>(sO + m * PITCH + pc * VE);
+            if (fold_rows | fold_cols) {                           // host: fused fold implies whole aligned channel pieces
+                float f[VE], o[VE];
+                unpack16<T>(v, f);
+                for (int ky = 0; ky <= fold_rows; ++ky)
+                    for (int kx = 0; kx <= fold_cols; ++kx) {
+                        if ((ky | kx) == 0) continue;
+                        unpack16<T>(*reinterpret_cast<const u32x4*>(sO + (m - (ky << p.tw_log2) + kx) * PITCH + pc * VE), o);
+#pragma unroll
+                        for (int e = 0; e < VE; ++e) f[e] += o[e];
+                    }
+                v = pack16<T>(f);
+            }
             if (dvec && n + VE <= p.Cout) {
                 u32x4 stored = v;
                 if (accum) {
@@ -497,10 +522,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
                 if (bnb) {                                         // host: bnb implies whole aligned pieces, out_step 1, no strip
                     float g[VE], yc[VE];
                     unpack16<T>(stored, g);
-                    unpack16<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.bnb_y) + (((int64_t)b * p.OHf + oy) * p.OWf + ox) * p.bnb_cs + n), yc);
+                    unpack16<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.bnb_y) + (((int64_t)b * p.OHf + oy - (p.fold_fused ? p.fold_top : 0)) * p.OWf + ox) * p.bnb_cs + n), yc);
                     if (p.bnb_a) {                                 // residual layer: the mask is the sign of the forward output
                         float av[VE];
-                        unpack16<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.bnb_a) + (((int64_t)b * p.OHf + oy) * p.OWf + ox) * p.bnb_acs + n), av);
+                        unpack16<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.bnb_a) + (((int64_t)b * p.OHf + oy - (p.fold_fused ? p.fold_top : 0)) * p.OWf + ox) * p.bnb_acs + n), av);
 #pragma unroll
                         for (int e = 0; e < VE; ++e) {
                             const float gg = (!p.bnb_relu || av[e] > 0.f) ? g[e] : 0.f;
@@ -586,9 +611,587 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
     }
 }
 
-struct TileCfg { int id, MI, NI, WM, WN; };
+
+// ------------------------------------------------------------------------------------------ conv_glds_kernel (bf16, stride 1)
+// Second kernel of the family, for the layers whose cost is the staging, not the contraction (every 9.66-GFLOP ResNet layer,
+// the decoder layers): ONE 512-thread workgroup per CU that owns the whole LDS.
+//   * Staging is LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write pass.  A ring of NBUF chunk buffers
+//     (halo rows + the chunk's weights of all taps) is filled NBUF-1 chunks ahead; one raw s_barrier per chunk, counted vmcnt
+//     (never 0 inside the loop), so HBM/L2 latency is covered by the chunks in flight instead of by co-resident workgroups.
+//     The DMA destination is lane-linear (M0 + lane*16), so the XOR slot swizzle of the 64-byte rows is applied to the per-lane
+//     SOURCE address (slot s of row r holds channel slot s ^ (r>>2)); the fragment reads use the same involution.
+//   * The 8 waves are MB pixel blocks (32*MI pixels each) x KS K-slices: every wave accumulates a (32*MI) x BN block over ITS
+//     share of the (tap, k-step) stages of each chunk (register blocking MI x NI = 2 x 2: one ds_read_b128 per MFMA instead of
+//     two on the 128x32 tile), and the two waves of a SIMD (w, w+4) carry the two tap halves (5 + 4 taps), so every matrix
+//     pipe sees the same 9 taps.  After the loop the K-slices are reduced through the (then free) ring in fixed slice order.
+//   * Epilogue as in conv_mfma_kernel (bias / folded BN / ReLU / accumulate / BN partials / fold mode / BN-backward sums).
+// MFMA row -> pixel of a 32-pixel sub-tile.  ds_read_b128 is serviced in 16-lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31};
+// with the natural order (lane = 2 image rows x 16 pixels) a group reads LDS rows a..a+3, a+12..a+15 and hw+a+4..hw+a+11, and
+// because the halo pitch hw = 18 is not a multiple of 16 two of them share a bank (rows congruent mod 16): +50 % LDS cycles
+// (SQ_LDS_BANK_CONFLICT).  Permuting the blocks of 4 rows so that each lane group covers 16 CONSECUTIVE pixels of one image row
+// makes every fragment read conflict free for any tap shift.  Pure relabelling: the epilogue stages row m at pixel perm(m).
+__device__ __forceinline__ int lane_pixel_perm(int m) {                  // m in [0, 32)
+    return (int)((0x73261540u >> ((m >> 2) * 4)) & 0xfu) * 4 + (m & 3);
+}
+
+__device__ __forceinline__ void wait_vmcnt_upto(int n) {               // n is wave-uniform
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+        case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+        case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* glb_void_ptr;
+
+// halo rows (padded to 16) a tile may have: 128-pixel tiles <= 208 (8x16 pixels + 3x3 halo = 180, two 8x8 images = 200),
+// 256-pixel tiles <= 400 (16x16 + halo = 324, four 8x8 images = 400)
+constexpr int v2_namax(int bm) { return bm <= 128 ? 13 : 25; }
+// compile-time ablation switches of conv_glds_kernel (tools/build_variant.sh -DSALT_V2_DBG=N; 0 in the shipped library):
+// 1 no DMA, 2 no MFMA, 4 no fragment reads, 8 return after the main loop, 16 return after the prologue
+#ifndef SALT_V2_DBG
+#define SALT_V2_DBG 0
+#endif
+constexpr int DBG = SALT_V2_DBG;
+
+template <int MI, int NI, int MB, int KS, int NT>
+__global__ __launch_bounds__(512, 2) void conv_glds_kernel(ConvKP p) {
+    constexpr int NAMAX = v2_namax(32 * MI * MB);
+    typedef bf16_t T;
+    static_assert(MB * KS == 8, "8 waves");
+    static_assert(KS == 2 || KS == 4, "K slices");
+    constexpr int NTHR = 512, VE = 8, KCE = 32;
+    constexpr int BM = 32 * MI * MB, BN = 32 * NI;
+    constexpr int NSUB = MI * NI;                                        // 32x32 sub-blocks of a wave's block
+    constexpr int OWN = NSUB >= KS ? NSUB / KS : 1;                      // sub-blocks a wave finalises after the slice reduction
+    static_assert(NSUB >= KS ? (NSUB % KS == 0) : (KS % NSUB == 0), "slice reduction");
+    constexpr int T0N = (NT + 1) / 2;                                    // taps of the first tap half
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int khalf = lane >> 5, l31 = lane & 31;
+    const int mb = wave % MB, sl = wave / MB;
+    const int taphalf = sl / (KS / 2), hsel = sl % (KS / 2);
+
+    // ---- tile coordinates (same XCD-aware order as conv_mfma_kernel)
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int n_tile = local % p.n_tiles;
+    const int m_tile = (local / p.n_tiles) * 8 + xcd;
+    if (m_tile >= p.m_tiles) return;
+    int tile = m_tile;
+    const int txi = tile % p.tiles_x; tile /= p.tiles_x;
+    const int tyi = tile % p.tiles_y;
+    const int tbi = tile / p.tiles_y;
+    const int oy0 = tyi << p.th_log2, ox0 = (txi << p.tw_log2) - p.ox_shift, b0 = tbi * p.nb;
+    const int n0 = n_tile * BN;
+    const int hhw = p.hh * p.hw;
+    const int phalo = p.nb * hhw;
+    const int iy0 = oy0 + p.min_dy, ix0 = ox0 + p.min_dx;
+    const T* xg0 = reinterpret_cast<const T*>(p.x) + (int64_t)b0 * p.H * p.W * p.x_cs;
+    const T* wg = reinterpret_cast<const T*>(p.w);
+    const unsigned char* zp = reinterpret_cast<const unsigned char*>(g_zero_piece);
+
+    // ---- DMA slots.  A chunk is NA + NB wave-instructions of 1 KB (16 LDS rows each): NA halo pieces (rows padded to a multiple
+    // of 16; pad rows and out-of-image pixels read the zero piece) and NB weight pieces.  Wave w owns the wave-instructions
+    // w, w + 8, ...; EVERY wave issues exactly NS instructions per chunk - a surplus slot copies the zero piece into a per-wave
+    // scratch KB behind the ring - so the vmcnt bookkeeping is a compile-time constant and the issue is branch free: the slots ride
+    // between the MFMA stages (one or two per stage) instead of in a burst after the barrier, where all eight waves queued behind
+    // the CU's address path and nobody fed the matrix cores (measured: DMA time + MFMA time, no overlap at all).
+    constexpr int NB_I = NT * BN / 16;                                   // weight wave-instructions per chunk
+    constexpr int NS = (NAMAX + NB_I + 7) / 8;                           // DMA instructions per wave and chunk
+    const int na = p.a_bytes >> 10;                                      // halo wave-instructions (host: a_bytes = 1 KB * ceil(phalo / 16))
+    const int buf_bytes = p.a_bytes + NB_I * 1024;
+    const int nbuf = p.nbuf;                                             // ring depth (host: 2 or 3)
+    const int dummy_off = nbuf * buf_bytes + wave * 1024;
+    const int w_chunk_bytes = NT * p.Cout * KCE * (int)sizeof(T);
+    const unsigned char* d_src[NS];
+    int d_inc[NS], d_off[NS];                                            // d_off < 0: surplus slot (scratch destination)
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const int j = wave + 8 * i;
+        d_src[i] = zp; d_inc[i] = 0; d_off[i] = -1;
+        if (j < na) {
+            d_off[i] = j * 1024;
+            const int row = j * 16 + (lane >> 2);
+            if (row < phalo) {
+                const int bl = (int)__umulhi((unsigned)row, p.hhw_magic);
+                const int r = row - bl * hhw;
+                const int hy = (int)__umulhi((unsigned)r, p.hw_magic);
+                const int hx = r - hy * p.hw;
+                int iy = iy0 + hy, ix = ix0 + hx;
+                bool valid = b0 + bl < p.B;
+                if (p.pad_mode) { iy = min(max(iy, 0), p.H - 1); ix = min(max(ix, 0), p.W - 1); }
+                else valid = valid && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                if (valid) {
+                    const int slot = (lane ^ (row >> 2)) & 3;            // LDS slot lane&3 of row `row` holds channel slot `slot`
+                    d_src[i] = reinterpret_cast<const unsigned char*>(xg0 + ((bl * p.H + iy) * p.W + ix) * p.x_cs + slot * VE);
+                    d_inc[i] = KCE * (int)sizeof(T);
+                }
+            }
+        } else if (j < na + NB_I) {
+            d_off[i] = p.a_bytes + (j - na) * 1024;
+            const int row = (j - na) * 16 + (lane >> 2);                 // t * BN + n
+            const int t = row / BN, n = row - t * BN;
+            if (n0 + n < p.Cout) {
+                const int slot = (lane ^ (n >> 2)) & 3;                  // BN % 16 == 0: (row >> 2) & 3 == (n >> 2) & 3
+                d_src[i] = reinterpret_cast<const unsigned char*>(wg + ((int64_t)t * p.Cout + n0 + n) * KCE + slot * VE);
+                d_inc[i] = w_chunk_bytes;
+            }
+        }
+    }
+    // issue slot i of the next chunk into ring slot `buf` (`live` false past the last chunk: zero piece -> scratch, same count)
+    auto issue_slot = [&](int i, int buf, bool live) {                   // i is a constant after unrolling
+        if (DBG & 1) return;
+        const bool real = live && d_off[i] >= 0;
+        const int dst = real ? buf * buf_bytes + d_off[i] : dummy_off;
+        const unsigned char* src = live ? d_src[i] : zp;
+        __builtin_amdgcn_global_load_lds((glb_void_ptr)src, (lds_void_ptr)(smem + dst), 16, 0, 0);
+        d_src[i] += d_inc[i];
+    };
+
+    // ---- fragment addressing
+    const bool perm = p.tw_log2 == 4;                                    // 16-pixel tile rows: conflict-free lane -> pixel order
+    int pbase[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = (mb * MI + i) * 32 + (perm ? lane_pixel_perm(l31) : l31);
+        const int tx = m & ((1 << p.tw_log2) - 1);
+        const int ty = (m >> p.tw_log2) & ((1 << p.th_log2) - 1);
+        const int bl = m >> (p.tw_log2 + p.th_log2);
+        pbase[i] = bl * hhw + ty * p.hw + tx;
+    }
+    int b_addr[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) b_addr[j] = p.a_bytes + swz_addr(j * 32 + l31, khalf);
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    struct Frag { u32x4 a[MI], b[NI]; };
+    auto mma_frag = [&](const Frag& f) {
+        if (DBG & 2) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[i][j][0] += __uint_as_float(f.a[i].x ^ f.b[j].y);
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.a[i]), __builtin_bit_cast(bf16x8, f.b[j]), acc[i][j], 0, 0, 0);
+    };
+
+    // main loop body for one tap half (TA .. TB-1 compile-time); KS == 2: both k-steps, KS == 4: the k-step hsel
+    auto run = [&](auto ta_c, auto tb_c) {
+        constexpr int TA = decltype(ta_c)::value, TB = decltype(tb_c)::value, NTL = TB - TA;
+        constexpr int NST = NTL * (KS == 2 ? 2 : 1);                     // stages per chunk of this wave
+        int a_addr[NTL][MI];
+#pragma unroll
+        for (int t = 0; t < NTL; ++t)
+#pragma unroll
+            for (int i = 0; i < MI; ++i) a_addr[t][i] = swz_addr(pbase[i] + p.tap_off[TA + t], khalf);
+        const int hx4 = (KS == 4) ? (hsel << 5) : 0;
+        auto load_frag = [&](int s, const unsigned char* base, Frag& f) {  // s is a constant after unrolling
+            const int tl = (KS == 2) ? (s >> 1) : s;
+            const int hx = (KS == 2) ? ((s & 1) << 5) : hx4;
+            if (DBG & 4) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) f.a[i] = u32x4{(unsigned)tl, 1u, 2u, 3u};
+#pragma unroll
+                for (int j = 0; j < NI; ++j) f.b[j] = u32x4{(unsigned)hx, 5u, 6u, 7u};
+                return;
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i) f.a[i] = *reinterpret_cast<const u32x4*>(base + (a_addr[tl][i] ^ hx));
+#pragma unroll
+            for (int j = 0; j < NI; ++j) f.b[j] = *reinterpret_cast<const u32x4*>(base + (TA + tl) * (BN * 64) + (b_addr[j] ^ hx));
+        };
+        // prologue: ring depth - 1 chunks in flight
+#pragma unroll 1
+        for (int c0 = 0; c0 < nbuf - 1; ++c0) {
+            const bool live = c0 < p.nchunk;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) issue_slot(i, c0, live);
+        }
+        int slot_c = 0, slot_i = nbuf - 1;                                // ring slot being computed / filled
+        for (int c = 0; c < p.nchunk; ++c) {
+            // chunk c landed: this wave's share by the counted vmcnt (the nbuf - 2 younger chunks may stay in flight), everybody's
+            // by the barrier; the barrier also says every wave is done reading the slot the DMA below overwrites (chunk c-1's)
+            if (!(DBG & 1)) {
+                if (nbuf == 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NS) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const bool live = c + nbuf - 1 < p.nchunk;
+            const int fill = slot_i;
+            slot_i = (slot_i + 1 == nbuf) ? 0 : slot_i + 1;
+            const unsigned char* base = smem + slot_c * buf_bytes;
+            slot_c = (slot_c + 1 == nbuf) ? 0 : slot_c + 1;
+            Frag f0, f1;
+            load_frag(0, base, f0);
+            __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
+            constexpr int SPS = (NS + NST - 1) / NST;                    // DMA slots per stage
+#pragma unroll
+            for (int s = 0; s < NST; s += 2) {
+                if (s + 1 < NST) load_frag(s + 1, base, f1);
+#pragma unroll
+                for (int u = 0; u < SPS; ++u) if (s * SPS + u < NS) issue_slot(s * SPS + u, fill, live);
+                mma_frag(f0);
+                if (s + 1 < NST) __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
+                if (!(DBG & 1)) __builtin_amdgcn_sched_group_barrier(0x010, SPS, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, MI * NI, 0);
+                if (s + 1 < NST) {
+                    if (s + 2 < NST) load_frag(s + 2, base, f0);
+#pragma unroll
+                    for (int u = 0; u < SPS; ++u) if ((s + 1) * SPS + u < NS) issue_slot((s + 1) * SPS + u, fill, live);
+                    mma_frag(f1);
+                    if (s + 2 < NST) __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
+                    if (!(DBG & 1)) __builtin_amdgcn_sched_group_barrier(0x010, SPS, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, MI * NI, 0);
+                }
+            }
+        }
+    };
+    if (DBG & 16) { if (tid == 0 && blockIdx.x == 0x7fffffff) reinterpret_cast<int*>(p.y)[0] = pbase[0] + (int)(size_t)d_src[0] + d_off[1] + b_addr[0]; return; }
+    if (taphalf == 0) run(std::integral_constant<int, 0>{}, std::integral_constant<int, T0N>{});
+    else run(std::integral_constant<int, T0N>{}, std::integral_constant<int, NT>{});
+    if (DBG & 8) {
+        float tsum = 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tsum += acc[i][j][r];
+        if (tsum == 123.456f) reinterpret_cast<float*>(p.y)[0] = tsum;
+        return;
+    }
+
+    // ---- K-slice reduction through LDS (the ring is free): sub-block u of a pixel block is finalised by slice u % KS (NSUB >= KS)
+    // or by slice u (NSUB < KS); partial sums are added in ascending slice order whatever the owner is (deterministic)
+    f32x16 fin[OWN];
+    int rowoff[OWN], coloff[OWN];
+    bool owner;
+    {
+        float* red = reinterpret_cast<float*>(smem);                     // [mb][u][slice][16][64] floats
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                                 // every wave is done with the ring
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int u = i * NI + j;
+                const int own_sl = NSUB >= KS ? (u % KS) : u;
+                if (sl != own_sl) {
+                    float* dst = red + ((((mb * NSUB + u) * KS + sl) * 16) * 64) + lane * 4;
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        const f32x4 v = {acc[i][j][r4 * 4], acc[i][j][r4 * 4 + 1], acc[i][j][r4 * 4 + 2], acc[i][j][r4 * 4 + 3]};
+                        *reinterpret_cast<f32x4*>(dst + r4 * 256) = v;
+                    }
+                }
+            }
+        __syncthreads();
+        owner = NSUB >= KS ? true : (sl < NSUB);
+#pragma unroll
+        for (int o = 0; o < OWN; ++o) {
+            // NSUB >= KS: owned sub-blocks u = sl + o * KS;  NSUB < KS: u = sl (owners only)
+            const int u = NSUB >= KS ? (sl + o * KS) : (sl < NSUB ? sl : 0);
+            const int i = u / NI, j = u % NI;
+            rowoff[o] = (mb * MI + i) * 32; coloff[o] = j * 32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) fin[o][r] = 0.f;
+            if (owner) {
+#pragma unroll
+                for (int s2 = 0; s2 < KS; ++s2) {
+                    if (s2 == sl) {
+                        // own partial: select acc[i][j] with compile-time indices
+#pragma unroll
+                        for (int ii = 0; ii < MI; ++ii)
+#pragma unroll
+                            for (int jj = 0; jj < NI; ++jj)
+                                if (ii * NI + jj == u) {
+#pragma unroll
+                                    for (int r = 0; r < 16; ++r) fin[o][r] += acc[ii][jj][r];
+                                }
+                    } else {
+                        const float* src = red + ((((mb * NSUB + u) * KS + s2) * 16) * 64) + lane * 4;
+#pragma unroll
+                        for (int r4 = 0; r4 < 4; ++r4) {
+                            const f32x4 v = *reinterpret_cast<const f32x4*>(src + r4 * 256);
+                            fin[o][r4 * 4] += v.x; fin[o][r4 * 4 + 1] += v.y; fin[o][r4 * 4 + 2] += v.z; fin[o][r4 * 4 + 3] += v.w;
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    if (DBG & 32) {
+        float tsum = 0.f;
+#pragma unroll
+        for (int o = 0; o < OWN; ++o)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tsum += fin[o][r];
+        if (tsum == 123.456f) reinterpret_cast<float*>(p.y)[0] = tsum;
+        return;
+    }
+    // ---- epilogue (conv_mfma_kernel's, generalised to "a wave owns OWN 32x32 sub-blocks at (rowoff, coloff)" and 512 threads)
+    constexpr int PITCH = BN + 16 / (int)sizeof(T);
+    constexpr int PPO = BN / VE;
+    constexpr int RB = BM / 32;                                          // 32-row blocks of the tile
+    T* sO = reinterpret_cast<T*>(smem);
+    float ssum[OWN], cntf[OWN];
+    unsigned vmask[OWN];
+#pragma unroll
+    for (int o = 0; o < OWN; ++o) { ssum[o] = 0.f; cntf[o] = 0.f; vmask[o] = 0xffffu; }
+    const bool want_stats = p.stats != nullptr;
+    const bool has_affine = p.bias || p.scale || p.shift || p.relu;
+    const bool full_tile = (b0 + p.nb <= p.B) && (oy0 + (1 << p.th_log2) <= p.OH) && ox0 >= 0 && (ox0 + (1 << p.tw_log2) <= p.OW);
+    if (want_stats) {
+#pragma unroll
+        for (int o = 0; o < OWN; ++o) {
+            if (full_tile) { cntf[o] = 16.f; }
+            else {
+                vmask[o] = 0u;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int mr = (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                    const int m = rowoff[o] + (perm ? lane_pixel_perm(mr) : mr);
+                    const int tx = m & ((1 << p.tw_log2) - 1);
+                    const int ty = (m >> p.tw_log2) & ((1 << p.th_log2) - 1);
+                    const int bl = m >> (p.tw_log2 + p.th_log2);
+                    const bool valid = (b0 + bl < p.B) && (oy0 + ty < p.OH) && (ox0 + tx < p.OW) && (ox0 + tx >= 0);
+                    if (valid) { vmask[o] |= 1u << r; cntf[o] += 1.f; }
+                }
+            }
+        }
+    }
+    __syncthreads();                                                     // the reduction scratch has been read
+    if (owner) {
+#pragma unroll
+        for (int o = 0; o < OWN; ++o) {
+            float bias = 0.f, sc = 1.f, sh = 0.f;
+            const int n = n0 + coloff[o] + l31;
+            if (has_affine) {
+                const bool nok = n < p.Cout;
+                bias = (nok && p.bias) ? p.bias[n] : 0.f;
+                sc = (nok && p.scale) ? p.scale[n] : 1.f;
+                sh = (nok && p.shift) ? p.shift[n] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = fin[o][r];
+                if (has_affine) {
+                    v = (v + bias) * sc + sh;
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    fin[o][r] = v;
+                }
+                if (want_stats && ((vmask[o] >> r) & 1u)) ssum[o] += v;
+                const int mr = (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                const int ml = rowoff[o] + (perm ? lane_pixel_perm(mr) : mr);
+                Elem<T>::st(sO + ml * PITCH + coloff[o] + l31, v);
+            }
+        }
+    }
+    __syncthreads();
+    {
+        T* yg = reinterpret_cast<T*>(p.y);
+        const bool y_vec = ((p.y_cs % VE) == 0) && ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0);
+        const bool bnb = p.bnb_partials != nullptr;
+        float b1[VE], b2[VE], bmu[VE], bis[VE], bsc[VE], bsh[VE];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) { b1[e] = 0.f; b2[e] = 0.f; bmu[e] = 0.f; bis[e] = 0.f; bsc[e] = 0.f; bsh[e] = 0.f; }
+        if (bnb) {
+            const int nb0 = n0 + (tid % PPO) * VE;
+#pragma unroll
+            for (int e = 0; e < VE; ++e)
+                if (nb0 + e < p.Cout) {
+                    bmu[e] = p.bnb_mean[nb0 + e]; bis[e] = p.bnb_invstd[nb0 + e];
+                    bsc[e] = p.bnb_gamma[nb0 + e] * bis[e]; bsh[e] = p.bnb_beta[nb0 + e] - bmu[e] * bsc[e];
+                }
+        }
+        if (DBG & 64) { if (sO[tid] == 12345) reinterpret_cast<T*>(p.y)[0] = sO[tid + 1]; return; }
+        for (int q = tid; q < BM * PPO; q += NTHR) {
+            const int m = q / PPO, pc = q - m * PPO;
+            const int tx = m & ((1 << p.tw_log2) - 1);
+            const int ty = (m >> p.tw_log2) & ((1 << p.th_log2) - 1);
+            const int bl = m >> (p.tw_log2 + p.th_log2);
+            const int oy = oy0 + ty, ox = ox0 + tx, b = b0 + bl;
+            const int n = n0 + pc * VE;
+            if (b >= p.B || oy >= p.OH || ox >= p.OW || ox < 0 || n >= p.Cout) continue;
+            T* dst = yg + (((int64_t)b * p.OHf + oy * p.out_step + p.out_oy) * p.OWf + ox * p.out_step + p.out_ox) * p.y_cs + n;
+            bool accum = p.accumulate != 0;
+            bool dvec = y_vec;
+            int fold_rows = 0, fold_cols = 0;                      // fused fold: ring pixels above / right of this edge pixel
+            if (p.fold_fused) {
+                // replicate-pad adjoint inside the tile: the pad ring (top rows, right columns of the extended grid) is never stored;
+                // the edge pixel it folds onto sums its ring pixels from the staged tile (the tile grid is laid out so that they
+                // share a tile: rows start at 0 with th > fold_top, columns at -ox_shift)
+                const int iy = oy - p.fold_top;
+                if (iy < 0 || ox >= p.OWf) continue;
+                dst = yg + (((int64_t)b * p.OHf + iy) * p.OWf + ox) * p.y_cs + n;
+                fold_rows = iy == 0 ? p.fold_top : 0;
+                fold_cols = ox == p.OWf - 1 ? p.fold_right : 0;
+            }
+            if (p.strip) {
+                const int iy = oy - p.fold_top, ix = ox - p.fold_left;
+                if (iy >= 0 && iy < p.OHf && ix >= 0 && ix < p.OWf) {
+                    dst = yg + (((int64_t)b * p.OHf + iy) * p.OWf + ix) * p.y_cs + n;
+                } else {
+                    const int64_t ring = (int64_t)(p.fold_top + p.fold_bottom) * p.OW + (int64_t)p.OHf * (p.fold_left + p.fold_right);
+                    dst = reinterpret_cast<T*>(p.strip) + ((int64_t)b * ring + fold_ring_index(oy, ox, p.OHf, p.OWf, p.fold_top, p.fold_bottom, p.fold_left, p.fold_right)) * p.strip_cs + n;
+                    accum = false;
+                    dvec = (p.strip_cs % VE) == 0;
+                }
+            }
+            u32x4 v = *reinterpret_cast<const u32x4*>(sO + m * PITCH + pc * VE);
+            if (fold_rows | fold_cols) {                           // host: fused fold implies whole aligned channel pieces
+                float f[VE], o[VE];
+                unpack16<T>(v, f);
+                for (int ky = 0; ky <= fold_rows; ++ky)
+                    for (int kx = 0; kx <= fold_cols; ++kx) {
+                        if ((ky | kx) == 0) continue;
+                        unpack16<T>(*reinterpret_cast<const u32x4*>(sO + (m - (ky << p.tw_log2) + kx) * PITCH + pc * VE), o);
+#pragma unroll
+                        for (int e = 0; e < VE; ++e) f[e] += o[e];
+                    }
+                v = pack16<T>(f);
+            }
+            if (dvec && n + VE <= p.Cout) {
+                u32x4 stored = v;
+                if (accum) {
+                    float f[VE], o[VE];
+                    unpack16<T>(v, f);
+                    unpack16<T>(*reinterpret_cast<const u32x4*>(dst), o);
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) f[e] += o[e];
+                    stored = pack16<T>(f);
+                }
+                *reinterpret_cast<u32x4*>(dst) = stored;
+                if (bnb) {
+                    float g[VE], yc[VE];
+                    unpack16<T>(stored, g);
+                    unpack16<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.bnb_y) + (((int64_t)b * p.OHf + oy - (p.fold_fused ? p.fold_top : 0)) * p.OWf + ox) * p.bnb_cs + n), yc);
+                    if (p.bnb_a) {
+                        float av[VE];
+                        unpack16<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.bnb_a) + (((int64_t)b * p.OHf + oy - (p.fold_fused ? p.fold_top : 0)) * p.OWf + ox) * p.bnb_acs + n), av);
+#pragma unroll
+                        for (int e = 0; e < VE; ++e) {
+                            const float gg = (!p.bnb_relu || av[e] > 0.f) ? g[e] : 0.f;
+                            b1[e] += gg; b2[e] += gg * (yc[e] - bmu[e]) * bis[e];
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < VE; ++e) {
+                            const float gg = (!p.bnb_relu || yc[e] * bsc[e] + bsh[e] > 0.f) ? g[e] : 0.f;
+                            b1[e] += gg; b2[e] += gg * (yc[e] - bmu[e]) * bis[e];
+                        }
+                    }
+                }
+            } else {
+                float f[VE];
+                unpack16<T>(v, f);
+#pragma unroll
+                for (int e = 0; e < VE; ++e)
+                    if (n + e < p.Cout) Elem<T>::st(dst + e, accum ? f[e] + Elem<T>::ld(dst + e) : f[e]);
+            }
+        }
+        if (bnb) {
+            float* sR = reinterpret_cast<float*>(smem);
+            const int row = tid / PPO, cl0 = (tid % PPO) * VE;
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < VE; ++e) { sR[(row * BN + cl0 + e) * 2] = b1[e]; sR[(row * BN + cl0 + e) * 2 + 1] = b2[e]; }
+            __syncthreads();
+            for (int e = tid; e < 2 * BN; e += NTHR) {
+                const int st = e >= BN ? 1 : 0, cl = e - st * BN;
+                float t = 0.f;
+                for (int r = 0; r < NTHR / PPO; ++r) t += sR[(r * BN + cl) * 2 + st];
+                if (n0 + cl < p.Cout) p.bnb_partials[((int64_t)m_tile * 2 + st) * p.Cout + n0 + cl] = t;
+            }
+        }
+    }
+    if (p.stats) {
+        // per 32-row block and channel: (sum, M2 about the block's own mean, count), merged over the tile's RB blocks in fixed order
+        float* sS = reinterpret_cast<float*>(smem);                      // [RB][BN][2] then [RB] counts
+        float* sC = sS + RB * BN * 2;
+        __syncthreads();
+        if (owner) {
+#pragma unroll
+            for (int o = 0; o < OWN; ++o) {
+                const float cnt = cntf[o] + __shfl_xor(cntf[o], 32);
+                const float s = ssum[o] + __shfl_xor(ssum[o], 32);
+                const float mean = cnt > 0.f ? s / cnt : 0.f;
+                float m2 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if ((vmask[o] >> r) & 1u) { const float d = fin[o][r] - mean; m2 += d * d; }
+                m2 += __shfl_xor(m2, 32);
+                const int rb = rowoff[o] >> 5;
+                if (khalf == 0) { sS[(rb * BN + coloff[o] + l31) * 2 + 0] = s; sS[(rb * BN + coloff[o] + l31) * 2 + 1] = m2; }
+                if (lane == 0 && coloff[o] == 0) sC[rb] = cnt;
+            }
+        }
+        __syncthreads();
+        const int part = p.stats_part0 + m_tile;
+        if (tid < BN) {
+            float N = 0.f, S = 0.f, M2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < RB; ++w) {
+                const float nk = sC[w];
+                if (nk > 0.f) {
+                    const float sk = sS[(w * BN + tid) * 2 + 0], mk = sS[(w * BN + tid) * 2 + 1];
+                    if (N == 0.f) { N = nk; S = sk; M2 = mk; }
+                    else {
+                        const float d = sk / nk - S / N;
+                        M2 += mk + d * d * (N * nk / (N + nk));
+                        S += sk; N += nk;
+                    }
+                }
+            }
+            const int n = n0 + tid;
+            if (n < p.Cout) {
+                p.stats[((int64_t)part * 2 + 0) * p.Cout + n] = S;
+                p.stats[((int64_t)part * 2 + 1) * p.Cout + n] = M2;
+            }
+            if (tid == 0 && n_tile == 0) p.stats_cnt[part] = N;
+        }
+    }
+}
+
+struct TileCfg { int id, MI, NI, WM, WN, KS; };   // KS > 0: conv_glds_kernel (WM = pixel blocks MB, WN = 1)
 // id -> (BM, BN): 1: 128x64, 2: 256x64, 3: 128x128, 4: 128x32, 5: 64x64
-const TileCfg kCfgs[] = {{1, 2, 1, 2, 2}, {2, 2, 2, 4, 1}, {3, 2, 2, 2, 2}, {4, 1, 1, 4, 1}, {5, 1, 1, 2, 2}};
+// conv_glds_kernel: 6: 256x64 (4 blocks x 2 slices), 7: 128x64 (2 x 4), 8: 128x32 (2 x 4)
+const TileCfg kCfgs[] = {{1, 2, 1, 2, 2, 0}, {2, 2, 2, 4, 1, 0}, {3, 2, 2, 2, 2, 0}, {4, 1, 1, 4, 1, 0}, {5, 1, 1, 2, 2, 0},
+                         {6, 2, 2, 4, 1, 2}, {7, 2, 2, 2, 1, 4}, {8, 2, 1, 2, 1, 4}};
 
 struct Plan {
     TileCfg cfg; ConvKP kp; dim3 grid; size_t lds; int parts;
@@ -600,7 +1203,16 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
     if (a->ntaps < 1 || a->ntaps > SALT_MAX_TAPS) SALT_FAIL(SALT_E_BADARG, "conv: ntaps %d", a->ntaps);
     if (a->in_step < 1 || a->in_step > 2 || a->out_step < 1 || a->out_step > 2) SALT_FAIL(SALT_E_BADARG, "conv: steps");
     if (a->OH < 1 || a->OW < 1) SALT_FAIL(SALT_E_BADARG, "conv: empty output grid");
-    if (!a->strip && ((a->OH - 1) * a->out_step + a->out_oy >= a->y.H || (a->OW - 1) * a->out_step + a->out_ox >= a->y.W))
+    const bool fold_fused = !a->strip && (a->fold_top > 0 || a->fold_right > 0);
+    if (fold_fused) {
+        const int ve = a->dtype == SALT_F32 ? 4 : 8;
+        if (a->fold_bottom || a->fold_left || a->fold_top < 0 || a->fold_right < 0 || a->out_step != 1 || a->out_oy || a->out_ox || a->stats ||
+            a->OH != a->y.H + a->fold_top || a->OW != a->y.W + a->fold_right)
+            SALT_FAIL(SALT_E_BADARG, "conv: fused fold needs OH/OW = y.H + top / y.W + right (top / right pads only), out_step 1, no stats");
+        if (a->y.C % ve || a->y.cs % ve || (reinterpret_cast<uintptr_t>(a->y.p) & 15))
+            SALT_FAIL(SALT_E_BADARG, "conv: fused fold needs 16-byte aligned whole channel pieces");
+    }
+    if (!a->strip && !fold_fused && ((a->OH - 1) * a->out_step + a->out_oy >= a->y.H || (a->OW - 1) * a->out_step + a->out_ox >= a->y.W))
         SALT_FAIL(SALT_E_BADARG, "conv: output grid exceeds buffer");
     if (a->x.B != a->y.B) SALT_FAIL(SALT_E_BADARG, "conv: batch mismatch");
     const int Cout = a->y.C;
@@ -614,9 +1226,29 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
     const int KCE_ = a->dtype == SALT_F32 ? 16 : 32;
     static const bool vt_off = getenv("SALT_CONV_NO_VT") != nullptr;
     const int vt = (!vt_off && a->ntaps == 1 && a->in_step == 1 && a->x.C % (4 * KCE_) == 0) ? 4 : 1;
+    // ---- conv_glds_kernel (one 512-thread workgroup per CU, LDS-DMA ring): bf16, unit input step, 9 or 4 real taps, whole aligned
+    // 64-byte channel chunks.  Decided from the geometry only (salt_conv_stats_parts plans with the same rule before the epilogue
+    // fields are known).
+    static const int v2_env = getenv("SALT_CONV_V2") ? atoi(getenv("SALT_CONV_V2")) : 1;     // 0: off, N >= 6: force config N
+    const bool v2_ok = a->dtype == SALT_BF16 && a->in_step == 1 && (a->ntaps == 9 || a->ntaps == 4) && a->x.C % 32 == 0 &&
+                       a->x.cs % 8 == 0 && (reinterpret_cast<uintptr_t>(a->x.p) & 15) == 0;
     // ---- tile config heuristic (overridable for tests/tuning)
     int id = a->cfg;
+    if (id >= 6 && !v2_ok) id = 0;            // a forced conv_glds config applies where the kernel does (tests force one config per graph)
     if (id == 2 && vt > 1) id = 1;            // 256-pixel tiles x 4 virtual taps exceed the halo-piece budget
+    if (id == 0 && v2_ok && v2_env && a->cfg == 0) {
+        if (v2_env >= 6) id = v2_env;
+        else {
+            // measured (tools/v2_sweep.sh, tools/v2_ablate.sh): the LDS-DMA kernel wins where conv_mfma_kernel's 128x32 tiles cannot
+            // fill the chip with 64-channel tiles - the 8x8 maps (2048-3200 pixels, 512-768 channels: 24.0 -> 18.1 us) - ties on the
+            // 16x16 / 32x32 maps and loses on the large maps, whose few channel chunks leave nothing to pipeline.  1 (default): the
+            // few-pixel layers only; 2: + the 16x16 maps; 3: every eligible layer.
+            const int64_t t256 = ((pixels + 255) / 256) * cdiv(Cout, 64), t128 = ((pixels + 127) / 128) * cdiv(Cout, 64);
+            if (t128 < 192 && Cout > 32) id = 8;
+            else if (v2_env >= 2 && t256 < 256 && Cout > 32) id = 7;
+            else if (v2_env >= 3) id = Cout <= 32 ? 8 : (t256 >= 256 ? 6 : 7);
+        }
+    }
     if (id == 0) {
         const bool big = a->in_step == 1 && a->OH >= 16 && a->OW >= 16 && pixels >= 256 * 256 * 2;
         if (Cout <= 32) id = 4;
@@ -642,6 +1274,17 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
         k.hh = (th - 1) * a->in_step + (max_dy - min_dy) + 1;
         k.hw = (tw - 1) * a->in_step + (max_dx - min_dx) + 1;
         const int phalo = k.nb * k.hh * k.hw * vt;
+        if (cfg->KS > 0) {
+            // LDS-DMA ring: halo rows + the chunk's weights of all taps per slot, 3 slots when they fit (2 chunks in flight), else 2
+            // (halo rows padded to whole 1-KB DMA instructions; 8 KB behind the ring take the surplus slots' copies)
+            const int64_t buf = (int64_t)cdiv(phalo, 16) * 1024 + (int64_t)a->ntaps * (32 * cfg->NI) * 64;
+            k.nbuf = 3 * buf + 8192 <= 160 * 1024 ? 3 : 2;
+            if (cdiv(phalo, 16) > v2_namax(BM) || 2 * buf + 8192 > 160 * 1024) {
+                if (attempt == 0 && cfg->id != 8) { for (const auto& c : kCfgs) if (c.id == 8) cfg = &c; continue; }
+                SALT_FAIL(SALT_E_UNSUPPORTED, "conv: halo tile of %d pixels too large for the LDS ring", phalo);
+            }
+            break;
+        }
         if (phalo * 4 > maxa_for(BM) * 256) {
             if (attempt == 0 && cfg->id != 5) { for (const auto& c : kCfgs) if (c.id == 5) cfg = &c; continue; }
             SALT_FAIL(SALT_E_UNSUPPORTED, "conv: halo tile of %d pixels too large", phalo);
@@ -661,10 +1304,15 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
     for (int t = 0; t < a->ntaps; ++t) k.tap_off[t] = (a->tap_dy[t] - min_dy) * k.hw + (a->tap_dx[t] - min_dx);
     k.vt = vt;
     if (vt > 1) { k.ntaps = vt; for (int t = 0; t < vt; ++t) k.tap_off[t] = t * k.nb * k.hh * k.hw; }
-    k.tiles_y = cdiv(a->OH, 1 << k.th_log2); k.tiles_x = cdiv(a->OW, 1 << k.tw_log2);
+    k.fold_fused = fold_fused ? 1 : 0;
+    k.ox_shift = (fold_fused && a->fold_right > 0) ? (1 << k.tw_log2) - a->fold_right : 0;
+    if (fold_fused && ((1 << k.th_log2) <= a->fold_top || (1 << k.tw_log2) <= a->fold_right))
+        SALT_FAIL(SALT_E_UNSUPPORTED, "conv: fused fold needs tiles larger than the pad (%d x %d)", 1 << k.th_log2, 1 << k.tw_log2);
+    k.tiles_y = cdiv(a->OH, 1 << k.th_log2); k.tiles_x = cdiv(a->OW + k.ox_shift, 1 << k.tw_log2);
     const int tiles_b = cdiv(a->x.B, k.nb);
     k.nchunk = cdiv(a->x.C, KCE * vt);
     k.a_bytes = k.nb * k.hh * k.hw * 64 * vt;
+    if (cfg->KS > 0) k.a_bytes = cdiv(k.nb * k.hh * k.hw, 16) * 1024;
     k.hhw_magic = (unsigned)((1ull << 32) / (unsigned)(k.hh * k.hw)) + 1u;
     k.hw_magic = (unsigned)((1ull << 32) / (unsigned)k.hw) + 1u;
     k.relu = a->relu; k.accumulate = a->accumulate; k.stats_part0 = a->stats_part0;
@@ -672,6 +1320,11 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
     k.m_tiles = tiles_b * k.tiles_y * k.tiles_x; k.n_tiles = cdiv(Cout, BN);
     pl->grid = dim3((unsigned)(cdiv(k.m_tiles, 8) * 8 * k.n_tiles), 1, 1);
     pl->lds = (size_t)k.a_bytes + (size_t)k.ntaps * BN * 64;
+    if (cfg->KS > 0) {
+        pl->lds = pl->lds * (size_t)k.nbuf + 8192;
+        const size_t red = (size_t)cfg->WM * (cfg->MI * cfg->NI) * cfg->KS * 4096;       // K-slice reduction scratch
+        if (red > pl->lds) pl->lds = red;
+    }
     {   // the epilogue stages the BM x BN output tile through the same LDS
         const size_t es = a->dtype == SALT_F32 ? 4 : 2;
         const size_t out_bytes = (size_t)(32 * cfg->MI * cfg->WM) * (BN * es + 16);
@@ -683,8 +1336,8 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
     k.bnb_mean = a->bnb_mean; k.bnb_invstd = a->bnb_invstd; k.bnb_gamma = a->bnb_gamma; k.bnb_beta = a->bnb_beta;
     if (a->bnb_partials) {
         const int ve = a->dtype == SALT_F32 ? 4 : 8;
-        if (a->strip || a->stats || a->out_step != 1 || a->out_oy || a->out_ox || a->OH != a->y.H || a->OW != a->y.W)
-            SALT_FAIL(SALT_E_BADARG, "conv: BatchNorm-backward sums need a plain full-grid launch");
+        if (a->strip || a->stats || a->out_step != 1 || a->out_oy || a->out_ox || (!fold_fused && (a->OH != a->y.H || a->OW != a->y.W)))
+            SALT_FAIL(SALT_E_BADARG, "conv: BatchNorm-backward sums need a plain (or fused-fold) full-grid launch");
         if (!view_ok(a->bnb_y) || a->bnb_y.B != a->y.B || a->bnb_y.H != a->y.H || a->bnb_y.W != a->y.W || a->bnb_y.C != a->y.C)
             SALT_FAIL(SALT_E_BADARG, "conv: bnb_y shape");
         if (!a->bnb_mean || !a->bnb_invstd || !a->bnb_gamma || !a->bnb_beta) SALT_FAIL(SALT_E_BADARG, "conv: bnb parameters missing");
@@ -693,7 +1346,7 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
             SALT_FAIL(SALT_E_BADARG, "conv: bnb_a shape / alignment");
         if (Cout % ve || a->y.cs % ve || a->bnb_y.cs % ve || ((reinterpret_cast<uintptr_t>(a->y.p) | reinterpret_cast<uintptr_t>(a->bnb_y.p)) & 15))
             SALT_FAIL(SALT_E_BADARG, "conv: BatchNorm-backward sums need 16-byte aligned whole channel pieces");
-        const size_t red_bytes = (size_t)(256 / (BN / ve)) * BN * 2 * sizeof(float);
+        const size_t red_bytes = (size_t)((cfg->KS > 0 ? 512 : 256) / (BN / ve)) * BN * 2 * sizeof(float);
         if (red_bytes > pl->lds) pl->lds = red_bytes;
     }
     if (pl->lds > 160 * 1024) SALT_FAIL(SALT_E_LDS, "conv: needs %zu bytes of LDS", pl->lds);
@@ -735,8 +1388,32 @@ int launch_cfg(const Plan& pl, hipStream_t st) {
     return launch_cfg_nt<T, MI, NI, WM, WN, 0>(pl, st);
 }
 
+template <int MI, int NI, int MB, int KS>
+int launch_glds(const Plan& pl, hipStream_t st) {
+    auto go = [&](auto kern, bool& attr_set) -> int {
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) SALT_FAIL((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, pl.grid, dim3(512), pl.lds, st, pl.kp);
+        SALT_CHECK_LAUNCH();
+        return SALT_OK;
+    };
+    static bool set9 = false, set4 = false;                  // per template instantiation
+    if (pl.kp.ntaps == 9) return go(conv_glds_kernel<MI, NI, MB, KS, 9>, set9);
+    return go(conv_glds_kernel<MI, NI, MB, KS, 4>, set4);
+}
+
 template <typename T>
 int launch_T(const Plan& pl, hipStream_t st) {
+    if constexpr (sizeof(T) == 2) {
+        switch (pl.cfg.id) {
+            case 6: return launch_glds<2, 2, 4, 2>(pl, st);
+            case 7: return launch_glds<2, 2, 2, 4>(pl, st);
+            case 8: return launch_glds<2, 1, 2, 4>(pl, st);
+        }
+    }
     switch (pl.cfg.id) {
         case 1: return launch_cfg<T, 2, 1, 2, 2>(pl, st);
         case 2: return launch_cfg<T, 2, 2, 4, 1>(pl, st);

@@ -106,15 +106,37 @@ __global__ void affine_act_kernel(salt_view y, const float* scale, const float* 
 // The kernel is latency-bound (a few hundred KB at most), so the layout maximises loads in flight: 256 threads = ROWS part-rows x
 // (256/ROWS) channels; a thread holds <= 16 partials in registers (one batch, no re-read in the second pass) up to ROWS*16
 // partials, more loop over batches and re-read in pass two.  ROWS = 64 is used for every layer (bn_rows_for).
+// cross-row sum of a double over the ROWS part-rows that share a channel: threads are laid out row * CPB + cl, so the rows of one
+// channel sit CPB lanes apart inside a wave (64 / CPB rows per wave) - xor-shuffles over the lane strides CPB .. 32 add them in a
+// fixed tree, and the 4 waves' results meet in LDS.  (Was: every thread walking all ROWS rows serially through LDS, twice.)
+template <int CPB>
+__device__ __forceinline__ double rows_sum(double v, double (*sm)[CPB], int cl) {
+#pragma unroll
+    for (int o = CPB; o < 64; o <<= 1) v += __shfl_xor(v, o);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();                                              // previous use of sm
+    if ((threadIdx.x & 63) < CPB) sm[wave][cl] = v;
+    __syncthreads();
+    return (sm[0][cl] + sm[1][cl]) + (sm[2][cl] + sm[3][cl]);
+}
+
 template <int ROWS>
 __global__ __launch_bounds__(256) void bn_finalize_kernel(salt_bn_finalize_args a) {
     constexpr int CPB = 256 / ROWS, U = 16;
-    __shared__ double sm[2][ROWS][CPB];
+    static_assert(CPB <= 64 && 64 % CPB == 0, "rows of a channel are CPB lanes apart inside a wave");
+    __shared__ double sm[4][CPB];
     const int cl = threadIdx.x % CPB, row = threadIdx.x / CPB;
     const int c = blockIdx.x * CPB + cl;
     const bool c_ok = c < a.C;
     const int nparts = a.nparts, C = a.C;
     const int nb = (nparts + ROWS * U - 1) / (ROWS * U);
+    // the per-channel parameters are needed only at the very end: fetch them now so that their latency hides under the merge
+    const bool writer = row == 0 && c_ok;
+    float gam = 0.f, bet = 0.f, rmean = 0.f, rvar = 0.f;
+    if (writer) {
+        gam = a.gamma[c]; bet = a.beta[c];
+        if (a.running_mean) { rmean = a.running_mean[c]; rvar = a.running_var[c]; }
+    }
     float sv[U], mv[U], nv[U];
     auto load_batch = [&](int b) {
 #pragma unroll
@@ -132,12 +154,12 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(salt_bn_finalize_args 
 #pragma unroll
         for (int u = 0; u < U; ++u) { n += (double)nv[u]; sacc += (double)sv[u]; }
     }
-    sm[0][row][cl] = n; sm[1][row][cl] = sacc;
-    __syncthreads();
-    double N = 0.0, S = 0.0;
-#pragma unroll 8
-    for (int r = 0; r < ROWS; ++r) { N += sm[0][r][cl]; S += sm[1][r][cl]; }
+    const double N = rows_sum<CPB>(n, sm, cl);
+    const double S = rows_sum<CPB>(sacc, sm, cl);
     const double mean = N > 0 ? S / N : 0.0;
+    // almost every partial covers a full tile: one reciprocal serves all of them (an fp64 division per partial was the longest
+    // dependent chain of this kernel)
+    const double nfull = (double)a.stats_cnt[0], rfull = 1.0 / nfull;
     double m2 = 0.0;
     for (int b = 0; b < nb; ++b) {
         if (nb > 1) load_batch(b);
@@ -145,27 +167,22 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(salt_bn_finalize_args 
         for (int u = 0; u < U; ++u) {
             if (nv[u] > 0.f) {
                 const double nk = (double)nv[u];
-                const double d = (double)sv[u] / nk - mean;
+                const double d = (double)sv[u] * (nk == nfull ? rfull : 1.0 / nk) - mean;
                 m2 += (double)mv[u] + nk * d * d;
             }
         }
     }
-    __syncthreads();
-    sm[0][row][cl] = m2;
-    __syncthreads();
+    const double M2 = rows_sum<CPB>(m2, sm, cl);
     if (threadIdx.x == 0 && blockIdx.x == 0 && a.num_batches_tracked) *a.num_batches_tracked += 1;
-    if (row != 0 || !c_ok) return;
-    double M2 = 0.0;
-#pragma unroll 8
-    for (int r = 0; r < ROWS; ++r) M2 += sm[0][r][cl];
+    if (!writer) return;
     const double var = N > 0 ? M2 / N : 0.0;
     const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
-    const float sc = a.gamma[c] * invstd;
-    a.mean[c] = (float)mean; a.invstd[c] = invstd; a.scale[c] = sc; a.shift[c] = a.beta[c] - (float)mean * sc;
+    const float sc = gam * invstd;
+    a.mean[c] = (float)mean; a.invstd[c] = invstd; a.scale[c] = sc; a.shift[c] = bet - (float)mean * sc;
     if (a.running_mean) {
         const double unb = N > 1 ? M2 / (N - 1) : var;
-        a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)mean;
-        a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unb;
+        a.running_mean[c] = (1.f - a.momentum) * rmean + a.momentum * (float)mean;
+        a.running_var[c] = (1.f - a.momentum) * rvar + a.momentum * (float)unb;
     }
 }
 
@@ -264,9 +281,15 @@ template <int ROWS>
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* partials, int nparts, int C, double M, const float* gamma, const float* invstd,
                                        float* dgamma, float* dbeta, int accumulate, float* coef) {
     constexpr int CPB = 256 / ROWS, U = 16;
-    __shared__ double sm[2][ROWS][CPB];
+    __shared__ double sm[4][CPB];
     const int cl = threadIdx.x % CPB, row = threadIdx.x / CPB;
     const int c = blockIdx.x * CPB + cl;
+    const bool writer = row == 0 && c < C;
+    float gam = 0.f, inv = 0.f, og = 0.f, ob = 0.f;                // fetched up front: their latency hides under the partial loads
+    if (writer) {
+        gam = gamma[c]; inv = invstd[c];
+        if (dgamma && accumulate) { og = dgamma[c]; ob = dbeta[c]; }
+    }
     double s1 = 0.0, s2 = 0.0;
     for (int k0 = row; k0 < nparts; k0 += ROWS * U) {
         float v1[U], v2[U];
@@ -280,14 +303,11 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* parti
 #pragma unroll
         for (int u = 0; u < U; ++u) { s1 += (double)v1[u]; s2 += (double)v2[u]; }
     }
-    sm[0][row][cl] = s1; sm[1][row][cl] = s2;
-    __syncthreads();
-    if (row != 0 || c >= C) return;
-    s1 = 0.0; s2 = 0.0;
-#pragma unroll 8
-    for (int r = 0; r < ROWS; ++r) { s1 += sm[0][r][cl]; s2 += sm[1][r][cl]; }
-    if (dgamma) { dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2; dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1; }
-    coef[c] = gamma[c] * invstd[c];
+    s1 = rows_sum<CPB>(s1, sm, cl);
+    s2 = rows_sum<CPB>(s2, sm, cl);
+    if (!writer) return;
+    if (dgamma) { dgamma[c] = accumulate ? og + (float)s2 : (float)s2; dbeta[c] = accumulate ? ob + (float)s1 : (float)s1; }
+    coef[c] = gam * inv;
     coef[C + c] = (float)(s1 / M);
     coef[2 * C + c] = (float)(s2 / M);
 }

@@ -533,7 +533,15 @@ class Graph:
                 self.bwd.add('pad_fold', dtype=self.dt, xp=(ext, Scratch('dgrad_ext', nbytes)), top=top, bottom=0, left=0, right=right,
                              x=x.gview(), accumulate=acc)
                 return
-            # fused fold: interior pixels go straight into x.grad, only the pad ring takes the detour through scratch
+            if x.C % self.ve == 0 and not os.environ.get('SALT_FOLD_STRIP'):
+                # fused fold: the launch tiles the extended grid so that every pad-ring pixel shares a tile with the edge pixel it folds
+                # onto; the epilogue sums them from the staged tile - no strip, no second pass, and (a plain store of the complete
+                # gradient) the launch can carry the BatchNorm-backward sums of x's producer
+                s = self._conv_launch(self.bwd, dy.gview(), pk.data_ptr(), td, 1, 0, x.gview(), Hp, Wp, accumulate=acc,
+                                      fold_top=top, fold_right=right, stream=self._bwd_pack_tag())
+                x.buf.grad_writers[-1][2] = s
+                return
+            # strip fold: interior pixels go straight into x.grad, only the pad ring takes the detour through scratch
             scs = _round_up(x.C, self.ve)
             ring = lib.salt_fold_strip_pixels(x.H, x.W, top, 0, 0, right)
             strip = Scratch('dgrad_ring', x.B * ring * scs * self._es())

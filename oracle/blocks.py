@@ -23,6 +23,54 @@ BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
 
+# ------------------------------------------------------------------ storage-precision emulation (bf16 whole-network tests)
+# The HIP bf16 path keeps fp32 accumulators / statistics / parameters but STORES every activation, every activation gradient and
+# the packed convolution weights in bf16.  ``with bf16_storage():`` makes the oracle round at the same tensor boundaries (forward
+# value and, through a straight-through autograd function, the gradient that flows back through the same boundary), so a test can
+# compare "HIP bf16 vs fp32" with "what bf16 storage costs an independent implementation".  Default: identity (plain fp32 oracle).
+class _RoundBoth(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().to(g.dtype)
+
+
+class _RoundFwd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+_EMULATE_BF16 = False
+
+
+def _st(x):
+    """an activation that the HIP path stores (and whose gradient it stores) in the compute dtype"""
+    return _RoundBoth.apply(x) if _EMULATE_BF16 else x
+
+
+def _w(w):
+    """a convolution weight as the MFMA kernels read it (packed compute-dtype copy of the fp32 master)"""
+    return _RoundFwd.apply(w) if _EMULATE_BF16 else w
+
+
+class bf16_storage:
+    def __enter__(self):
+        global _EMULATE_BF16
+        self._old, _EMULATE_BF16 = _EMULATE_BF16, True
+
+    def __exit__(self, *a):
+        global _EMULATE_BF16
+        _EMULATE_BF16 = self._old
+
+
 def batch_norm(sd, p, x, train):
     """nn.BatchNorm2d with torch defaults (eps 1e-5, momentum 0.1, affine, running stats)."""
     if train and (p + 'num_batches_tracked') in sd:
@@ -33,8 +81,8 @@ def batch_norm(sd, p, x, train):
 
 def conv_bn_relu(sd, p, x, train):
     """unet_models.ConvBnRelu: 3x3 conv, zero pad 1, bias -> BN -> ReLU.  Keys p+'conv.{0,1}.*'."""
-    y = F.conv2d(x, sd[p + 'conv.0.weight'], sd[p + 'conv.0.bias'], padding=1)
-    return F.relu(batch_norm(sd, p + 'conv.1.', y, train))
+    y = _st(F.conv2d(x, _w(sd[p + 'conv.0.weight']), sd[p + 'conv.0.bias'], padding=1))
+    return _st(F.relu(batch_norm(sd, p + 'conv.1.', y, train)))
 
 
 def conv2d_bn_relu(sd, p, x, train, use_relu=True, use_batch_norm=True, use_padding=True):
@@ -47,36 +95,36 @@ def conv2d_bn_relu(sd, p, x, train, use_relu=True, use_batch_norm=True, use_padd
     rows, cols = w.shape[2], w.shape[3]
     if use_padding:
         x = F.pad(x, (0, cols - 1, rows - 1, 0), mode='replicate')
-    y = F.conv2d(x, w, sd[p + 'conv.bias'])
+    y = _st(F.conv2d(x, _w(w), sd[p + 'conv.bias']))
     if use_batch_norm:
         y = batch_norm(sd, p + 'batch_norm.', y, train)
     if use_relu:
         y = F.relu(y)
-    return y
+    return _st(y) if (use_batch_norm or use_relu) else y
 
 
 def deconv_conv2d_bn_relu(sd, p, x, train, use_relu=True, use_batch_norm=True):
     """base.DeconvConv2dBnRelu: ConvTranspose2d k3 s2 p1 op1 -> BN -> ReLU."""
-    y = F.conv_transpose2d(x, sd[p + 'deconv.weight'], sd[p + 'deconv.bias'],
-                           stride=2, padding=1, output_padding=1)
+    y = _st(F.conv_transpose2d(x, _w(sd[p + 'deconv.weight']), sd[p + 'deconv.bias'],
+                               stride=2, padding=1, output_padding=1))
     if use_batch_norm:
         y = batch_norm(sd, p + 'batch_norm.', y, train)
     if use_relu:
         y = F.relu(y)
-    return y
+    return _st(y) if (use_batch_norm or use_relu) else y
 
 
 def upsample_bilinear(x, scale):
     """nn.Upsample(mode='bilinear') as executed by torch 2.10 (align_corners=False)."""
-    return F.interpolate(x, scale_factor=scale, mode='bilinear', align_corners=False)
+    return _st(F.interpolate(x, scale_factor=scale, mode='bilinear', align_corners=False))
 
 
 def decoder_block_v1(sd, p, x, train):
     """unet_models.DecoderBlockV1: ConvBnRelu -> ConvT k3 s2 p1 op1 -> BN -> ReLU."""
     y = conv_bn_relu(sd, p + 'block.0.', x, train)
-    y = F.conv_transpose2d(y, sd[p + 'block.1.weight'], sd[p + 'block.1.bias'],
-                           stride=2, padding=1, output_padding=1)
-    return F.relu(batch_norm(sd, p + 'block.2.', y, train))
+    y = _st(F.conv_transpose2d(y, _w(sd[p + 'block.1.weight']), sd[p + 'block.1.bias'],
+                               stride=2, padding=1, output_padding=1))
+    return _st(F.relu(batch_norm(sd, p + 'block.2.', y, train)))
 
 
 def decoder_block_v2(sd, p, x, train, is_deconv=True):
@@ -84,8 +132,8 @@ def decoder_block_v2(sd, p, x, train, is_deconv=True):
     upsample branch (ConvBnRelu, bilinear x2).  Both branches own parameters; one runs."""
     if is_deconv:
         y = conv_bn_relu(sd, p + 'deconv.0.', x, train)
-        y = F.conv_transpose2d(y, sd[p + 'deconv.1.weight'], sd[p + 'deconv.1.bias'], stride=2, padding=1)
-        return F.relu(batch_norm(sd, p + 'deconv.2.', y, train))
+        y = _st(F.conv_transpose2d(y, _w(sd[p + 'deconv.1.weight']), sd[p + 'deconv.1.bias'], stride=2, padding=1))
+        return _st(F.relu(batch_norm(sd, p + 'deconv.2.', y, train)))
     y = conv_bn_relu(sd, p + 'upsample.0.', x, train)
     return upsample_bilinear(y, 2)
 
@@ -110,7 +158,7 @@ def decoder_block(sd, p, x, e, train):
         x = torch.cat([x, e], 1)
     x = conv2d_bn_relu(sd, p + 'conv1.', x, train)
     x = conv2d_bn_relu(sd, p + 'conv2.', x, train)
-    return F.relu(channel_se(sd, p + 'channel_se.', x) + spatial_se(sd, p + 'spatial_se.', x))
+    return _st(F.relu(channel_se(sd, p + 'channel_se.', x) + spatial_se(sd, p + 'spatial_se.', x)))
 
 
 # ------------------------------------------------------------------ torchvision-layout ResNet
@@ -120,31 +168,31 @@ RESNET_CFG = {18: ('basic', [2, 2, 2, 2]), 34: ('basic', [3, 4, 6, 3]), 50: ('bo
 
 
 def basic_block(sd, p, x, train, stride):
-    y = F.conv2d(x, sd[p + 'conv1.weight'], None, stride=stride, padding=1)
-    y = F.relu(batch_norm(sd, p + 'bn1.', y, train))
-    y = F.conv2d(y, sd[p + 'conv2.weight'], None, padding=1)
+    y = _st(F.conv2d(x, _w(sd[p + 'conv1.weight']), None, stride=stride, padding=1))
+    y = _st(F.relu(batch_norm(sd, p + 'bn1.', y, train)))
+    y = _st(F.conv2d(y, _w(sd[p + 'conv2.weight']), None, padding=1))
     y = batch_norm(sd, p + 'bn2.', y, train)
     if (p + 'downsample.0.weight') in sd:
-        x = F.conv2d(x, sd[p + 'downsample.0.weight'], None, stride=stride)
-        x = batch_norm(sd, p + 'downsample.1.', x, train)
-    return F.relu(y + x)
+        x = _st(F.conv2d(x, _w(sd[p + 'downsample.0.weight']), None, stride=stride))
+        x = _st(batch_norm(sd, p + 'downsample.1.', x, train))
+    return _st(F.relu(y + x))
 
 
 def bottleneck(sd, p, x, train, stride):
     """torchvision 0.2.0 Bottleneck: 1x1 -> 3x3 (stride here) -> 1x1 (x4), BN after each."""
-    y = F.relu(batch_norm(sd, p + 'bn1.', F.conv2d(x, sd[p + 'conv1.weight']), train))
-    y = F.relu(batch_norm(sd, p + 'bn2.', F.conv2d(y, sd[p + 'conv2.weight'], None, stride=stride, padding=1), train))
-    y = batch_norm(sd, p + 'bn3.', F.conv2d(y, sd[p + 'conv3.weight']), train)
+    y = _st(F.relu(batch_norm(sd, p + 'bn1.', _st(F.conv2d(x, _w(sd[p + 'conv1.weight']))), train)))
+    y = _st(F.relu(batch_norm(sd, p + 'bn2.', _st(F.conv2d(y, _w(sd[p + 'conv2.weight']), None, stride=stride, padding=1)), train)))
+    y = batch_norm(sd, p + 'bn3.', _st(F.conv2d(y, _w(sd[p + 'conv3.weight']))), train)
     if (p + 'downsample.0.weight') in sd:
-        x = F.conv2d(x, sd[p + 'downsample.0.weight'], None, stride=stride)
-        x = batch_norm(sd, p + 'downsample.1.', x, train)
-    return F.relu(y + x)
+        x = _st(F.conv2d(x, _w(sd[p + 'downsample.0.weight']), None, stride=stride))
+        x = _st(batch_norm(sd, p + 'downsample.1.', x, train))
+    return _st(F.relu(y + x))
 
 
 def resnet_stem(sd, p, x, train, pool0=False):
     """conv7x7 s2 p3 (no bias) -> BN -> ReLU [-> MaxPool 3x3 s2 p1 iff pool0]."""
-    y = F.conv2d(x, sd[p + 'conv1.weight'], None, stride=2, padding=3)
-    y = F.relu(batch_norm(sd, p + 'bn1.', y, train))
+    y = _st(F.conv2d(_st(x), _w(sd[p + 'conv1.weight']), None, stride=2, padding=3))
+    y = _st(F.relu(batch_norm(sd, p + 'bn1.', y, train)))
     if pool0:
         y = F.max_pool2d(y, 3, 2, 1)
     return y

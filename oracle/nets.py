@@ -30,7 +30,7 @@ def unet_resnet(sd, x, train, depth=34, use_hypercolumn=True, pool0=False, p='')
     e5 = B.resnet_layer(sd, e, e4, train, depth, 4)
     c = B.conv2d_bn_relu(sd, p + 'center.0.', e5, train)
     c = B.conv2d_bn_relu(sd, p + 'center.1.', c, train)
-    c = F.avg_pool2d(c, 2, 2)
+    c = B._st(F.avg_pool2d(c, 2, 2))
     d5 = B.decoder_block(sd, p + 'dec5.', c, e5, train)
     d4 = B.decoder_block(sd, p + 'dec4.', d5, e4, train)
     d3 = B.decoder_block(sd, p + 'dec3.', d4, e3, train)

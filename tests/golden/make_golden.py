@@ -239,8 +239,12 @@ def main():
         CF.fill_module(net, canonical=canonical_fn(net))
         net.double().train()
         o = net(X.double())
-        loss = models.lovasz_loss(o, T.double()) * 1.0
+        # the loss keeps the reference's fp32 arithmetic (lovasz_losses.py:107 casts the labels to float; models.py:326-328), the
+        # network forward/backward is float64
+        o32 = o.detach().float().requires_grad_(True)
+        loss = models.lovasz_loss(o32, T) * 1.0
         loss.backward()
+        o.backward(o32.grad.double())
         out = OrderedDict(train_logits64=o.detach(), train_loss64=loss.detach())
         names, gnorm = [], []
         for k, p in net.named_parameters():

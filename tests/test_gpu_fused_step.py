@@ -176,10 +176,15 @@ def test_grad_scale_half_on_doubled_gradients_equals_plain_step(branch):
 
 def test_bf16_whole_network_vs_fp32_oracle_c2_shape():
     """BASELINE C2's dtype and shape ([32,3,128,128], bf16 activations / MFMA inputs, fp32 accumulation, masters, statistics and
-    loss) against the fp32 oracle: eval logits, train-mode logits, loss and every parameter gradient of one fused step."""
-    from oracle import nets as ON, specs as OS, losses as OL
+    loss).  Yardsticks: (1) the fp32 oracle - eval logits, masks and both losses must agree to bf16 resolution; (2) the SAME oracle
+    with bf16 STORAGE emulated at the tensor boundaries where the HIP path stores bf16 (oracle.blocks.bf16_storage): at random
+    initialisation train-mode BatchNorm through ~55 layers amplifies storage rounding to ~7 % in the logits and to a gradient
+    cosine of ~0.76 in ANY bf16-storage implementation, so the train-step bounds are "no worse than the independent emulation",
+    not chosen constants."""
+    from oracle import nets as ON, specs as OS, losses as OL, blocks as OB
+    from salt_amd import losses as HL
     torch.manual_seed(5)
-    m = _segmentation_model('UNetResNet', 'lovasz', dtype='bf16')
+    m = _segmentation_model('UNetResNet', 'bce_dice', dtype='bf16')
     spec = OS.SPECS['UNetResNet'](with_fc=True)
     sd = OS.init_state(spec, seed=7)
     m.model.load_state_dict({k: sd[k] for k in m.model.state_dict() if k in sd}, strict=False)
@@ -195,28 +200,54 @@ def test_bf16_whole_network_vs_fp32_oracle_c2_shape():
     def rel_l2(a, b):
         return float((a.double() - b.double()).norm() / b.double().norm())
     e_eval = rel_l2(y, yr)
-    # bf16 has 8 significand bits: one rounding is 2^-9 = 2e-3 relative; ~50 layers of independent roundings -> ~1.5e-2
-    assert e_eval < 3e-2, e_eval
     agree = float(((y[:, 1] > 0) == (yr[:, 1] > 0)).float().mean())
-    assert agree > 0.995, agree                                          # the masks differ only where |logit| is within bf16 noise
     m.model.train()
     dead = set(m.model.dead_parameter_names())
     keys = [k for k in OS.trainable_keys(spec) if k not in dead]
-    for k in keys:
-        sd[k].requires_grad_(True)
-    out_r = ON.unet_resnet(sd, x, True)
-    loss_r = OL.lovasz_loss(out_r, t)
-    loss_r.backward()
+
+    def oracle_step(emulate):
+        s2 = {k: v.detach().clone() for k, v in sd.items()}
+        for k in keys:
+            s2[k].requires_grad_(True)
+        if emulate:
+            with OB.bf16_storage():
+                o = ON.unet_resnet(s2, x, True)
+        else:
+            o = ON.unet_resnet(s2, x, True)
+        # gradients under the smooth BCE+Dice loss: at initialisation every hinge error is 1 +- 1e-2, so the Lovasz sort order (and
+        # with it dL/dlogits) is decided by noise below bf16 resolution - that would measure the loss, not the network
+        l = OL.mixed_dice_bce_loss(o, t)
+        l.backward()
+        return o.detach(), float(l), {k: s2[k].grad for k in keys}
+    out_r, loss_r, g_r = oracle_step(False)
+    out_e, loss_e, g_e = oracle_step(True)
     metrics = m._fit_loop([x, t])
     torch.cuda.synchronize()
     cnet = m.model.engine().net((32, 3, 128, 128), True)
-    e_train = rel_l2(cnet.logits.cpu(), out_r.detach())
-    assert e_train < 3e-2, e_train
-    assert abs(float(metrics['sum']) - float(loss_r)) < 1e-2 * max(1.0, abs(float(loss_r))), (float(metrics['sum']), float(loss_r))
-    worst, cos, n = _grad_report(m.model, {k: sd[k].grad for k in keys})
-    print('bf16 C2: eval logits relL2 %.3e, train logits relL2 %.3e, loss %.5f vs %.5f, grad cosine %.5f, worst tensor relL2 %.3e (%s)'
-          % (e_eval, e_train, float(metrics['sum']), float(loss_r), cos, worst[0], worst[1]))
-    assert n > 120 and cos > 0.99 and worst[0] < 0.35, (worst, cos, n)
+    logits = cnet.logits.cpu()
+    e_train, e_train_emu = rel_l2(logits, out_r), rel_l2(out_e, out_r)
+    worst, cos, n = _grad_report(m.model, g_r)
+    flat_r = torch.cat([g_r[k].double().reshape(-1) for k in keys])
+    flat_e = torch.cat([g_e[k].double().reshape(-1) for k in keys])
+    cos_emu = float((flat_r * flat_e).sum() / (flat_r.norm() * flat_e.norm()))
+    lv, _ = HL.native_loss(cnet.logits, t.to(DEV), 'lovasz', want_grad=False)
+    lv_r = float(OL.lovasz_loss(out_r, t))
+    print('bf16 C2: eval logits relL2 %.3e (mask agreement %.5f) | train logits relL2 HIP %.3e / emulated bf16 storage %.3e | BCE+Dice %.5f '
+          'vs %.5f | Lovasz %.5f vs %.5f | gradient cosine HIP %.4f / emulated %.4f' % (e_eval, agree, e_train, e_train_emu,
+                                                                                      float(metrics['sum']), loss_r, float(lv), lv_r, cos, cos_emu))
+    assert e_eval < 3e-2, e_eval                                          # measured 1e-2: ~55 bf16 roundings of 2^-9 each
+    assert agree > 0.995, agree                                           # masks differ only where |logit| is within bf16 noise of 0
+    assert abs(float(metrics['sum']) - loss_r) < 1e-2 * max(1.0, abs(loss_r)) and abs(float(lv) - lv_r) < 1e-2 * max(1.0, abs(lv_r))
+    assert e_train <= 1.25 * e_train_emu + 5e-3, (e_train, e_train_emu)
+    assert n > 120 and (1 - cos) <= 1.25 * (1 - cos_emu) + 1e-2, (cos, cos_emu)
+    own = dict(m.model.named_parameters())
+    eng = m.model.engine()
+    for k in ('final.1.weight', 'final.0.conv.weight', 'dec1.conv2.conv.weight', 'dec3.conv1.conv.weight', 'center.0.conv.weight',
+              'encoders.encoder.layer3.2.conv1.weight', 'encoders.encoder.layer1.0.conv1.weight', 'encoders.encoder.conv1.weight'):
+        off, cnt = eng.grad_range(own[k])
+        e_hip = rel_l2(eng.grads[off:off + cnt].view(own[k].shape).cpu(), g_r[k])
+        e_emu = rel_l2(g_e[k], g_r[k])
+        assert e_hip <= 1.3 * e_emu + 1e-2, (k, e_hip, e_emu)
 
 
 _RCCL_WORKER = r'''
