@@ -120,19 +120,28 @@ def op_bytes(name, s, es):
     return 0.0
 
 
+PMC_FILE = 'profiles/r02_pmc_traffic.json'
+
+
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json; tools/pmc_traffic.sh
-    regenerates it - PMC counters cannot be read from inside the timed process).  None when the file is absent."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
-    try:
-        k = json.load(open(path))['kernels'][kernel]
-        return round((k['read_MB_per_launch'] + k['write_MB_per_launch']) * 1e6)
-    except (OSError, KeyError, ValueError):
-        return None
+    """HBM bytes per launch, averaged over the kernels named in the tuple `kernel`, from the committed rocprofv3 --pmc passes (PMC_FILE;
+    tools/pmc_traffic.sh regenerates it - PMC counters cannot be read from inside the timed process).  None when the file is absent."""
+    for path in (os.path.join(ROOT, PMC_FILE), os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')):
+        try:
+            ks = json.load(open(path))['kernels']
+            sel = [v for k, v in ks.items() if k in kernel]
+            n = sum(v.get('launches_per_step', 1) for v in sel)
+            tot = sum((v['read_MB_per_launch'] + v['write_MB_per_launch']) * v.get('launches_per_step', 1) for v in sel)
+            if n:
+                return round(tot / n * 1e6)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 CPU_LEG_THREADS = 16        # a fixed, modest thread count: GPU boxes advertise 256 logical CPUs but oversubscribing them makes
-CPU_LEG_BATCH = 8           # the torch CPU kernels orders of magnitude slower; the sample is 1 warm-up + 3 timed steps of batch 8
+CPU_LEG_BATCH = 8           # the torch CPU kernels orders of magnitude slower; SURVEY.md 8(d): batch 8, median of 10 steps after 2 warm-ups
+CPU_LEG_STEPS, CPU_LEG_WARMUP = 10, 2
 CPU_LEG_TIMEOUT_S = 150
 
 
@@ -153,7 +162,7 @@ def cpu_baseline_leg(arch_name, loss_name, channels):
     xc, tc = preprocess(img, msk, True, channels)
     times = []
     t_start = time.perf_counter()
-    for it in range(4):
+    for it in range(CPU_LEG_WARMUP + CPU_LEG_STEPS):
         t1 = time.perf_counter()
         for p in params:
             p.grad = None
@@ -163,20 +172,21 @@ def cpu_baseline_leg(arch_name, loss_name, channels):
         with torch.no_grad():
             OL.adam_l2_step([p.data for p in params], [p.grad for p in params], m_, v_, it + 1)
         times.append(time.perf_counter() - t1)
-        if time.perf_counter() - t_start > 60 and len(times) >= 2:
+        if time.perf_counter() - t_start > 100 and len(times) >= CPU_LEG_WARMUP + 2:
             break
-    timed = times[1:]
+    timed = times[CPU_LEG_WARMUP:]
     med = float(np.median(timed))
-    print(json.dumps({'value': round(cb / med, 2), 'unit': 'images/s', 'cores': CPU_LEG_THREADS, 'kind': 'port',
-                      'sample': 'oracle (plain PyTorch CPU fp32, %d threads) same network/loss/optimizer, batch %d, median of %d steps after 1 warm-up'
-                                % (torch.get_num_threads(), cb, len(timed))}))
+    print(json.dumps({'value': round(cb / med, 2), 'unit': 'images/s', 'cores': CPU_LEG_THREADS, 'host_logical_cpus': os.cpu_count(), 'kind': 'port',
+                      'sample': 'oracle (plain PyTorch CPU fp32, %d threads of the %d logical CPUs of this host) %s, %s loss, Adam; batch %d, '
+                                'median of %d steps after %d warm-ups' % (torch.get_num_threads(), os.cpu_count(), arch_name, loss_name, cb,
+                                                                         len(timed), CPU_LEG_WARMUP)}))
 
 
-def cpu_baseline_subprocess(args, arch_name):
+def cpu_baseline_subprocess(loss, arch_name):
     """Run the CPU leg in a child with a hard time limit so that the default bench run always finishes in minutes."""
     import subprocess
     env = dict(os.environ, OMP_NUM_THREADS=str(CPU_LEG_THREADS), MKL_NUM_THREADS=str(CPU_LEG_THREADS))
-    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-leg', arch_name, '--loss', args.loss]
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-leg', arch_name, '--loss', loss]
     try:
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=CPU_LEG_TIMEOUT_S)
         line = [x for x in r.stdout.splitlines() if x.startswith('{')]
@@ -185,7 +195,131 @@ def cpu_baseline_subprocess(args, arch_name):
         note = 'cpu leg failed: ' + (r.stderr.strip().splitlines() or ['?'])[-1][:200]
     except subprocess.TimeoutExpired:
         note = 'cpu leg exceeded %d s' % CPU_LEG_TIMEOUT_S
-    return {'value': None, 'unit': 'images/s', 'cores': CPU_LEG_THREADS, 'kind': 'port', 'sample': note}
+    return {'value': None, 'unit': 'images/s', 'cores': CPU_LEG_THREADS, 'host_logical_cpus': os.cpu_count(), 'kind': 'port', 'sample': note}
+
+
+WORKLOADS = {'r34_hyper': ('UNetResNet', 3, 'architectures.unet.UNetResNet(34, hypercolumn)'),
+             'ternaus34': ('TernausUNetResNet', 3, 'unet_models.UNetResNet(34, deconv)'),
+             'vanilla': ('VanillaUNet', 1, 'vanilla 4-level U-Net (16 filters, 1 channel)')}
+
+
+def conv_roofline(model, B, channels, dtype, loss, reps):
+    """Event pair around every operator of one step (salt_program_run_timed): the operator with the largest share and its
+    algorithmic FLOP rate.  Returns (roofline dict, op table, serial ms, side-stream ms, algorithmic FLOPs per step)."""
+    eng = model.model.engine()
+    net = eng.net((B, channels, 128, 128), True)
+    groups = {}
+    for _ in range(reps):
+        eng.refresh(True)
+        torch.cuda.synchronize()                     # the data-gradient weight packs run on the side stream
+        for prog in (net.fwd, net.loss_program(loss, 1.0), net.bwd):
+            for name, s, ms in prog.run_timed():
+                g = groups.setdefault(name, [0.0, 0.0, 0, 0.0])
+                g[0] += ms; g[1] += op_flops(name, s); g[2] += 1
+                g[3] += op_bytes(name, s, 2 if dtype == 'bf16' else 4)
+    total_ms = sum(g[0] for g in groups.values()) / reps
+    dn, (dms, dfl, dcnt, dby) = max(groups.items(), key=lambda kv: kv[1][0])
+    peak = MFMA_PEAK_TFLOPS[dtype]
+    ach = dfl / (dms * 1e-3) / 1e12 if dms > 0 else 0.0
+    kern = {'conv': 'conv_mfma_kernel + conv_glds_kernel (fwd + dgrad launches)', 'conv_wgrad': 'conv_wgrad_kernel'}.get(dn, dn)
+    roof = {'kernel': kern, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+            'algorithmic_bytes_per_launch': round(dby / dcnt) if dcnt else None, 'launches_per_step': dcnt // reps,
+            'avg_launch_us': round(1e3 * dms / dcnt, 2), 'share_of_step': round(dms / reps / total_ms, 3),
+            'algorithmic_gflop_per_step': round(dfl / reps / 1e9, 2)}
+    ops = {k: round(v[0] / reps, 3) for k, v in sorted(groups.items(), key=lambda kv: -kv[1][0])[:8]}
+    side = sum(v[0] for k, v in groups.items() if k in ('conv_wgrad', 'wgrad_reduce', 'conv_first_wgrad', 'stem_grad_unfold')) / reps
+    return roof, ops, total_ms, side, sum(g[1] for g in groups.values()) / reps, dn
+
+
+def train_config(workload, dtype, B, loss, steps, warmup, dev, rank=0, world=1, reps=1):
+    """Build the model of one training configuration, run `warmup` + `steps` timed fused steps on resident data; -> (model, batches, s)."""
+    from salt_amd.models import SegmentationModel
+    arch_name, channels, _ = WORKLOADS[workload]
+    arch = {'model_params': {'architecture': arch_name, 'out_channels': 2, 'activation': 'sigmoid', 'loss': loss, 'compute_dtype': dtype},
+            'optimizer_params': {'lr': 1e-4}, 'regularizer_params': {'regularize': True, 'weight_decay_conv2d': 1e-4}}
+    torch.manual_seed(1234)
+    model = SegmentationModel(arch, {'epochs': 1}, {})
+    model._to_device()
+    model.model.train()
+    model.dp.broadcast_parameters(model.model)
+    pool_batches = 8
+    img, msk = synth_tiles(B * pool_batches, seed=1234 + 17 * rank)     # resident pool, different tiles on every rank
+    X, T = preprocess(img, msk, True, channels)
+    X, T = X.to(dev), T.to(dev)
+    batches = [(X[i * B:(i + 1) * B], T[i * B:(i + 1) * B]) for i in range(pool_batches)]
+    for i in range(warmup):
+        model._fit_loop(list(batches[i % pool_batches]))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    model.dp.measure = world > 1
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss_v = model._fit_loop(list(batches[(warmup + i) % pool_batches]))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te[0])
+    return model, batches, elapsed, float(loss_v['sum'])
+
+
+def extra_configs(dev, steps=12, warmup=4):
+    """The other BASELINE.json configurations, measured in the same run (each a few hundred milliseconds): C1 vanilla fp32,
+    ResNet34 fp32, C3's per-GPU shape (batch 64), C4 inference with 4-flip TTA."""
+    out = {}
+
+    def one(tag, workload, dtype, B, note):
+        model, batches, elapsed, _ = train_config(workload, dtype, B, 'lovasz', steps, warmup, dev)
+        _, channels, _ = WORKLOADS[workload]
+        net = model.model.engine().net((B, channels, 128, 128), True)
+        net.x.copy_(batches[0][0]); net.target.copy_(batches[0][1])
+        roof, _, _, _, fl, _ = conv_roofline(model, B, channels, dtype, 'lovasz', 1)
+        out[tag] = {'config': note, 'images_per_s': round(B * steps / elapsed, 1), 'ms_per_step': round(1e3 * elapsed / steps, 3), 'dtype': dtype,
+                    'steps': steps, 'warmup': warmup, 'step_tflops': round(fl / (elapsed / steps) / 1e12, 1),
+                    'conv_tflops': roof['achieved'], 'conv_frac_of_mfma_peak': roof['frac'], 'mfma_peak_tflops': roof['peak']}
+        del model, batches, net
+        torch.cuda.empty_cache()
+    one('C1_vanilla_f32_b32', 'vanilla', 'f32', 32, 'vanilla 4-level U-Net, 101x101 pad->128, batch 32, fp32, training step (Lovasz, Adam)')
+    one('R34_hyper_f32_b32', 'r34_hyper', 'f32', 32, 'ResNet34 hypercolumn U-Net, 128x128, batch 32, fp32 (exact-f32 MFMA), training step')
+    one('C3_R34_hyper_bf16_b64', 'r34_hyper', 'bf16', 64, 'ResNet34 hypercolumn U-Net + Lovasz hinge, 128x128, batch 64 per GPU, bf16, training step')
+    # C4: ResNet152 hypercolumn U-Net, 256x256, batch 16, 4-flip TTA inference (flip -> one forward of 64 -> sigmoid -> inverse flip -> mean
+    # -> centre crop -> threshold), bf16
+    from salt_amd import architectures as A, inference as I
+    torch.manual_seed(0)
+    net = A.UNetResNet(152, 2, use_hypercolumn=True, dropout_2d=0.0, pretrained=False)
+    net.set_compute_dtype('bf16')
+    net.to(dev).eval()
+    X = torch.randn(16, 3, 256, 256, device=dev)
+
+    def step():
+        return I.crop_threshold(I.predict_tta(net, X, True, True), (202, 202), 0.5, cls=1)
+    step(); step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n4 = 4
+    for _ in range(n4):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n4
+    cnet = net.engine().net((64, 3, 256, 256), False)
+    fl = ms = 0.0
+    for name, s_, m_ in cnet.fwd.run_timed():
+        if name == 'conv':
+            fl += op_flops(name, s_); ms += m_
+    out['C4_R152_hyper_bf16_256_b16_tta4'] = {
+        'config': 'ResNet152 hypercolumn U-Net, 256x256, batch 16 per GPU, 4-flip TTA inference incl. crop + threshold, bf16',
+        'images_per_s': round(16 / dt, 1), 'forward_images_per_s': round(64 / dt, 1), 'ms_per_batch': round(dt * 1e3, 2), 'steps': n4, 'warmup': 2,
+        'whole_pass_tflops': round(2 * 384.7e9 * 64 / dt / 1e12, 1), 'conv_tflops': round(fl / (ms * 1e-3) / 1e12, 1) if ms else None,
+        'conv_frac_of_mfma_peak': round(fl / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS['bf16'], 4) if ms else None, 'dtype': 'bf16'}
+    del net, cnet, X
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -199,6 +333,7 @@ def main():
     ap.add_argument('--loss', default='lovasz', choices=['lovasz', 'bce_dice'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-iou', action='store_true')
+    ap.add_argument('--no-configs', action='store_true', help='skip the other BASELINE configurations (C1, fp32, C3 shape, C4)')
     ap.add_argument('--cpu-leg', default=None, help=argparse.SUPPRESS)       # child mode of the cpu_baseline leg
     args = ap.parse_args()
     if args.cpu_leg:
@@ -236,98 +371,43 @@ def main():
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
     dev = torch.device('cuda', local)
 
-    import salt_amd
-    from salt_amd.models import SegmentationModel
+    import salt_amd  # noqa: F401
 
-    arch_name = {'r34_hyper': 'UNetResNet', 'ternaus34': 'TernausUNetResNet', 'vanilla': 'VanillaUNet'}[args.workload]
-    channels = 1 if args.workload == 'vanilla' else 3
-    arch = {'model_params': {'architecture': arch_name, 'out_channels': 2, 'activation': 'sigmoid', 'loss': args.loss,
-                             'compute_dtype': args.dtype},
-            'optimizer_params': {'lr': 1e-4}, 'regularizer_params': {'regularize': True, 'weight_decay_conv2d': 1e-4}}
-    torch.manual_seed(1234)
-    model = SegmentationModel(arch, {'epochs': 1}, {})
-    model._to_device()
-    model.model.train()
-    model.dp.broadcast_parameters(model.model)
-
-    # resident synthetic data: a pool of minibatches per rank (different tiles on every rank)
+    arch_name, channels, wl_desc = WORKLOADS[args.workload]
     B = args.batch
-    pool_batches = 8
-    img, msk = synth_tiles(B * pool_batches, seed=1234 + 17 * rank)
-    X, T = preprocess(img, msk, True, channels)
-    X, T = X.to(dev), T.to(dev)
-    batches = [(X[i * B:(i + 1) * B], T[i * B:(i + 1) * B]) for i in range(pool_batches)]
-
-    def step(i):
-        return model._fit_loop(list(batches[i % pool_batches]))
-
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = step(args.warmup + i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te[0])
+    model, batches, elapsed, final_loss = train_config(args.workload, args.dtype, B, args.loss, args.steps, args.warmup, dev, rank, world)
     value = world * B * args.steps / elapsed
-    final_loss = float(loss['sum'])
 
     out = {'metric': 'training images/sec, U-Net ResNet34 101x101 (pad->128) bs32/GPU', 'value': round(value, 2), 'unit': 'images/s',
            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),
            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
            'config': {'workload': '%s 128x128 (101 resized+edge-padded) batch %d/GPU, %s loss, Adam lr1e-4 L2 1e-4, train-mode BN'
-                                  % ({'r34_hyper': 'architectures.unet.UNetResNet(34, hypercolumn)', 'ternaus34': 'unet_models.UNetResNet(34, deconv)',
-                                      'vanilla': 'vanilla 4-level U-Net (16 filters, 1 channel)'}[args.workload], B, args.loss),
+                                  % (wl_desc, B, args.loss),
                       'global_batch': B * world, 'image': [128, 128], 'parallelism': 'dp%d' % world},
            'final_loss': round(final_loss, 5)}
+    if world > 1 or model.dp._active():
+        # how to read a scaling run: every rank is one RCCL rank; `exposed_allreduce_ms` is what the compute stream still waited for
+        # after its last backward kernel (the collectives of the earlier buckets ran underneath backward)
+        ex = model.dp.exposed_allreduce_ms()
+        out['rccl_ranks'] = dist.get_world_size() if dist.is_initialized() else 1
+        out['allreduce'] = {'buckets': len(list(model.dp._plans.values())[0]) if model.dp._plans else 0,
+                            'gradient_bytes': int(model.model.engine().n_live * 4),
+                            'exposed_allreduce_ms_per_step_rank0': round(ex, 4) if ex is not None else None}
 
     # ------------------------------------------------------------------ live roofline (rank 0): event pair around every operator
     if rank == 0:
         eng = model.model.engine()
         net = eng.net((B, channels, 128, 128), True)
         net.x.copy_(batches[0][0]); net.target.copy_(batches[0][1])
-        groups = {}
-        reps = 3
-        for _ in range(reps):
-            eng.refresh(True)
-            torch.cuda.synchronize()                     # the data-gradient weight packs run on the side stream
-            for prog in (net.fwd, net.loss_program(args.loss, 1.0), net.bwd):
-                for name, s, ms in prog.run_timed():
-                    kname = name
-                    g = groups.setdefault(kname, [0.0, 0.0, 0, 0.0])
-                    g[0] += ms; g[1] += op_flops(name, s); g[2] += 1
-                    if len(g) == 3:
-                        g.append(0.0)
-                    g[3] += op_bytes(name, s, 2 if args.dtype == 'bf16' else 4)
-        total_ms = sum(g[0] for g in groups.values()) / reps
-        dom = max(groups.items(), key=lambda kv: kv[1][0])
-        dn, (dms, dfl, dcnt, dby) = dom
-        peak = MFMA_PEAK_TFLOPS[args.dtype]
-        ach = dfl / (dms * 1e-3) / 1e12 if dms > 0 else 0.0
-        kern = {'conv': 'conv_mfma_kernel (fwd + dgrad launches)', 'conv_wgrad': 'conv_wgrad_kernel'}.get(dn, dn)
-        out['roofline'] = {'kernel': kern, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                           'frac': round(ach / peak, 4),
-                           'traffic': pmc_traffic({'conv': 'conv_mfma_kernel', 'conv_wgrad': 'conv_wgrad_kernel'}.get(dn, dn)) if args.dtype == 'bf16' and args.workload == 'r34_hyper' and B == 32 else None,
-                           'traffic_unit': 'bytes per launch (rocprofv3 PMC FETCH_SIZE*2 + WRITE_SIZE, profiles/r01_pmc_traffic.json)',
-                           'algorithmic_bytes_per_launch': round(dby / dcnt) if dcnt else None,
-                           'launches_per_step': dcnt // reps,
-                           'avg_launch_us': round(1e3 * dms / dcnt, 2), 'share_of_step': round(dms / reps / total_ms, 3),
-                           'algorithmic_gflop_per_step': round(dfl / reps / 1e9, 2)}
-        out['op_time_ms'] = {k: round(v[0] / reps, 3) for k, v in sorted(groups.items(), key=lambda kv: -kv[1][0])[:8]}
+        roof, ops, total_ms, side_ms, all_fl, dn = conv_roofline(model, B, channels, args.dtype, args.loss, 3)
+        headline = args.dtype == 'bf16' and args.workload == 'r34_hyper' and B == 32
+        roof['traffic'] = pmc_traffic({'conv': ('conv_mfma_kernel', 'conv_glds_kernel'), 'conv_wgrad': ('conv_wgrad_kernel',)}.get(dn, (dn,))) if headline else None
+        roof['traffic_unit'] = 'bytes per launch (rocprofv3 PMC FETCH_SIZE*2 + WRITE_SIZE, %s)' % PMC_FILE
+        out['roofline'] = roof
+        out['op_time_ms'] = ops
         out['op_time_serial_ms'] = round(total_ms, 3)          # every operator run back to back on ONE stream (no wgrad overlap)
-        out['op_time_side_stream_ms'] = round(sum(v[0] for k, v in groups.items() if k in ('conv_wgrad', 'wgrad_reduce', 'conv_first_wgrad', 'stem_grad_unfold')) / reps, 3)
-        all_fl = sum(g[1] for g in groups.values()) / reps
-        out['step_tflops'] = round(all_fl * world / (elapsed / args.steps) / 1e12 / world, 2)
+        out['op_time_side_stream_ms'] = round(side_ms, 3)
+        out['step_tflops'] = round(all_fl / (elapsed / args.steps) / 1e12, 2)
 
     # ------------------------------------------------------------------ val IoU on held-out synthetic tiles (after the K steps)
     if not args.no_iou and rank == 0:
@@ -341,11 +421,21 @@ def main():
                 preds.append((lg[:, 1, 13:114, 14:115] > 0).cpu().numpy())      # crop 128->101 (postprocessing.py:24-38), sigmoid>0.5
         model.model.train()
         out['val_iou'] = round(iou_metric(np.concatenate(preds), vm > 0.5), 4)
-        out['val_iou_note'] = 'mean IoU on 128 held-out synthetic tiles after %d training steps from random init' % (args.warmup + args.steps)
+        out['val_iou_note'] = ('mean IoU on 128 held-out synthetic tiles after %d training steps from random init (a smoke signal that the '
+                               'step learns, not an accuracy result)' % (args.warmup + args.steps))
+
+    # ------------------------------------------------------------------ the other BASELINE configurations, same run (N = 1 only)
+    if rank == 0 and world == 1 and not args.no_configs:
+        del model, batches
+        torch.cuda.empty_cache()
+        out['configs'] = extra_configs(dev)
 
     # ------------------------------------------------------------------ CPU baseline: the oracle on the host cores (bounded sample)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out['cpu_baseline'] = cpu_baseline_subprocess(args, arch_name)
+        out['cpu_baseline'] = cpu_baseline_subprocess(args.loss, arch_name)
+        if not args.no_configs:
+            # BASELINE C0: the vanilla U-Net on the CPU (batch 8), the reference's own CPU-runnable case
+            out['configs']['C0_vanilla_cpu_b8'] = cpu_baseline_subprocess('lovasz', 'VanillaUNet')
     if rank == 0:
         print(json.dumps(out))
     if dist.is_initialized():

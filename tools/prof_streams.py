@@ -1,0 +1,35 @@
+#!/usr/bin/env python
+"""Per-queue view of a training step from a rocprofv3 rocpd database: busy time per HIP stream (hardware queue), the kernels on
+each, and the phases of the step (forward / loss / backward / optimizer) by wall time.  usage: python tools/prof_streams.py <db> [skip]"""
+import sqlite3, sys
+from collections import defaultdict
+path = sys.argv[1]; skip = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+c = sqlite3.connect(path)
+t = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
+kd = [x for x in t if 'kernel_dispatch' in x][0]; ks = [x for x in t if 'kernel_symbol' in x][0]
+cols = [r[1] for r in c.execute('pragma table_info(%s)' % kd)]
+qcol = 'queue_id' if 'queue_id' in cols else ('stream_id' if 'stream_id' in cols else None)
+rows = list(c.execute("select s.kernel_name, d.start, d.end, d.%s from %s d join %s s on d.kernel_id=s.id order by d.start" % (qcol, kd, ks)))
+marks = [i for i, r in enumerate(rows) if 'adam_kernel' in r[0]]
+steps = [(marks[i] + 1, marks[i + 1] + 1) for i in range(skip, len(marks) - 1)]
+n = len(steps)
+perq = defaultdict(lambda: [0.0, 0, defaultdict(float)])
+phase = defaultdict(float)
+for b, e in steps:
+    seg = rows[b:e]
+    t0 = rows[b - 1][2]
+    lov = [r for r in seg if 'lovasz' in r[0] or 'bce_dice' in r[0]]
+    for name, s, en, q in seg:
+        perq[q][0] += (en - s) / 1e3; perq[q][1] += 1
+        perq[q][2][name.replace('_ZN12_GLOBAL__N_1', '').replace('.kd', '')[:48]] += (en - s) / 1e3
+    if lov:
+        phase['forward (step start -> loss start)'] += (lov[0][1] - t0) / 1e3
+        phase['loss'] += (lov[-1][2] - lov[0][1]) / 1e3
+        phase['backward + optimizer (loss end -> adam end)'] += (seg[-1][2] - lov[-1][2]) / 1e3
+print('# %d steps' % n)
+for k, v in phase.items():
+    print('%-48s %9.1f us' % (k, v / n))
+for q, (tot, cnt, names) in sorted(perq.items(), key=lambda kv: -kv[1][0]):
+    print('queue %s: busy %.1f us/step, %.0f dispatches/step' % (q, tot / n, cnt / n))
+    for k, v in sorted(names.items(), key=lambda kv: -kv[1])[:12]:
+        print('      %-50s %9.1f' % (k, v / n))
