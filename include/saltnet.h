@@ -683,6 +683,10 @@ int salt_program_run_streams(const salt_program_entry* entries, int begin, int e
 /* join_at_end == 0: the caller orders its consumers after BOTH streams itself (bucketed all-reduce between backward segments) */
 int salt_program_run_streams_ex(const salt_program_entry* entries, int begin, int end, void* main_stream, void* side_stream, int join_at_end);
 int salt_graph_capture(const salt_program_entry* entries, int n, void* stream, void** graph_exec_out);
+/* whole-step capture: every salt_program_run* call between begin and end on `stream` (and on the side stream the two-stream executor
+ * forks to) is recorded instead of executed; `stream` must not be the default stream */
+int salt_graph_begin(void* stream);
+int salt_graph_end(void* stream, void** graph_exec_out);
 int salt_graph_launch(void* graph_exec, void* stream);
 int salt_graph_destroy(void* graph_exec);
 

@@ -107,6 +107,8 @@ lib.salt_program_run_timed.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_i
 lib.salt_program_run_streams.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
 lib.salt_graph_capture.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
 lib.salt_graph_launch.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+lib.salt_graph_begin.argtypes = [ctypes.c_void_p]
+lib.salt_graph_end.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
 lib.salt_graph_destroy.argtypes = [ctypes.c_void_p]
 
 DECLARED_SYMBOLS = [p[0] for p in _PROTOS] + ['salt_last_error']

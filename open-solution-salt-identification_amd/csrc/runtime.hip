@@ -20,7 +20,7 @@ void salt_set_error(const char* fmt, ...) {
 
 extern "C" const char* salt_last_error(void) { return g_err; }
 
-extern "C" int salt_abi_version(void) { return 12; }
+extern "C" int salt_abi_version(void) { return 13; }
 
 extern "C" int salt_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name_len) {
     int dev = 0;
@@ -81,7 +81,9 @@ struct EventPool {
 };
 thread_local EventPool g_events;
 thread_local hipEvent_t g_fork_event = nullptr;
-const bool g_fork_handoff = !getenv("SALT_NO_FORK_HANDOFF");
+const bool g_fork_handoff_env = !getenv("SALT_NO_FORK_HANDOFF");
+thread_local bool g_capturing = false;         // hipExtLaunchKernelGGL stop events are not capturable: plain event forks while a graph records
+#define g_fork_handoff (g_fork_handoff_env && !g_capturing)
 }  // namespace
 
 hipEvent_t salt_take_fork_event() { hipEvent_t e = g_fork_event; g_fork_event = nullptr; return e; }
@@ -144,6 +146,30 @@ extern "C" int salt_graph_capture(const salt_program_entry* e, int n, void* stre
     err = hipStreamEndCapture(st, &graph);
     if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     if (err != hipSuccess) SALT_FAIL((int)err, "hipStreamEndCapture: %s", hipGetErrorString(err));
+    hipGraphExec_t exec = nullptr;
+    err = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (err != hipSuccess) SALT_FAIL((int)err, "hipGraphInstantiate: %s", hipGetErrorString(err));
+    *out = (void*)exec;
+    return SALT_OK;
+}
+
+// Capture of a whole step (several programs, two streams): bracket any sequence of salt_program_run* calls.  The side stream joins
+// the capture through the executor's own event forks and must have re-joined `stream` (join_at_end) before salt_graph_end.
+extern "C" int salt_graph_begin(void* stream) {
+    if (!stream) SALT_FAIL(SALT_E_BADARG, "graph capture needs a non-default stream");
+    hipError_t err = hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal);
+    if (err != hipSuccess) SALT_FAIL((int)err, "hipStreamBeginCapture: %s", hipGetErrorString(err));
+    g_capturing = true;
+    return SALT_OK;
+}
+
+extern "C" int salt_graph_end(void* stream, void** out) {
+    g_capturing = false;
+    if (!stream || !out) SALT_FAIL(SALT_E_BADARG, "graph_end: bad args");
+    hipGraph_t graph = nullptr;
+    hipError_t err = hipStreamEndCapture((hipStream_t)stream, &graph);
+    if (err != hipSuccess) { if (graph) (void)hipGraphDestroy(graph); SALT_FAIL((int)err, "hipStreamEndCapture: %s", hipGetErrorString(err)); }
     hipGraphExec_t exec = nullptr;
     err = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);

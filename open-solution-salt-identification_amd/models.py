@@ -102,6 +102,10 @@ class SegmentationModel(Model):
                                    model=self.model, **architecture_config['optimizer_params'])
         self.callbacks = callbacks_network(self.callbacks_config)
         self.dp = parallel.DataParallel.from_env()
+        # one-GPU training replays the whole step as a hipGraph (training_config['step_graph'] / SALT_STEP_GRAPH=0|1)
+        import os
+        self._eager_done = set()
+        self.step_graph = bool(int(os.environ.get('SALT_STEP_GRAPH', '1' if (training_config or {}).get('step_graph', True) else '0')))
 
     # ------------------------------------------------------------------ reference surface
     def set_model(self):
@@ -168,16 +172,30 @@ class SegmentationModel(Model):
             batch_loss = loss_function(outputs_batch, target) * weight
             batch_loss.backward()
             self.dp.allreduce_gradients(self.model.engine(), self.optimizer)   # SUM over ranks; Adam's grad_scale carries 1/world
-        self.optimizer.step()
+        if getattr(self, '_graph_stepped', False):
+            self._graph_stepped = False                  # Adam ran inside the captured step
+        else:
+            self.optimizer.step()
         return {'sum': batch_loss}
 
     def _fused_step(self, X, target, kind, weight):
         eng = self.model.engine(X.device)
+        if self.step_graph and not self.dp._active() and (id(eng), tuple(X.shape), kind) in self._eager_done:
+            # the whole step (pack, forward, loss, backward, Adam; both streams) replayed as ONE hipGraph launch (the first step of
+            # a shape runs eagerly: lazy one-time work - kernel attributes, workspace allocation - must not fall into the capture)
+            net = eng.net(tuple(X.shape), True)
+            net.x.copy_(X)
+            net.target.copy_(target[:, :net.logits.shape[1]])
+            self.optimizer.grad_scale = 1.0
+            eng.run_step_graph(net, kind, weight, self.optimizer)
+            self._graph_stepped = True
+            return net.loss[0].clone()
         net = eng.forward(X.contiguous().float(), True)
         K = net.logits.shape[1]
         net.target.copy_(target[:, :K])
         net.loss_program(kind, weight).run()
         self.dp.backward(eng, net, self.optimizer)
+        self._eager_done.add((id(eng), tuple(X.shape), kind))
         return net.loss[0].clone()
 
     def transform(self, datagen, validation_datagen=None, *args, **kwargs):

@@ -98,6 +98,7 @@ class Engine:
         self._folded_version = None
         self.world = 1
         self.side_stream = torch.cuda.Stream(device=device)     # weight-gradient kernels overlap the data-gradient chain
+        self._step_graphs = {}
 
     # ------------------------------------------------------------------ flat parameter storage
     def _flatten(self):
@@ -260,6 +261,66 @@ class Engine:
         if key not in self.nets:
             self.nets[key] = CompiledNet(self, tuple(shape), train, self.module.num_classes)
         return self.nets[key]
+
+    # ------------------------------------------------------------------ one training step as ONE hipGraph
+    def step_graph(self, net, kind, loss_scale, optimizer):
+        """Capture pack -> forward (two streams) -> data-gradient packs -> loss -> backward (two streams) -> Adam of one compiled
+        instance into a hipGraph (cached); replaying it is one launch instead of ~490.  Everything the step touches is static
+        device memory; the learning rate / bias corrections live in the optimizer's device `hyper` vector (adam_tick)."""
+        key = (id(net), kind, float(loss_scale), id(optimizer))
+        g = self._step_graphs.get(key)
+        if g is not None:
+            return g
+        if getattr(self, '_pack_batched_n', -1) != len(self._pack_ops):
+            self._build_pack_batch()
+        optimizer._bind()
+        optimizer._sync_hyper()
+        loss_prog = net.loss_program(kind, loss_scale)
+        st = self._graph_stream = getattr(self, '_graph_stream', None) or torch.cuda.Stream(device=self.device)
+        torch.cuda.synchronize()
+        exec_ = ctypes.c_void_p()
+        with torch.cuda.stream(st):
+            _abi.check(lib.salt_graph_begin(ctypes.c_void_p(st.cuda_stream)), 'graph_begin')
+            try:
+                self._pack_batched.run(stream=st)
+                net.fwd.run(stream=st, side=self.side_stream)
+                if len(self._pack_batched_bwd):
+                    # fork: the data-gradient packs run on the side stream under the loss kernel; backward's first operator joins
+                    lib.salt_program_run_streams_ex(ctypes.cast(self._pack_fork_entries(), ctypes.c_void_p), 0, 1, ctypes.c_void_p(st.cuda_stream),
+                                                    ctypes.c_void_p(self.side_stream.cuda_stream), 0)
+                loss_prog.run(stream=st)
+                net.bwd.run(stream=st, side=self.side_stream)
+                optimizer.prog.run(stream=st)
+            finally:
+                rc = lib.salt_graph_end(ctypes.c_void_p(st.cuda_stream), ctypes.byref(exec_))
+            _abi.check(rc, 'graph_end')
+        torch.cuda.synchronize()
+        self._step_graphs[key] = exec_
+        return exec_
+
+    def _pack_fork_entries(self):
+        """The data-gradient pack launch as a one-entry program tagged for the side stream (the executor forks with an event)."""
+        if getattr(self, '_pack_fork', None) is None or self._pack_fork[0] is not self._pack_batched_bwd:
+            Entry = _abi.STRUCTS['salt_program_entry']
+            arr = (Entry * 1)()
+            name, fn, s = self._pack_batched_bwd.ops[0]
+            arr[0].fn = ctypes.cast(fn, ctypes.c_void_p).value
+            arr[0].args = ctypes.addressof(s)
+            arr[0].stream = 1
+            self._pack_fork = (self._pack_batched_bwd, arr)
+        return self._pack_fork[1]
+
+    def run_step_graph(self, net, kind, loss_scale, optimizer):
+        exec_ = self.step_graph(net, kind, loss_scale, optimizer)
+        optimizer._sync_hyper()
+        cur = torch.cuda.current_stream()
+        st = self._graph_stream
+        st.wait_stream(cur)                                  # the input / target copies of this step
+        _abi.check(lib.salt_graph_launch(exec_, ctypes.c_void_p(st.cuda_stream)), 'graph_launch')
+        cur.wait_stream(st)
+        optimizer.steps += 1
+        self._packed_version = self._packed_bwd_version = self.wver      # the graph packed the weights it started from ...
+        self.touch(weights=True, stats=True)                             # ... and Adam / BatchNorm moved them
 
     def forward(self, x, train):
         _require_gpu(x.device)

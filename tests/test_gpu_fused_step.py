@@ -250,6 +250,38 @@ def test_bf16_whole_network_vs_fp32_oracle_c2_shape():
         assert e_hip <= 1.3 * e_emu + 1e-2, (k, e_hip, e_emu)
 
 
+def test_step_graph_replay_equals_eager_steps():
+    """The training step captured into ONE hipGraph (pack, two-stream forward, loss, two-stream backward, Adam) and replayed must
+    reproduce the eagerly launched steps bit for bit: same kernels, same order, same static buffers."""
+    results = {}
+    for mode in ('eager', 'graph'):
+        torch.manual_seed(11)
+        m = _segmentation_model('UNetResNet', 'lovasz', dtype='bf16', lr=1e-3)
+        m.step_graph = mode == 'graph'
+        m._to_device()
+        m.model.train()
+        g = torch.Generator().manual_seed(5)
+        X = torch.randn(4, 3, 128, 128, generator=g)
+        M = (torch.rand(4, 1, 128, 128, generator=g) > 0.6).float()
+        Tt = torch.cat([1 - M, M], 1)
+        ls = [float(m._fit_loop([X + 0.01 * i, Tt])['sum']) for i in range(5)]        # step 0 eager, step 1 captures, 2.. replay
+        torch.cuda.synchronize()
+        eng = m.model.engine()
+        sd = {k: v.detach().clone() for k, v in m.model.state_dict().items()}
+        results[mode] = (ls, eng.flat.clone(), eng.grads.clone(), sd, m.optimizer.steps, len(eng._step_graphs))
+        # the eval-mode program sees the weights the captured Adam wrote (packed copies are refreshed)
+        m.model.eval()
+        with torch.no_grad():
+            results[mode] += (m.model(X.to(DEV)).float().cpu(),)
+    assert results['graph'][5] == 1 and results['eager'][5] == 0
+    assert results['eager'][4] == results['graph'][4] == 5
+    assert results['eager'][0] == results['graph'][0]
+    assert torch.equal(results['eager'][2], results['graph'][2]) and torch.equal(results['eager'][1], results['graph'][1])
+    for k, v in results['eager'][3].items():
+        assert torch.equal(v, results['graph'][3][k]), k                         # BatchNorm running statistics, num_batches_tracked
+    assert torch.equal(results['eager'][6], results['graph'][6])
+
+
 _RCCL_WORKER = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, %(root)r)
