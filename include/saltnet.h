@@ -115,6 +115,13 @@ typedef struct {
     const float* bnb_beta;
     float* bnb_partials;
     int bnb_relu;
+    /* Phase-fused stride-2 launch (nphase == 4): the four output-parity phases of a transposed convolution / stride-2 data gradient in
+     * ONE launch.  Every phase runs the same `ntaps` tap offsets over x and writes y at (2 oy + ay, 2 ox + ax), phase = 2 ay + ax
+     * (out_oy / out_ox are ignored, out_step must be 2, OH x OW is the per-phase grid); phase p reads the packed weights at
+     * w + p * w_phase_elems elements (taps a phase does not have are packed as zeros: tap_kh < 0 in salt_pack_conv_weight).  BN
+     * statistics partials are numbered over all phases.  nphase <= 1: a plain launch. */
+    int nphase;
+    int64_t w_phase_elems;
 } salt_conv_args;
 int salt_conv(const salt_conv_args*, void* stream);
 /* number of stats partials a launch with these args writes (host sizes the workspace with it) */
@@ -166,7 +173,7 @@ typedef struct {
     int KH;
     int KW;
     int ntaps;
-    int tap_kh[SALT_MAX_TAPS];
+    int tap_kh[SALT_MAX_TAPS];   /* < 0: a zero tap (phase-fused launches) */
     int tap_kw[SALT_MAX_TAPS];
     int transpose;
     void* wp;
@@ -390,6 +397,10 @@ typedef struct {              /* gradient to the first maximal element of each w
     int accumulate;
 } salt_maxpool2_bwd_args;
 int salt_maxpool2_bwd(const salt_maxpool2_bwd_args*, void* stream);
+/* nn.MaxPool2d(3, stride 2, padding 1): the ResNet stem pool of ResNetEncoders(pool0=True) (architectures/encoders.py:23-27); same
+ * argument structs, y / dy are ceil(H/2) x ceil(W/2); the gradient goes to the first maximum of every (overlapping) window */
+int salt_maxpool3s2(const salt_maxpool2_args*, void* stream);
+int salt_maxpool3s2_bwd(const salt_maxpool2_bwd_args*, void* stream);
 
 typedef struct {              /* nn.AvgPool2d(2,2) (unet.py:62); bwd: dx = dy/4 */
     int dtype;

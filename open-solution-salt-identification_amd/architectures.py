@@ -245,12 +245,15 @@ class ResNetEncoders(EmitOnly):
         super().__init__()
         if encoder_depth not in ResNet.CFG:
             raise NotImplementedError('only 18, 34, 50, 101, 152 version of Resnet are implemented')
-        if pool0:
-            # with the stem max-pool the reference's forward (unet.py:89-109) has no compensating up-sampling: its logits come out at
-            # half the input resolution and no longer match the loaders' targets - the registry never sets it (models.py:15-19)
-            raise NotImplementedError('pool0=True (stem max-pool) is off the reference default path (models.py:15-19)')
+        # pool0: the stem is followed by torchvision's MaxPool2d(3, 2, 1) (encoders.py:23-27).  The reference's decoder has no
+        # compensating up-sampling, so the logits then come out at HALF the input resolution (unet.py:89-109); the registry never
+        # sets it (models.py:15-19) - reproduced as is
+        self.pool0 = pool0
         self.encoder = resnet(encoder_depth, pretrained)
-        self.conv1 = nn.Sequential(self.encoder.conv1, self.encoder.bn1, self.encoder.relu)
+        if pool0:
+            self.conv1 = nn.Sequential(self.encoder.conv1, self.encoder.bn1, self.encoder.relu, self.encoder.maxpool)
+        else:
+            self.conv1 = nn.Sequential(self.encoder.conv1, self.encoder.bn1, self.encoder.relu)
         self.encoder2 = self.encoder.layer1
         self.encoder3 = self.encoder.layer2
         self.encoder4 = self.encoder.layer3
@@ -345,12 +348,20 @@ class UNetResNet(HipNetwork):
     def dead_parameter_names(self):
         return ['encoders.encoder.fc.weight', 'encoders.encoder.fc.bias']
 
+    def output_shape(self, shape):
+        B, _, H, W = shape
+        s = 2 if self.encoders.pool0 else 1
+        return (B, self.num_classes, H // s, W // s)
+
     def emit(self, g, x_nchw, logits):
         enc = self.encoders.encoder
         B, _, H, W = x_nchw.shape
         b, d = self.bottom, self.bottom // 8
         exp = 1 if b == 512 else 4
         c1 = g.conv_first(x_nchw, enc.conv1, enc.bn1, relu=True, name='stem')
+        if self.encoders.pool0:
+            c1 = g.maxpool3s2(c1, name='stem.pool')
+            H, W = H // 2, W // 2                    # everything downstream runs at half the resolution
         # concat-free skips: the encoder writes each feature map straight into the decoder's input buffer
         cat5 = g.new_act(B, H // 16, W // 16, b // 2 + b, 'cat5')                   # [up(center) | e5]
         cat4 = g.new_act(B, H // 8, W // 8, d + 256 * exp, 'cat4')                   # [up(dec5)   | e4]

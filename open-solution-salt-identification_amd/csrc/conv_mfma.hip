@@ -37,6 +37,7 @@ struct ConvKP {
     int nchunk, a_bytes;
     int relu, accumulate, stats_part0;
     void* strip; int strip_cs, fold_top, fold_bottom, fold_left, fold_right;     // fold mode (strip != nullptr)
+    int nphase, m_tiles_ph; int64_t w_phase_elems;   // phase-fused stride-2 launch: 4 output-parity phases, one packed weight block each
     int fold_fused, ox_shift;        // fused fold (strip == nullptr, fold_top / fold_right > 0): tile columns start at -ox_shift
     unsigned hhw_magic, hw_magic;                                                // x / d == umulhi(x, 2^32 / d + 1) for x * d < 2^32
     int m_tiles, n_tiles;
@@ -111,7 +112,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
     const int n_tile = local % p.n_tiles;
     const int m_tile = (local / p.n_tiles) * 8 + xcd;
     if (m_tile >= p.m_tiles) return;
-    int tile = m_tile;
+    int tile = m_tile, out_oy = p.out_oy, out_ox = p.out_ox;
+    int64_t w_off = 0;
+    if (p.nphase > 1) {                       // phase-fused stride-2 launch: the tile's output parity selects offset and weight block
+        const int ph = m_tile / p.m_tiles_ph;
+        tile = m_tile - ph * p.m_tiles_ph;
+        out_oy = ph >> 1; out_ox = ph & 1;
+        w_off = ph * p.w_phase_elems;
+    }
     const int txi = tile % p.tiles_x; tile /= p.tiles_x;
     const int tyi = tile % p.tiles_y;
     const int tbi = tile / p.tiles_y;
@@ -121,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
     const int phalo = p.nb * hhw;
     const int iy0 = oy0 * p.in_step + p.min_dy, ix0 = ox0 * p.in_step + p.min_dx;
     const T* xg = reinterpret_cast<const T*>(p.x);
-    const T* wg = reinterpret_cast<const T*>(p.w);
+    const T* wg = reinterpret_cast<const T*>(p.w) + w_off;
     const bool x_vec = ((p.x_cs % VE) == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
 
     // ---- per-thread halo staging pieces (fixed for the whole chunk loop); offsets are relative to image b0 (fit 32 bits)
@@ -470,7 +478,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
             const int oy = oy0 + ty, ox = ox0 + tx, b = b0 + bl;
             const int n = n0 + pc * VE;
             if (b >= p.B || oy >= p.OH || ox >= p.OW || ox < 0 || n >= p.Cout) continue;
-            T* dst = yg + (((int64_t)b * p.OHf + oy * p.out_step + p.out_oy) * p.OWf + ox * p.out_step + p.out_ox) * p.y_cs + n;
+            T* dst = yg + (((int64_t)b * p.OHf + oy * p.out_step + out_oy) * p.OWf + ox * p.out_step + out_ox) * p.y_cs + n;
             bool accum = p.accumulate != 0;
             bool dvec = y_vec;
             int fold_rows = 0, fold_cols = 0;                      // fused fold: ring pixels above / right of this edge pixel
@@ -696,7 +704,14 @@ __global__ __launch_bounds__(512, 2) void conv_glds_kernel(ConvKP p) {
     const int n_tile = local % p.n_tiles;
     const int m_tile = (local / p.n_tiles) * 8 + xcd;
     if (m_tile >= p.m_tiles) return;
-    int tile = m_tile;
+    int tile = m_tile, out_oy = p.out_oy, out_ox = p.out_ox;
+    int64_t w_off = 0;
+    if (p.nphase > 1) {                       // phase-fused stride-2 launch: the tile's output parity selects offset and weight block
+        const int ph = m_tile / p.m_tiles_ph;
+        tile = m_tile - ph * p.m_tiles_ph;
+        out_oy = ph >> 1; out_ox = ph & 1;
+        w_off = ph * p.w_phase_elems;
+    }
     const int txi = tile % p.tiles_x; tile /= p.tiles_x;
     const int tyi = tile % p.tiles_y;
     const int tbi = tile / p.tiles_y;
@@ -706,7 +721,7 @@ __global__ __launch_bounds__(512, 2) void conv_glds_kernel(ConvKP p) {
     const int phalo = p.nb * hhw;
     const int iy0 = oy0 + p.min_dy, ix0 = ox0 + p.min_dx;
     const T* xg0 = reinterpret_cast<const T*>(p.x) + (int64_t)b0 * p.H * p.W * p.x_cs;
-    const T* wg = reinterpret_cast<const T*>(p.w);
+    const T* wg = reinterpret_cast<const T*>(p.w) + w_off;
     const unsigned char* zp = reinterpret_cast<const unsigned char*>(g_zero_piece);
 
     // ---- DMA slots.  A chunk is NA + NB wave-instructions of 1 KB (16 LDS rows each): NA halo pieces (rows padded to a multiple
@@ -1047,7 +1062,7 @@ __global__ __launch_bounds__(512, 2) void conv_glds_kernel(ConvKP p) {
             const int oy = oy0 + ty, ox = ox0 + tx, b = b0 + bl;
             const int n = n0 + pc * VE;
             if (b >= p.B || oy >= p.OH || ox >= p.OW || ox < 0 || n >= p.Cout) continue;
-            T* dst = yg + (((int64_t)b * p.OHf + oy * p.out_step + p.out_oy) * p.OWf + ox * p.out_step + p.out_ox) * p.y_cs + n;
+            T* dst = yg + (((int64_t)b * p.OHf + oy * p.out_step + out_oy) * p.OWf + ox * p.out_step + out_ox) * p.y_cs + n;
             bool accum = p.accumulate != 0;
             bool dvec = y_vec;
             int fold_rows = 0, fold_cols = 0;                      // fused fold: ring pixels above / right of this edge pixel
@@ -1221,7 +1236,7 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
         min_dy = a->tap_dy[t] < min_dy ? a->tap_dy[t] : min_dy; max_dy = a->tap_dy[t] > max_dy ? a->tap_dy[t] : max_dy;
         min_dx = a->tap_dx[t] < min_dx ? a->tap_dx[t] : min_dx; max_dx = a->tap_dx[t] > max_dx ? a->tap_dx[t] : max_dx;
     }
-    const int64_t pixels = (int64_t)a->x.B * a->OH * a->OW;
+    const int64_t pixels = (int64_t)a->x.B * a->OH * a->OW * (a->nphase > 1 ? a->nphase : 1);
     // 1x1 stride-1 convolution with Cin a multiple of 4 chunks: 4 channel chunks per barrier round (virtual taps, see the kernel)
     const int KCE_ = a->dtype == SALT_F32 ? 16 : 32;
     static const bool vt_off = getenv("SALT_CONV_NO_VT") != nullptr;
@@ -1305,10 +1320,12 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
     k.vt = vt;
     if (vt > 1) { k.ntaps = vt; for (int t = 0; t < vt; ++t) k.tap_off[t] = t * k.nb * k.hh * k.hw; }
     k.fold_fused = fold_fused ? 1 : 0;
-    k.ox_shift = (fold_fused && a->fold_right > 0) ? (1 << k.tw_log2) - a->fold_right : 0;
+    // fused fold: the tile columns are RIGHT-aligned with the extended grid (the last tile ends at OW), so the right pad columns
+    // share a tile with the last image column whatever W is; rows start at 0, the top pad rows share the first tile with row 0
+    k.tiles_y = cdiv(a->OH, 1 << k.th_log2); k.tiles_x = cdiv(a->OW, 1 << k.tw_log2);
+    k.ox_shift = (fold_fused && a->fold_right > 0) ? k.tiles_x * (1 << k.tw_log2) - a->OW : 0;
     if (fold_fused && ((1 << k.th_log2) <= a->fold_top || (1 << k.tw_log2) <= a->fold_right))
         SALT_FAIL(SALT_E_UNSUPPORTED, "conv: fused fold needs tiles larger than the pad (%d x %d)", 1 << k.th_log2, 1 << k.tw_log2);
-    k.tiles_y = cdiv(a->OH, 1 << k.th_log2); k.tiles_x = cdiv(a->OW + k.ox_shift, 1 << k.tw_log2);
     const int tiles_b = cdiv(a->x.B, k.nb);
     k.nchunk = cdiv(a->x.C, KCE * vt);
     k.a_bytes = k.nb * k.hh * k.hw * 64 * vt;
@@ -1318,6 +1335,13 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
     k.relu = a->relu; k.accumulate = a->accumulate; k.stats_part0 = a->stats_part0;
     k.strip = a->strip; k.strip_cs = a->strip_cs; k.fold_top = a->fold_top; k.fold_bottom = a->fold_bottom; k.fold_left = a->fold_left; k.fold_right = a->fold_right;
     k.m_tiles = tiles_b * k.tiles_y * k.tiles_x; k.n_tiles = cdiv(Cout, BN);
+    k.nphase = a->nphase > 1 ? a->nphase : 1; k.m_tiles_ph = k.m_tiles; k.w_phase_elems = a->w_phase_elems;
+    if (k.nphase > 1) {
+        if (k.nphase != 4 || a->out_step != 2 || a->strip || fold_fused || a->bnb_partials || a->w_phase_elems <= 0 ||
+            (a->OH - 1) * 2 + 1 >= a->y.H || (a->OW - 1) * 2 + 1 >= a->y.W)
+            SALT_FAIL(SALT_E_BADARG, "conv: a phase-fused launch is 4 output-parity phases of an out_step 2 grid that fits y for every parity");
+        k.m_tiles *= 4;
+    }
     pl->grid = dim3((unsigned)(cdiv(k.m_tiles, 8) * 8 * k.n_tiles), 1, 1);
     pl->lds = (size_t)k.a_bytes + (size_t)k.ntaps * BN * 64;
     if (cfg->KS > 0) {
@@ -1330,7 +1354,7 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
         const size_t out_bytes = (size_t)(32 * cfg->MI * cfg->WM) * (BN * es + 16);
         if (out_bytes > pl->lds) pl->lds = out_bytes;
     }
-    pl->parts = tiles_b * k.tiles_y * k.tiles_x;
+    pl->parts = tiles_b * k.tiles_y * k.tiles_x * k.nphase;
     k.bnb_partials = a->bnb_partials; k.bnb_y = a->bnb_y.p; k.bnb_cs = a->bnb_y.cs; k.bnb_relu = a->bnb_relu;
     k.bnb_a = a->bnb_a.p; k.bnb_acs = a->bnb_a.cs;
     k.bnb_mean = a->bnb_mean; k.bnb_invstd = a->bnb_invstd; k.bnb_gamma = a->bnb_gamma; k.bnb_beta = a->bnb_beta;
@@ -1441,7 +1465,7 @@ __global__ void pack_weight_kernel(PackKP p) {
         const int t = (int)(r % p.ntaps);
         const int ch = (int)(r / p.ntaps) * KCE + kc;
         float v = 0.f;
-        if (ch < p.C) {
+        if (ch < p.C && p.tap_kh[t] >= 0) {
             const int d0 = p.transpose ? ch : n, d1 = p.transpose ? n : ch;
             v = p.w[(((int64_t)d0 * p.D1 + d1) * p.KH + p.tap_kh[t]) * p.KW + p.tap_kw[t]];
         }
@@ -1473,7 +1497,7 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const salt_pack_conv_
         const int chunk = ch / KCE, kc = ch - chunk * KCE;
         const float* src = a.w + ((int64_t)n * a.D1 + ch) * a.KH * a.KW;
         for (int t = 0; t < a.ntaps; ++t) {
-            const float v = ch < C ? src[a.tap_kh[t] * a.KW + a.tap_kw[t]] : 0.f;
+            const float v = (ch < C && a.tap_kh[t] >= 0) ? src[a.tap_kh[t] * a.KW + a.tap_kw[t]] : 0.f;      // tap_kh < 0: a zero tap
             Elem<T>::st(out + (((int64_t)chunk * a.ntaps + t) * N + n) * KCE + kc, v);
         }
         return;
@@ -1487,7 +1511,7 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const salt_pack_conv_
         const int t = (int)(r % a.ntaps);
         const int ch = (int)(r / a.ntaps) * KCE + kc;
         float v = 0.f;
-        if (ch < C) {
+        if (ch < C && a.tap_kh[t] >= 0) {
             const int d0 = a.transpose ? ch : n, d1 = a.transpose ? n : ch;
             v = a.w[(((int64_t)d0 * a.D1 + d1) * a.KH + a.tap_kh[t]) * a.KW + a.tap_kw[t]];
         }
@@ -2357,7 +2381,11 @@ int wgrad_plan(const salt_conv_wgrad_args* a, WgradKP* k, int* nsplit_out) {
     static const int target_wgs = getenv("SALT_WGRAD_WGS") ? atoi(getenv("SALT_WGRAD_WGS")) : 512;
     static const int min_tiles = getenv("SALT_WGRAD_TPW") ? atoi(getenv("SALT_WGRAD_TPW")) : 8;
     int ns = target_wgs / (k->a_blocks * k->b_blocks);
-    if (ns > k->ntiles / min_tiles) ns = k->ntiles / min_tiles;
+    // the stem (64 x 16 channels, launched on the MAIN stream at the very end of backward, nothing left to overlap with): finer
+    // split.  NOT for the other single-block layers: their launches share the chip with the data-gradient chain, and 256 instead
+    // of 128 weight-gradient workgroups starved it (7.0 -> 8.5 ms per step)
+    const int mt = (k->a_blocks * k->b_blocks == 1 && a->q.C <= 16 && min_tiles >= 2) ? min_tiles / 2 : min_tiles;
+    if (ns > k->ntiles / mt) ns = k->ntiles / mt;
     if (ns < 1) ns = 1;
     if (ns > k->ntiles) ns = k->ntiles;
     *nsplit_out = ns;
@@ -2449,7 +2477,7 @@ extern "C" int salt_pack_conv_weight(const salt_pack_conv_weight_args* a, void* 
     const int KCE = a->dtype == SALT_F32 ? 16 : 32;
     p.nchunk = cdiv(p.C, KCE);
     for (int t = 0; t < a->ntaps; ++t) {
-        if (a->tap_kh[t] < 0 || a->tap_kh[t] >= a->KH || a->tap_kw[t] < 0 || a->tap_kw[t] >= a->KW) SALT_FAIL(SALT_E_BADARG, "pack: tap");
+        if (a->tap_kh[t] >= a->KH || a->tap_kw[t] < 0 || a->tap_kw[t] >= a->KW) SALT_FAIL(SALT_E_BADARG, "pack: tap");      // tap_kh < 0: zero tap
         p.tap_kh[t] = a->tap_kh[t]; p.tap_kw[t] = a->tap_kw[t];
     }
     const int64_t total = (int64_t)p.nchunk * p.ntaps * p.N * KCE;

@@ -490,6 +490,81 @@ __global__ void maxpool2_bwd_kernel(salt_view x, salt_view dy, salt_view dx, int
     }
 }
 
+// nn.MaxPool2d(kernel 3, stride 2, padding 1): the ResNet stem pool the reference applies when pool0 is set (encoders.py:23-27).
+// Padding is -inf (never selected).  Backward: torch routes an output's gradient to the FIRST maximum of its window in row-major
+// window order; windows overlap, so an input pixel gathers from up to 4 outputs (deterministic, no atomics).
+template <typename T, bool VEC>
+__global__ void maxpool3s2_kernel(salt_view x, salt_view y) {
+    constexpr int N = Unit<T, VEC>::N;
+    const int cpv = x.C / N;
+    const int64_t units = (int64_t)y.B * y.H * y.W * cpv;
+    for (int64_t u = blockIdx.x * 256LL + threadIdx.x; u < units; u += gridDim.x * 256LL) {
+        int64_t pix = u / cpv; const int c0 = (int)(u - pix * cpv) * N;
+        const int ox = (int)(pix % y.W); int64_t r = pix / y.W; const int oy = (int)(r % y.H); const int b = (int)(r / y.H);
+        float m[N], f[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) m[j] = -INFINITY;
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = 2 * oy - 1 + ky;
+            if (iy < 0 || iy >= x.H) continue;
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = 2 * ox - 1 + kx;
+                if (ix < 0 || ix >= x.W) continue;
+                Unit<T, VEC>::ld((const T*)x.p + (((int64_t)b * x.H + iy) * x.W + ix) * x.cs + c0, f);
+#pragma unroll
+                for (int j = 0; j < N; ++j) m[j] = fmaxf(m[j], f[j]);
+            }
+        }
+        Unit<T, VEC>::st((T*)y.p + pix * y.cs + c0, m);
+    }
+}
+
+template <typename T, bool VEC>
+__global__ void maxpool3s2_bwd_kernel(salt_view x, salt_view dy, salt_view dx, int accumulate) {
+    constexpr int N = Unit<T, VEC>::N;
+    const int cpv = x.C / N;
+    const int64_t units = (int64_t)x.B * x.H * x.W * cpv;
+    for (int64_t u = blockIdx.x * 256LL + threadIdx.x; u < units; u += gridDim.x * 256LL) {
+        int64_t pix = u / cpv; const int c0 = (int)(u - pix * cpv) * N;
+        const int ix = (int)(pix % x.W); int64_t r = pix / x.W; const int iy = (int)(r % x.H); const int b = (int)(r / x.H);
+        float o[N], me[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) o[j] = 0.f;
+        Unit<T, VEC>::ld((const T*)x.p + pix * x.cs + c0, me);
+        // outputs whose window [2o-1, 2o+1] contains this pixel: o in {floor(i/2), floor((i+1)/2)}
+        for (int oy = iy >> 1; oy <= (iy + 1) >> 1; ++oy) {
+            if (oy >= dy.H) continue;
+            for (int ox = ix >> 1; ox <= (ix + 1) >> 1; ++ox) {
+                if (ox >= dy.W) continue;
+                float g[N], f[N];
+                bool first[N];                                   // is this pixel the first maximum of window (oy, ox)?
+#pragma unroll
+                for (int j = 0; j < N; ++j) first[j] = true;
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int wy = 2 * oy - 1 + ky;
+                    if (wy < 0 || wy >= x.H) continue;
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int wx = 2 * ox - 1 + kx;
+                        if (wx < 0 || wx >= x.W || (wy == iy && wx == ix)) continue;
+                        Unit<T, VEC>::ld((const T*)x.p + (((int64_t)b * x.H + wy) * x.W + wx) * x.cs + c0, f);
+                        const bool before = wy < iy || (wy == iy && wx < ix);         // earlier in row-major window order
+#pragma unroll
+                        for (int j = 0; j < N; ++j) if (before ? f[j] >= me[j] : f[j] > me[j]) first[j] = false;
+                    }
+                }
+                Unit<T, VEC>::ld((const T*)dy.p + (((int64_t)b * dy.H + oy) * dy.W + ox) * dy.cs + c0, g);
+#pragma unroll
+                for (int j = 0; j < N; ++j) if (first[j]) o[j] += g[j];
+            }
+        }
+        T* dst = (T*)dx.p + pix * dx.cs + c0;
+        if (accumulate) { float old[N]; Unit<T, VEC>::ld(dst, old);
+#pragma unroll
+            for (int j = 0; j < N; ++j) o[j] += old[j]; }
+        Unit<T, VEC>::st(dst, o);
+    }
+}
+
 template <typename T, bool VEC>
 __global__ void avgpool2_kernel(salt_view x, salt_view y, int backward, int accumulate) {
     constexpr int N = Unit<T, VEC>::N;
@@ -848,6 +923,33 @@ extern "C" int salt_maxpool2_bwd(const salt_maxpool2_bwd_args* a, void* stream) 
         const bool v = vec_ok(a->x, ve) && vec_ok(a->dy, ve) && vec_ok(a->dx, ve);
         const int64_t units = view_pixels(a->x) * (a->x.C / (v ? ve : 1));
         EW_LAUNCH(maxpool2_bwd_kernel, T, v, units, (hipStream_t)stream, a->x, a->dy, a->dx, a->accumulate);
+    })
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}
+
+extern "C" int salt_maxpool3s2(const salt_maxpool2_args* a, void* stream) {
+    if (!a || !view_ok(a->x) || !view_ok(a->y) || a->y.H != (a->x.H + 1) / 2 || a->y.W != (a->x.W + 1) / 2 || a->y.C != a->x.C || a->y.B != a->x.B)
+        SALT_FAIL(SALT_E_BADARG, "maxpool3s2: bad views (output is ceil(H / 2) x ceil(W / 2))");
+    SALT_DISPATCH_DTYPE(a->dtype, T, {
+        const int ve = Elem<T>::VE;
+        const bool v = vec_ok(a->x, ve) && vec_ok(a->y, ve);
+        const int64_t units = view_pixels(a->y) * (a->y.C / (v ? ve : 1));
+        EW_LAUNCH(maxpool3s2_kernel, T, v, units, (hipStream_t)stream, a->x, a->y);
+    })
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}
+
+extern "C" int salt_maxpool3s2_bwd(const salt_maxpool2_bwd_args* a, void* stream) {
+    if (!a || !view_ok(a->x) || !view_ok(a->dy) || !view_ok(a->dx) || !same_shape(a->x, a->dx) || a->dy.H != (a->x.H + 1) / 2 ||
+        a->dy.W != (a->x.W + 1) / 2 || a->dy.C != a->x.C)
+        SALT_FAIL(SALT_E_BADARG, "maxpool3s2_bwd: bad views");
+    SALT_DISPATCH_DTYPE(a->dtype, T, {
+        const int ve = Elem<T>::VE;
+        const bool v = vec_ok(a->x, ve) && vec_ok(a->dy, ve) && vec_ok(a->dx, ve);
+        const int64_t units = view_pixels(a->x) * (a->x.C / (v ? ve : 1));
+        EW_LAUNCH(maxpool3s2_bwd_kernel, T, v, units, (hipStream_t)stream, a->x, a->dy, a->dx, a->accumulate);
     })
     SALT_CHECK_LAUNCH();
     return SALT_OK;

@@ -555,12 +555,20 @@ class Graph:
             s = self._conv_launch(self.bwd, dy.gview(), pk.data_ptr(), td, 1, 0, x.gview(), x.H, x.W, accumulate=acc, stream=self._bwd_pack_tag())
             x.buf.grad_writers[-1][2] = s          # a plain full-grid launch: can carry the BatchNorm-backward sums of x's producer
             return
-        # stride 2: one launch per output parity phase (a transposed convolution)
+        # stride 2: the data gradient is a transposed convolution - four output-parity phases
         phases = []
         for ay in range(2):
             for ax in range(2):
                 sel = [i for i, t in enumerate(taps) if (t[2] - ay) % 2 == 0 and (t[3] - ax) % 2 == 0]
                 phases.append((ay, ax, sel))
+        fused = self._phase_fused([[(((ay - taps[i][2]) // 2, (ax - taps[i][3]) // 2), tk[i]) for i in sel] for ay, ax, sel in phases], x.H, x.W)
+        if fused is not None:
+            # ONE launch for all four phases (each its own packed weight block; taps a phase lacks are zero weights)
+            td_u, phase_taps = fused
+            pk_t, elems = eng.packed_phases(conv, phase_taps, transposed=True, bwd=True)
+            self._conv_launch(self.bwd, dy.gview(), pk_t.data_ptr(), td_u, 1, 0, x.gview(), x.H // 2, x.W // 2, out_step=2, accumulate=acc,
+                              nphase=4, w_phase_elems=elems, stream=self._bwd_pack_tag())
+            return
         if any(not sel for _, _, sel in phases) and not acc:
             self.fill(x, 0.0, grad=True)
             acc = 1
@@ -572,6 +580,34 @@ class Graph:
             td = [((ay - taps[i][2]) // 2, (ax - taps[i][3]) // 2) for i in sel]
             self._conv_launch(self.bwd, dy.gview(), pk_s.data_ptr(), td, 1, 0, x.gview(), oh, ow, out_step=2, out_oy=ay, out_ox=ax, accumulate=acc,
                               stream=self._bwd_pack_tag())
+
+    def _phase_fused(self, per_phase, H, W):
+        """per_phase: for each of the 4 output-parity phases a list of ((dy, dx), (kh, kw)).  -> (unified tap offsets, per-phase
+        (kh, kw) | None lists) when the phases can share one launch (even grid, <= 9 distinct offsets, at least two non-empty
+        phases), else None."""
+        if os.environ.get('SALT_NO_PHASE_FUSE') or H % 2 or W % 2:
+            return None
+        offs = sorted({o for ph in per_phase for o, _ in ph})
+        if not offs or len(offs) > 9 or sum(1 for ph in per_phase if ph) < 2:
+            return None
+        # every phase runs ALL unified offsets (missing ones against zero weights): worth one launch instead of four only while the
+        # padded work stays below ~2x (k3: 16 taps for 9 real ones; k4: 36 for 16 - not fused)
+        if 4 * len(offs) > 1.8 * sum(len(ph) for ph in per_phase):
+            return None
+        if len(offs) not in (4, 9):               # the kernels unroll 4- and 9-tap loops; pad other counts with a repeated zero tap
+            offs = offs + [offs[0]] * ((4 if len(offs) < 4 else 9) - len(offs))
+        phase_taps = []
+        for ph in per_phase:
+            d = dict(ph)
+            used = set()
+            row = []
+            for o in offs:
+                if o in d and o not in used:
+                    row.append(d[o]); used.add(o)
+                else:
+                    row.append(None)
+            phase_taps.append(row)
+        return offs, phase_taps
 
     def fill(self, act, value, grad=False):
         assert value == 0.0
@@ -603,16 +639,40 @@ class Graph:
                 sel = [(u, v, (fy + p - u) // 2, (fx + p - v) // 2) for u in range(KH) for v in range(KW)
                        if (fy + p - u) % 2 == 0 and (fx + p - v) % 2 == 0]
                 phases.append((fy, fx, sel))
+        fused = self._phase_fused([[((s_[2], s_[3]), (s_[0], s_[1])) for s_ in sel] for _, _, sel in phases], OH, OW)
+        total_parts, stats, cnt = 0, None, None
+        if fused is not None:
+            # ONE launch for the four output-parity phases of the transposed convolution
+            td_u, phase_taps = fused
+            pk_t, elems = eng.packed_phases(deconv, phase_taps, transposed=True)
+            if train_bn:
+                S = STRUCTS['salt_conv_args']()
+                fill(S, dtype=self.dt, x=x.view(), w=1, ntaps=len(td_u), tap_dy=[t[0] for t in td_u], tap_dx=[t[1] for t in td_u], in_step=1, pad_mode=0,
+                     y=tgt.view(), OH=x.H, OW=x.W, out_step=2, nphase=4, w_phase_elems=elems)
+                total_parts = lib.salt_conv_stats_parts(ctypes.byref(S))
+                if total_parts < 0:
+                    raise SaltError('conv plan failed: ' + lib.salt_last_error().decode())
+                stats = Scratch('stats', 4 * lib.salt_bn_stats_floats(total_parts, Cout))
+                cnt = Scratch('stats_cnt', total_parts * 4)
+                self._conv_launch(self.fwd, x.view(), pk_t.data_ptr(), td_u, 1, 0, tgt.view(), x.H, x.W, out_step=2, bias=bias, stats=stats, stats_cnt=cnt,
+                                  nphase=4, w_phase_elems=elems)
+            elif bn is not None:
+                self._conv_launch(self.fwd, x.view(), pk_t.data_ptr(), td_u, 1, 0, tgt.view(), x.H, x.W, out_step=2, bias=bias,
+                                  scale=w['scale'].data_ptr(), shift=w['shift'].data_ptr(), relu=int(relu), nphase=4, w_phase_elems=elems)
+            else:
+                self._conv_launch(self.fwd, x.view(), pk_t.data_ptr(), td_u, 1, 0, tgt.view(), x.H, x.W, out_step=2, bias=bias, relu=int(relu),
+                                  nphase=4, w_phase_elems=elems)
+            phases = []
         part0 = 0
-        total_parts = 0
         plans = []
         for fy, fx, sel in phases:
             td = [(s[2], s[3]) for s in sel]
             n = self._conv_parts(x.view(), td, 1, shaped_view(1, x.B, x.H, x.W, Cout), x.H, x.W) if train_bn else 0
             plans.append(n)
             total_parts += n
-        stats = Scratch('stats', 4 * lib.salt_bn_stats_floats(total_parts, Cout)) if train_bn else None
-        cnt = Scratch('stats_cnt', total_parts * 4) if train_bn else None
+        if fused is None:
+            stats = Scratch('stats', 4 * lib.salt_bn_stats_floats(total_parts, Cout)) if train_bn else None
+            cnt = Scratch('stats_cnt', total_parts * 4) if train_bn else None
         for (fy, fx, sel), n in zip(phases, plans):
             pk = eng.packed(deconv, [(s[0], s[1]) for s in sel], transposed=True)       # n = cout (D1), c = cin (D0)
             td = [(s[2], s[3]) for s in sel]
@@ -781,6 +841,18 @@ class Graph:
             def backward():
                 acc = x.grad_state()
                 self.bwd.add('maxpool2_bwd', dtype=self.dt, x=x.view(), dy=out.gview(), dx=x.gview(), accumulate=acc)
+            self.tape.append(backward)
+        return out
+
+    def maxpool3s2(self, x, out=None, name=''):
+        """nn.MaxPool2d(3, 2, 1) - the ResNet stem pool of ResNetEncoders(pool0=True) (architectures/encoders.py:23-27)."""
+        if out is None:
+            out = self.new_act(x.B, (x.H + 1) // 2, (x.W + 1) // 2, x.C, name)
+        self.fwd.add('maxpool3s2', dtype=self.dt, x=x.view(), y=out.view())
+        if self.train:
+            def backward():
+                acc = x.grad_state()
+                self.bwd.add('maxpool3s2_bwd', dtype=self.dt, x=x.view(), dy=out.gview(), dx=x.gview(), accumulate=acc)
             self.tape.append(backward)
         return out
 

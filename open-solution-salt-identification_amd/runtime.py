@@ -168,6 +168,30 @@ class Engine:
         self._pack_batched_n = -1
         return t
 
+    def packed_phases(self, conv, phase_taps, transposed, bwd=False):
+        """Packed weights of a phase-fused stride-2 launch: one block of len(phase_taps[0]) taps per output-parity phase, contiguous;
+        ``phase_taps[p][t]`` is (kh, kw) or None (a tap that phase does not have: packed as zeros).  -> (tensor, elements per phase)"""
+        key = (id(conv), tuple(tuple(t) for t in phase_taps), bool(transposed), 'phases')
+        D0, D1, KH, KW = conv.weight.shape
+        n, c = (D1, D0) if transposed else (D0, D1)
+        nt = len(phase_taps[0])
+        elems = lib.salt_packed_weight_elems(DT_CODE[self.dtype], nt, n, c)
+        if key in self._packed:
+            return self._packed[key], elems
+        t = torch.zeros(elems * len(phase_taps), dtype=TORCH_DT[self.dtype], device=self.device)
+        for ph, taps in enumerate(phase_taps):
+            pkey = key + (ph,)
+            self._pack_is_bwd[pkey] = bool(bwd)
+            self._pack_keys.append(pkey)
+            self._pack_ops.add('pack_conv_weight', dtype=DT_CODE[self.dtype], w=conv.weight.data_ptr(), D0=D0, D1=D1, KH=KH, KW=KW, ntaps=nt,
+                               tap_kh=[(tp[0] if tp is not None else -1) for tp in taps], tap_kw=[(tp[1] if tp is not None else 0) for tp in taps],
+                               transpose=int(transposed), wp=t.data_ptr() + ph * elems * t.element_size())
+        self._pack_ops._entries = None
+        self._packed[key] = t
+        self._packed_version = -1
+        self._pack_batched_n = -1
+        return t, elems
+
     def packed_stem(self, conv):
         key = (id(conv), 'stem')
         if key in self._packed:

@@ -258,6 +258,36 @@ def main():
             out['fullgrad64:' + k] = named[k].grad
         save('F11_' + tag + '_f64', **out)
 
+    # ---- F13: architectures.unet.UNetResNet(34, hypercolumn, pool0=True): the stem max-pool 3x3 s2 p1 (encoders.py:23-27); the
+    # reference's logits then come out at half the input resolution, so the training step uses the 2x sub-sampled target
+    if not ONLY or 'F13_unet_resnet34_hyper_pool0' in ONLY:
+        net = unet.UNetResNet(34, 2, dropout_2d=0.0, pretrained=False, use_hypercolumn=True, pool0=True)
+        canon = canonical_fn(net)
+        CF.fill_module(net, canonical=canon)
+        net.eval()
+        with torch.no_grad():
+            logits = net(X)
+        out = OrderedDict(x=X, t=T[:, :, ::2, ::2].contiguous(), eval_logits=logits, eval_mask=(logits[:, 1] > 0).to(torch.uint8))
+        out['keys'] = np.array(list(net.state_dict().keys()))
+        net.train()
+        params = [p for p in net.parameters() if p.requires_grad]
+        opt = torch.optim.Adam([{'params': params, 'weight_decay': 1e-4}], lr=1e-4)
+        opt.zero_grad()
+        o = net(X)
+        loss = models.lovasz_loss(o, out['t']) * 1.0
+        loss.backward()
+        out['train_logits'] = o
+        out['train_loss'] = loss
+        names, gnorm, has_grad = [], [], []
+        for k, p in net.named_parameters():
+            names.append(k)
+            has_grad.append(p.grad is not None)
+            gnorm.append(float(p.grad.double().norm()) if p.grad is not None else 0.0)
+        out['param_names'] = np.array(names)
+        out['param_has_grad'] = np.array(has_grad)
+        out['grad_norm'] = np.array(gnorm)
+        save('F13_unet_resnet34_hyper_pool0', **out)
+
     # ---- F9 / F10: numpy helpers pulled from files that cannot be imported (executed unmodified)
     ns = {'np': np}
     extract_functions('common_blocks/augmentation.py',

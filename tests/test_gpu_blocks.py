@@ -230,7 +230,8 @@ def test_first_layer_conv_vs_torch():
         assert_close(bn.running_var.cpu(), rb.running_var, 1e-4, 'running_var')
 
 
-@pytest.mark.parametrize('case', [(2, 16, 20, 24, 24), (1, 64, 16, 16, 64), (3, 32, 8, 8, 40), (2, 24, 33, 19, 16)])
+@pytest.mark.parametrize('case', [(2, 16, 20, 24, 24), (1, 64, 16, 16, 64), (3, 32, 8, 8, 40), (2, 24, 33, 19, 16), (5, 32, 2, 2, 16), (3, 16, 4, 3, 24),
+                                  (3, 16, 9, 18, 24)])
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 @pytest.mark.parametrize('replicate', [True, False])
 def test_two_conv_bn_relu_layers_vs_torch(case, dtype, replicate):
@@ -289,3 +290,25 @@ def test_two_conv_bn_relu_layers_vs_torch(case, dtype, replicate):
         else:
             l2 = float((got.double() - want.double()).norm() / want.double().norm())
             assert l2 <= 2 * tol, '%s: rel-L2 %.3e' % (name, l2)
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('shape', [(2, 16, 12, 10), (1, 8, 7, 9), (3, 5, 16, 16)])
+def test_maxpool3s2_with_ties_vs_torch(dtype, shape):
+    """nn.MaxPool2d(3, 2, 1) (the pool0 stem pool): forward and the first-maximum gradient routing through overlapping windows, on
+    small-integer inputs (many ties) and odd sizes."""
+    from gpu_harness import BlockRun
+    from torch import nn
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(3)
+    x = torch.randint(-2, 3, (B, C, H, W), generator=g).float()
+    mod = nn.Sequential(nn.Conv2d(1, 1, 1))                      # BlockRun wants a module with parameters
+    run = BlockRun(mod, [x], lambda gr, a: gr.maxpool3s2(a), train=True, dtype=dtype)
+    y = run.forward()
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    assert torch.equal(y, yr.detach())
+    gy = torch.randint(-3, 4, tuple(yr.shape), generator=g).float()
+    yr.backward(gy)
+    gx, _ = run.backward(gy.to('cuda:0'))
+    assert torch.equal(gx[0], xr.grad)

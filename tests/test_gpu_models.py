@@ -172,6 +172,39 @@ def test_one_training_step_matches_reference(tag):
         assert abs(float(sd[k].double().sum()) - s) <= (3e-3 if deep else 1e-3) * max(1.0, abs(s)), k
 
 
+def test_pool0_stem_maxpool_matches_reference_golden():
+    """ResNetEncoders(pool0=True) (architectures/encoders.py:23-27): stem + MaxPool2d(3, 2, 1); the reference's logits then come out at
+    half the input resolution (unet.py:89-109).  Eval logits / bit-exact masks and one Lovasz training step vs the golden."""
+    from salt_amd import architectures as A, losses
+    fx = golden('F13_unet_resnet34_hyper_pool0')
+    net = _fill_closed_form(A.UNetResNet(34, 2, dropout_2d=0.0, pretrained=False, use_hypercolumn=True, pool0=True))
+    assert list(net.state_dict().keys()) == fx['keys'].tolist()
+    net.to(DEV).eval()
+    with torch.no_grad():
+        logits = net(T(fx['x']).to(DEV)).cpu()
+    assert tuple(logits.shape) == (2, 2, 32, 32)
+    assert_close(logits, fx['eval_logits'], 1e-3, 'eval logits')
+    assert np.array_equal((logits[:, 1] > 0).numpy().astype(np.uint8), fx['eval_mask'])
+    net.train()
+    out = net(T(fx['x']).to(DEV))
+    assert_close(out.detach().cpu(), fx['train_logits'], 2e-3, 'train logits')
+    loss = losses.lovasz_loss(out, T(fx['t']).to(DEV))
+    loss.backward()
+    ref = float(fx['train_loss'])
+    assert abs(float(loss) - ref) < 2e-3 * max(1.0, abs(ref)), (float(loss), ref)
+    idx = {n: i for i, n in enumerate(fx['param_names'].tolist())}
+    eng = net.engine()
+    checked, worst = 0, (0.0, '')
+    for k, p in net.named_parameters():
+        i = idx[k]
+        if fx['param_has_grad'][i] and fx['grad_norm'][i] > 1e-4:
+            off, n = eng.grad_range(p)
+            gn = float(eng.grads[off:off + n].double().norm())
+            worst = max(worst, (abs(gn - fx['grad_norm'][i]) / fx['grad_norm'][i], k))
+            checked += 1
+    assert checked > 100 and worst[0] < 1e-2, (checked, worst)
+
+
 def test_vanilla_unet_matches_oracle_c1_shape():
     """BASELINE C1: vanilla 4-level U-Net, [32,1,128,128] fp32 — eval logits/masks and one train step vs the oracle."""
     from salt_amd import architectures as A
