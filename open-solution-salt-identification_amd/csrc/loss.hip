@@ -339,193 +339,6 @@ __global__ __launch_bounds__(LT) void lovasz_pf_kernel(salt_lovasz_args a) {
     }
 }
 
-// Group variant (the one that is launched): the 4 chunks of a prefetch group are ranked and scattered TOGETHER - one set of
-// barriers per 4096 keys instead of per 1024 (the per-chunk loop was 4 barriers of ~0.4 us for ~0.1 us of work).  The scatter order
-// is still (chunk, wave, lane) ascending, i.e. the same stable sort and bit-identical results.  The 64-long per-digit prefix over
-// (chunk, wave) is done by all 1024 threads in two halves of 16 steps instead of by 256 threads in 64 dependent steps.
-__global__ __launch_bounds__(LT) void lovasz_g4_kernel(salt_lovasz_args a) {
-    __shared__ unsigned hist[2][256];
-    __shared__ unsigned base[256];
-    __shared__ unsigned wcount[LG][LW][256];
-    __shared__ unsigned utot[LG][256];
-    __shared__ float red[LW];
-    __shared__ unsigned scan_w[LG][LW];
-    __shared__ unsigned carry_s;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int P = a.P;
-    const float* z = a.logits + (int64_t)b * P;
-    const float* y = a.target + (int64_t)b * P;
-    unsigned* k0 = a.ws_keys + (int64_t)b * P;
-    unsigned* v0 = a.ws_vals + (int64_t)b * P;
-    unsigned* k1 = a.ws_keys + ((int64_t)a.B + b) * P;
-    unsigned* v1 = a.ws_vals + ((int64_t)a.B + b) * P;
-    const int nchunks = (P + LT - 1) / LT, ngroups = (nchunks + LG - 1) / LG;
-
-    if (tid < 256) { hist[0][tid] = 0; hist[1][tid] = 0; }
-    __syncthreads();
-    float gsum = 0.f;
-    for (int i = tid; i < P; i += LT) {
-        const float lab = y[i] > 0.5f ? 1.f : 0.f;
-        const float e = 1.f - z[i] * (2.f * lab - 1.f);
-        const unsigned key = desc_key(e);
-        k0[i] = key;
-        v0[i] = ((unsigned)i << 1) | (lab > 0.5f ? 1u : 0u);
-        atomicAdd(&hist[0][key & 255u], 1u);
-        gsum += lab;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) gsum += __shfl_xor(gsum, o);
-    if (lane == 0) red[wave] = gsum;
-    __syncthreads();
-    float G = 0.f;
-    for (int w = 0; w < LW; ++w) G += red[w];
-    __syncthreads();
-
-    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const int pd = tid & 255, pu = tid >> 8;                      // prefix role: digit pd, chunk pu of the group (LT / 256 == LG)
-    for (int pass = 0; pass < 4; ++pass) {
-        const unsigned* ki = (pass & 1) ? k1 : k0; const unsigned* vi = (pass & 1) ? v1 : v0;
-        unsigned* ko = (pass & 1) ? k0 : k1; unsigned* vo = (pass & 1) ? v0 : v1;
-        const int shift = pass * 8;
-        unsigned* hcur = hist[pass & 1];
-        unsigned* hnext = hist[(pass + 1) & 1];
-        unsigned ck[LG], cv[LG], nk[LG], nv[LG];
-#pragma unroll
-        for (int u = 0; u < LG; ++u) { const int i = u * LT + tid; ck[u] = i < P ? ki[i] : 0u; cv[u] = i < P ? vi[i] : 0u; }
-        if (tid < 64) {
-            unsigned c[4], sm = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { c[j] = hcur[tid * 4 + j]; sm += c[j]; }
-            unsigned incl = sm;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-            unsigned run = incl - sm;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { base[tid * 4 + j] = run; run += c[j]; }
-        }
-        __syncthreads();
-        if (tid < 256) hcur[tid] = 0;
-        for (int g = 0; g < ngroups; ++g) {
-            const int cn = (g + 1) * LG;
-#pragma unroll
-            for (int u = 0; u < LG; ++u) { const int i = (cn + u) * LT + tid; nk[u] = i < P ? ki[i] : 0u; nv[u] = i < P ? vi[i] : 0u; }
-            for (int i = tid; i < LG * LW * 256; i += LT) (&wcount[0][0][0])[i] = 0;
-            __syncthreads();
-            unsigned d[LG], rank[LG];
-            bool ok[LG];
-#pragma unroll
-            for (int u = 0; u < LG; ++u) {
-                ok[u] = (g * LG + u) * LT + tid < P;
-                d[u] = ok[u] ? ((ck[u] >> shift) & 255u) : 256u;
-                unsigned long long m = __ballot(ok[u]);
-#pragma unroll
-                for (int bit = 0; bit < 8; ++bit) {
-                    const unsigned long long bm = __ballot((d[u] >> bit) & 1u);
-                    m &= ((d[u] >> bit) & 1u) ? bm : ~bm;
-                }
-                rank[u] = (unsigned)__popcll(m & lt_mask);
-                if (ok[u] && rank[u] == 0) wcount[u][wave][d[u]] = (unsigned)__popcll(m);
-            }
-            __syncthreads();
-            {   // exclusive prefix over (chunk, wave) per digit: per-chunk totals first ...
-                unsigned t = 0;
-#pragma unroll
-                for (int w = 0; w < LW; ++w) t += wcount[pu][w][pd];
-                utot[pu][pd] = t;
-            }
-            __syncthreads();
-            {   // ... then every (chunk, digit) thread rewrites its 16 wave counters as offsets
-                unsigned run = base[pd];
-#pragma unroll
-                for (int u = 0; u < LG; ++u) if (u < pu) run += utot[u][pd];
-#pragma unroll
-                for (int w = 0; w < LW; ++w) { const unsigned c = wcount[pu][w][pd]; wcount[pu][w][pd] = run; run += c; }
-            }
-            __syncthreads();
-            if (tid < 256) base[tid] += utot[0][tid] + utot[1][tid] + utot[2][tid] + utot[3][tid];
-#pragma unroll
-            for (int u = 0; u < LG; ++u) {
-                if (ok[u]) {
-                    const unsigned dst = wcount[u][wave][d[u]] + rank[u];
-                    ko[dst] = ck[u]; vo[dst] = cv[u];
-                    if (pass < 3) atomicAdd(&hnext[(ck[u] >> (shift + 8)) & 255u], 1u);
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < LG; ++u) { ck[u] = nk[u]; cv[u] = nv[u]; }
-        }
-        __syncthreads();
-    }
-
-    // ---- fused scan + Jaccard gradient + dot + scatter, 4 chunks per barrier round
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    float lsum = 0.f;
-    const float gscale = a.loss_scale / (float)a.B;
-    float* dz = a.dlogits ? a.dlogits + (int64_t)b * P : nullptr;
-    unsigned ck[LG], cv[LG], nk[LG], nv[LG];
-#pragma unroll
-    for (int u = 0; u < LG; ++u) { const int i = u * LT + tid; ck[u] = i < P ? k0[i] : 0u; cv[u] = i < P ? v0[i] : 0u; }
-    for (int g = 0; g < ngroups; ++g) {
-        const int cn = (g + 1) * LG;
-#pragma unroll
-        for (int u = 0; u < LG; ++u) { const int i = (cn + u) * LT + tid; nk[u] = i < P ? k0[i] : 0u; nv[u] = i < P ? v0[i] : 0u; }
-        unsigned incl[LG];
-#pragma unroll
-        for (int u = 0; u < LG; ++u) {
-            const bool ok = (g * LG + u) * LT + tid < P;
-            incl[u] = ok ? (cv[u] & 1u) : 0u;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl[u], o); if (lane >= o) incl[u] += t; }
-            if (lane == 63) scan_w[u][wave] = incl[u];
-        }
-        __syncthreads();
-        unsigned run = carry_s;
-#pragma unroll
-        for (int u = 0; u < LG; ++u) {
-            unsigned woff = run;
-            unsigned tot = 0;
-#pragma unroll
-            for (int w = 0; w < LW; ++w) { const unsigned sw = scan_w[u][w]; if (w < wave) woff += sw; tot += sw; }
-            run += tot;
-            const int i = (g * LG + u) * LT + tid;
-            if (i < P) {
-                const unsigned val = cv[u], lab = val & 1u;
-                const unsigned c_k = woff + incl[u];
-                const float e = key_to_float(ck[u]);
-                const float kf = (float)(i + 1), ckf = (float)c_k, ckm = (float)(c_k - lab);
-                const float jk = __fsub_rn(1.f, __fdiv_rn(G - ckf, G + (kf - ckf)));
-                float jm = 0.f;
-                if (i > 0) jm = __fsub_rn(1.f, __fdiv_rn(G - ckm, G + ((kf - 1.f) - ckm)));
-                const float gk = (i > 0) ? __fsub_rn(jk, jm) : jk;
-                const float el = e > 0.f ? e : expm1f(e);
-                lsum += el * gk;
-                if (dz) {
-                    const float dd = e > 0.f ? 1.f : __expf(e);
-                    const float sg = lab ? 1.f : -1.f;
-                    dz[val >> 1] = -sg * dd * gk * gscale;
-                }
-            }
-        }
-        __syncthreads();
-        if (tid == 0) carry_s = run;
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < LG; ++u) { ck[u] = nk[u]; cv[u] = nv[u]; }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
-    if (lane == 0) red[wave] = lsum;
-    __syncthreads();
-    if (tid == 0) {
-        float t = 0.f;
-        for (int w = 0; w < LW; ++w) t += red[w];
-        if (P == 0) t = 0.f;
-        a.loss_per_image[b] = t;
-    }
-}
-
 __global__ void mean_kernel(const float* v, int n, float scale, float* out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         float s = 0.f;
@@ -698,11 +511,9 @@ __global__ __launch_bounds__(256) void iou_sweep_kernel(IouKP k) {
 extern "C" int salt_lovasz_hinge(const salt_lovasz_args* a, void* stream) {
     if (!a || !a->logits || !a->target || a->B < 1 || a->P < 0 || !a->ws_keys || !a->ws_vals || !a->loss_per_image || !a->loss)
         SALT_FAIL(SALT_E_BADARG, "lovasz: bad args");
-    static const bool plain = getenv("SALT_LOVASZ_PLAIN") != nullptr;       // A/B switches: the non-prefetching kernel,
-    static const bool pf = getenv("SALT_LOVASZ_PF") != nullptr;             // the chunk-at-a-time prefetching kernel
+    static const bool plain = getenv("SALT_LOVASZ_PLAIN") != nullptr;       // A/B switch: the non-prefetching kernel
     if (plain) hipLaunchKernelGGL(lovasz_kernel, dim3(a->B), dim3(LT), 0, (hipStream_t)stream, *a);
-    else if (pf) hipLaunchKernelGGL(lovasz_pf_kernel, dim3(a->B), dim3(LT), 0, (hipStream_t)stream, *a);
-    else hipLaunchKernelGGL(lovasz_g4_kernel, dim3(a->B), dim3(LT), 0, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL(lovasz_pf_kernel, dim3(a->B), dim3(LT), 0, (hipStream_t)stream, *a);
     SALT_CHECK_LAUNCH();
     hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a->loss_per_image, a->B, a->loss_scale, a->loss);
     SALT_CHECK_LAUNCH();
