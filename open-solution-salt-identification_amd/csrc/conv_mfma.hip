@@ -2190,16 +2190,25 @@ __global__ __launch_bounds__(512) void conv_wgrad_fast8_kernel(WgradKP p) {
 // lane constant plus a compile-time offset of the k-step, so the unrolled loop has no address arithmetic; the branch-free loader and
 // the 16-byte slab stores are those of conv_wgrad_fast_kernel.  The generic kernel spent ~34 us per tile here, most of it on one
 // global load in flight at a time.
-template <bool PAD>
+// KSPLIT / SIDE: a layer with <= 32 output or input channels fills a quarter / half of the 64 x 64 channel block, and the exact-f32
+// MFMA (64 cycles for K = 2) makes the idle waves expensive (vanilla U-Net, 16-64 channels: 200 us per launch whatever the layer).
+// KSPLIT = 4 (both sides <= 32): all four waves work on the SAME 32 x 32 channel block and take a quarter of the tile's 64 k-steps
+// each; KSPLIT = 2 (SIDE 0: the a side <= 32, SIDE 1: the b side <= 32): the two waves that would idle split the k-steps with their
+// partners.  The partial accumulators meet in LDS after the tile loop (fixed order: k-slice 0 + 1 + 2 + 3).
+template <bool PAD, int KSPLIT = 1, int SIDE = 0>
 __global__ __launch_bounds__(256) void conv_wgrad_fast32_kernel(WgradKP p) {
     typedef float T;
     constexpr int NT = 9, KS = 64, PPR = 16, ROWB = 256, BMP = 128;
+    constexpr int JN = KS / KSPLIT;                                   // k-steps per wave and tile
     constexpr int MAXP = BMP * PPR / 256, MAXQ = 12, NPIECE = MAXP + MAXQ;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sP = smem;
     unsigned char* sQ = smem + BMP * ROWB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wa = wave >> 1, wb = wave & 1;
+    // wave roles: channel sub-block (wa, wb) and k-slice ks
+    const int wa = KSPLIT == 4 ? 0 : (KSPLIT == 2 && SIDE == 0 ? 0 : wave >> 1);
+    const int wb = KSPLIT == 4 ? 0 : (KSPLIT == 2 && SIDE == 1 ? 0 : wave & 1);
+    const int ks = KSPLIT == 4 ? wave : (KSPLIT == 2 ? (SIDE == 0 ? wave >> 1 : wave & 1) : 0);
     const int blk = blockIdx.x;
     const int ab = blk % p.a_blocks;
     const int bb = (blk / p.a_blocks) % p.b_blocks;
@@ -2282,10 +2291,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_fast32_kernel(WgradKP p) {
 
     // ---- fragment addressing: k-step j covers pixels 2 j + khalf = (row j >> 3, column (2 j & 15) + khalf) of the 8 x 16 tile
     const int khalf = lane >> 5, l31 = lane & 31;
-    const int pa_lane = khalf * ROWB + (wa * 32 + l31) * 4;            // + 2 j rows: an immediate
+    // k-slice ks starts at k-step ks * JN = pixel row 2 ks JN of the tile (JN is a multiple of 8: whole 16-pixel tile rows)
+    const int pa_lane = (khalf + 2 * JN * ks) * ROWB + (wa * 32 + l31) * 4;            // + 2 j rows: an immediate
     int qt[NT];                                                        // per-tap lane constant; + ((j >> 3) * 18 + (2 j & 15)) rows: an immediate
 #pragma unroll
-    for (int t = 0; t < NT; ++t) qt[t] = (khalf + p.tap_off[t]) * ROWB + (wb * 32 + l31) * 4;
+    for (int t = 0; t < NT; ++t) qt[t] = (khalf + p.tap_off[t] + (ks * JN / 8) * 18) * ROWB + (wb * 32 + l31) * 4;
     struct Frag { float a, b[NT]; };
     auto read_frags = [&](int j, Frag& fr) {
         fr.a = *reinterpret_cast<const float*>(sP + pa_lane + (2 * j) * ROWB);
@@ -2310,25 +2320,58 @@ __global__ __launch_bounds__(256) void conv_wgrad_fast32_kernel(WgradKP p) {
         advance(cur);
         const TileCtx x = make_ctx(cur, tile + p.nsplit < p.ntiles);
         read_frags(0, f0);
+        constexpr int LEVERY = JN >= 3 * NPIECE ? 3 : 1;              // next tile's 20 pieces: one every third k-step (every step when k is split)
+        constexpr int LPS = (NPIECE * LEVERY + JN - 1) / JN;          // pieces per loading k-step
 #pragma unroll
-        for (int j = 0; j < KS; ++j) {
+        for (int j = 0; j < JN; ++j) {
             Frag& fc = (j & 1) ? f1 : f0;
             Frag& fn = (j & 1) ? f0 : f1;
-            if (j + 1 < KS) read_frags(j + 1, fn);
-            const bool ld = (j % 3 == 0) && (j / 3 < NPIECE);         // the next tile's 20 pieces: one every third k-step
-            if (ld) issue_piece(j / 3, x);
+            if (j + 1 < JN) read_frags(j + 1, fn);
+            const bool ld = (j % LEVERY == 0) && ((j / LEVERY) * LPS < NPIECE);
+            if (ld) {
+#pragma unroll
+                for (int u = 0; u < LPS; ++u) if ((j / LEVERY) * LPS + u < NPIECE) issue_piece((j / LEVERY) * LPS + u, x);
+            }
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fc.b[t], fc.a, acc[t], 0, 0, 0);
-            if (j + 1 < KS) {
+            if (j + 1 < JN) {
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    if (ld && t == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    if (ld && t < LPS) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 }
             }
         }
+    }
+    if constexpr (KSPLIT > 1) {
+        // sum the k-slices of every (wa, wb) sub-block tap by tap through LDS: slice s > 0 parks its accumulator, slice 0 adds them in
+        // ascending slice order.  Waves of the same sub-block: KSPLIT 4: all four; KSPLIT 2: the pair that shares (wa, wb).
+        float* red = reinterpret_cast<float*>(smem);                  // [pair][slice - 1][16][64]
+        const int pair = KSPLIT == 4 ? 0 : (SIDE == 0 ? (wave & 1) : (wave >> 1));
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            __syncthreads();                                           // tile loop / previous tap done with this LDS
+            if (ks > 0) {
+                float* dst = red + ((pair * (KSPLIT - 1) + ks - 1) * 16) * 64 + lane * 4;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(dst + g * 256) = f32x4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+            }
+            __syncthreads();
+            if (ks == 0) {
+#pragma unroll
+                for (int s2 = 1; s2 < KSPLIT; ++s2) {
+                    const float* src = red + ((pair * (KSPLIT - 1) + s2 - 1) * 16) * 64 + lane * 4;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(src + g * 256);
+                        acc[t][4 * g] += v.x; acc[t][4 * g + 1] += v.y; acc[t][4 * g + 2] += v.z; acc[t][4 * g + 3] += v.w;
+                    }
+                }
+            }
+        }
+        if (ks > 0) return;
     }
     // ---- partial slab partials[split][t][a][b]: lane = a-row, 4 consecutive registers = 4 consecutive b
     const int a = a0 + wa * 32 + l31;
@@ -2379,7 +2422,10 @@ int wgrad_plan(const salt_conv_wgrad_args* a, WgradKP* k, int* nsplit_out) {
     // every split costs a partial slab (written here, read again by the reduce): bound the workgroup count and give each
     // workgroup enough pixel tiles to amortise its slab
     static const int target_wgs = getenv("SALT_WGRAD_WGS") ? atoi(getenv("SALT_WGRAD_WGS")) : 512;
-    static const int min_tiles = getenv("SALT_WGRAD_TPW") ? atoi(getenv("SALT_WGRAD_TPW")) : 8;
+    // bf16: >= 8 pixel tiles per split (every split costs a 147 KB slab round trip).  fp32: 2 - the exact-f32 MFMA is 16x slower, so a
+    // workgroup's 1024 pixels were ~200 us of matrix work on 32 workgroups (vanilla U-Net fp32: 7.47 -> 6.13 ms per step)
+    static const int min_tiles_env = getenv("SALT_WGRAD_TPW") ? atoi(getenv("SALT_WGRAD_TPW")) : 0;
+    const int min_tiles = min_tiles_env > 0 ? min_tiles_env : (a->dtype == SALT_F32 ? (k->a_blocks * k->b_blocks <= 4 ? 2 : 4) : 8);
     int ns = target_wgs / (k->a_blocks * k->b_blocks);
     // the stem (64 x 16 channels, launched on the MAIN stream at the very end of backward, nothing left to overlap with): finer
     // split.  NOT for the other single-block layers: their launches share the chip with the data-gradient chain, and 256 instead
@@ -2554,7 +2600,12 @@ static int launch_wgrad(const WgradKP& k, hipStream_t st) {
                     k.tw_log2 == 4 && k.th_log2 == 3 && k.nb == 1 && k.q_step == 1 && k.hw == 18 && k.hh == 10;
         for (int t = 0; t < 9 && fast; ++t) fast = k.tap_off[t] == (t / 3) * 18 + t % 3;
         if (fast) {
+            static const bool nosplit = getenv("SALT_WGRAD32_NOSPLIT") != nullptr;
+            const bool a32 = !nosplit && k.Ca <= 32, b32 = !nosplit && k.Cb <= 32;
             auto kern = k.pad_mode ? conv_wgrad_fast32_kernel<true> : conv_wgrad_fast32_kernel<false>;
+            if (a32 && b32) kern = k.pad_mode ? conv_wgrad_fast32_kernel<true, 4, 0> : conv_wgrad_fast32_kernel<false, 4, 0>;
+            else if (a32) kern = k.pad_mode ? conv_wgrad_fast32_kernel<true, 2, 0> : conv_wgrad_fast32_kernel<false, 2, 0>;
+            else if (b32) kern = k.pad_mode ? conv_wgrad_fast32_kernel<true, 2, 1> : conv_wgrad_fast32_kernel<false, 2, 1>;
             if (lds > 64 * 1024) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 if (e != hipSuccess) SALT_FAIL((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e)); }
             hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, k);
