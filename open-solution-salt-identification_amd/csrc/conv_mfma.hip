@@ -87,6 +87,255 @@ __device__ __attribute__((aligned(16))) unsigned int g_zero_piece[4] = {0u, 0u, 
 constexpr int MAXA = 9;     // halo pieces per thread: P_halo*4 <= 9*256 (6*256 for the 256-pixel tile: keeps its prefetch registers in budget)
 constexpr int maxa_for(int bm) { return bm >= 256 ? 6 : MAXA; }
 
+// Epilogue of one output tile, shared by conv_mfma_kernel and conv_mfma_persist_kernel.  C layout (32x32): col n = lane&31,
+// row m = (r&3) + 8*(r>>2) + 4*(lane>>5).  The accumulator tile goes through LDS (free after the main loop) so that the global stores
+// are whole 16-byte pieces of NHWC pixel rows (a wave writes full 128-B lines) instead of 2/4-byte scattered stores.
+struct TileCoord { int m_tile, n_tile, oy0, ox0, b0, n0, out_oy, out_ox; };
+
+template <typename T, int MI, int NI, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue(const ConvKP& p, const TileCoord& tc, f32x16 (&acc)[MI][NI], unsigned char* smem) {
+    constexpr int BN = 32 * NI * WN;
+    constexpr int VE = Elem<T>::VE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int khalf = lane >> 5, l31 = lane & 31;
+    const int m_tile = tc.m_tile, n_tile = tc.n_tile, oy0 = tc.oy0, ox0 = tc.ox0, b0 = tc.b0, n0 = tc.n0, out_oy = tc.out_oy, out_ox = tc.out_ox;
+    int nrow[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) nrow[j] = (wn * NI + j) * 32 + l31;
+    constexpr int BM = 32 * MI * WM;
+    constexpr int PITCH = BN + 16 / (int)sizeof(T);               // elements per LDS row (16-byte pad: no bank aliasing of rows)
+    constexpr int PPO = BN / VE;                                   // 16-byte pieces per output pixel row
+    T* sO = reinterpret_cast<T*>(smem);
+    float ssum[NI], cntf = 0.f;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) ssum[j] = 0.f;
+    unsigned vmask[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) vmask[i] = 0xffffu;
+    // everything below is specialised on three workgroup-uniform facts so that the common launches do not pay for the rare ones:
+    // statistics wanted (train-mode forward only), an affine / ReLU epilogue present (eval only), tile fully inside the output grid
+    const bool want_stats = p.stats != nullptr;
+    const bool has_affine = p.bias || p.scale || p.shift || p.relu;
+    const bool full_tile = (b0 + p.nb <= p.B) && (oy0 + (1 << p.th_log2) <= p.OH) && ox0 >= 0 && (ox0 + (1 << p.tw_log2) <= p.OW);
+    if (want_stats) {
+        if (full_tile) {
+            cntf = 16.f * MI;
+        } else {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                vmask[i] = 0u;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                    const int tx = m & ((1 << p.tw_log2) - 1);
+                    const int ty = (m >> p.tw_log2) & ((1 << p.th_log2) - 1);
+                    const int bl = m >> (p.tw_log2 + p.th_log2);
+                    const bool valid = (b0 + bl < p.B) && (oy0 + ty < p.OH) && (ox0 + tx < p.OW) && (ox0 + tx >= 0);
+                    if (valid) { vmask[i] |= 1u << r; cntf += 1.f; }
+                }
+            }
+        }
+    }
+    __syncthreads();                                               // every wave is done reading sA / sB
+    auto stage = [&](auto affine_c, auto stats_c) {
+        constexpr bool AFF = decltype(affine_c)::value, ST = decltype(stats_c)::value;
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            float bias = 0.f, sc = 1.f, sh = 0.f;
+            if constexpr (AFF) {
+                const int n = n0 + nrow[j];
+                const bool nok = n < p.Cout;
+                bias = (nok && p.bias) ? p.bias[n] : 0.f;
+                sc = (nok && p.scale) ? p.scale[n] : 1.f;
+                sh = (nok && p.shift) ? p.shift[n] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r];
+                    if constexpr (AFF) {
+                        v = (v + bias) * sc + sh;
+                        if (p.relu) v = fmaxf(v, 0.f);
+                        acc[i][j][r] = v;
+                    }
+                    if constexpr (ST) { if ((vmask[i] >> r) & 1u) ssum[j] += v; }
+                    const int ml = (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                    Elem<T>::st(sO + ml * PITCH + nrow[j], v);
+                }
+            }
+        }
+    };
+    if (has_affine) { if (want_stats) stage(std::true_type{}, std::true_type{}); else stage(std::true_type{}, std::false_type{}); }
+    else { if (want_stats) stage(std::false_type{}, std::true_type{}); else stage(std::false_type{}, std::false_type{}); }
+    __syncthreads();
+    {
+        T* yg = reinterpret_cast<T*>(p.y);
+        const bool y_vec = ((p.y_cs % VE) == 0) && ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0);
+        // BatchNorm-backward sums of the stored values: a thread's channel piece (tid % PPO) is the same for all of its pixels
+        const bool bnb = p.bnb_partials != nullptr;
+        float b1[VE], b2[VE], bmu[VE], bis[VE], bsc[VE], bsh[VE];
+#pragma unroll
+        for (int e = 0; e < VE; ++e) { b1[e] = 0.f; b2[e] = 0.f; bmu[e] = 0.f; bis[e] = 0.f; bsc[e] = 0.f; bsh[e] = 0.f; }
+        if (bnb) {
+            const int nb0 = n0 + (tid % PPO) * VE;
+#pragma unroll
+            for (int e = 0; e < VE; ++e)
+                if (nb0 + e < p.Cout) {
+                    bmu[e] = p.bnb_mean[nb0 + e]; bis[e] = p.bnb_invstd[nb0 + e];
+                    bsc[e] = p.bnb_gamma[nb0 + e] * bis[e]; bsh[e] = p.bnb_beta[nb0 + e] - bmu[e] * bsc[e];
+                }
+        }
+        for (int q = tid; q < BM * PPO; q += 256) {
+            const int m = q / PPO, pc = q - m * PPO;
+            const int tx = m & ((1 << p.tw_log2) - 1);
+            const int ty = (m >> p.tw_log2) & ((1 << p.th_log2) - 1);
+            const int bl = m >> (p.tw_log2 + p.th_log2);
+            const int oy = oy0 + ty, ox = ox0 + tx, b = b0 + bl;
+            const int n = n0 + pc * VE;
+            if (b >= p.B || oy >= p.OH || ox >= p.OW || ox < 0 || n >= p.Cout) continue;
+            T* dst = yg + (((int64_t)b * p.OHf + oy * p.out_step + out_oy) * p.OWf + ox * p.out_step + out_ox) * p.y_cs + n;
+            bool accum = p.accumulate != 0;
+            bool dvec = y_vec;
+            int fold_rows = 0, fold_cols = 0;                      // fused fold: ring pixels above / right of this edge pixel
+            if (p.fold_fused) {
+                // replicate-pad adjoint inside the tile: the pad ring (top rows, right columns of the extended grid) is never stored;
+                // the edge pixel it folds onto sums its ring pixels from the staged tile (the tile grid is laid out so that they
+                // share a tile: rows start at 0 with th > fold_top, columns at -ox_shift)
+                const int iy = oy - p.fold_top;
+                if (iy < 0 || ox >= p.OWf) continue;
+                dst = yg + (((int64_t)b * p.OHf + iy) * p.OWf + ox) * p.y_cs + n;
+                fold_rows = iy == 0 ? p.fold_top : 0;
+                fold_cols = ox == p.OWf - 1 ? p.fold_right : 0;
+            }
+            if (p.strip) {                                         // fold mode: interior -> y (unpadded), pad ring -> strip
+                const int iy = oy - p.fold_top, ix = ox - p.fold_left;
+                if (iy >= 0 && iy < p.OHf && ix >= 0 && ix < p.OWf) {
+                    dst = yg + (((int64_t)b * p.OHf + iy) * p.OWf + ix) * p.y_cs + n;
+                } else {
+                    const int64_t ring = (int64_t)(p.fold_top + p.fold_bottom) * p.OW + (int64_t)p.OHf * (p.fold_left + p.fold_right);
+                    dst = reinterpret_cast<T*>(p.strip) + ((int64_t)b * ring + fold_ring_index(oy, ox, p.OHf, p.OWf, p.fold_top, p.fold_bottom, p.fold_left, p.fold_right)) * p.strip_cs + n;
+                    accum = false;
+                    dvec = (p.strip_cs % VE) == 0;
+                }
+            }
+            u32x4 v = *reinterpret_cast<const u32x4*>(sO + m * PITCH + pc * VE);
+            if (fold_rows | fold_cols) {                           // host: fused fold implies whole aligned channel pieces
+                float f[VE], o[VE];
+                unpack16<T>(v, f);
+                for (int ky = 0; ky <= fold_rows; ++ky)
+                    for (int kx = 0; kx <= fold_cols; ++kx) {
+                        if ((ky | kx) == 0) continue;
+                        unpack16<T>(*reinterpret_cast<const u32x4*>(sO + (m - (ky << p.tw_log2) + kx) * PITCH + pc * VE), o);
+#pragma unroll
+                        for (int e = 0; e < VE; ++e) f[e] += o[e];
+                    }
+                v = pack16<T>(f);
+            }
+            if (dvec && n + VE <= p.Cout) {
+                u32x4 stored = v;
+                if (accum) {
+                    float f[VE], o[VE];
+                    unpack16<T>(v, f);
+                    unpack16<T>(*reinterpret_cast<const u32x4*>(dst), o);
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) f[e] += o[e];
+                    stored = pack16<T>(f);
+                }
+                *reinterpret_cast<u32x4*>(dst) = stored;
+                if (bnb) {                                         // host: bnb implies whole aligned pieces, out_step 1, no strip
+                    float g[VE], yc[VE];
+                    unpack16<T>(stored, g);
+                    unpack16<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.bnb_y) + (((int64_t)b * p.OHf + oy - (p.fold_fused ? p.fold_top : 0)) * p.OWf + ox) * p.bnb_cs + n), yc);
+                    if (p.bnb_a) {                                 // residual layer: the mask is the sign of the forward output
+                        float av[VE];
+                        unpack16<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.bnb_a) + (((int64_t)b * p.OHf + oy - (p.fold_fused ? p.fold_top : 0)) * p.OWf + ox) * p.bnb_acs + n), av);
+#pragma unroll
+                        for (int e = 0; e < VE; ++e) {
+                            const float gg = (!p.bnb_relu || av[e] > 0.f) ? g[e] : 0.f;
+                            b1[e] += gg; b2[e] += gg * (yc[e] - bmu[e]) * bis[e];
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < VE; ++e) {
+                            const float gg = (!p.bnb_relu || yc[e] * bsc[e] + bsh[e] > 0.f) ? g[e] : 0.f;
+                            b1[e] += gg; b2[e] += gg * (yc[e] - bmu[e]) * bis[e];
+                        }
+                    }
+                }
+            } else {
+                float f[VE];
+                unpack16<T>(v, f);
+#pragma unroll
+                for (int e = 0; e < VE; ++e)
+                    if (n + e < p.Cout) Elem<T>::st(dst + e, accum ? f[e] + Elem<T>::ld(dst + e) : f[e]);
+            }
+        }
+        if (bnb) {
+            // cross-row sums: 256/PPO rows of BN channels x 2 statistics through LDS, rows added in ascending order
+            float* sR = reinterpret_cast<float*>(smem);
+            const int row = tid / PPO, cl0 = (tid % PPO) * VE;
+            __syncthreads();                                       // the output tile in LDS has been stored
+#pragma unroll
+            for (int e = 0; e < VE; ++e) { sR[(row * BN + cl0 + e) * 2] = b1[e]; sR[(row * BN + cl0 + e) * 2 + 1] = b2[e]; }
+            __syncthreads();
+            for (int e = tid; e < 2 * BN; e += 256) {
+                const int st = e >= BN ? 1 : 0, cl = e - st * BN;
+                float t = 0.f;
+                for (int r = 0; r < 256 / PPO; ++r) t += sR[(r * BN + cl) * 2 + st];
+                if (n0 + cl < p.Cout) p.bnb_partials[((int64_t)m_tile * 2 + st) * p.Cout + n0 + cl] = t;
+            }
+        }
+    }
+    if (p.stats) {
+        // BatchNorm partial of this workgroup: per-wave (sum, M2 about the wave's mean, count) from the registers, then the WM
+        // wave rows are merged in fixed order (Chan) through LDS so that one (sum, M2, count) row per workgroup reaches HBM.
+        cntf += __shfl_xor(cntf, 32);
+        float* sS = reinterpret_cast<float*>(smem);                // [WM][BN][2] then [WM] counts
+        float* sC = sS + WM * BN * 2;
+        __syncthreads();                                           // the output tile in LDS has been stored
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            float s = ssum[j] + __shfl_xor(ssum[j], 32);
+            const float mean = cntf > 0.f ? s / cntf : 0.f;
+            float m2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if ((vmask[i] >> r) & 1u) { const float d = acc[i][j][r] - mean; m2 += d * d; }
+            m2 += __shfl_xor(m2, 32);
+            if (khalf == 0) { sS[(wm * BN + nrow[j]) * 2 + 0] = s; sS[(wm * BN + nrow[j]) * 2 + 1] = m2; }
+        }
+        if (lane == 0 && wn == 0) sC[wm] = cntf;
+        __syncthreads();
+        const int part = p.stats_part0 + m_tile;
+        if (tid < BN) {
+            float N = 0.f, S = 0.f, M2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) {
+                const float nk = sC[w];
+                if (nk > 0.f) {
+                    const float sk = sS[(w * BN + tid) * 2 + 0], mk = sS[(w * BN + tid) * 2 + 1];
+                    if (N == 0.f) { N = nk; S = sk; M2 = mk; }
+                    else {
+                        const float d = sk / nk - S / N;
+                        M2 += mk + d * d * (N * nk / (N + nk));
+                        S += sk; N += nk;
+                    }
+                }
+            }
+            const int n = n0 + tid;
+            if (n < p.Cout) {
+                p.stats[((int64_t)part * 2 + 0) * p.Cout + n] = S;
+                p.stats[((int64_t)part * 2 + 1) * p.Cout + n] = M2;
+            }
+            if (tid == 0 && n_tile == 0) p.stats_cnt[part] = N;
+        }
+    }
+}
+
 // NT > 0: tap count known at compile time (9 for every 3x3): the tap loop is fully unrolled so the compiler keeps the tap
 // offsets in SGPRs, folds the weight-row offsets into ds_read immediates and hoists the next taps' fragment reads above the
 // current MFMAs (the runtime-loop form serialised s_load -> address VALU -> ds_read -> MFMA per tap).
@@ -383,242 +632,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
         }
     }
 
-    // ---- epilogue.  C layout (32x32): col n = lane&31, row m = (r&3) + 8*(r>>2) + 4*(lane>>5).
-    // The accumulator tile goes through LDS (free after the main loop) so that the global stores are whole 16-byte
-    // pieces of NHWC pixel rows (a wave writes full 128-B lines) instead of 2/4-byte scattered stores.
-    constexpr int BM = 32 * MI * WM;
-    constexpr int PITCH = BN + 16 / (int)sizeof(T);               // elements per LDS row (16-byte pad: no bank aliasing of rows)
-    constexpr int PPO = BN / VE;                                   // 16-byte pieces per output pixel row
-    T* sO = reinterpret_cast<T*>(smem);
-    float ssum[NI], cntf = 0.f;
-#pragma unroll
-    for (int j = 0; j < NI; ++j) ssum[j] = 0.f;
-    unsigned vmask[MI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i) vmask[i] = 0xffffu;
-    // everything below is specialised on three workgroup-uniform facts so that the common launches do not pay for the rare ones:
-    // statistics wanted (train-mode forward only), an affine / ReLU epilogue present (eval only), tile fully inside the output grid
-    const bool want_stats = p.stats != nullptr;
-    const bool has_affine = p.bias || p.scale || p.shift || p.relu;
-    const bool full_tile = (b0 + p.nb <= p.B) && (oy0 + (1 << p.th_log2) <= p.OH) && ox0 >= 0 && (ox0 + (1 << p.tw_log2) <= p.OW);
-    if (want_stats) {
-        if (full_tile) {
-            cntf = 16.f * MI;
-        } else {
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                vmask[i] = 0u;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                    const int tx = m & ((1 << p.tw_log2) - 1);
-                    const int ty = (m >> p.tw_log2) & ((1 << p.th_log2) - 1);
-                    const int bl = m >> (p.tw_log2 + p.th_log2);
-                    const bool valid = (b0 + bl < p.B) && (oy0 + ty < p.OH) && (ox0 + tx < p.OW) && (ox0 + tx >= 0);
-                    if (valid) { vmask[i] |= 1u << r; cntf += 1.f; }
-                }
-            }
-        }
-    }
-    __syncthreads();                                               // every wave is done reading sA / sB
-    auto stage = [&](auto affine_c, auto stats_c) {
-        constexpr bool AFF = decltype(affine_c)::value, ST = decltype(stats_c)::value;
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            float bias = 0.f, sc = 1.f, sh = 0.f;
-            if constexpr (AFF) {
-                const int n = n0 + nrow[j];
-                const bool nok = n < p.Cout;
-                bias = (nok && p.bias) ? p.bias[n] : 0.f;
-                sc = (nok && p.scale) ? p.scale[n] : 1.f;
-                sh = (nok && p.shift) ? p.shift[n] : 0.f;
-            }
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = acc[i][j][r];
-                    if constexpr (AFF) {
-                        v = (v + bias) * sc + sh;
-                        if (p.relu) v = fmaxf(v, 0.f);
-                        acc[i][j][r] = v;
-                    }
-                    if constexpr (ST) { if ((vmask[i] >> r) & 1u) ssum[j] += v; }
-                    const int ml = (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                    Elem<T>::st(sO + ml * PITCH + nrow[j], v);
-                }
-            }
-        }
-    };
-    if (has_affine) { if (want_stats) stage(std::true_type{}, std::true_type{}); else stage(std::true_type{}, std::false_type{}); }
-    else { if (want_stats) stage(std::false_type{}, std::true_type{}); else stage(std::false_type{}, std::false_type{}); }
-    __syncthreads();
-    {
-        T* yg = reinterpret_cast<T*>(p.y);
-        const bool y_vec = ((p.y_cs % VE) == 0) && ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0);
-        // BatchNorm-backward sums of the stored values: a thread's channel piece (tid % PPO) is the same for all of its pixels
-        const bool bnb = p.bnb_partials != nullptr;
-        float b1[VE], b2[VE], bmu[VE], bis[VE], bsc[VE], bsh[VE];
-#pragma unroll
-        for (int e = 0; e < VE; ++e) { b1[e] = 0.f; b2[e] = 0.f; bmu[e] = 0.f; bis[e] = 0.f; bsc[e] = 0.f; bsh[e] = 0.f; }
-        if (bnb) {
-            const int nb0 = n0 + (tid % PPO) * VE;
-#pragma unroll
-            for (int e = 0; e < VE; ++e)
-                if (nb0 + e < p.Cout) {
-                    bmu[e] = p.bnb_mean[nb0 + e]; bis[e] = p.bnb_invstd[nb0 + e];
-                    bsc[e] = p.bnb_gamma[nb0 + e] * bis[e]; bsh[e] = p.bnb_beta[nb0 + e] - bmu[e] * bsc[e];
-                }
-        }
-        for (int q = tid; q < BM * PPO; q += 256) {
-            const int m = q / PPO, pc = q - m * PPO;
-            const int tx = m & ((1 << p.tw_log2) - 1);
-            const int ty = (m >> p.tw_log2) & ((1 << p.th_log2) - 1);
-            const int bl = m >> (p.tw_log2 + p.th_log2);
-            const int oy = oy0 + ty, ox = ox0 + tx, b = b0 + bl;
-            const int n = n0 + pc * VE;
-            if (b >= p.B || oy >= p.OH || ox >= p.OW || ox < 0 || n >= p.Cout) continue;
-            T* dst = yg + (((int64_t)b * p.OHf + oy * p.out_step + out_oy) * p.OWf + ox * p.out_step + out_ox) * p.y_cs + n;
-            bool accum = p.accumulate != 0;
-            bool dvec = y_vec;
-            int fold_rows = 0, fold_cols = 0;                      // fused fold: ring pixels above / right of this edge pixel
-            if (p.fold_fused) {
-                // replicate-pad adjoint inside the tile: the pad ring (top rows, right columns of the extended grid) is never stored;
-                // the edge pixel it folds onto sums its ring pixels from the staged tile (the tile grid is laid out so that they
-                // share a tile: rows start at 0 with th > fold_top, columns at -ox_shift)
-                const int iy = oy - p.fold_top;
-                if (iy < 0 || ox >= p.OWf) continue;
-                dst = yg + (((int64_t)b * p.OHf + iy) * p.OWf + ox) * p.y_cs + n;
-                fold_rows = iy == 0 ? p.fold_top : 0;
-                fold_cols = ox == p.OWf - 1 ? p.fold_right : 0;
-            }
-            if (p.strip) {                                         // fold mode: interior -> y (unpadded), pad ring -> strip
-                const int iy = oy - p.fold_top, ix = ox - p.fold_left;
-                if (iy >= 0 && iy < p.OHf && ix >= 0 && ix < p.OWf) {
-                    dst = yg + (((int64_t)b * p.OHf + iy) * p.OWf + ix) * p.y_cs + n;
-                } else {
-                    const int64_t ring = (int64_t)(p.fold_top + p.fold_bottom) * p.OW + (int64_t)p.OHf * (p.fold_left + p.fold_right);
-                    dst = reinterpret_cast<T*>(p.strip) + ((int64_t)b * ring + fold_ring_index(oy, ox, p.OHf, p.OWf, p.fold_top, p.fold_bottom, p.fold_left, p.fold_right)) * p.strip_cs + n;
-                    accum = false;
-                    dvec = (p.strip_cs % VE) == 0;
-                }
-            }
-            u32x4 v = *reinterpret_cast<const u32x4*>(sO + m * PITCH + pc * VE);
-            if (fold_rows | fold_cols) {                           // host: fused fold implies whole aligned channel pieces
-                float f[VE], o[VE];
-                unpack16<T>(v, f);
-                for (int ky = 0; ky <= fold_rows; ++ky)
-                    for (int kx = 0; kx <= fold_cols; ++kx) {
-                        if ((ky | kx) == 0) continue;
-                        unpack16<T>(*reinterpret_cast<const u32x4*>(sO + (m - (ky << p.tw_log2) + kx) * PITCH + pc * VE), o);
-#pragma unroll
-                        for (int e = 0; e < VE; ++e) f[e] += o[e];
-                    }
-                v = pack16<T>(f);
-            }
-            if (dvec && n + VE <= p.Cout) {
-                u32x4 stored = v;
-                if (accum) {
-                    float f[VE], o[VE];
-                    unpack16<T>(v, f);
-                    unpack16<T>(*reinterpret_cast<const u32x4*>(dst), o);
-#pragma unroll
-                    for (int e = 0; e < VE; ++e) f[e] += o[e];
-                    stored = pack16<T>(f);
-                }
-                *reinterpret_cast<u32x4*>(dst) = stored;
-                if (bnb) {                                         // host: bnb implies whole aligned pieces, out_step 1, no strip
-                    float g[VE], yc[VE];
-                    unpack16<T>(stored, g);
-                    unpack16<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.bnb_y) + (((int64_t)b * p.OHf + oy - (p.fold_fused ? p.fold_top : 0)) * p.OWf + ox) * p.bnb_cs + n), yc);
-                    if (p.bnb_a) {                                 // residual layer: the mask is the sign of the forward output
-                        float av[VE];
-                        unpack16<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.bnb_a) + (((int64_t)b * p.OHf + oy - (p.fold_fused ? p.fold_top : 0)) * p.OWf + ox) * p.bnb_acs + n), av);
-#pragma unroll
-                        for (int e = 0; e < VE; ++e) {
-                            const float gg = (!p.bnb_relu || av[e] > 0.f) ? g[e] : 0.f;
-                            b1[e] += gg; b2[e] += gg * (yc[e] - bmu[e]) * bis[e];
-                        }
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < VE; ++e) {
-                            const float gg = (!p.bnb_relu || yc[e] * bsc[e] + bsh[e] > 0.f) ? g[e] : 0.f;
-                            b1[e] += gg; b2[e] += gg * (yc[e] - bmu[e]) * bis[e];
-                        }
-                    }
-                }
-            } else {
-                float f[VE];
-                unpack16<T>(v, f);
-#pragma unroll
-                for (int e = 0; e < VE; ++e)
-                    if (n + e < p.Cout) Elem<T>::st(dst + e, accum ? f[e] + Elem<T>::ld(dst + e) : f[e]);
-            }
-        }
-        if (bnb) {
-            // cross-row sums: 256/PPO rows of BN channels x 2 statistics through LDS, rows added in ascending order
-            float* sR = reinterpret_cast<float*>(smem);
-            const int row = tid / PPO, cl0 = (tid % PPO) * VE;
-            __syncthreads();                                       // the output tile in LDS has been stored
-#pragma unroll
-            for (int e = 0; e < VE; ++e) { sR[(row * BN + cl0 + e) * 2] = b1[e]; sR[(row * BN + cl0 + e) * 2 + 1] = b2[e]; }
-            __syncthreads();
-            for (int e = tid; e < 2 * BN; e += 256) {
-                const int st = e >= BN ? 1 : 0, cl = e - st * BN;
-                float t = 0.f;
-                for (int r = 0; r < 256 / PPO; ++r) t += sR[(r * BN + cl) * 2 + st];
-                if (n0 + cl < p.Cout) p.bnb_partials[((int64_t)m_tile * 2 + st) * p.Cout + n0 + cl] = t;
-            }
-        }
-    }
-    if (p.stats) {
-        // BatchNorm partial of this workgroup: per-wave (sum, M2 about the wave's mean, count) from the registers, then the WM
-        // wave rows are merged in fixed order (Chan) through LDS so that one (sum, M2, count) row per workgroup reaches HBM.
-        cntf += __shfl_xor(cntf, 32);
-        float* sS = reinterpret_cast<float*>(smem);                // [WM][BN][2] then [WM] counts
-        float* sC = sS + WM * BN * 2;
-        __syncthreads();                                           // the output tile in LDS has been stored
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            float s = ssum[j] + __shfl_xor(ssum[j], 32);
-            const float mean = cntf > 0.f ? s / cntf : 0.f;
-            float m2 = 0.f;
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if ((vmask[i] >> r) & 1u) { const float d = acc[i][j][r] - mean; m2 += d * d; }
-            m2 += __shfl_xor(m2, 32);
-            if (khalf == 0) { sS[(wm * BN + nrow[j]) * 2 + 0] = s; sS[(wm * BN + nrow[j]) * 2 + 1] = m2; }
-        }
-        if (lane == 0 && wn == 0) sC[wm] = cntf;
-        __syncthreads();
-        const int part = p.stats_part0 + m_tile;
-        if (tid < BN) {
-            float N = 0.f, S = 0.f, M2 = 0.f;
-#pragma unroll
-            for (int w = 0; w < WM; ++w) {
-                const float nk = sC[w];
-                if (nk > 0.f) {
-                    const float sk = sS[(w * BN + tid) * 2 + 0], mk = sS[(w * BN + tid) * 2 + 1];
-                    if (N == 0.f) { N = nk; S = sk; M2 = mk; }
-                    else {
-                        const float d = sk / nk - S / N;
-                        M2 += mk + d * d * (N * nk / (N + nk));
-                        S += sk; N += nk;
-                    }
-                }
-            }
-            const int n = n0 + tid;
-            if (n < p.Cout) {
-                p.stats[((int64_t)part * 2 + 0) * p.Cout + n] = S;
-                p.stats[((int64_t)part * 2 + 1) * p.Cout + n] = M2;
-            }
-            if (tid == 0 && n_tile == 0) p.stats_cnt[part] = N;
-        }
-    }
+    conv_epilogue<T, MI, NI, WM, WN>(p, TileCoord{m_tile, n_tile, oy0, ox0, b0, n0, out_oy, out_ox}, acc, smem);
 }
-
 
 // ------------------------------------------------------------------------------------------ conv_glds_kernel (bf16, stride 1)
 // Second kernel of the family, for the layers whose cost is the staging, not the contraction (every 9.66-GFLOP ResNet layer,
