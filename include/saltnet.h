@@ -122,6 +122,21 @@ typedef struct {
      * statistics partials are numbered over all phases.  nphase <= 1: a plain launch. */
     int nphase;
     int64_t w_phase_elems;
+    /* In-launch BatchNorm finalize.  fin != NULL (a const salt_bn_finalize_args*, declared below; its stats / stats_cnt / nparts are
+     * ignored): the launch accumulates its per-tile (sum, sum of squares, count) into fin_acc with fp64 atomics - 8 shards
+     * [8][2 * Cout + 1] doubles, shard = workgroup id % 8 (one per XCD), summed in shard order - takes a ticket on fin_ticket, and the
+     * workgroup that arrives last computes what salt_bn_finalize would have (mean / invstd / scale / shift, running statistics) before
+     * the launch ends: no partials round trip, no separate launch.  `stats` must be NULL.  fin_acc and fin_ticket must be zero before
+     * the first launch; every launch leaves them zero.  One launch per BatchNorm layer (no stats_part0 chaining).  The fp64 sums are
+     * order dependent in their last bits only (the fp32 results are reproducible in practice, not by construction).
+     * bnb_fin != NULL (a const salt_bn_bwd_args*): the same for the BatchNorm-backward sums of bnb_*: the last workgroup writes
+     * dgamma / dbeta / coef, and salt_bn_bwd then runs with partials_ready = 2 (apply pass only).  bnb_partials is ignored (may be NULL). */
+    const void* fin;
+    double* fin_acc;
+    uint32_t* fin_ticket;
+    const void* bnb_fin;
+    double* bnb_acc;          /* [8][2 * Cout] */
+    uint32_t* bnb_ticket;
 } salt_conv_args;
 int salt_conv(const salt_conv_args*, void* stream);
 /* number of stats partials a launch with these args writes (host sizes the workspace with it) */
@@ -368,6 +383,9 @@ typedef struct {              /* backward of a = relu?(bn(y) (+res)) in train mo
     salt_view dres;           /* out: grad wrt residual (masked da); dres.p == NULL: none */
     int accumulate_dres;
     int partials_ready;       /* 1: `partials` ([nparts][2][C], any nparts >= 1) was filled by the producer of da (salt_conv_args.bnb_*) */
+                              /* 2: the producer also finalized (salt_conv_args.bnb_fin): coef / dgamma / dbeta are ready, only the apply pass runs */
+    double* fin_acc;          /* partials_ready == 0 and fin_acc != NULL: the reduction pass accumulates into [8][2][C] fp64 shards and its last block */
+    uint32_t* fin_ticket;     /* finalizes (no partials, no finalize launch); both zero before the first call, left zero (see salt_conv_args.fin) */
 } salt_bn_bwd_args;
 int salt_bn_bwd(const salt_bn_bwd_args*, void* stream);
 int salt_bn_bwd_parts(const salt_bn_bwd_args*);

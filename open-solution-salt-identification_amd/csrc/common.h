@@ -96,3 +96,84 @@ __host__ __device__ inline int fold_ring_index(int r, int c, int H, int W, int t
     if (r >= top + H) return (top + (r - top - H)) * Wp + c;
     return (top + bottom) * Wp + (r - top) * (left + right) + (c < left ? c : c - W);
 }
+// ---- in-launch BatchNorm finalize (saltnet.h: salt_conv_args.fin / bnb_fin, salt_bn_bwd_args.fin_acc) ------------------------------
+struct BnFin {
+    double* acc; unsigned* ticket;
+    const float* gamma; const float* beta; float* running_mean; float* running_var; int64_t* nbt;
+    float momentum, eps; float* mean; float* invstd; float* scale; float* shift;
+};
+struct BnbFin { double* acc; unsigned* ticket; float* dgamma; float* dbeta; float* coef; int accumulate; double M; };
+// ---- in-launch BatchNorm finalize: sharded fp64 accumulators + arrival ticket ----------------------------------------------------
+// Every workgroup adds its tile's sums to the shard of its XCD (workgroup id % 8: 64 arrivals per address instead of 512) with
+// device-scope fp64 atomics, waits until they have been performed (vmcnt), and takes a ticket; the workgroup that draws the last ticket
+// collects the shards with atomic exchanges (which also leave them zero for the next launch) and finalizes.  Atomics on both sides:
+// no release / acquire fence, no L2 write-back of the output tile on the way (MI355X_MICROARCH.md, hand-off forms).
+__device__ __forceinline__ void fin_add(double* p, double v) { unsafeAtomicAdd(p, v); }
+__device__ __forceinline__ double fin_take(double* p) {
+    return __longlong_as_double((long long)__hip_atomic_exchange(reinterpret_cast<unsigned long long*>(p), 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+// true in every thread of the workgroup that arrived last; lds_flag: a free word of the kernel's one LDS array
+__device__ __forceinline__ bool fin_arrive(unsigned* ticket, unsigned total, unsigned* lds_flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this wave's atomics have been performed
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool last = t == total - 1u;
+        if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *lds_flag = last ? 1u : 0u;
+    }
+    __syncthreads();
+    return *lds_flag != 0u;
+}
+// forward statistics: acc = [8][2 C + 1] (sum, sum of squares, count); same arithmetic as bn_finalize_kernel from there on
+__device__ inline void fin_forward(const BnFin& f, int C, double* lds_n) {
+    const int tid = threadIdx.x, nthr = blockDim.x, stride = 2 * C + 1;
+    if (tid == 0) {
+        double n = 0.0;
+        for (int s = 0; s < 8; ++s) n += fin_take(f.acc + s * stride + 2 * C);
+        *lds_n = n;
+        if (f.nbt) *f.nbt += 1;
+    }
+    __syncthreads();
+    const double N = *lds_n;
+    for (int c = tid; c < C; c += nthr) {
+        double sv[8], qv[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) { sv[s] = fin_take(f.acc + s * stride + c); qv[s] = fin_take(f.acc + s * stride + C + c); }
+        double S = 0.0, Q = 0.0;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) { S += sv[s]; Q += qv[s]; }
+        const double mean = N > 0 ? S / N : 0.0;
+        double M2 = Q - S * mean;
+        if (M2 < 0.0) M2 = 0.0;
+        const double var = N > 0 ? M2 / N : 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
+        const float sc = f.gamma[c] * invstd;
+        f.mean[c] = (float)mean; f.invstd[c] = invstd; f.scale[c] = sc; f.shift[c] = f.beta[c] - (float)mean * sc;
+        if (f.running_mean) {
+            const double unb = N > 1 ? M2 / (N - 1) : var;
+            f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * (float)mean;
+            f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)unb;
+        }
+    }
+}
+// backward sums: acc = [8][2 C]; same arithmetic as bn_bwd_finalize_kernel
+__device__ inline void fin_backward(const BnbFin& f, const float* gamma, const float* invstd, int C) {
+    const int tid = threadIdx.x, nthr = blockDim.x, stride = 2 * C;
+    for (int c = tid; c < C; c += nthr) {
+        double v1[8], v2[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) { v1[s] = fin_take(f.acc + s * stride + c); v2[s] = fin_take(f.acc + s * stride + C + c); }
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) { s1 += v1[s]; s2 += v2[s]; }
+        if (f.dgamma) {
+            f.dgamma[c] = f.accumulate ? f.dgamma[c] + (float)s2 : (float)s2;
+            f.dbeta[c] = f.accumulate ? f.dbeta[c] + (float)s1 : (float)s1;
+        }
+        f.coef[c] = gamma[c] * invstd[c];
+        f.coef[C + c] = (float)(s1 / f.M);
+        f.coef[2 * C + c] = (float)(s2 / f.M);
+    }
+}
+

@@ -46,6 +46,7 @@ struct ConvKP {
     // BatchNorm-backward sums of the stored tile (saltnet.h, salt_conv_args.bnb_*); bnb_partials == nullptr: off
     const void* bnb_y; const void* bnb_a; int bnb_cs, bnb_acs, bnb_relu;
     const float* bnb_mean; const float* bnb_invstd; const float* bnb_gamma; const float* bnb_beta; float* bnb_partials;
+    BnFin fin; BnbFin bnbf;          // in-launch BatchNorm finalize (saltnet.h, salt_conv_args.fin / bnb_fin; common.h); acc == nullptr: off
 };
 
 template <typename T> struct Mma;
@@ -115,7 +116,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKP& p, const TileCoord& 
     for (int i = 0; i < MI; ++i) vmask[i] = 0xffffu;
     // everything below is specialised on three workgroup-uniform facts so that the common launches do not pay for the rare ones:
     // statistics wanted (train-mode forward only), an affine / ReLU epilogue present (eval only), tile fully inside the output grid
-    const bool want_stats = p.stats != nullptr;
+    const bool want_stats = p.stats != nullptr || p.fin.acc != nullptr;
     const bool has_affine = p.bias || p.scale || p.shift || p.relu;
     const bool full_tile = (b0 + p.nb <= p.B) && (oy0 + (1 << p.th_log2) <= p.OH) && ox0 >= 0 && (ox0 + (1 << p.tw_log2) <= p.OW);
     if (want_stats) {
@@ -174,7 +175,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKP& p, const TileCoord& 
         T* yg = reinterpret_cast<T*>(p.y);
         const bool y_vec = ((p.y_cs % VE) == 0) && ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0);
         // BatchNorm-backward sums of the stored values: a thread's channel piece (tid % PPO) is the same for all of its pixels
-        const bool bnb = p.bnb_partials != nullptr;
+        const bool bnb = p.bnb_partials != nullptr || p.bnbf.acc != nullptr;
         float b1[VE], b2[VE], bmu[VE], bis[VE], bsc[VE], bsh[VE];
 #pragma unroll
         for (int e = 0; e < VE; ++e) { b1[e] = 0.f; b2[e] = 0.f; bmu[e] = 0.f; bis[e] = 0.f; bsc[e] = 0.f; bsh[e] = 0.f; }
@@ -284,11 +285,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvKP& p, const TileCoord& 
                 const int st = e >= BN ? 1 : 0, cl = e - st * BN;
                 float t = 0.f;
                 for (int r = 0; r < 256 / PPO; ++r) t += sR[(r * BN + cl) * 2 + st];
-                if (n0 + cl < p.Cout) p.bnb_partials[((int64_t)m_tile * 2 + st) * p.Cout + n0 + cl] = t;
+                if (n0 + cl < p.Cout) {
+                    if (p.bnbf.acc) fin_add(p.bnbf.acc + ((blockIdx.x & 7) * 2 + st) * p.Cout + n0 + cl, (double)t);
+                    else p.bnb_partials[((int64_t)m_tile * 2 + st) * p.Cout + n0 + cl] = t;
+                }
+            }
+            if (p.bnbf.acc) {
+                unsigned* flag = reinterpret_cast<unsigned*>(sR + (256 / PPO) * BN * 2);
+                if (fin_arrive(p.bnbf.ticket, (unsigned)(p.m_tiles * p.n_tiles), flag)) fin_backward(p.bnbf, p.bnb_gamma, p.bnb_invstd, p.Cout);
             }
         }
     }
-    if (p.stats) {
+    if (want_stats) {
         // BatchNorm partial of this workgroup: per-wave (sum, M2 about the wave's mean, count) from the registers, then the WM
         // wave rows are merged in fixed order (Chan) through LDS so that one (sum, M2, count) row per workgroup reaches HBM.
         cntf += __shfl_xor(cntf, 32);
@@ -327,11 +335,24 @@ __device__ __forceinline__ void conv_epilogue(const ConvKP& p, const TileCoord& 
                 }
             }
             const int n = n0 + tid;
-            if (n < p.Cout) {
-                p.stats[((int64_t)part * 2 + 0) * p.Cout + n] = S;
-                p.stats[((int64_t)part * 2 + 1) * p.Cout + n] = M2;
+            if (p.fin.acc) {
+                double* a = p.fin.acc + (blockIdx.x & 7) * (2 * p.Cout + 1);
+                if (n < p.Cout && N > 0.f) {
+                    fin_add(a + n, (double)S);
+                    fin_add(a + p.Cout + n, (double)M2 + (double)S * (double)S / (double)N);
+                }
+                if (tid == 0 && n_tile == 0) fin_add(a + 2 * p.Cout, (double)N);
+            } else {
+                if (n < p.Cout) {
+                    p.stats[((int64_t)part * 2 + 0) * p.Cout + n] = S;
+                    p.stats[((int64_t)part * 2 + 1) * p.Cout + n] = M2;
+                }
+                if (tid == 0 && n_tile == 0) p.stats_cnt[part] = N;
             }
-            if (tid == 0 && n_tile == 0) p.stats_cnt[part] = N;
+        }
+        if (p.fin.acc) {
+            unsigned* flag = reinterpret_cast<unsigned*>(sC + WM + 2);
+            if (fin_arrive(p.fin.ticket, (unsigned)(p.m_tiles * p.n_tiles), flag)) fin_forward(p.fin, p.Cout, reinterpret_cast<double*>(smem));
         }
     }
 }
@@ -1002,7 +1023,7 @@ __global__ __launch_bounds__(512, 2) void conv_glds_kernel(ConvKP p) {
     unsigned vmask[OWN];
 #pragma unroll
     for (int o = 0; o < OWN; ++o) { ssum[o] = 0.f; cntf[o] = 0.f; vmask[o] = 0xffffu; }
-    const bool want_stats = p.stats != nullptr;
+    const bool want_stats = p.stats != nullptr || p.fin.acc != nullptr;
     const bool has_affine = p.bias || p.scale || p.shift || p.relu;
     const bool full_tile = (b0 + p.nb <= p.B) && (oy0 + (1 << p.th_log2) <= p.OH) && ox0 >= 0 && (ox0 + (1 << p.tw_log2) <= p.OW);
     if (want_stats) {
@@ -1055,7 +1076,7 @@ __global__ __launch_bounds__(512, 2) void conv_glds_kernel(ConvKP p) {
     {
         T* yg = reinterpret_cast<T*>(p.y);
         const bool y_vec = ((p.y_cs % VE) == 0) && ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0);
-        const bool bnb = p.bnb_partials != nullptr;
+        const bool bnb = p.bnb_partials != nullptr || p.bnbf.acc != nullptr;
         float b1[VE], b2[VE], bmu[VE], bis[VE], bsc[VE], bsh[VE];
 #pragma unroll
         for (int e = 0; e < VE; ++e) { b1[e] = 0.f; b2[e] = 0.f; bmu[e] = 0.f; bis[e] = 0.f; bsc[e] = 0.f; bsh[e] = 0.f; }
@@ -1165,11 +1186,18 @@ __global__ __launch_bounds__(512, 2) void conv_glds_kernel(ConvKP p) {
                 const int st = e >= BN ? 1 : 0, cl = e - st * BN;
                 float t = 0.f;
                 for (int r = 0; r < NTHR / PPO; ++r) t += sR[(r * BN + cl) * 2 + st];
-                if (n0 + cl < p.Cout) p.bnb_partials[((int64_t)m_tile * 2 + st) * p.Cout + n0 + cl] = t;
+                if (n0 + cl < p.Cout) {
+                    if (p.bnbf.acc) fin_add(p.bnbf.acc + ((blockIdx.x & 7) * 2 + st) * p.Cout + n0 + cl, (double)t);
+                    else p.bnb_partials[((int64_t)m_tile * 2 + st) * p.Cout + n0 + cl] = t;
+                }
+            }
+            if (p.bnbf.acc) {
+                unsigned* flag = reinterpret_cast<unsigned*>(sR + (NTHR / PPO) * BN * 2);
+                if (fin_arrive(p.bnbf.ticket, (unsigned)(p.m_tiles * p.n_tiles), flag)) fin_backward(p.bnbf, p.bnb_gamma, p.bnb_invstd, p.Cout);
             }
         }
     }
-    if (p.stats) {
+    if (want_stats) {
         // per 32-row block and channel: (sum, M2 about the block's own mean, count), merged over the tile's RB blocks in fixed order
         float* sS = reinterpret_cast<float*>(smem);                      // [RB][BN][2] then [RB] counts
         float* sC = sS + RB * BN * 2;
@@ -1208,11 +1236,24 @@ __global__ __launch_bounds__(512, 2) void conv_glds_kernel(ConvKP p) {
                 }
             }
             const int n = n0 + tid;
-            if (n < p.Cout) {
-                p.stats[((int64_t)part * 2 + 0) * p.Cout + n] = S;
-                p.stats[((int64_t)part * 2 + 1) * p.Cout + n] = M2;
+            if (p.fin.acc) {
+                double* a = p.fin.acc + (blockIdx.x & 7) * (2 * p.Cout + 1);
+                if (n < p.Cout && N > 0.f) {
+                    fin_add(a + n, (double)S);
+                    fin_add(a + p.Cout + n, (double)M2 + (double)S * (double)S / (double)N);
+                }
+                if (tid == 0 && n_tile == 0) fin_add(a + 2 * p.Cout, (double)N);
+            } else {
+                if (n < p.Cout) {
+                    p.stats[((int64_t)part * 2 + 0) * p.Cout + n] = S;
+                    p.stats[((int64_t)part * 2 + 1) * p.Cout + n] = M2;
+                }
+                if (tid == 0 && n_tile == 0) p.stats_cnt[part] = N;
             }
-            if (tid == 0 && n_tile == 0) p.stats_cnt[part] = N;
+        }
+        if (p.fin.acc) {
+            unsigned* flag = reinterpret_cast<unsigned*>(sC + RB + 2);
+            if (fin_arrive(p.fin.ticket, (unsigned)(p.m_tiles * p.n_tiles), flag)) fin_forward(p.fin, p.Cout, reinterpret_cast<double*>(smem));
         }
     }
 }
@@ -1236,7 +1277,7 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
     const bool fold_fused = !a->strip && (a->fold_top > 0 || a->fold_right > 0);
     if (fold_fused) {
         const int ve = a->dtype == SALT_F32 ? 4 : 8;
-        if (a->fold_bottom || a->fold_left || a->fold_top < 0 || a->fold_right < 0 || a->out_step != 1 || a->out_oy || a->out_ox || a->stats ||
+        if (a->fold_bottom || a->fold_left || a->fold_top < 0 || a->fold_right < 0 || a->out_step != 1 || a->out_oy || a->out_ox || a->stats || a->fin ||
             a->OH != a->y.H + a->fold_top || a->OW != a->y.W + a->fold_right)
             SALT_FAIL(SALT_E_BADARG, "conv: fused fold needs OH/OW = y.H + top / y.W + right (top / right pads only), out_step 1, no stats");
         if (a->y.C % ve || a->y.cs % ve || (reinterpret_cast<uintptr_t>(a->y.p) & 15))
@@ -1352,7 +1393,7 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
     k.m_tiles = tiles_b * k.tiles_y * k.tiles_x; k.n_tiles = cdiv(Cout, BN);
     k.nphase = a->nphase > 1 ? a->nphase : 1; k.m_tiles_ph = k.m_tiles; k.w_phase_elems = a->w_phase_elems;
     if (k.nphase > 1) {
-        if (k.nphase != 4 || a->out_step != 2 || a->strip || fold_fused || a->bnb_partials || a->w_phase_elems <= 0 ||
+        if (k.nphase != 4 || a->out_step != 2 || a->strip || fold_fused || a->bnb_partials || a->bnb_fin || a->w_phase_elems <= 0 ||
             (a->OH - 1) * 2 + 1 >= a->y.H || (a->OW - 1) * 2 + 1 >= a->y.W)
             SALT_FAIL(SALT_E_BADARG, "conv: a phase-fused launch is 4 output-parity phases of an out_step 2 grid that fits y for every parity");
         k.m_tiles *= 4;
@@ -1373,9 +1414,9 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
     k.bnb_partials = a->bnb_partials; k.bnb_y = a->bnb_y.p; k.bnb_cs = a->bnb_y.cs; k.bnb_relu = a->bnb_relu;
     k.bnb_a = a->bnb_a.p; k.bnb_acs = a->bnb_a.cs;
     k.bnb_mean = a->bnb_mean; k.bnb_invstd = a->bnb_invstd; k.bnb_gamma = a->bnb_gamma; k.bnb_beta = a->bnb_beta;
-    if (a->bnb_partials) {
+    if (a->bnb_partials || a->bnb_fin) {
         const int ve = a->dtype == SALT_F32 ? 4 : 8;
-        if (a->strip || a->stats || a->out_step != 1 || a->out_oy || a->out_ox || (!fold_fused && (a->OH != a->y.H || a->OW != a->y.W)))
+        if (a->strip || a->stats || a->fin || a->out_step != 1 || a->out_oy || a->out_ox || (!fold_fused && (a->OH != a->y.H || a->OW != a->y.W)))
             SALT_FAIL(SALT_E_BADARG, "conv: BatchNorm-backward sums need a plain (or fused-fold) full-grid launch");
         if (!view_ok(a->bnb_y) || a->bnb_y.B != a->y.B || a->bnb_y.H != a->y.H || a->bnb_y.W != a->y.W || a->bnb_y.C != a->y.C)
             SALT_FAIL(SALT_E_BADARG, "conv: bnb_y shape");
@@ -1385,8 +1426,24 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
             SALT_FAIL(SALT_E_BADARG, "conv: bnb_a shape / alignment");
         if (Cout % ve || a->y.cs % ve || a->bnb_y.cs % ve || ((reinterpret_cast<uintptr_t>(a->y.p) | reinterpret_cast<uintptr_t>(a->bnb_y.p)) & 15))
             SALT_FAIL(SALT_E_BADARG, "conv: BatchNorm-backward sums need 16-byte aligned whole channel pieces");
-        const size_t red_bytes = (size_t)((cfg->KS > 0 ? 512 : 256) / (BN / ve)) * BN * 2 * sizeof(float);
+        const size_t red_bytes = (size_t)((cfg->KS > 0 ? 512 : 256) / (BN / ve)) * BN * 2 * sizeof(float) + 16;
         if (red_bytes > pl->lds) pl->lds = red_bytes;
+    }
+    k.fin.acc = nullptr; k.bnbf.acc = nullptr;
+    if (a->fin) {
+        const salt_bn_finalize_args* f = static_cast<const salt_bn_finalize_args*>(a->fin);
+        if (a->stats || a->stats_part0 || a->strip || !a->fin_acc || !a->fin_ticket || f->C != Cout || !f->gamma || !f->beta || !f->mean || !f->invstd ||
+            !f->scale || !f->shift)
+            SALT_FAIL(SALT_E_BADARG, "conv: in-launch BatchNorm finalize needs fin_acc / fin_ticket, no stats partials, and complete finalize arguments");
+        k.fin = BnFin{a->fin_acc, a->fin_ticket, f->gamma, f->beta, f->running_mean, f->running_var, f->num_batches_tracked,
+                            f->momentum, f->eps, f->mean, f->invstd, f->scale, f->shift};
+    }
+    if (a->bnb_fin) {
+        const salt_bn_bwd_args* f = static_cast<const salt_bn_bwd_args*>(a->bnb_fin);
+        if (!a->bnb_acc || !a->bnb_ticket || !f->coef || f->y.C != Cout || (f->dgamma && !f->dbeta))
+            SALT_FAIL(SALT_E_BADARG, "conv: in-launch BatchNorm-backward finalize needs bnb_acc / bnb_ticket and the salt_bn_bwd arguments");
+        k.bnbf = BnbFin{a->bnb_acc, a->bnb_ticket, f->dgamma, f->dbeta, f->coef, f->accumulate_param_grads,
+                                (double)f->y.B * f->y.H * f->y.W};
     }
     if (pl->lds > 160 * 1024) SALT_FAIL(SALT_E_LDS, "conv: needs %zu bytes of LDS", pl->lds);
     return SALT_OK;

@@ -206,7 +206,7 @@ __global__ void bn_fold_kernel(salt_bn_fold_args a) {
 template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(salt_view da, salt_view a, salt_view y, int relu,
                                                             const float* mean, const float* invstd, const float* gamma, const float* beta,
-                                                            float* partials, int64_t pix_per_block) {
+                                                            float* partials, int64_t pix_per_block, BnbFin fin) {
     constexpr int N = Unit<T, VEC>::N;
     extern __shared__ float sm[];
     const int C = y.C, cpv = C / N;
@@ -270,9 +270,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(salt_view da, salt_v
             const int st = e >= E ? 1 : 0, cl = e - st * E;
             float t = 0.f;
             for (int r = 0; r < R; ++r) t += sm[(r * E + cl) * 2 + st];
-            partials[((int64_t)blockIdx.x * 2 + st) * C + cv0 * N + cl] = t;
+            if (fin.acc) fin_add(fin.acc + ((blockIdx.x & 7) * 2 + st) * C + cv0 * N + cl, (double)t);
+            else partials[((int64_t)blockIdx.x * 2 + st) * C + cv0 * N + cl] = t;
         }
         __syncthreads();
+    }
+    if (fin.acc) {                                             // in-launch finalize (salt_bn_bwd_args.fin_acc): the last block writes coef / dgamma / dbeta
+        const int cvn0 = cpv < 256 ? cpv : 256;
+        unsigned* flag = reinterpret_cast<unsigned*>(sm + (256 / cvn0) * cvn0 * N * 2);
+        if (fin_arrive(fin.ticket, gridDim.x, flag)) fin_backward(fin, gamma, invstd, C);
     }
 }
 
@@ -853,10 +859,11 @@ extern "C" int salt_bn_bwd(const salt_bn_bwd_args* a, void* stream) {
     if (a->relu && a->a.p && (!view_ok(a->a) || !same_shape(a->a, a->y))) SALT_FAIL(SALT_E_BADARG, "bn_bwd: forward output shape");
     if (a->relu && !a->a.p && (a->dres.p || !a->beta)) SALT_FAIL(SALT_E_BADARG, "bn_bwd: the ReLU mask can be recomputed from y only without a residual (and needs beta)");
     if (a->dres.p && !same_shape(a->dres, a->y)) SALT_FAIL(SALT_E_BADARG, "bn_bwd: dres shape");
-    if (!a->mean || !a->invstd || !a->gamma || !a->partials || !a->coef) SALT_FAIL(SALT_E_BADARG, "bn_bwd: missing buffers");
+    if (!a->mean || !a->invstd || !a->gamma || (!a->partials && a->partials_ready != 2 && !(a->fin_acc && !a->partials_ready)) || !a->coef) SALT_FAIL(SALT_E_BADARG, "bn_bwd: missing buffers");
     int64_t per = 0;
     int nparts = bn_bwd_nparts(a, &per);
-    if (a->partials_ready) {                                // the producer of da reduced already (salt_conv_args.bnb_*)
+    if (a->partials_ready == 2) {                           // ... and finalized (salt_conv_args.bnb_fin): coef / dgamma / dbeta are ready
+    } else if (a->partials_ready) {                         // the producer of da reduced already (salt_conv_args.bnb_*)
         if (a->nparts < 1) SALT_FAIL(SALT_E_BADARG, "bn_bwd: partials_ready needs nparts >= 1");
         nparts = a->nparts;
     } else if (a->nparts != nparts) SALT_FAIL(SALT_E_BADARG, "bn_bwd: nparts %d, expected %d", a->nparts, nparts);
@@ -868,13 +875,16 @@ extern "C" int salt_bn_bwd(const salt_bn_bwd_args* a, void* stream) {
         const int N = v ? ve : 1;
         const int cpv = C / N;
         const int cvn = cpv < 256 ? cpv : 256;
-        const size_t lds = (size_t)(256 / cvn) * cvn * N * 2 * sizeof(float);
+        const size_t lds = (size_t)(256 / cvn) * cvn * N * 2 * sizeof(float) + 16;
+        const bool fin_here = !a->partials_ready && a->fin_acc != nullptr;        // the reduce launch finalizes (no partials, no finalize launch)
+        if (fin_here && !a->fin_ticket) SALT_FAIL(SALT_E_BADARG, "bn_bwd: fin_acc without fin_ticket");
+        const BnbFin fin{fin_here ? a->fin_acc : nullptr, a->fin_ticket, a->dgamma, a->dbeta, a->coef, a->accumulate_param_grads, (double)view_pixels(a->y)};
         if (!a->partials_ready) {
-            if (v) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), dim3(nparts), dim3(256), lds, st, a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->gamma, a->beta, a->partials, per);
-            else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), dim3(nparts), dim3(256), lds, st, a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->gamma, a->beta, a->partials, per);
+            if (v) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), dim3(nparts), dim3(256), lds, st, a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->gamma, a->beta, a->partials, per, fin);
+            else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), dim3(nparts), dim3(256), lds, st, a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->gamma, a->beta, a->partials, per, fin);
             SALT_CHECK_LAUNCH();
         }
-        {
+        if (a->partials_ready != 2 && !fin_here) {
             const int rows = bn_rows_for(nparts);
             const double M = (double)view_pixels(a->y);
             if (rows == 4) hipLaunchKernelGGL(bn_bwd_finalize_kernel<4>, dim3(cdiv(C, 64)), dim3(256), 0, st, a->partials, nparts, C, M, a->gamma, a->invstd, a->dgamma, a->dbeta, a->accumulate_param_grads, a->coef);

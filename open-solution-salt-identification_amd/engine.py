@@ -371,13 +371,32 @@ class Graph:
         return n
 
     # ------------------------------------------------------------------ BatchNorm plumbing
-    def _bn_train_fwd(self, y, bn, relu, res, out, nparts, stats, cnt):
+    @staticmethod
+    def _fin_on():
+        """In-launch BatchNorm finalize (salt_conv_args.fin / bnb_fin); SALT_BN_FIN=0 keeps the separate finalize launches."""
+        return os.environ.get('SALT_BN_FIN', '1') != '0'
+
+    def _fin_buffers(self, ndoubles):
+        acc = self.alloc((ndoubles,), torch.float64)
+        ticket = self.alloc((4,), torch.int32)
+        return acc.data_ptr(), ticket.data_ptr()
+
+    def _bn_train_fwd(self, y, bn, relu, res, out, nparts, stats, cnt, producer=None):
+        """``producer``: the argument struct of the ONE convolution launch that writes y - it then finalizes the statistics itself
+        (salt_conv_args.fin) and no bn_finalize operator is emitted."""
         w = self.engine.bn_work(bn)
         nbt = bn.num_batches_tracked.data_ptr() if bn.num_batches_tracked is not None else None
-        self.fwd.add('bn_finalize', stats=stats, stats_cnt=cnt, nparts=nparts, C=bn.num_features, gamma=bn.weight.data_ptr(),
-                     beta=bn.bias.data_ptr(), running_mean=bn.running_mean.data_ptr(), running_var=bn.running_var.data_ptr(),
-                     num_batches_tracked=nbt, momentum=bn.momentum, eps=bn.eps, mean=w['mean'].data_ptr(), invstd=w['invstd'].data_ptr(),
-                     scale=w['scale'].data_ptr(), shift=w['shift'].data_ptr())
+        fin = dict(C=bn.num_features, gamma=bn.weight.data_ptr(),
+                   beta=bn.bias.data_ptr(), running_mean=bn.running_mean.data_ptr(), running_var=bn.running_var.data_ptr(),
+                   num_batches_tracked=nbt, momentum=bn.momentum, eps=bn.eps, mean=w['mean'].data_ptr(), invstd=w['invstd'].data_ptr(),
+                   scale=w['scale'].data_ptr(), shift=w['shift'].data_ptr())
+        if producer is not None:
+            F = fill(STRUCTS['salt_bn_finalize_args'](), **fin)
+            self.keep.append(F)
+            acc, ticket = self._fin_buffers(8 * (2 * bn.num_features + 1))
+            self.fwd.set_fields(producer, fin=ctypes.addressof(F), fin_acc=acc, fin_ticket=ticket)
+        else:
+            self.fwd.add('bn_finalize', stats=stats, stats_cnt=cnt, nparts=nparts, **fin)
         if res is not None and getattr(res, 'on_side', False):
             self.join()                          # the residual branch ran on the side stream
         self.fwd.add('affine_act', dtype=self.dt, y=y.view(), scale=w['scale'].data_ptr(), shift=w['shift'].data_ptr(),
@@ -411,15 +430,25 @@ class Graph:
             if nparts < 1:
                 raise SaltError('conv plan failed: ' + lib.salt_last_error().decode())
             self._n_bnb = getattr(self, '_n_bnb', 0) + 1
-            partials, ready = Scratch('bnb%d' % self._n_bnb, nparts * 2 * C * 4), 1
+            if self._fin_on():
+                partials, ready = None, 2          # the launch also finalizes (salt_conv_args.bnb_fin): bn_bwd is the apply pass only
+            else:
+                partials, ready = Scratch('bnb%d' % self._n_bnb, nparts * 2 * C * 4), 1
             self.bwd.set_fields(s, bnb_y=y.view(), bnb_mean=w['mean'].data_ptr(), bnb_invstd=w['invstd'].data_ptr(), bnb_gamma=bn.weight.data_ptr(),
                                 bnb_beta=bn.bias.data_ptr(), bnb_partials=partials, bnb_relu=int(relu),
                                 bnb_a=out.view() if (relu and res is not None) else null_view())
+            producer = s
         # without a residual a = relu(y*scale + shift): the kernel recomputes the mask from y and never reads `a`
-        self.bwd.add('bn_bwd', dtype=self.dt, da=out.gview(), a=out.view() if (relu and res is not None) else null_view(), y=y.view(), relu=int(relu),
-                     mean=w['mean'].data_ptr(), invstd=w['invstd'].data_ptr(), gamma=bn.weight.data_ptr(), beta=bn.bias.data_ptr(),
-                     partials=partials, nparts=nparts, dgamma=gw, dbeta=gb, accumulate_param_grads=0,
-                     coef=coef.data_ptr(), dy=y.gview(), dres=dres, accumulate_dres=acc_res, partials_ready=ready)
+        s2 = self.bwd.add('bn_bwd', dtype=self.dt, da=out.gview(), a=out.view() if (relu and res is not None) else null_view(), y=y.view(), relu=int(relu),
+                          mean=w['mean'].data_ptr(), invstd=w['invstd'].data_ptr(), gamma=bn.weight.data_ptr(), beta=bn.bias.data_ptr(),
+                          partials=partials, nparts=nparts, dgamma=gw, dbeta=gb, accumulate_param_grads=0,
+                          coef=coef.data_ptr(), dy=y.gview(), dres=dres, accumulate_dres=acc_res, partials_ready=ready)
+        if ready == 2:
+            acc, ticket = self._fin_buffers(8 * 2 * C)
+            self.bwd.set_fields(producer, bnb_fin=ctypes.addressof(s2), bnb_acc=acc, bnb_ticket=ticket)
+        elif ready == 0 and self._fin_on():
+            acc, ticket = self._fin_buffers(8 * 2 * C)       # the reduction pass of bn_bwd finalizes in-launch
+            self.bwd.set_fields(s2, fin_acc=acc, fin_ticket=ticket)
 
     # ------------------------------------------------------------------ dense convolution (+BN +ReLU +residual)
     def conv(self, x, conv, bn=None, relu=False, res=None, out=None, replicate=False, name=''):
@@ -452,9 +481,13 @@ class Graph:
         if bn is not None and self.train:
             y = self.new_act(x.B, OH, OW, Cout, name + '.y')
             nparts = self._conv_parts(x.view(), td, stride, y.view(), OH, OW)
-            stats, cnt = Scratch('stats' + self._scratch_sfx, 4 * lib.salt_bn_stats_floats(nparts, Cout)), Scratch('stats_cnt' + self._scratch_sfx, nparts * 4)
-            self._conv_launch(self.fwd, x.view(), pk.data_ptr(), td, stride, pad_mode, y.view(), OH, OW, bias=bias, stats=stats, stats_cnt=cnt)
-            w = self._bn_train_fwd(y, bn, relu, res, out, nparts, stats, cnt)
+            if self._fin_on():
+                prod = self._conv_launch(self.fwd, x.view(), pk.data_ptr(), td, stride, pad_mode, y.view(), OH, OW, bias=bias)
+                w = self._bn_train_fwd(y, bn, relu, res, out, nparts, None, None, producer=prod)
+            else:
+                stats, cnt = Scratch('stats' + self._scratch_sfx, 4 * lib.salt_bn_stats_floats(nparts, Cout)), Scratch('stats_cnt' + self._scratch_sfx, nparts * 4)
+                self._conv_launch(self.fwd, x.view(), pk.data_ptr(), td, stride, pad_mode, y.view(), OH, OW, bias=bias, stats=stats, stats_cnt=cnt)
+                w = self._bn_train_fwd(y, bn, relu, res, out, nparts, stats, cnt)
         elif bn is not None:
             w = eng.bn_work(bn)
             if res is None:
@@ -640,7 +673,7 @@ class Graph:
                        if (fy + p - u) % 2 == 0 and (fx + p - v) % 2 == 0]
                 phases.append((fy, fx, sel))
         fused = self._phase_fused([[((s_[2], s_[3]), (s_[0], s_[1])) for s_ in sel] for _, _, sel in phases], OH, OW)
-        total_parts, stats, cnt = 0, None, None
+        total_parts, stats, cnt, fin_prod = 0, None, None, None
         if fused is not None:
             # ONE launch for the four output-parity phases of the transposed convolution
             td_u, phase_taps = fused
@@ -652,10 +685,14 @@ class Graph:
                 total_parts = lib.salt_conv_stats_parts(ctypes.byref(S))
                 if total_parts < 0:
                     raise SaltError('conv plan failed: ' + lib.salt_last_error().decode())
-                stats = Scratch('stats', 4 * lib.salt_bn_stats_floats(total_parts, Cout))
-                cnt = Scratch('stats_cnt', total_parts * 4)
-                self._conv_launch(self.fwd, x.view(), pk_t.data_ptr(), td_u, 1, 0, tgt.view(), x.H, x.W, out_step=2, bias=bias, stats=stats, stats_cnt=cnt,
-                                  nphase=4, w_phase_elems=elems)
+                if self._fin_on():
+                    fin_prod = self._conv_launch(self.fwd, x.view(), pk_t.data_ptr(), td_u, 1, 0, tgt.view(), x.H, x.W, out_step=2, bias=bias,
+                                                 nphase=4, w_phase_elems=elems)
+                else:
+                    stats = Scratch('stats', 4 * lib.salt_bn_stats_floats(total_parts, Cout))
+                    cnt = Scratch('stats_cnt', total_parts * 4)
+                    self._conv_launch(self.fwd, x.view(), pk_t.data_ptr(), td_u, 1, 0, tgt.view(), x.H, x.W, out_step=2, bias=bias, stats=stats, stats_cnt=cnt,
+                                      nphase=4, w_phase_elems=elems)
             elif bn is not None:
                 self._conv_launch(self.fwd, x.view(), pk_t.data_ptr(), td_u, 1, 0, tgt.view(), x.H, x.W, out_step=2, bias=bias,
                                   scale=w['scale'].data_ptr(), shift=w['shift'].data_ptr(), relu=int(relu), nphase=4, w_phase_elems=elems)
@@ -687,7 +724,7 @@ class Graph:
                                   bias=bias, relu=int(relu))
             part0 += n
         if train_bn:
-            self._bn_train_fwd(tgt, bn, relu, None, out, total_parts, stats, cnt)
+            self._bn_train_fwd(tgt, bn, relu, None, out, total_parts, stats, cnt, producer=fin_prod)
         if self.train:
             def backward():
                 if bn is None:
@@ -758,9 +795,13 @@ class Graph:
         if self.train:
             y = self.new_act(B, OH, OW, Cout, name + '.y')
             nparts = self._conv_parts(z.view(), taps, 1, y.view(), OH, OW)
-            stats, cnt = Scratch('stats' + self._scratch_sfx, 4 * lib.salt_bn_stats_floats(nparts, Cout)), Scratch('stats_cnt' + self._scratch_sfx, nparts * 4)
-            self._conv_launch(self.fwd, z.view(), wp.data_ptr(), taps, 1, 0, y.view(), OH, OW, stats=stats, stats_cnt=cnt)
-            w = self._bn_train_fwd(y, bn, relu, None, out, nparts, stats, cnt)
+            if self._fin_on():
+                prod = self._conv_launch(self.fwd, z.view(), wp.data_ptr(), taps, 1, 0, y.view(), OH, OW)
+                w = self._bn_train_fwd(y, bn, relu, None, out, nparts, None, None, producer=prod)
+            else:
+                stats, cnt = Scratch('stats' + self._scratch_sfx, 4 * lib.salt_bn_stats_floats(nparts, Cout)), Scratch('stats_cnt' + self._scratch_sfx, nparts * 4)
+                self._conv_launch(self.fwd, z.view(), wp.data_ptr(), taps, 1, 0, y.view(), OH, OW, stats=stats, stats_cnt=cnt)
+                w = self._bn_train_fwd(y, bn, relu, None, out, nparts, stats, cnt)
 
             def backward():
                 self._bn_train_bwd(y, bn, relu, None, out, w)

@@ -234,14 +234,18 @@ def test_first_layer_conv_vs_torch():
                                   (3, 16, 9, 18, 24)])
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 @pytest.mark.parametrize('replicate', [True, False])
-def test_two_conv_bn_relu_layers_vs_torch(case, dtype, replicate):
-    """Two stacked 3x3 conv + BN + ReLU layers against torch CPU fp32: forward, data gradient, weight and BN gradients.
+@pytest.mark.parametrize('fin', [1, 0])
+def test_two_conv_bn_relu_layers_vs_torch(case, dtype, replicate, fin, monkeypatch):
+    """fin: in-launch BatchNorm finalize (salt_conv_args.fin / bnb_fin: fp64 shard atomics + last-arriver finalize) vs the separate
+    salt_bn_finalize / bn_bwd finalize launches over per-tile partials.
+    Two stacked 3x3 conv + BN + ReLU layers against torch CPU fp32: forward, data gradient, weight and BN gradients.
     replicate: the reference's replicate top/right padding (architectures/base.py:21-27) - fold-mode data gradient and the
     pipelined weight-gradient kernel's clamp loader on ragged tiles.  Zero padding: the second layer's data gradient is the only
     writer of dL/d(first activation), so its epilogue must also produce the first layer's BatchNorm-backward sums
     (salt_conv_args.bnb_*; checked on the emitted program)."""
     from gpu_harness import BlockRun
     from torch import nn
+    monkeypatch.setenv('SALT_BN_FIN', str(fin))
     B, Cin, H, W, Cmid = case
     Cout = Cmid + 8
     c1, b1, c2, b2 = nn.Conv2d(Cin, Cmid, 3, 1, 0, bias=False), nn.BatchNorm2d(Cmid), nn.Conv2d(Cmid, Cout, 3, 1, 0, bias=False), nn.BatchNorm2d(Cout)
@@ -282,7 +286,8 @@ def test_two_conv_bn_relu_layers_vs_torch(case, dtype, replicate):
     # the data-gradient launch of layer 2 completes dL/d(a1) - also for the replicate-padded variant, whose pad-ring fold is fused
     # into the launch's epilogue - so it carries layer 1's BatchNorm-backward sums whenever the channel pieces are whole
     fusable = Cmid % (4 if dtype == 'f32' else 8) == 0
-    assert ready == [0, 1 if fusable else 0], ready                  # backward order: layer 2, then layer 1
+    assert ready == [0, (2 if fin else 1) if fusable else 0], ready  # backward order: layer 2, then layer 1
+    assert sum(1 for name, _, _ in run.g.fwd.ops if name == 'bn_finalize') == (0 if fin else 2)
     pairs = [('dgrad', gx[0], xr.grad)] + [(k, grads[k], dict(ref.named_parameters())[k].grad) for k in grads]
     for name, got, want in pairs:
         if dtype == 'f32':
@@ -290,6 +295,13 @@ def test_two_conv_bn_relu_layers_vs_torch(case, dtype, replicate):
         else:
             l2 = float((got.double() - want.double()).norm() / want.double().norm())
             assert l2 <= 2 * tol, '%s: rel-L2 %.3e' % (name, l2)
+    for i, b in ((1, b1), (3, b2)):                                  # running statistics (the in-launch finalize writes them too)
+        assert_close(b.running_mean.cpu(), ref[i].running_mean, tol * (1 if dtype == 'f32' else 2), 'running_mean')
+        assert_close(b.running_var.cpu(), ref[i].running_var, tol * (1 if dtype == 'f32' else 2), 'running_var')
+        assert int(b.num_batches_tracked) == 1
+    # a second forward through the same program: the accumulators and tickets were left zero
+    y2 = run.forward()
+    assert torch.equal(y2, y) or float((y2.float() - y.float()).abs().max()) <= 1e-6 * float(y.float().abs().max())
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
