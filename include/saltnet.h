@@ -130,7 +130,10 @@ typedef struct {
      * the first launch; every launch leaves them zero.  One launch per BatchNorm layer (no stats_part0 chaining).  The fp64 sums are
      * order dependent in their last bits only (the fp32 results are reproducible in practice, not by construction).
      * bnb_fin != NULL (a const salt_bn_bwd_args*): the same for the BatchNorm-backward sums of bnb_*: the last workgroup writes
-     * dgamma / dbeta / coef, and salt_bn_bwd then runs with partials_ready = 2 (apply pass only).  bnb_partials is ignored (may be NULL). */
+     * dgamma / dbeta / coef, and salt_bn_bwd then runs with partials_ready = 2 (apply pass only).  bnb_partials is ignored (may be NULL).
+     * fin_ticket == NULL with fin_acc != NULL (bnb_ticket == NULL with bnb_acc != NULL): the launch only ADDS to the shards - no wait,
+     * no ticket, fin / bnb_fin unused - and the consumer finalizes them (salt_affine_act_args.fin_acc; salt_bn_bwd with
+     * partials_ready = 3).  The shards must then be cleared by the caller before the next launch (one salt_zero over all layers). */
     const void* fin;
     double* fin_acc;
     uint32_t* fin_ticket;
@@ -360,6 +363,12 @@ typedef struct {              /* a = relu?( y*scale + shift (+ res) ) */
     salt_view res;            /* res.p == NULL: none */
     int relu;
     salt_view a;
+    /* Consumer-side BatchNorm finalize: fin_acc != NULL (the [8][2 C + 1] fp64 shards a salt_conv launch with fin_acc and NO
+     * fin_ticket added its statistics to; fin = the const salt_bn_finalize_args* of the layer): scale / shift are ignored - every
+     * workgroup derives them from the shards, workgroup 0 stores mean / invstd / scale / shift and updates the running statistics.
+     * The shards are NOT cleared (salt_zero them before the producer's next launch). */
+    const void* fin;
+    const double* fin_acc;
 } salt_affine_act_args;
 int salt_affine_act(const salt_affine_act_args*, void* stream);
 
@@ -384,8 +393,10 @@ typedef struct {              /* backward of a = relu?(bn(y) (+res)) in train mo
     int accumulate_dres;
     int partials_ready;       /* 1: `partials` ([nparts][2][C], any nparts >= 1) was filled by the producer of da (salt_conv_args.bnb_*) */
                               /* 2: the producer also finalized (salt_conv_args.bnb_fin): coef / dgamma / dbeta are ready, only the apply pass runs */
+                              /* 3: the producer added the sums to fin_acc (salt_conv_args.bnb_acc without ticket): the apply pass finalizes them */
     double* fin_acc;          /* partials_ready == 0 and fin_acc != NULL: the reduction pass accumulates into [8][2][C] fp64 shards and its last block */
-    uint32_t* fin_ticket;     /* finalizes (no partials, no finalize launch); both zero before the first call, left zero (see salt_conv_args.fin) */
+    uint32_t* fin_ticket;     /* finalizes (no partials, no finalize launch); both zero before the first call, left zero (see salt_conv_args.fin).
+                               * fin_ticket == NULL: no in-launch finalize - the apply pass finalizes the shards; the caller clears them */
 } salt_bn_bwd_args;
 int salt_bn_bwd(const salt_bn_bwd_args*, void* stream);
 int salt_bn_bwd_parts(const salt_bn_bwd_args*);

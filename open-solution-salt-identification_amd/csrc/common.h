@@ -112,8 +112,13 @@ __device__ __forceinline__ void fin_add(double* p, double v) { unsafeAtomicAdd(p
 __device__ __forceinline__ double fin_take(double* p) {
     return __longlong_as_double((long long)__hip_atomic_exchange(reinterpret_cast<unsigned long long*>(p), 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
-// true in every thread of the workgroup that arrived last; lds_flag: a free word of the kernel's one LDS array
+// true in every thread of the workgroup that arrived last; lds_flag: a free word of the kernel's one LDS array.  One ticket word for
+// the whole grid: a two-level ticket (one word per shard + one over the shards) measured SLOWER (8.25 vs 8.18 ms per step) - the
+// second dependent round trip costs more than 512 arrivals on one word.
 __device__ __forceinline__ bool fin_arrive(unsigned* ticket, unsigned total, unsigned* lds_flag) {
+#ifdef SALT_FIN_NOARRIVE                                            // timing experiment only: what the hand-off costs (results are wrong)
+    return false;
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // this wave's atomics have been performed
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -128,21 +133,20 @@ __device__ __forceinline__ bool fin_arrive(unsigned* ticket, unsigned total, uns
 // forward statistics: acc = [8][2 C + 1] (sum, sum of squares, count); same arithmetic as bn_finalize_kernel from there on
 __device__ inline void fin_forward(const BnFin& f, int C, double* lds_n) {
     const int tid = threadIdx.x, nthr = blockDim.x, stride = 2 * C + 1;
-    if (tid == 0) {
-        double n = 0.0;
-        for (int s = 0; s < 8; ++s) n += fin_take(f.acc + s * stride + 2 * C);
-        *lds_n = n;
-        if (f.nbt) *f.nbt += 1;
-    }
-    __syncthreads();
-    const double N = *lds_n;
+    (void)lds_n;
+    // every thread reads the eight shard counts itself (plain device-scope loads, in flight together with its channel exchanges:
+    // one round trip); thread 0 zeroes them once everybody has read
+    double nv[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+        nv[s] = __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(f.acc + s * stride + 2 * C), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     for (int c = tid; c < C; c += nthr) {
         double sv[8], qv[8];
 #pragma unroll
         for (int s = 0; s < 8; ++s) { sv[s] = fin_take(f.acc + s * stride + c); qv[s] = fin_take(f.acc + s * stride + C + c); }
-        double S = 0.0, Q = 0.0;
+        double S = 0.0, Q = 0.0, N = 0.0;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) { S += sv[s]; Q += qv[s]; }
+        for (int s = 0; s < 8; ++s) { S += sv[s]; Q += qv[s]; N += nv[s]; }
         const double mean = N > 0 ? S / N : 0.0;
         double M2 = Q - S * mean;
         if (M2 < 0.0) M2 = 0.0;
@@ -156,6 +160,9 @@ __device__ inline void fin_forward(const BnFin& f, int C, double* lds_n) {
             f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)unb;
         }
     }
+    __syncthreads();                                               // every thread holds the counts
+    if (tid < 8) __hip_atomic_store(reinterpret_cast<unsigned long long*>(f.acc + tid * stride + 2 * C), 0ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0 && f.nbt) *f.nbt += 1;
 }
 // backward sums: acc = [8][2 C]; same arithmetic as bn_bwd_finalize_kernel
 __device__ inline void fin_backward(const BnbFin& f, const float* gamma, const float* invstd, int C) {
@@ -177,3 +184,57 @@ __device__ inline void fin_backward(const BnbFin& f, const float* gamma, const f
     }
 }
 
+
+// ---- consumer-side finalize: the producer launch only ADDS to the shards (ticket == nullptr: no wait, no ticket - the arrive +
+// last-arriver tail measured 7.5 us per launch, more than half of what the fusion saved); the launch boundary orders the atomics
+// before the consumer, whose every workgroup recomputes the per-channel coefficients from the 8 shards into LDS (thread per channel,
+// all shard loads in flight together: one round trip); workgroup 0 also stores them for later readers.  The accumulators are
+// zeroed by ONE salt_zero launch per program run (the shards of all layers are slices of one arena).
+__device__ inline void fin_forward_consumer(const BnFin& f, int C, float* sm_scale, float* sm_shift, bool store) {
+    const int stride = 2 * C + 1;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double sv[8], qv[8], nv[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) { sv[s] = f.acc[s * stride + c]; qv[s] = f.acc[s * stride + C + c]; nv[s] = f.acc[s * stride + 2 * C]; }
+        double S = 0.0, Q = 0.0, N = 0.0;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) { S += sv[s]; Q += qv[s]; N += nv[s]; }
+        const double mean = N > 0 ? S / N : 0.0;
+        double M2 = Q - S * mean;
+        if (M2 < 0.0) M2 = 0.0;
+        const double var = N > 0 ? M2 / N : 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
+        const float sc = f.gamma[c] * invstd, sh = f.beta[c] - (float)mean * sc;
+        sm_scale[c] = sc; sm_shift[c] = sh;
+        if (store) {
+            f.mean[c] = (float)mean; f.invstd[c] = invstd; f.scale[c] = sc; f.shift[c] = sh;
+            if (f.running_mean) {
+                const double unb = N > 1 ? M2 / (N - 1) : var;
+                f.running_mean[c] = (1.f - f.momentum) * f.running_mean[c] + f.momentum * (float)mean;
+                f.running_var[c] = (1.f - f.momentum) * f.running_var[c] + f.momentum * (float)unb;
+            }
+        }
+    }
+    if (store && threadIdx.x == 0 && f.nbt) *f.nbt += 1;
+}
+// sm_k: [3][C] = k (gamma invstd), c1 (sum1 / M), c2 (sum2 / M)
+__device__ inline void fin_backward_consumer(const BnbFin& f, const float* gamma, const float* invstd, int C, float* sm_k, bool store) {
+    const int stride = 2 * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double v1[8], v2[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) { v1[s] = f.acc[s * stride + c]; v2[s] = f.acc[s * stride + C + c]; }
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) { s1 += v1[s]; s2 += v2[s]; }
+        const float k0 = gamma[c] * invstd[c], k1 = (float)(s1 / f.M), k2 = (float)(s2 / f.M);
+        sm_k[c] = k0; sm_k[C + c] = k1; sm_k[2 * C + c] = k2;
+        if (store) {
+            if (f.dgamma) {
+                f.dgamma[c] = f.accumulate ? f.dgamma[c] + (float)s2 : (float)s2;
+                f.dbeta[c] = f.accumulate ? f.dbeta[c] + (float)s1 : (float)s1;
+            }
+            if (f.coef) { f.coef[c] = k0; f.coef[C + c] = k1; f.coef[2 * C + c] = k2; }
+        }
+    }
+}

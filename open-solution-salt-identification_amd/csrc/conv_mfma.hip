@@ -170,7 +170,62 @@ __device__ __forceinline__ void conv_epilogue(const ConvKP& p, const TileCoord& 
     };
     if (has_affine) { if (want_stats) stage(std::true_type{}, std::true_type{}); else stage(std::true_type{}, std::false_type{}); }
     else { if (want_stats) stage(std::false_type{}, std::true_type{}); else stage(std::false_type{}, std::false_type{}); }
+    // BatchNorm statistics of this workgroup: per-wave (sum, M2 about the wave's mean, count) from the registers, then the WM wave
+    // rows are merged in fixed order (Chan) through LDS - in a region BEHIND the staged output tile, so that the merge shares the
+    // barrier of the tile and (in-launch finalize) the atomics are in flight while the tile is stored.
+    constexpr int STATS_OFF = (BM * PITCH * (int)sizeof(T) + 15) & ~15;
+    float* sS = reinterpret_cast<float*>(smem + STATS_OFF);            // [WM][BN][2] then [WM] counts
+    float* sC = sS + WM * BN * 2;
+    if (want_stats) {
+        cntf += __shfl_xor(cntf, 32);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            float s = ssum[j] + __shfl_xor(ssum[j], 32);
+            const float mean = cntf > 0.f ? s / cntf : 0.f;
+            float m2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if ((vmask[i] >> r) & 1u) { const float d = acc[i][j][r] - mean; m2 += d * d; }
+            m2 += __shfl_xor(m2, 32);
+            if (khalf == 0) { sS[(wm * BN + nrow[j]) * 2 + 0] = s; sS[(wm * BN + nrow[j]) * 2 + 1] = m2; }
+        }
+        if (lane == 0 && wn == 0) sC[wm] = cntf;
+    }
     __syncthreads();
+    if (want_stats && tid < BN) {
+        const int part = p.stats_part0 + m_tile;
+        float N = 0.f, S = 0.f, M2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) {
+            const float nk = sC[w];
+            if (nk > 0.f) {
+                const float sk = sS[(w * BN + tid) * 2 + 0], mk = sS[(w * BN + tid) * 2 + 1];
+                if (N == 0.f) { N = nk; S = sk; M2 = mk; }
+                else {
+                    const float d = sk / nk - S / N;
+                    M2 += mk + d * d * (N * nk / (N + nk));
+                    S += sk; N += nk;
+                }
+            }
+        }
+        const int n = n0 + tid;
+        if (p.fin.acc) {
+            double* a = p.fin.acc + (blockIdx.x & 7) * (2 * p.Cout + 1);
+            if (n < p.Cout && N > 0.f) {
+                fin_add(a + n, (double)S);
+                fin_add(a + p.Cout + n, (double)M2 + (double)S * (double)S / (double)N);
+            }
+            if (tid == 0 && n_tile == 0) fin_add(a + 2 * p.Cout, (double)N);
+        } else {
+            if (n < p.Cout) {
+                p.stats[((int64_t)part * 2 + 0) * p.Cout + n] = S;
+                p.stats[((int64_t)part * 2 + 1) * p.Cout + n] = M2;
+            }
+            if (tid == 0 && n_tile == 0) p.stats_cnt[part] = N;
+        }
+    }
     {
         T* yg = reinterpret_cast<T*>(p.y);
         const bool y_vec = ((p.y_cs % VE) == 0) && ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0);
@@ -290,70 +345,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvKP& p, const TileCoord& 
                     else p.bnb_partials[((int64_t)m_tile * 2 + st) * p.Cout + n0 + cl] = t;
                 }
             }
-            if (p.bnbf.acc) {
+            if (p.bnbf.acc && p.bnbf.ticket) {
                 unsigned* flag = reinterpret_cast<unsigned*>(sR + (256 / PPO) * BN * 2);
                 if (fin_arrive(p.bnbf.ticket, (unsigned)(p.m_tiles * p.n_tiles), flag)) fin_backward(p.bnbf, p.bnb_gamma, p.bnb_invstd, p.Cout);
             }
         }
     }
-    if (want_stats) {
-        // BatchNorm partial of this workgroup: per-wave (sum, M2 about the wave's mean, count) from the registers, then the WM
-        // wave rows are merged in fixed order (Chan) through LDS so that one (sum, M2, count) row per workgroup reaches HBM.
-        cntf += __shfl_xor(cntf, 32);
-        float* sS = reinterpret_cast<float*>(smem);                // [WM][BN][2] then [WM] counts
-        float* sC = sS + WM * BN * 2;
-        __syncthreads();                                           // the output tile in LDS has been stored
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            float s = ssum[j] + __shfl_xor(ssum[j], 32);
-            const float mean = cntf > 0.f ? s / cntf : 0.f;
-            float m2 = 0.f;
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if ((vmask[i] >> r) & 1u) { const float d = acc[i][j][r] - mean; m2 += d * d; }
-            m2 += __shfl_xor(m2, 32);
-            if (khalf == 0) { sS[(wm * BN + nrow[j]) * 2 + 0] = s; sS[(wm * BN + nrow[j]) * 2 + 1] = m2; }
-        }
-        if (lane == 0 && wn == 0) sC[wm] = cntf;
-        __syncthreads();
-        const int part = p.stats_part0 + m_tile;
-        if (tid < BN) {
-            float N = 0.f, S = 0.f, M2 = 0.f;
-#pragma unroll
-            for (int w = 0; w < WM; ++w) {
-                const float nk = sC[w];
-                if (nk > 0.f) {
-                    const float sk = sS[(w * BN + tid) * 2 + 0], mk = sS[(w * BN + tid) * 2 + 1];
-                    if (N == 0.f) { N = nk; S = sk; M2 = mk; }
-                    else {
-                        const float d = sk / nk - S / N;
-                        M2 += mk + d * d * (N * nk / (N + nk));
-                        S += sk; N += nk;
-                    }
-                }
-            }
-            const int n = n0 + tid;
-            if (p.fin.acc) {
-                double* a = p.fin.acc + (blockIdx.x & 7) * (2 * p.Cout + 1);
-                if (n < p.Cout && N > 0.f) {
-                    fin_add(a + n, (double)S);
-                    fin_add(a + p.Cout + n, (double)M2 + (double)S * (double)S / (double)N);
-                }
-                if (tid == 0 && n_tile == 0) fin_add(a + 2 * p.Cout, (double)N);
-            } else {
-                if (n < p.Cout) {
-                    p.stats[((int64_t)part * 2 + 0) * p.Cout + n] = S;
-                    p.stats[((int64_t)part * 2 + 1) * p.Cout + n] = M2;
-                }
-                if (tid == 0 && n_tile == 0) p.stats_cnt[part] = N;
-            }
-        }
-        if (p.fin.acc) {
-            unsigned* flag = reinterpret_cast<unsigned*>(sC + WM + 2);
-            if (fin_arrive(p.fin.ticket, (unsigned)(p.m_tiles * p.n_tiles), flag)) fin_forward(p.fin, p.Cout, reinterpret_cast<double*>(smem));
-        }
+    if (p.fin.acc && p.fin.ticket) {                               // in-launch finalize: the atomics were issued before the tile stores
+        unsigned* flag = reinterpret_cast<unsigned*>(smem + STATS_OFF) + WM * BN * 2 + WM + 2;
+        if (fin_arrive(p.fin.ticket, (unsigned)(p.m_tiles * p.n_tiles), flag)) fin_forward(p.fin, p.Cout, nullptr);
     }
 }
 
@@ -1191,7 +1191,7 @@ __global__ __launch_bounds__(512, 2) void conv_glds_kernel(ConvKP p) {
                     else p.bnb_partials[((int64_t)m_tile * 2 + st) * p.Cout + n0 + cl] = t;
                 }
             }
-            if (p.bnbf.acc) {
+            if (p.bnbf.acc && p.bnbf.ticket) {
                 unsigned* flag = reinterpret_cast<unsigned*>(sR + (NTHR / PPO) * BN * 2);
                 if (fin_arrive(p.bnbf.ticket, (unsigned)(p.m_tiles * p.n_tiles), flag)) fin_backward(p.bnbf, p.bnb_gamma, p.bnb_invstd, p.Cout);
             }
@@ -1251,7 +1251,7 @@ __global__ __launch_bounds__(512, 2) void conv_glds_kernel(ConvKP p) {
                 if (tid == 0 && n_tile == 0) p.stats_cnt[part] = N;
             }
         }
-        if (p.fin.acc) {
+        if (p.fin.acc && p.fin.ticket) {
             unsigned* flag = reinterpret_cast<unsigned*>(sC + RB + 2);
             if (fin_arrive(p.fin.ticket, (unsigned)(p.m_tiles * p.n_tiles), flag)) fin_forward(p.fin, p.Cout, reinterpret_cast<double*>(smem));
         }
@@ -1277,7 +1277,7 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
     const bool fold_fused = !a->strip && (a->fold_top > 0 || a->fold_right > 0);
     if (fold_fused) {
         const int ve = a->dtype == SALT_F32 ? 4 : 8;
-        if (a->fold_bottom || a->fold_left || a->fold_top < 0 || a->fold_right < 0 || a->out_step != 1 || a->out_oy || a->out_ox || a->stats || a->fin ||
+        if (a->fold_bottom || a->fold_left || a->fold_top < 0 || a->fold_right < 0 || a->out_step != 1 || a->out_oy || a->out_ox || a->stats || a->fin_acc ||
             a->OH != a->y.H + a->fold_top || a->OW != a->y.W + a->fold_right)
             SALT_FAIL(SALT_E_BADARG, "conv: fused fold needs OH/OW = y.H + top / y.W + right (top / right pads only), out_step 1, no stats");
         if (a->y.C % ve || a->y.cs % ve || (reinterpret_cast<uintptr_t>(a->y.p) & 15))
@@ -1393,7 +1393,7 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
     k.m_tiles = tiles_b * k.tiles_y * k.tiles_x; k.n_tiles = cdiv(Cout, BN);
     k.nphase = a->nphase > 1 ? a->nphase : 1; k.m_tiles_ph = k.m_tiles; k.w_phase_elems = a->w_phase_elems;
     if (k.nphase > 1) {
-        if (k.nphase != 4 || a->out_step != 2 || a->strip || fold_fused || a->bnb_partials || a->bnb_fin || a->w_phase_elems <= 0 ||
+        if (k.nphase != 4 || a->out_step != 2 || a->strip || fold_fused || a->bnb_partials || a->bnb_acc || a->w_phase_elems <= 0 ||
             (a->OH - 1) * 2 + 1 >= a->y.H || (a->OW - 1) * 2 + 1 >= a->y.W)
             SALT_FAIL(SALT_E_BADARG, "conv: a phase-fused launch is 4 output-parity phases of an out_step 2 grid that fits y for every parity");
         k.m_tiles *= 4;
@@ -1407,16 +1407,18 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
     }
     {   // the epilogue stages the BM x BN output tile through the same LDS
         const size_t es = a->dtype == SALT_F32 ? 4 : 2;
-        const size_t out_bytes = (size_t)(32 * cfg->MI * cfg->WM) * (BN * es + 16);
+        size_t out_bytes = (size_t)(32 * cfg->MI * cfg->WM) * (BN * es + 16);
+        // conv_mfma_kernel merges the BatchNorm statistics of its waves in a region behind the staged tile ([WM][BN][2] + [WM] floats + flag)
+        if (cfg->KS == 0 && (a->stats || a->fin_acc)) out_bytes += 16 + (size_t)cfg->WM * BN * 8 + (size_t)cfg->WM * 4 + 32;
         if (out_bytes > pl->lds) pl->lds = out_bytes;
     }
     pl->parts = tiles_b * k.tiles_y * k.tiles_x * k.nphase;
     k.bnb_partials = a->bnb_partials; k.bnb_y = a->bnb_y.p; k.bnb_cs = a->bnb_y.cs; k.bnb_relu = a->bnb_relu;
     k.bnb_a = a->bnb_a.p; k.bnb_acs = a->bnb_a.cs;
     k.bnb_mean = a->bnb_mean; k.bnb_invstd = a->bnb_invstd; k.bnb_gamma = a->bnb_gamma; k.bnb_beta = a->bnb_beta;
-    if (a->bnb_partials || a->bnb_fin) {
+    if (a->bnb_partials || a->bnb_acc) {
         const int ve = a->dtype == SALT_F32 ? 4 : 8;
-        if (a->strip || a->stats || a->fin || a->out_step != 1 || a->out_oy || a->out_ox || (!fold_fused && (a->OH != a->y.H || a->OW != a->y.W)))
+        if (a->strip || a->stats || a->fin_acc || a->out_step != 1 || a->out_oy || a->out_ox || (!fold_fused && (a->OH != a->y.H || a->OW != a->y.W)))
             SALT_FAIL(SALT_E_BADARG, "conv: BatchNorm-backward sums need a plain (or fused-fold) full-grid launch");
         if (!view_ok(a->bnb_y) || a->bnb_y.B != a->y.B || a->bnb_y.H != a->y.H || a->bnb_y.W != a->y.W || a->bnb_y.C != a->y.C)
             SALT_FAIL(SALT_E_BADARG, "conv: bnb_y shape");
@@ -1430,20 +1432,28 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
         if (red_bytes > pl->lds) pl->lds = red_bytes;
     }
     k.fin.acc = nullptr; k.bnbf.acc = nullptr;
-    if (a->fin) {
-        const salt_bn_finalize_args* f = static_cast<const salt_bn_finalize_args*>(a->fin);
-        if (a->stats || a->stats_part0 || a->strip || !a->fin_acc || !a->fin_ticket || f->C != Cout || !f->gamma || !f->beta || !f->mean || !f->invstd ||
-            !f->scale || !f->shift)
-            SALT_FAIL(SALT_E_BADARG, "conv: in-launch BatchNorm finalize needs fin_acc / fin_ticket, no stats partials, and complete finalize arguments");
-        k.fin = BnFin{a->fin_acc, a->fin_ticket, f->gamma, f->beta, f->running_mean, f->running_var, f->num_batches_tracked,
-                            f->momentum, f->eps, f->mean, f->invstd, f->scale, f->shift};
+    if (a->fin_acc) {
+        if (a->stats || a->stats_part0 || a->strip) SALT_FAIL(SALT_E_BADARG, "conv: fin_acc excludes stats partials and fold mode");
+        k.fin = BnFin{};
+        k.fin.acc = a->fin_acc;
+        if (a->fin_ticket) {                                    // in-launch finalize by the last arriver
+            const salt_bn_finalize_args* f = static_cast<const salt_bn_finalize_args*>(a->fin);
+            if (!f || f->C != Cout || !f->gamma || !f->beta || !f->mean || !f->invstd || !f->scale || !f->shift)
+                SALT_FAIL(SALT_E_BADARG, "conv: in-launch BatchNorm finalize needs complete finalize arguments");
+            k.fin = BnFin{a->fin_acc, a->fin_ticket, f->gamma, f->beta, f->running_mean, f->running_var, f->num_batches_tracked,
+                          f->momentum, f->eps, f->mean, f->invstd, f->scale, f->shift};
+        }
     }
-    if (a->bnb_fin) {
-        const salt_bn_bwd_args* f = static_cast<const salt_bn_bwd_args*>(a->bnb_fin);
-        if (!a->bnb_acc || !a->bnb_ticket || !f->coef || f->y.C != Cout || (f->dgamma && !f->dbeta))
-            SALT_FAIL(SALT_E_BADARG, "conv: in-launch BatchNorm-backward finalize needs bnb_acc / bnb_ticket and the salt_bn_bwd arguments");
-        k.bnbf = BnbFin{a->bnb_acc, a->bnb_ticket, f->dgamma, f->dbeta, f->coef, f->accumulate_param_grads,
-                                (double)f->y.B * f->y.H * f->y.W};
+    if (a->bnb_acc) {
+        k.bnbf = BnbFin{};
+        k.bnbf.acc = a->bnb_acc;
+        if (a->bnb_ticket) {
+            const salt_bn_bwd_args* f = static_cast<const salt_bn_bwd_args*>(a->bnb_fin);
+            if (!f || !f->coef || f->y.C != Cout || (f->dgamma && !f->dbeta))
+                SALT_FAIL(SALT_E_BADARG, "conv: in-launch BatchNorm-backward finalize needs the salt_bn_bwd arguments");
+            k.bnbf = BnbFin{a->bnb_acc, a->bnb_ticket, f->dgamma, f->dbeta, f->coef, f->accumulate_param_grads,
+                            (double)f->y.B * f->y.H * f->y.W};
+        }
     }
     if (pl->lds > 160 * 1024) SALT_FAIL(SALT_E_LDS, "conv: needs %zu bytes of LDS", pl->lds);
     return SALT_OK;

@@ -46,12 +46,20 @@ inline int ew_blocks(int64_t units) {
          else hipExtLaunchKernelGGL((KERN<T, false>), dim3(ew_blocks(units)), dim3(256), 0, stream, nullptr, ev_, 0, __VA_ARGS__); } while (0)
 
 // ---------------------------------------------------------------- affine + act (+ residual)
-template <typename T, bool VEC, int U = 2>
-__global__ void affine_act_kernel(salt_view y, const float* scale, const float* shift, salt_view res, int relu, salt_view a) {
+// FIN: scale / shift are not read from memory - every workgroup finalizes the producer's fp64 statistics shards itself
+// (fin_forward_consumer, common.h) into LDS; workgroup 0 stores mean / invstd / scale / shift / running statistics.
+template <typename T, bool VEC, int U = 2, bool FIN = false>
+__global__ void affine_act_kernel(salt_view y, const float* scale, const float* shift, salt_view res, int relu, salt_view a, BnFin fin) {
     constexpr int N = Unit<T, VEC>::N;
     const int cpv = y.C / N;
     const int64_t units = (int64_t)y.B * y.H * y.W * cpv;
     const int64_t stride = gridDim.x * 256LL;
+    if constexpr (FIN) {
+        extern __shared__ float fin_sm[];
+        fin_forward_consumer(fin, y.C, fin_sm, fin_sm + y.C, blockIdx.x == 0);
+        __syncthreads();
+        scale = fin_sm; shift = fin_sm + y.C;                  // generic address space: the loads below become LDS reads
+    }
     if (stride % cpv == 0) {
         // the thread's channel piece is the same in every iteration: per-channel parameters live in registers, U units in flight
         const int64_t u0 = blockIdx.x * 256LL + threadIdx.x;
@@ -275,7 +283,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(salt_view da, salt_v
         }
         __syncthreads();
     }
-    if (fin.acc) {                                             // in-launch finalize (salt_bn_bwd_args.fin_acc): the last block writes coef / dgamma / dbeta
+    if (fin.acc && fin.ticket) {                               // in-launch finalize (salt_bn_bwd_args.fin_acc): the last block writes coef / dgamma / dbeta
         const int cvn0 = cpv < 256 ? cpv : 256;
         unsigned* flag = reinterpret_cast<unsigned*>(sm + (256 / cvn0) * cvn0 * N * 2);
         if (fin_arrive(fin.ticket, gridDim.x, flag)) fin_backward(fin, gamma, invstd, C);
@@ -318,12 +326,20 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* parti
     coef[2 * C + c] = (float)(s2 / M);
 }
 
-template <typename T, bool VEC>
+// FIN: coef is not read from memory - every workgroup finalizes the fp64 shards of the BatchNorm-backward sums itself
+// (fin_backward_consumer) into LDS; workgroup 0 stores dgamma / dbeta / coef.
+template <typename T, bool VEC, bool FIN = false>
 __global__ void bn_bwd_apply_kernel(salt_view da, salt_view a, salt_view y, int relu, const float* mean, const float* invstd,
-                                    const float* gamma, const float* beta, const float* coef, salt_view dy, salt_view dres, int acc_dres) {
+                                    const float* gamma, const float* beta, const float* coef, salt_view dy, salt_view dres, int acc_dres, BnbFin fin) {
     constexpr int N = Unit<T, VEC>::N;
     const int C = y.C, cpv = C / N;
     const int64_t units = (int64_t)y.B * y.H * y.W * cpv;
+    if constexpr (FIN) {
+        extern __shared__ float fin_sm[];
+        fin_backward_consumer(fin, gamma, invstd, C, fin_sm, blockIdx.x == 0);
+        __syncthreads();
+        coef = fin_sm;
+    }
     {
         const int64_t stride_ = gridDim.x * 256LL;
         if (stride_ % cpv == 0) {
@@ -805,11 +821,23 @@ extern "C" int salt_affine_act(const salt_affine_act_args* a, void* stream) {
     if (!a || !view_ok(a->y) || !view_ok(a->a) || !same_shape(a->y, a->a)) SALT_FAIL(SALT_E_BADARG, "affine_act: bad views");
     if (a->res.p && !same_shape(a->y, a->res)) SALT_FAIL(SALT_E_BADARG, "affine_act: residual shape");
     if ((a->scale == nullptr) != (a->shift == nullptr)) SALT_FAIL(SALT_E_BADARG, "affine_act: scale/shift");
+    if (a->fin_acc && a->y.C > 4096) SALT_FAIL(SALT_E_BADARG, "affine_act: fin_acc supports <= 4096 channels");
     SALT_DISPATCH_DTYPE(a->dtype, T, {
         const int ve = Elem<T>::VE;
         const bool v = vec_ok(a->y, ve) && vec_ok(a->a, ve) && vec_ok(a->res, ve);
         const int64_t units = view_pixels(a->y) * (a->y.C / (v ? ve : 1));
-        EW_LAUNCH_U(affine_act_kernel, T, v, 2, units, (hipStream_t)stream, a->y, a->scale, a->shift, a->res, a->relu, a->a);
+        if (a->fin_acc) {
+            const salt_bn_finalize_args* f = static_cast<const salt_bn_finalize_args*>(a->fin);
+            if (!f || f->C != a->y.C || !f->gamma || !f->beta || !f->mean || !f->invstd || !f->scale || !f->shift)
+                SALT_FAIL(SALT_E_BADARG, "affine_act: fin_acc needs the complete salt_bn_finalize arguments");
+            const BnFin fin{const_cast<double*>(a->fin_acc), nullptr, f->gamma, f->beta, f->running_mean, f->running_var, f->num_batches_tracked,
+                            f->momentum, f->eps, f->mean, f->invstd, f->scale, f->shift};
+            const size_t lds = (size_t)a->y.C * 2 * sizeof(float);
+            if (v) hipLaunchKernelGGL((affine_act_kernel<T, true, 2, true>), dim3(ew_blocks(units)), dim3(256), lds, (hipStream_t)stream, a->y, nullptr, nullptr, a->res, a->relu, a->a, fin);
+            else hipLaunchKernelGGL((affine_act_kernel<T, false, 2, true>), dim3(ew_blocks(units)), dim3(256), lds, (hipStream_t)stream, a->y, nullptr, nullptr, a->res, a->relu, a->a, fin);
+        } else {
+            EW_LAUNCH_U(affine_act_kernel, T, v, 2, units, (hipStream_t)stream, a->y, a->scale, a->shift, a->res, a->relu, a->a, BnFin{});
+        }
     })
     SALT_CHECK_LAUNCH();
     return SALT_OK;
@@ -859,10 +887,10 @@ extern "C" int salt_bn_bwd(const salt_bn_bwd_args* a, void* stream) {
     if (a->relu && a->a.p && (!view_ok(a->a) || !same_shape(a->a, a->y))) SALT_FAIL(SALT_E_BADARG, "bn_bwd: forward output shape");
     if (a->relu && !a->a.p && (a->dres.p || !a->beta)) SALT_FAIL(SALT_E_BADARG, "bn_bwd: the ReLU mask can be recomputed from y only without a residual (and needs beta)");
     if (a->dres.p && !same_shape(a->dres, a->y)) SALT_FAIL(SALT_E_BADARG, "bn_bwd: dres shape");
-    if (!a->mean || !a->invstd || !a->gamma || (!a->partials && a->partials_ready != 2 && !(a->fin_acc && !a->partials_ready)) || !a->coef) SALT_FAIL(SALT_E_BADARG, "bn_bwd: missing buffers");
+    if (!a->mean || !a->invstd || !a->gamma || (!a->partials && a->partials_ready != 2 && a->partials_ready != 3 && !(a->fin_acc && !a->partials_ready)) || !a->coef) SALT_FAIL(SALT_E_BADARG, "bn_bwd: missing buffers");
     int64_t per = 0;
     int nparts = bn_bwd_nparts(a, &per);
-    if (a->partials_ready == 2) {                           // ... and finalized (salt_conv_args.bnb_fin): coef / dgamma / dbeta are ready
+    if (a->partials_ready == 2 || a->partials_ready == 3) {  // ... and finalized (salt_conv_args.bnb_fin): coef / dgamma / dbeta are ready; 3: see below
     } else if (a->partials_ready) {                         // the producer of da reduced already (salt_conv_args.bnb_*)
         if (a->nparts < 1) SALT_FAIL(SALT_E_BADARG, "bn_bwd: partials_ready needs nparts >= 1");
         nparts = a->nparts;
@@ -876,15 +904,20 @@ extern "C" int salt_bn_bwd(const salt_bn_bwd_args* a, void* stream) {
         const int cpv = C / N;
         const int cvn = cpv < 256 ? cpv : 256;
         const size_t lds = (size_t)(256 / cvn) * cvn * N * 2 * sizeof(float) + 16;
-        const bool fin_here = !a->partials_ready && a->fin_acc != nullptr;        // the reduce launch finalizes (no partials, no finalize launch)
-        if (fin_here && !a->fin_ticket) SALT_FAIL(SALT_E_BADARG, "bn_bwd: fin_acc without fin_ticket");
+        // fin_acc: the sums go through fp64 shards instead of partials.  With fin_ticket the reduce launch's last block finalizes
+        // (coef ready for the apply pass); without, the apply pass finalizes the shards itself (partials_ready 3: they were filled
+        // by the producer of da, salt_conv_args.bnb_acc)
+        const bool fin_here = !a->partials_ready && a->fin_acc != nullptr;
+        const bool fin_apply = a->fin_acc != nullptr && !a->fin_ticket && (a->partials_ready == 0 || a->partials_ready == 3);
+        if (a->partials_ready == 3 && !fin_apply) SALT_FAIL(SALT_E_BADARG, "bn_bwd: partials_ready 3 needs fin_acc and no fin_ticket");
+        if (fin_apply && C > 4096) SALT_FAIL(SALT_E_BADARG, "bn_bwd: fin_acc supports <= 4096 channels");
         const BnbFin fin{fin_here ? a->fin_acc : nullptr, a->fin_ticket, a->dgamma, a->dbeta, a->coef, a->accumulate_param_grads, (double)view_pixels(a->y)};
         if (!a->partials_ready) {
             if (v) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), dim3(nparts), dim3(256), lds, st, a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->gamma, a->beta, a->partials, per, fin);
             else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), dim3(nparts), dim3(256), lds, st, a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->gamma, a->beta, a->partials, per, fin);
             SALT_CHECK_LAUNCH();
         }
-        if (a->partials_ready != 2 && !fin_here) {
+        if (a->partials_ready != 2 && a->partials_ready != 3 && !fin_here) {
             const int rows = bn_rows_for(nparts);
             const double M = (double)view_pixels(a->y);
             if (rows == 4) hipLaunchKernelGGL(bn_bwd_finalize_kernel<4>, dim3(cdiv(C, 64)), dim3(256), 0, st, a->partials, nparts, C, M, a->gamma, a->invstd, a->dgamma, a->dbeta, a->accumulate_param_grads, a->coef);
@@ -893,7 +926,15 @@ extern "C" int salt_bn_bwd(const salt_bn_bwd_args* a, void* stream) {
             SALT_CHECK_LAUNCH();
         }
         const int64_t units = view_pixels(a->y) * cpv;
-        EW_LAUNCH_EV(bn_bwd_apply_kernel, T, v, units, st, salt_take_fork_event(), a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->gamma, a->beta, a->coef, a->dy, a->dres, a->accumulate_dres);
+        if (fin_apply) {
+            const BnbFin fa{a->fin_acc, nullptr, a->dgamma, a->dbeta, a->coef, a->accumulate_param_grads, (double)view_pixels(a->y)};
+            const size_t lds3 = (size_t)C * 3 * sizeof(float);
+            hipEvent_t ev_ = salt_take_fork_event();
+            if (v) hipExtLaunchKernelGGL((bn_bwd_apply_kernel<T, true, true>), dim3(ew_blocks(units)), dim3(256), lds3, st, nullptr, ev_, 0, a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->gamma, a->beta, nullptr, a->dy, a->dres, a->accumulate_dres, fa);
+            else hipExtLaunchKernelGGL((bn_bwd_apply_kernel<T, false, true>), dim3(ew_blocks(units)), dim3(256), lds3, st, nullptr, ev_, 0, a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->gamma, a->beta, nullptr, a->dy, a->dres, a->accumulate_dres, fa);
+        } else {
+            EW_LAUNCH_EV(bn_bwd_apply_kernel, T, v, units, st, salt_take_fork_event(), a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->gamma, a->beta, a->coef, a->dy, a->dres, a->accumulate_dres, BnbFin{});
+        }
     })
     SALT_CHECK_LAUNCH();
     return SALT_OK;

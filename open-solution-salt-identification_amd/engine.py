@@ -271,6 +271,13 @@ class Graph:
         self._touched = []
         self.grad_ready = []
         self._scratch_sfx = ''
+        # fp64 statistics shards of the train-mode BatchNorm layers (SALT_BN_FIN=2): slices of one arena per program, cleared by ONE
+        # salt_zero at the head of the program
+        self._fin_bytes = {'fwd': 0, 'bwd': 0}
+        self._fin_patches = []                   # (struct, field, 'fwd' | 'bwd', byte offset)
+        self._fin_zero = {}
+        if train and self._fin_mode() == 2:
+            self._fin_zero['fwd'] = self.fwd.add('zero', p=1, bytes=0)
 
     # ------------------------------------------------------------------ memory
     def alloc(self, shape, dtype, zero=True):
@@ -318,7 +325,21 @@ class Graph:
                     obj = getattr(obj, a)
                 setattr(obj, path[-1], self.scratch[sc.name].data_ptr())
             prog.finalize()
+        for which, z in self._fin_zero.items():
+            nb = self._fin_bytes[which]
+            arena = self.alloc((max(nb // 8, 1),), torch.float64)
+            fill(z, p=arena.data_ptr(), bytes=nb)
+            for st, field, w, off in self._fin_patches:
+                if w == which:
+                    setattr(st, field, arena.data_ptr() + off)
         return self
+
+    def _fin_slot(self, which, ndoubles, *targets):
+        """Reserve ``ndoubles`` fp64 of the program's statistics arena; ``targets`` = (struct, field) pairs that receive its address."""
+        off = self._fin_bytes[which]
+        self._fin_bytes[which] = off + _round_up(ndoubles * 8, 64)
+        for st, field in targets:
+            self._fin_patches.append((st, field, which, off))
 
     def _gp(self, param):
         """Gradient pointer of a parameter; remembers that the current backward closure finalises it."""
@@ -329,6 +350,8 @@ class Graph:
         """Emit the backward program (reverse tape order).  Also records, per parameter, the program position
         after which its gradient is final (parallel.plan_buckets turns that into all-reduce buckets)."""
         self.grad_ready = []
+        if self.train and self._fin_mode() == 2 and 'bwd' not in self._fin_zero:
+            self._fin_zero['bwd'] = self.bwd.add('zero', p=1, bytes=0)
         for fn in reversed(self.tape):
             self._touched = []
             fn()
@@ -372,13 +395,19 @@ class Graph:
 
     # ------------------------------------------------------------------ BatchNorm plumbing
     @staticmethod
-    def _fin_on():
-        """In-launch BatchNorm finalize (salt_conv_args.fin / bnb_fin); SALT_BN_FIN=0 keeps the separate finalize launches."""
-        return os.environ.get('SALT_BN_FIN', '1') != '0'
+    def _fin_mode():
+        """SALT_BN_FIN: how the train-mode BatchNorm sums travel.  2 (default): fp64 shard atomics in the producing launch, finalized
+        by the consumer (salt_affine_act / the apply pass of salt_bn_bwd); 1: the same shards, finalized in the producing launch by the
+        workgroup that draws the last ticket; 0: per-tile partials + separate finalize launches."""
+        return int(os.environ.get('SALT_BN_FIN', '2'))
+
+    @classmethod
+    def _fin_on(cls):
+        return cls._fin_mode() != 0
 
     def _fin_buffers(self, ndoubles):
         acc = self.alloc((ndoubles,), torch.float64)
-        ticket = self.alloc((4,), torch.int32)
+        ticket = self.alloc((16,), torch.int32)
         return acc.data_ptr(), ticket.data_ptr()
 
     def _bn_train_fwd(self, y, bn, relu, res, out, nparts, stats, cnt, producer=None):
@@ -390,17 +419,23 @@ class Graph:
                    beta=bn.bias.data_ptr(), running_mean=bn.running_mean.data_ptr(), running_var=bn.running_var.data_ptr(),
                    num_batches_tracked=nbt, momentum=bn.momentum, eps=bn.eps, mean=w['mean'].data_ptr(), invstd=w['invstd'].data_ptr(),
                    scale=w['scale'].data_ptr(), shift=w['shift'].data_ptr())
+        F = None
         if producer is not None:
             F = fill(STRUCTS['salt_bn_finalize_args'](), **fin)
             self.keep.append(F)
-            acc, ticket = self._fin_buffers(8 * (2 * bn.num_features + 1))
-            self.fwd.set_fields(producer, fin=ctypes.addressof(F), fin_acc=acc, fin_ticket=ticket)
+            if self._fin_mode() == 1:
+                acc, ticket = self._fin_buffers(8 * (2 * bn.num_features + 1))
+                self.fwd.set_fields(producer, fin=ctypes.addressof(F), fin_acc=acc, fin_ticket=ticket)
+                F = None
         else:
             self.fwd.add('bn_finalize', stats=stats, stats_cnt=cnt, nparts=nparts, **fin)
         if res is not None and getattr(res, 'on_side', False):
             self.join()                          # the residual branch ran on the side stream
-        self.fwd.add('affine_act', dtype=self.dt, y=y.view(), scale=w['scale'].data_ptr(), shift=w['shift'].data_ptr(),
-                     res=res.view() if res is not None else null_view(), relu=int(relu), a=out.view())
+        sa = self.fwd.add('affine_act', dtype=self.dt, y=y.view(), scale=w['scale'].data_ptr(), shift=w['shift'].data_ptr(),
+                          res=res.view() if res is not None else null_view(), relu=int(relu), a=out.view())
+        if F is not None:                        # the producer only adds to the shards; this operator finalizes them
+            self.fwd.set_fields(sa, fin=ctypes.addressof(F))
+            self._fin_slot('fwd', 8 * (2 * bn.num_features + 1), (producer, 'fin_acc'), (sa, 'fin_acc'))
         return w
 
     def _bn_train_bwd(self, y, bn, relu, res, out, w):
@@ -430,7 +465,9 @@ class Graph:
             if nparts < 1:
                 raise SaltError('conv plan failed: ' + lib.salt_last_error().decode())
             self._n_bnb = getattr(self, '_n_bnb', 0) + 1
-            if self._fin_on():
+            if self._fin_mode() == 2:
+                partials, ready = None, 3          # the launch adds the sums to fp64 shards; the apply pass of bn_bwd finalizes them
+            elif self._fin_mode() == 1:
                 partials, ready = None, 2          # the launch also finalizes (salt_conv_args.bnb_fin): bn_bwd is the apply pass only
             else:
                 partials, ready = Scratch('bnb%d' % self._n_bnb, nparts * 2 * C * 4), 1
@@ -443,10 +480,14 @@ class Graph:
                           mean=w['mean'].data_ptr(), invstd=w['invstd'].data_ptr(), gamma=bn.weight.data_ptr(), beta=bn.bias.data_ptr(),
                           partials=partials, nparts=nparts, dgamma=gw, dbeta=gb, accumulate_param_grads=0,
                           coef=coef.data_ptr(), dy=y.gview(), dres=dres, accumulate_dres=acc_res, partials_ready=ready)
-        if ready == 2:
+        if ready == 3:
+            self._fin_slot('bwd', 8 * 2 * C, (producer, 'bnb_acc'), (s2, 'fin_acc'))
+        elif ready == 2:
             acc, ticket = self._fin_buffers(8 * 2 * C)
             self.bwd.set_fields(producer, bnb_fin=ctypes.addressof(s2), bnb_acc=acc, bnb_ticket=ticket)
-        elif ready == 0 and self._fin_on():
+        elif ready == 0 and self._fin_mode() == 2:
+            self._fin_slot('bwd', 8 * 2 * C, (s2, 'fin_acc'))       # reduction pass -> shards -> apply pass
+        elif ready == 0 and self._fin_mode() == 1:
             acc, ticket = self._fin_buffers(8 * 2 * C)       # the reduction pass of bn_bwd finalizes in-launch
             self.bwd.set_fields(s2, fin_acc=acc, fin_ticket=ticket)
 

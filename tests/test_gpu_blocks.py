@@ -234,10 +234,11 @@ def test_first_layer_conv_vs_torch():
                                   (3, 16, 9, 18, 24)])
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
 @pytest.mark.parametrize('replicate', [True, False])
-@pytest.mark.parametrize('fin', [1, 0])
+@pytest.mark.parametrize('fin', [2, 1, 0])
 def test_two_conv_bn_relu_layers_vs_torch(case, dtype, replicate, fin, monkeypatch):
-    """fin: in-launch BatchNorm finalize (salt_conv_args.fin / bnb_fin: fp64 shard atomics + last-arriver finalize) vs the separate
-    salt_bn_finalize / bn_bwd finalize launches over per-tile partials.
+    """fin (SALT_BN_FIN): 2 = fp64 shard atomics in the producing launch, finalized by the consumer (salt_affine_act / the apply pass of
+    salt_bn_bwd); 1 = the same shards finalized in the producing launch by the last-arriving workgroup (salt_conv_args.fin / bnb_fin);
+    0 = per-tile partials and separate salt_bn_finalize / bn_bwd finalize launches.
     Two stacked 3x3 conv + BN + ReLU layers against torch CPU fp32: forward, data gradient, weight and BN gradients.
     replicate: the reference's replicate top/right padding (architectures/base.py:21-27) - fold-mode data gradient and the
     pipelined weight-gradient kernel's clamp loader on ragged tiles.  Zero padding: the second layer's data gradient is the only
@@ -286,7 +287,7 @@ def test_two_conv_bn_relu_layers_vs_torch(case, dtype, replicate, fin, monkeypat
     # the data-gradient launch of layer 2 completes dL/d(a1) - also for the replicate-padded variant, whose pad-ring fold is fused
     # into the launch's epilogue - so it carries layer 1's BatchNorm-backward sums whenever the channel pieces are whole
     fusable = Cmid % (4 if dtype == 'f32' else 8) == 0
-    assert ready == [0, (2 if fin else 1) if fusable else 0], ready  # backward order: layer 2, then layer 1
+    assert ready == [0, {2: 3, 1: 2, 0: 1}[fin] if fusable else 0], ready  # backward order: layer 2, then layer 1
     assert sum(1 for name, _, _ in run.g.fwd.ops if name == 'bn_finalize') == (0 if fin else 2)
     pairs = [('dgrad', gx[0], xr.grad)] + [(k, grads[k], dict(ref.named_parameters())[k].grad) for k in grads]
     for name, got, want in pairs:
