@@ -71,11 +71,18 @@ extern "C" int salt_program_run_timed(const salt_program_entry* e, int begin, in
 }
 
 namespace {
+// The fork / join events only order two streams of ONE device: a device-scope release is all they need.  The default event does a
+// system-scope fence (L2 write-back + invalidate for host visibility) when it transitions to recorded.  SALT_EVENT_FLAGS: 0 default
+// events, 1 hipEventDisableSystemFence, 2 hipEventReleaseToDevice.
+unsigned fork_event_flags() {
+    static const int mode = getenv("SALT_EVENT_FLAGS") ? atoi(getenv("SALT_EVENT_FLAGS")) : 0;
+    return mode == 1 ? hipEventDisableSystemFence : (mode == 2 ? hipEventReleaseToDevice : 0u);
+}
 struct EventPool {
     hipEvent_t ev[2] = {nullptr, nullptr};
     int ensure() {
         for (int i = 0; i < 2; ++i)
-            if (!ev[i] && hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) return -1;
+            if (!ev[i] && hipEventCreateWithFlags(&ev[i], hipEventDisableTiming | fork_event_flags()) != hipSuccess) return -1;
         return 0;
     }
 };
@@ -97,9 +104,45 @@ extern "C" int salt_program_run_streams_ex(const salt_program_entry* e, int begi
     if (!e || begin < 0 || end < begin) SALT_FAIL(SALT_E_BADARG, "program: bad range");
     if (g_events.ensure()) SALT_FAIL(SALT_E_BADARG, "hipEventCreate failed");
     hipStream_t ms = (hipStream_t)main_stream, ss = (hipStream_t)side_stream;
+    static const bool one_stream = getenv("SALT_ONE_STREAM") != nullptr;      // A/B: every entry on the main stream, in program order
+    if (one_stream) {
+        (void)hipEventRecord(g_events.ev[1], ss);                 // whatever the caller enqueued on the side stream before (weight packs)
+        (void)hipStreamWaitEvent(ms, g_events.ev[1], 0);
+        return salt_program_run_range(e, begin, end, main_stream);
+    }
     bool main_dirty = true, side_used = false;       // main_dirty: main has work the side stream has not been ordered after
+    // Fork coalescing (SALT_FORK_EVERY = K > 1): side-stream entries are held back until K groups of them are pending, then issued
+    // behind ONE fork.  A held entry only ever runs later than its program position, so its inputs are complete; every cross-queue
+    // dependency costs the main queue ~10 us of dispatch stall (rocprofv3 timeline), a held entry costs the side stream its head start.
+    static const int fork_every = getenv("SALT_FORK_EVERY") ? atoi(getenv("SALT_FORK_EVERY")) : 8;
+    int pending[64], npending = 0, groups = 0;
+    bool prev_side = false;
+    auto flush = [&]() -> int {
+        if (!npending) return 0;
+        if (main_dirty) {
+            (void)hipEventRecord(g_events.ev[0], ms);
+            (void)hipStreamWaitEvent(ss, g_events.ev[0], 0);
+            main_dirty = false;
+        }
+        for (int k = 0; k < npending; ++k) {
+            const int j = pending[k];
+            const int rc = e[j].fn(e[j].args, side_stream);
+            if (rc) { char prev[400]; strncpy(prev, g_err, sizeof(prev) - 1); prev[sizeof(prev) - 1] = 0; salt_set_error("program entry %d failed (%d): %s", j, rc, prev); return rc; }
+        }
+        npending = 0; groups = 0; side_used = true;
+        return 0;
+    };
     for (int i = begin; i < end; ++i) {
         const bool side = e[i].stream == 1;
+        if (fork_every > 1) {
+            if (side) {
+                if (npending == 64) { const int rc = flush(); if (rc) return rc; }
+                pending[npending++] = i; prev_side = true;
+                continue;
+            }
+            if (prev_side) { ++groups; prev_side = false; }
+            if (groups >= fork_every || e[i].stream == 2 || e[i].stream == 3) { const int rc = flush(); if (rc) return rc; }
+        }
         if ((e[i].stream == 2 && side_used) || e[i].stream == 3) {   // a main-stream entry that consumes side-stream results:
             (void)hipEventRecord(g_events.ev[1], ss);                 // 2 = produced inside this range, 3 = enqueued on the side
             (void)hipStreamWaitEvent(ms, g_events.ev[1], 0);          // stream before the call (data-gradient weight packs)
@@ -110,7 +153,7 @@ extern "C" int salt_program_run_streams_ex(const salt_program_entry* e, int begi
             (void)hipStreamWaitEvent(ss, g_events.ev[0], 0);
             main_dirty = false;
         }
-        const bool handoff = g_fork_handoff && !side && i + 1 < end && e[i + 1].stream == 1;
+        const bool handoff = g_fork_handoff && fork_every <= 1 && !side && i + 1 < end && e[i + 1].stream == 1;
         if (handoff) g_fork_event = g_events.ev[0];        // the entry may attach it to its last launch as the stop event
         const int rc = e[i].fn(e[i].args, side ? side_stream : main_stream);
         const bool taken = handoff && g_fork_event == nullptr;
@@ -125,6 +168,7 @@ extern "C" int salt_program_run_streams_ex(const salt_program_entry* e, int begi
         else if (taken) { (void)hipStreamWaitEvent(ss, g_events.ev[0], 0); main_dirty = false; }
         else main_dirty = true;
     }
+    { const int rc = flush(); if (rc) return rc; }
     if (side_used && join_at_end) {
         (void)hipEventRecord(g_events.ev[1], ss);
         (void)hipStreamWaitEvent(ms, g_events.ev[1], 0);
