@@ -559,8 +559,12 @@ typedef struct {
     float* loss;              /* [1]: mean over images * loss_scale */
     float* dlogits;           /* fp32 NCHW or NULL (forward only) */
     float loss_scale;         /* loss weight (models.py:194) and 1/world for data parallel */
+    uint32_t* ws_split;       /* NULL, or [B * salt_lovasz_split_words(P)] words: images of >= 4096 elements are then sorted by several
+                                 workgroups each (segments of 2048 positions, 1 + 4 + 1 launches); same positions, ties and gradients */
 } salt_lovasz_args;
 int salt_lovasz_hinge(const salt_lovasz_args*, void* stream);
+/* words per image of salt_lovasz_args.ws_split (0: the split form does not apply to this size) */
+int64_t salt_lovasz_split_words(int P);
 
 /* 0.2*mean_c dice(sigmoid) + 0.9*BCEWithLogits (models.py:315-340,361-388), sums over the whole batch */
 typedef struct {

@@ -339,6 +339,206 @@ __global__ __launch_bounds__(LT) void lovasz_pf_kernel(salt_lovasz_args a) {
     }
 }
 
+// ---------------------------------------------------------------- Lovasz hinge, split over several workgroups per image
+// The one-workgroup-per-image kernel above is a chain of ~500 barriers on 32 of the 256 CUs (265 us for B = 32).  The split form
+// gives every image S segments of SL = 2048 consecutive positions, one 256-thread workgroup each, and runs the SAME stable LSD
+// radix sort as 1 + 4 launches - the launch boundary is the only cross-workgroup synchronisation:
+//   keys    : keys / payload of the segment, histogram of digit 0 per segment              -> H0[b][seg][256]
+//   pass p  : digit base of the segment = (keys of all segments with a smaller digit) + (same digit in earlier segments), from
+//             H_p; stable ranking chunk by chunk exactly as above (4 waves instead of 16); scatter; the histogram of digit p+1 is
+//             collected per DESTINATION segment in LDS and flushed with integer atomics into H_(p+1) (three rotating buffers: the
+//             one read in the previous pass is cleared for the next); the last pass counts the positives per destination segment
+//   scan    : label scan with the carry of the earlier segments, Jaccard gradient, dot, scatter; per-segment loss partials that
+//             lovasz_mean_split_kernel adds in fixed order.
+// Integer atomics only: results do not depend on scheduling.  Positions, ties and the fp32 operation sequence of g_k are those of
+// lovasz_kernel, so gradients are bit-identical to it; the loss differs in the last bits (different summation tree).
+constexpr int ST = 256, SWV = ST / 64, SL = 2048, SCH = SL / ST, SMAXSEG = 64;
+struct LovaszSplit { int S; unsigned* hist; unsigned* pos; float* part; };      // hist [3][B][S][256], pos [B][S], part [B][S]
+
+__global__ __launch_bounds__(ST) void lovasz_keys_kernel(salt_lovasz_args a, LovaszSplit sp) {
+    __shared__ unsigned h[256];
+    const int b = blockIdx.x / sp.S, seg = blockIdx.x % sp.S, tid = threadIdx.x;
+    const int P = a.P, i0 = seg * SL, i1 = min(i0 + SL, P);
+    const float* z = a.logits + (int64_t)b * P;
+    const float* y = a.target + (int64_t)b * P;
+    unsigned* k0 = a.ws_keys + (int64_t)b * P;
+    unsigned* v0 = a.ws_vals + (int64_t)b * P;
+    h[tid] = 0;
+    __syncthreads();
+    for (int i = i0 + tid; i < i1; i += ST) {
+        const float lab = y[i] > 0.5f ? 1.f : 0.f;
+        const float e = 1.f - z[i] * (2.f * lab - 1.f);
+        const unsigned key = desc_key(e);
+        k0[i] = key;
+        v0[i] = ((unsigned)i << 1) | (lab > 0.5f ? 1u : 0u);
+        atomicAdd(&h[key & 255u], 1u);
+    }
+    __syncthreads();
+    const int64_t slot = ((int64_t)b * sp.S + seg) * 256 + tid, hb = (int64_t)a.B * sp.S * 256;
+    sp.hist[slot] = h[tid];
+    sp.hist[hb + slot] = 0;                                       // buffer 1 collects digit 1 during pass 0
+    if (tid == 0) sp.pos[b * sp.S + seg] = 0;
+}
+
+__global__ __launch_bounds__(ST) void lovasz_pass_kernel(salt_lovasz_args a, LovaszSplit sp, int pass) {
+    extern __shared__ unsigned nh[];                              // [S][256] next digit per destination segment (+ [S] positives)
+    __shared__ unsigned base[256];
+    __shared__ unsigned wcount2[2][SWV][256];                     // double buffered: no barrier between a chunk's scatter and the next chunk's reset
+    __shared__ unsigned scan_w[SWV];
+    const int b = blockIdx.x / sp.S, seg = blockIdx.x % sp.S, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int P = a.P, S = sp.S, i0 = seg * SL;
+    const unsigned* ki = a.ws_keys + ((int64_t)((pass & 1) ? a.B : 0) + b) * P;
+    const unsigned* vi = a.ws_vals + ((int64_t)((pass & 1) ? a.B : 0) + b) * P;
+    unsigned* ko = a.ws_keys + ((int64_t)((pass & 1) ? 0 : a.B) + b) * P;
+    unsigned* vo = a.ws_vals + ((int64_t)((pass & 1) ? 0 : a.B) + b) * P;
+    const int64_t hb = (int64_t)a.B * S * 256;
+    const unsigned* Hc = sp.hist + (pass % 3) * hb + (int64_t)b * S * 256;
+    unsigned* Hn = sp.hist + ((pass + 1) % 3) * hb + (int64_t)b * S * 256;
+    unsigned* Hz = sp.hist + ((pass + 2) % 3) * hb + (int64_t)b * S * 256;
+    const int shift = pass * 8;
+    // the segment's keys: all SCH chunks in registers before the first barrier
+    unsigned ck[SCH], cv[SCH];
+#pragma unroll
+    for (int u = 0; u < SCH; ++u) { const int i = i0 + u * ST + tid; ck[u] = i < P ? ki[i] : 0u; cv[u] = i < P ? vi[i] : 0u; }
+    // ---- digit bases of this segment
+    {
+        unsigned tot = 0, before = 0;
+        for (int s2 = 0; s2 < S; ++s2) { const unsigned c = Hc[s2 * 256 + tid]; tot += c; if (s2 < seg) before += c; }
+        unsigned incl = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        if (lane == 63) scan_w[wave] = incl;
+        for (int e = tid; e < S * 256 + S; e += ST) nh[e] = 0;
+        __syncthreads();
+        unsigned woff = 0;
+        for (int w = 0; w < wave; ++w) woff += scan_w[w];
+        base[tid] = woff + incl - tot + before;
+        Hz[seg * 256 + tid] = 0;                                  // read in the previous pass, collects digit pass+2 in the next
+    }
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int u = 0; u < SCH; ++u) {
+        const int c0 = i0 + u * ST;
+        if (c0 >= P) break;                                       // uniform
+        unsigned (*wcount)[256] = wcount2[u & 1];
+#pragma unroll
+        for (int w = 0; w < SWV; ++w) wcount[w][tid] = 0;
+        __syncthreads();                                          // also publishes base[] / nh[] on the first round
+        const bool ok = c0 + tid < P;
+        const unsigned key = ck[u];
+        const unsigned d = ok ? ((key >> shift) & 255u) : 256u;
+        unsigned long long m = __ballot(ok);
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+            const unsigned long long bm = __ballot((d >> bit) & 1u);
+            m &= ((d >> bit) & 1u) ? bm : ~bm;
+        }
+        const unsigned rank = (unsigned)__popcll(m & lt_mask);
+        if (ok && rank == 0) wcount[wave][d] = (unsigned)__popcll(m);
+        __syncthreads();
+        {
+            unsigned run = base[tid];
+#pragma unroll
+            for (int w = 0; w < SWV; ++w) { const unsigned c = wcount[w][tid]; wcount[w][tid] = run; run += c; }
+            base[tid] = run;
+        }
+        __syncthreads();
+        if (ok) {
+            const unsigned dst = wcount[wave][d] + rank;
+            ko[dst] = key; vo[dst] = cv[u];
+            const unsigned ds = dst / SL;
+            if (pass < 3) atomicAdd(&nh[ds * 256 + ((key >> (shift + 8)) & 255u)], 1u);
+            else if (cv[u] & 1u) atomicAdd(&nh[S * 256 + ds], 1u);
+        }
+    }
+    __syncthreads();
+    if (pass < 3) {
+        for (int e = tid; e < S * 256; e += ST) { const unsigned c = nh[e]; if (c) atomicAdd(&Hn[e], c); }
+    } else if (tid < S) {
+        const unsigned c = nh[S * 256 + tid];
+        if (c) atomicAdd(&sp.pos[b * S + tid], c);
+    }
+}
+
+__global__ __launch_bounds__(ST) void lovasz_scan_kernel(salt_lovasz_args a, LovaszSplit sp) {
+    __shared__ unsigned scan_w[SWV];
+    __shared__ float red[SWV];
+    const int b = blockIdx.x / sp.S, seg = blockIdx.x % sp.S, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int P = a.P, S = sp.S, i0 = seg * SL;
+    const unsigned* k0 = a.ws_keys + (int64_t)b * P;              // after 4 passes the sorted sequence is back in buffer 0
+    const unsigned* v0 = a.ws_vals + (int64_t)b * P;
+    unsigned ck[SCH], cv[SCH];
+#pragma unroll
+    for (int u = 0; u < SCH; ++u) { const int i = i0 + u * ST + tid; ck[u] = i < P ? k0[i] : 0u; cv[u] = i < P ? v0[i] : 0u; }
+    unsigned gtot = 0, carry = 0;
+    for (int s2 = 0; s2 < S; ++s2) { const unsigned c = sp.pos[b * S + s2]; gtot += c; if (s2 < seg) carry += c; }
+    const float G = (float)gtot;
+    const float gscale = a.loss_scale / (float)a.B;
+    float* dz = a.dlogits ? a.dlogits + (int64_t)b * P : nullptr;
+    float lsum = 0.f;
+#pragma unroll
+    for (int u = 0; u < SCH; ++u) {
+        const int i = i0 + u * ST + tid;
+        if (i0 + u * ST >= P) break;
+        const bool ok = i < P;
+        const unsigned val = ok ? cv[u] : 0u;
+        const unsigned lab = val & 1u;
+        unsigned incl = ok ? lab : 0u;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        __syncthreads();                                          // scan_w of the previous chunk has been read
+        if (lane == 63) scan_w[wave] = incl;
+        __syncthreads();
+        unsigned woff = carry, ctot = 0;
+        for (int w = 0; w < SWV; ++w) { if (w < wave) woff += scan_w[w]; ctot += scan_w[w]; }
+        const unsigned c_k = woff + incl;
+        carry += ctot;
+        if (ok) {
+            const float e = key_to_float(ck[u]);
+            const float kf = (float)(i + 1), ckf = (float)c_k, ckm = (float)(c_k - lab);
+            // the reference's fp32 sequence (lovasz_losses.py:27-32), as in lovasz_kernel
+            const float jk = __fsub_rn(1.f, __fdiv_rn(G - ckf, G + (kf - ckf)));
+            float jm = 0.f;
+            if (i > 0) jm = __fsub_rn(1.f, __fdiv_rn(G - ckm, G + ((kf - 1.f) - ckm)));
+            const float gk = (i > 0) ? __fsub_rn(jk, jm) : jk;
+            const float el = e > 0.f ? e : expm1f(e);
+            lsum += el * gk;
+            if (dz) {
+                const float d = e > 0.f ? 1.f : __expf(e);
+                const float sg = lab ? 1.f : -1.f;
+                dz[val >> 1] = -sg * d * gk * gscale;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
+    __syncthreads();
+    if (lane == 0) red[wave] = lsum;
+    __syncthreads();
+    if (tid == 0) {
+        float t = 0.f;
+        for (int w = 0; w < SWV; ++w) t += red[w];
+        sp.part[b * S + seg] = t;
+    }
+}
+
+__global__ void lovasz_mean_split_kernel(const float* part, int B, int S, float scale, float* per_image, float* out) {
+    __shared__ float sm[1024];
+    const int tid = threadIdx.x;
+    for (int b = tid; b < B; b += blockDim.x) {
+        float t = 0.f;
+        for (int s2 = 0; s2 < S; ++s2) t += part[b * S + s2];
+        per_image[b] = t;
+        if (b < 1024) sm[b] = t;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float t = 0.f;
+        for (int b = 0; b < B; ++b) t += (b < 1024) ? sm[b] : per_image[b];
+        out[0] = t * scale / (float)B;
+    }
+}
+
 __global__ void mean_kernel(const float* v, int n, float scale, float* out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         float s = 0.f;
@@ -508,10 +708,31 @@ __global__ __launch_bounds__(256) void iou_sweep_kernel(IouKP k) {
 
 }  // namespace
 
+extern "C" int64_t salt_lovasz_split_words(int P) {
+    const int S = (P + SL - 1) / SL;
+    if (P < 2 * SL || S > SMAXSEG) return 0;
+    return (int64_t)3 * S * 256 + 2 * S;
+}
+
 extern "C" int salt_lovasz_hinge(const salt_lovasz_args* a, void* stream) {
     if (!a || !a->logits || !a->target || a->B < 1 || a->P < 0 || !a->ws_keys || !a->ws_vals || !a->loss_per_image || !a->loss)
         SALT_FAIL(SALT_E_BADARG, "lovasz: bad args");
     static const bool plain = getenv("SALT_LOVASZ_PLAIN") != nullptr;       // A/B switch: the non-prefetching kernel
+    static const bool nosplit = getenv("SALT_LOVASZ_NOSPLIT") != nullptr;   // A/B switch: one workgroup per image
+    const int S = (a->P + SL - 1) / SL;
+    if (a->ws_split && !plain && !nosplit && a->P >= 2 * SL && S <= SMAXSEG) {
+        hipStream_t st = (hipStream_t)stream;
+        LovaszSplit sp{S, a->ws_split, a->ws_split + (int64_t)3 * a->B * S * 256, reinterpret_cast<float*>(a->ws_split + (int64_t)3 * a->B * S * 256 + (int64_t)a->B * S)};
+        const dim3 grid(a->B * S);
+        hipLaunchKernelGGL(lovasz_keys_kernel, grid, dim3(ST), 0, st, *a, sp);
+        const size_t lds = (size_t)(S * 256 + S) * sizeof(unsigned);
+        for (int pass = 0; pass < 4; ++pass) hipLaunchKernelGGL(lovasz_pass_kernel, grid, dim3(ST), lds, st, *a, sp, pass);
+        hipLaunchKernelGGL(lovasz_scan_kernel, grid, dim3(ST), 0, st, *a, sp);
+        SALT_CHECK_LAUNCH();
+        hipLaunchKernelGGL(lovasz_mean_split_kernel, dim3(1), dim3(256), 0, st, sp.part, a->B, S, a->loss_scale, a->loss_per_image, a->loss);
+        SALT_CHECK_LAUNCH();
+        return SALT_OK;
+    }
     if (plain) hipLaunchKernelGGL(lovasz_kernel, dim3(a->B), dim3(LT), 0, (hipStream_t)stream, *a);
     else hipLaunchKernelGGL(lovasz_pf_kernel, dim3(a->B), dim3(LT), 0, (hipStream_t)stream, *a);
     SALT_CHECK_LAUNCH();

@@ -42,9 +42,12 @@ def native_loss(logits, target, kind, want_grad=True, loss_scale=1.0):
         wk = _workspace(('k', dev, sid), 2 * B * P, torch.int32, dev)
         wv = _workspace(('v', dev, sid), 2 * B * P, torch.int32, dev)
         lpi = torch.empty(B, dtype=torch.float32, device=dev)
+        sw = int(lib.salt_lovasz_split_words(P))                 # > 0: several workgroups per image (segments of the sort)
+        ws = _workspace(('s', dev, sid), B * sw, torch.int32, dev) if sw else None
         a = STRUCTS['salt_lovasz_args']()
         fill(a, logits=logits.data_ptr(), target=target.data_ptr(), B=B, P=P, ws_keys=wk.data_ptr(), ws_vals=wv.data_ptr(),
-             loss_per_image=lpi.data_ptr(), loss=loss.data_ptr(), dlogits=dl.data_ptr() if want_grad else None, loss_scale=loss_scale)
+             loss_per_image=lpi.data_ptr(), loss=loss.data_ptr(), dlogits=dl.data_ptr() if want_grad else None, loss_scale=loss_scale,
+             ws_split=ws.data_ptr() if ws is not None else None)
         check(lib.salt_lovasz_hinge(ctypes.byref(a), st), 'lovasz_hinge')
     elif kind == 'bce_dice':
         a = STRUCTS['salt_bce_dice_args']()

@@ -59,9 +59,11 @@ class CompiledNet:
             P = K * H * W
             wk = g.alloc((2, B, P), torch.int32, zero=False)
             wv = g.alloc((2, B, P), torch.int32, zero=False)
+            sw = int(lib.salt_lovasz_split_words(P))             # > 0: several workgroups per image (segments of the sort)
+            ws = g.alloc((B * sw,), torch.int32, zero=False) if sw else None
             p.add('lovasz_hinge', logits=self.logits.data_ptr(), target=self.target.data_ptr(), B=B, P=P, ws_keys=wk.data_ptr(),
                   ws_vals=wv.data_ptr(), loss_per_image=self.loss_per_image.data_ptr(), loss=self.loss.data_ptr(),
-                  dlogits=self.dlogits.data_ptr(), loss_scale=loss_scale)
+                  dlogits=self.dlogits.data_ptr(), loss_scale=loss_scale, ws_split=ws.data_ptr() if ws is not None else None)
         elif kind == 'bce_dice':
             S = _abi.STRUCTS['salt_bce_dice_args']()
             _abi.fill(S, B=B, C=K, HW=H * W)

@@ -67,6 +67,51 @@ def test_lovasz_full_size_vs_oracle_and_properties():
     assert float(per_image.max()) <= 1.0 / B + 1e-6
 
 
+@pytest.mark.parametrize('shape', [(3, 2, 64, 64), (2, 2, 70, 70), (5, 2, 128, 128), (2, 1, 101, 101), (1, 2, 256, 256)])
+@pytest.mark.parametrize('kind', ['random', 'ties', 'all0', 'all1'])
+def test_lovasz_split_sort_equals_single_workgroup_sort(shape, kind):
+    """The split form (several workgroups per image, segments of 2048 positions, 1 + 4 + 1 launches) against the one-workgroup
+    kernel through the C-ABI: same positions and tie order => bit-identical gradients; the loss differs by its summation tree only.
+    Ragged last segments (9800, 10201 elements), heavy ties, empty and full masks."""
+    import ctypes
+    from salt_amd import _abi
+    B, C, H, W = shape
+    P = C * H * W
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    z = torch.randn(B, C, H, W, generator=g) * 2
+    if kind == 'ties':
+        z = torch.round(z * 2) / 2                               # a handful of distinct values: long tie groups
+    m = (torch.rand(B, 1, H, W, generator=g) < 0.3).float()
+    if kind == 'all0':
+        m.zero_()
+    if kind == 'all1':
+        m.fill_(1)
+    t = torch.cat([1 - m, m], 1)[:, :C].contiguous()
+    z, t = z.to(DEV).contiguous(), t.to(DEV)
+    sw = int(_abi.lib.salt_lovasz_split_words(P))
+    assert sw > 0
+
+    def run(split):
+        wk = torch.empty(2 * B * P, dtype=torch.int32, device=DEV)
+        wv = torch.empty(2 * B * P, dtype=torch.int32, device=DEV)
+        ws = torch.full((B * sw,), 0x55555555, dtype=torch.int32, device=DEV) if split else None      # garbage: the kernels initialise it
+        lpi = torch.empty(B, device=DEV); loss = torch.zeros(1, device=DEV); dl = torch.full_like(z, float('nan'))
+        a = _abi.STRUCTS['salt_lovasz_args']()
+        _abi.fill(a, logits=z.data_ptr(), target=t.data_ptr(), B=B, P=P, ws_keys=wk.data_ptr(), ws_vals=wv.data_ptr(), loss_per_image=lpi.data_ptr(),
+                  loss=loss.data_ptr(), dlogits=dl.data_ptr(), loss_scale=1.0, ws_split=ws.data_ptr() if split else None)
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for _ in range(2):                                       # twice: the workspace is left reusable
+            _abi.check(_abi.lib.salt_lovasz_hinge(ctypes.byref(a), st), 'lovasz')
+        torch.cuda.synchronize()
+        return float(loss), lpi.cpu(), dl.cpu()
+
+    l1, p1, g1 = run(False)
+    l2, p2, g2 = run(True)
+    assert torch.equal(g1, g2), float((g1 - g2).abs().max())
+    assert abs(l1 - l2) <= 2e-6 * max(1.0, abs(l1)), (l1, l2)
+    assert float((p1 - p2).abs().max()) <= 2e-6 * max(1.0, float(p1.abs().max()))
+
+
 def test_bce_dice_vs_reference_golden():
     from salt_amd import losses
     fx = golden('F7_bce_dice')
