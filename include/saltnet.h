@@ -513,6 +513,8 @@ typedef struct {
     float* gate_c;            /* [B][C]  (saved) */
     float* gate_s;            /* [B][H*W] (saved) */
     salt_view y;
+    double* gap_acc;          /* NULL, or [B][C] fp64 ZEROED by the caller: the pooling pass adds its channel sums there (atomics) and the
+                                 apply pass derives the gates of its image in its prologue - two launches instead of three; gap_partials unused */
 } salt_scse_args;
 int salt_scse(const salt_scse_args*, void* stream);
 int salt_scse_parts(const salt_scse_args*);
@@ -541,6 +543,8 @@ typedef struct {
     float* dgap;              /* [B][C] workspace */
     salt_view dx;
     int accumulate;
+    double* acc;              /* NULL, or [B][2C+1] fp64 ZEROED by the caller: the first pass adds its per-part sums there (atomics) and the
+                                 FC backward reads them - no parts-reduction launch; partials unused */
 } salt_scse_bwd_args;
 int salt_scse_bwd(const salt_scse_bwd_args*, void* stream);
 

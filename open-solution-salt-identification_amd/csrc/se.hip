@@ -16,7 +16,7 @@ template <typename T> struct P16 {
 
 // per-image partial channel sums: partials[b][part][C]
 template <typename T>
-__global__ __launch_bounds__(256) void gap_partial_kernel(salt_view x, float* partials, int nparts, int pix_per_part) {
+__global__ __launch_bounds__(256) void gap_partial_kernel(salt_view x, float* partials, int nparts, int pix_per_part, double* acc) {
     constexpr int N = P16<T>::N;
     extern __shared__ float sm[];
     const int C = x.C, cpv = C / N, R = 256 / cpv;
@@ -40,7 +40,73 @@ __global__ __launch_bounds__(256) void gap_partial_kernel(salt_view x, float* pa
     for (int c = threadIdx.x; c < C; c += 256) {
         float t = 0.f;
         for (int r = 0; r < R; ++r) t += sm[r * C + c];
-        partials[((int64_t)b * nparts + part) * C + c] = t;
+        if (acc) unsafeAtomicAdd(acc + (int64_t)b * C + c, (double)t);      // <= 64 parts meet per address; the consumer's prologue reads the sum
+        else partials[((int64_t)b * nparts + part) * C + c] = t;
+    }
+}
+
+// Apply pass with the per-image FC in its prologue (salt_scse_args.gap_acc): one workgroup per (image, pixel part) recomputes
+// gap -> hidden -> gate_c of ITS image from the fp64 channel sums the launch before left in gap_acc (2 C R MACs: nothing), part 0
+// stores them for backward.  Replaces se_fc_kernel + the grid-stride apply kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void scse_apply_fc_kernel(salt_view x, const double* acc, int R, float inv_hw, const float* w1, const float* b1,
+                                                            const float* w2, const float* b2, float* gap, float* hidden, float* gate_c,
+                                                            const float* ws, const float* bs, float* gate_s, salt_view y, int cpv_log2,
+                                                            int nparts, int pix_per_part) {
+    constexpr int N = P16<T>::N;
+    extern __shared__ float sm[];       // [C] gap, [R] hidden, [C] gate
+    const int C = x.C, cpv = 1 << cpv_log2, RW = 256 >> cpv_log2;
+    const int b = blockIdx.x / nparts, part = blockIdx.x % nparts;
+    const int hw = x.H * x.W;
+    float* sg = sm; float* shid = sm + C; float* sgate = sm + C + R;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float t = (float)acc[(int64_t)b * C + c] * inv_hw;
+        sg[c] = t;
+        if (part == 0) gap[b * C + c] = t;
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < R; r += 256) {
+        float t = b1[r];
+        for (int c = 0; c < C; ++c) t += w1[r * C + c] * sg[c];
+        t = fmaxf(t, 0.f);
+        shid[r] = t;
+        if (part == 0) hidden[b * R + r] = t;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float t = b2[c];
+        for (int r = 0; r < R; ++r) t += w2[c * R + r] * shid[r];
+        const float g = 1.f / (1.f + __expf(-t));
+        sgate[c] = g;
+        if (part == 0) gate_c[b * C + c] = g;
+    }
+    __syncthreads();
+    const int p0 = part * pix_per_part, p1 = min(p0 + pix_per_part, hw);
+    const int row = threadIdx.x >> cpv_log2, cv = threadIdx.x & (cpv - 1);
+    const float bsv = bs[0];
+    float wsv[N], gc[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) { wsv[j] = ws[cv * N + j]; gc[j] = sgate[cv * N + j]; }
+    const int iters = (p1 - p0 + RW - 1) / RW;
+    for (int it = 0; it < iters; ++it) {
+        const int pix = p0 + it * RW + row;
+        const bool ok = pix < p1;
+        const int64_t gp = (int64_t)b * hw + pix;
+        float f[N];
+        float dot = 0.f;
+        if (ok) {
+            P16<T>::ld((const T*)x.p + gp * x.cs + cv * N, f);
+#pragma unroll
+            for (int j = 0; j < N; ++j) dot += f[j] * wsv[j];
+        }
+        for (int s2 = 1; s2 < cpv; s2 <<= 1) dot += __shfl_xor(dot, s2);
+        if (ok) {
+            const float gs = 1.f / (1.f + __expf(-(dot + bsv)));
+#pragma unroll
+            for (int j = 0; j < N; ++j) f[j] = fmaxf(f[j] * (gc[j] + gs), 0.f);
+            P16<T>::st((T*)y.p + gp * y.cs + cv * N, f);
+            if (cv == 0) gate_s[gp] = gs;
+        }
     }
 }
 
@@ -104,7 +170,7 @@ __global__ void scse_apply_kernel(salt_view x, const float* gate_c, const float*
 template <typename T>
 __global__ __launch_bounds__(256) void scse_bwd1_kernel(salt_view x, salt_view y, salt_view dy, const float* gate_c, const float* gate_s,
                                                         const float* ws, salt_view dx, int accumulate, float* partials, int nparts,
-                                                        int pix_per_part, int cpv_log2) {
+                                                        int pix_per_part, int cpv_log2, double* acc) {
     constexpr int N = P16<T>::N;
     extern __shared__ float sm[];
     const int C = x.C, cpv = 1 << cpv_log2, R = 256 >> cpv_log2;
@@ -162,7 +228,8 @@ __global__ __launch_bounds__(256) void scse_bwd1_kernel(salt_view x, salt_view y
         if (e < C) { for (int r = 0; r < R; ++r) t += sg[r * C + e]; }
         else if (e < 2 * C) { for (int r = 0; r < R; ++r) t += sw[r * C + e - C]; }
         else { for (int r = 0; r < R; ++r) t += sb[r]; }
-        out[e] = t;
+        if (acc) unsafeAtomicAdd(acc + (int64_t)b * (2 * C + 1) + e, (double)t);   // per-image sums over the parts: no se_parts_reduce launch
+        else out[e] = t;
     }
 }
 
@@ -180,7 +247,8 @@ __global__ void se_parts_reduce_kernel(float* partials, int nparts, int width) {
 // `partials` rows have already been reduced over parts (row 0 of every image holds the sums).
 __global__ __launch_bounds__(1024) void se_fc_bwd_kernel(const float* partials, int nparts, int B, int C, int R, const float* w1, const float* w2,
                                  const float* gap, const float* hidden, const float* gate_c,
-                                 float* g_w1, float* g_b1, float* g_w2, float* g_b2, float* g_ws, float* g_bs, float* dgap, float inv_hw) {
+                                 float* g_w1, float* g_b1, float* g_w2, float* g_b2, float* g_ws, float* g_bs, float* dgap, float inv_hw,
+                                 const double* acc) {
     // everything the loops touch repeatedly is staged in LDS first (one coalesced sweep); the batch loops then run out of LDS
     extern __shared__ float sm[];       // du [B][C], dh [B][R], gp [B][C], hd [B][R], ps [B][C+1] (spatial-SE sums)
     float* du = sm; float* dh = du + B * C; float* gp = dh + B * R; float* hd = gp + B * C; float* ps = hd + B * R;
@@ -188,11 +256,12 @@ __global__ __launch_bounds__(1024) void se_fc_bwd_kernel(const float* partials, 
     for (int i = tid; i < B * C; i += nt) {
         const int b = i / C, c = i - b * C;
         const float* row = partials + ((int64_t)b * nparts) * (2 * C + 1);
+        const double* arow = acc + (int64_t)b * (2 * C + 1);
         const float g = gate_c[i];
-        du[i] = row[c] * g * (1.f - g);
+        du[i] = (acc ? (float)arow[c] : row[c]) * g * (1.f - g);
         gp[i] = gap[i];
-        ps[b * (C + 1) + c] = row[C + c];
-        if (c == 0) ps[b * (C + 1) + C] = row[2 * C];
+        ps[b * (C + 1) + c] = acc ? (float)arow[C + c] : row[C + c];
+        if (c == 0) ps[b * (C + 1) + C] = acc ? (float)arow[2 * C] : row[2 * C];
     }
     for (int i = tid; i < B * R; i += nt) hd[i] = hidden[i];
     __syncthreads();
@@ -273,7 +342,7 @@ extern "C" int salt_scse_parts(const salt_scse_args* a) {
 
 extern "C" int salt_scse(const salt_scse_args* a, void* stream) {
     if (!a || !view_ok(a->x) || !view_ok(a->y) || a->x.C != a->y.C || a->R < 1 || !a->w1 || !a->b1 || !a->w2 || !a->b2 || !a->ws || !a->bs ||
-        !a->gap_partials || !a->gap || !a->hidden || !a->gate_c || !a->gate_s) SALT_FAIL(SALT_E_BADARG, "scse: bad args");
+        (!a->gap_partials && !a->gap_acc) || !a->gap || !a->hidden || !a->gate_c || !a->gate_s) SALT_FAIL(SALT_E_BADARG, "scse: bad args");
     int per = 0;
     const int nparts = scse_nparts(a->x, &per);
     if (a->nparts != nparts) SALT_FAIL(SALT_E_BADARG, "scse: nparts %d, expected %d", a->nparts, nparts);
@@ -282,8 +351,15 @@ extern "C" int salt_scse(const salt_scse_args* a, void* stream) {
     SALT_DISPATCH_DTYPE(a->dtype, T, {
         if (!se_ok<T>(a->x) || !se_ok<T>(a->y)) SALT_FAIL(SALT_E_UNSUPPORTED, "scse: C=%d must be a power of two with 16-byte aligned rows", C);
         constexpr int VE = Elem<T>::VE;
-        hipLaunchKernelGGL(gap_partial_kernel<T>, dim3(a->x.B * nparts), dim3(256), 256 * VE * sizeof(float), st, a->x, a->gap_partials, nparts, per);
+        hipLaunchKernelGGL(gap_partial_kernel<T>, dim3(a->x.B * nparts), dim3(256), 256 * VE * sizeof(float), st, a->x, a->gap_partials, nparts, per, a->gap_acc);
         SALT_CHECK_LAUNCH();
+        if (a->gap_acc) {
+            hipLaunchKernelGGL(scse_apply_fc_kernel<T>, dim3(a->x.B * nparts), dim3(256), (2 * C + a->R) * sizeof(float), st, a->x, a->gap_acc, a->R,
+                               1.0f / (float)(a->x.H * a->x.W), a->w1, a->b1, a->w2, a->b2, a->gap, a->hidden, a->gate_c, a->ws, a->bs, a->gate_s, a->y,
+                               ilog2_ceil(C / VE), nparts, per);
+            SALT_CHECK_LAUNCH();
+            return SALT_OK;
+        }
         hipLaunchKernelGGL(se_fc_kernel, dim3(a->x.B), dim3(256), (C + a->R) * sizeof(float), st, a->gap_partials, nparts, C, a->R,
                            1.0f / (float)(a->x.H * a->x.W), a->w1, a->b1, a->w2, a->b2, a->gap, a->hidden, a->gate_c);
         SALT_CHECK_LAUNCH();
@@ -298,7 +374,7 @@ extern "C" int salt_scse(const salt_scse_args* a, void* stream) {
 
 extern "C" int salt_scse_bwd(const salt_scse_bwd_args* a, void* stream) {
     if (!a || !view_ok(a->x) || !view_ok(a->y) || !view_ok(a->dy) || !view_ok(a->dx) || !a->w1 || !a->w2 || !a->ws || !a->gap || !a->hidden ||
-        !a->gate_c || !a->gate_s || !a->partials || !a->g_w1 || !a->g_b1 || !a->g_w2 || !a->g_b2 || !a->g_ws || !a->g_bs || !a->dgap)
+        !a->gate_c || !a->gate_s || (!a->partials && !a->acc) || !a->g_w1 || !a->g_b1 || !a->g_w2 || !a->g_b2 || !a->g_ws || !a->g_bs || !a->dgap)
         SALT_FAIL(SALT_E_BADARG, "scse_bwd: bad args");
     int per = 0;
     const int nparts = scse_nparts(a->x, &per);
@@ -320,12 +396,14 @@ extern "C" int salt_scse_bwd(const salt_scse_bwd_args* a, void* stream) {
         constexpr int VE = Elem<T>::VE;
         const int cpv_log2 = ilog2_ceil(C / VE);
         hipLaunchKernelGGL(scse_bwd1_kernel<T>, dim3(B * nparts), dim3(256), (512 * VE + 256) * sizeof(float), st, a->x, a->y, a->dy, a->gate_c,
-                           a->gate_s, a->ws, a->dx, a->accumulate, a->partials, nparts, per, cpv_log2);
+                           a->gate_s, a->ws, a->dx, a->accumulate, a->partials, nparts, per, cpv_log2, a->acc);
         SALT_CHECK_LAUNCH();
-        hipLaunchKernelGGL(se_parts_reduce_kernel, dim3(B), dim3(256), 0, st, a->partials, nparts, 2 * C + 1);
-        SALT_CHECK_LAUNCH();
+        if (!a->acc) {
+            hipLaunchKernelGGL(se_parts_reduce_kernel, dim3(B), dim3(256), 0, st, a->partials, nparts, 2 * C + 1);
+            SALT_CHECK_LAUNCH();
+        }
         hipLaunchKernelGGL(se_fc_bwd_kernel, dim3(1), dim3(1024), fc_lds, st, a->partials, nparts, B, C, a->R, a->w1, a->w2, a->gap, a->hidden,
-                           a->gate_c, a->g_w1, a->g_b1, a->g_w2, a->g_b2, a->g_ws, a->g_bs, a->dgap, 1.0f / (float)(a->x.H * a->x.W));
+                           a->gate_c, a->g_w1, a->g_b1, a->g_w2, a->g_b2, a->g_ws, a->g_bs, a->dgap, 1.0f / (float)(a->x.H * a->x.W), a->acc);
         SALT_CHECK_LAUNCH();
         const int64_t units = view_pixels(a->dx) * (C / VE);
         const int blocks = (int)((units + 255) / 256 < 4096 ? (units + 255) / 256 : 4096);

@@ -994,18 +994,23 @@ class Graph:
         fill(S, x=x.view())
         nparts = lib.salt_scse_parts(ctypes.byref(S))
         gap, hid, gc, gs = self.f32(B * C), self.f32(B * R), self.f32(B * C), self.f32(B * x.H * x.W)
-        self.fwd.add('scse', dtype=self.dt, x=x.view(), w1=l1.weight.data_ptr(), b1=l1.bias.data_ptr(), w2=l2.weight.data_ptr(),
-                     b2=l2.bias.data_ptr(), R=R, ws=cs.weight.data_ptr(), bs=cs.bias.data_ptr(), gap_partials=Scratch('se', B * nparts * (2 * C + 1) * 4),
-                     nparts=nparts, gap=gap.data_ptr(), hidden=hid.data_ptr(), gate_c=gc.data_ptr(), gate_s=gs.data_ptr(), y=out.view())
+        sf = self.fwd.add('scse', dtype=self.dt, x=x.view(), w1=l1.weight.data_ptr(), b1=l1.bias.data_ptr(), w2=l2.weight.data_ptr(),
+                          b2=l2.bias.data_ptr(), R=R, ws=cs.weight.data_ptr(), bs=cs.bias.data_ptr(), gap_partials=Scratch('se', B * nparts * (2 * C + 1) * 4),
+                          nparts=nparts, gap=gap.data_ptr(), hidden=hid.data_ptr(), gate_c=gc.data_ptr(), gate_s=gs.data_ptr(), y=out.view())
+        shards = self.train and self._fin_mode() == 2 and os.environ.get('SALT_SE_SHARDS', '1') != '0'   # per-image sums through the zeroed fp64 arena (see _fin_slot)
+        if shards:
+            self._fin_slot('fwd', B * C, (sf, 'gap_acc'))
         if self.train:
             def backward():
                 acc = x.grad_state()
                 dgap = self.f32(B * C)
                 gp = self._gp
-                self.bwd.add('scse_bwd', dtype=self.dt, x=x.view(), y=out.view(), dy=out.gview(), w1=l1.weight.data_ptr(), w2=l2.weight.data_ptr(),
-                             R=R, ws=cs.weight.data_ptr(), gap=gap.data_ptr(), hidden=hid.data_ptr(), gate_c=gc.data_ptr(), gate_s=gs.data_ptr(),
-                             partials=Scratch('se', B * nparts * (2 * C + 1) * 4), nparts=nparts, g_w1=gp(l1.weight), g_b1=gp(l1.bias),
-                             g_w2=gp(l2.weight), g_b2=gp(l2.bias), g_ws=gp(cs.weight), g_bs=gp(cs.bias), dgap=dgap.data_ptr(),
-                             dx=x.gview(), accumulate=acc)
+                sb = self.bwd.add('scse_bwd', dtype=self.dt, x=x.view(), y=out.view(), dy=out.gview(), w1=l1.weight.data_ptr(), w2=l2.weight.data_ptr(),
+                                  R=R, ws=cs.weight.data_ptr(), gap=gap.data_ptr(), hidden=hid.data_ptr(), gate_c=gc.data_ptr(), gate_s=gs.data_ptr(),
+                                  partials=Scratch('se', B * nparts * (2 * C + 1) * 4), nparts=nparts, g_w1=gp(l1.weight), g_b1=gp(l1.bias),
+                                  g_w2=gp(l2.weight), g_b2=gp(l2.bias), g_ws=gp(cs.weight), g_bs=gp(cs.bias), dgap=dgap.data_ptr(),
+                                  dx=x.gview(), accumulate=acc)
+                if shards:
+                    self._fin_slot('bwd', B * (2 * C + 1), (sb, 'acc'))
             self.tape.append(backward)
         return out

@@ -352,11 +352,11 @@ class Engine:
         _require_gpu(x.device)
         net = self.net(x.shape, train)
         net.x.copy_(x)
-        late = train and not os.environ.get('SALT_PACK_BWD_EARLY')
+        late = train and bool(os.environ.get('SALT_PACK_BWD_LATE'))   # round 2: the loss is ~65 us now, too short to hide the packs
         self.refresh(train, defer_bwd=late)
         net.fwd.run(side=None if os.environ.get('SALT_NO_FWD_SIDE') else self.side_stream)
         if late:
-            self.refresh(True)                               # data-gradient packs: behind the forward pass, under the loss
+            self.refresh(True)                               # data-gradient packs behind the forward pass (A/B: SALT_PACK_BWD_LATE)
         if train:
             self.touch(weights=False, stats=True)            # BN running statistics moved
         return net
