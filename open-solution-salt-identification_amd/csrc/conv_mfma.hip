@@ -20,6 +20,12 @@
 #include <cstdlib>
 #include <type_traits>
 #include "common.h"
+#ifndef SALT_K1_DBG
+#define SALT_K1_DBG 0
+#endif
+#ifndef SALT_K1_FAST_STORE
+#define SALT_K1_FAST_STORE 1
+#endif
 
 namespace {
 
@@ -43,6 +49,7 @@ struct ConvKP {
     int m_tiles, n_tiles;
     int vt;                          // virtual taps of a 1x1 convolution: vt channel chunks staged per barrier round (1 = off)
     int nbuf;                        // conv_glds_kernel: depth of the LDS chunk ring (2 | 3)
+    int y_small;                     // y / bnb_y / bnb_a hold < 2^31 elements each: the epilogue may use 32-bit offsets
     // BatchNorm-backward sums of the stored tile (saltnet.h, salt_conv_args.bnb_*); bnb_partials == nullptr: off
     const void* bnb_y; const void* bnb_a; int bnb_cs, bnb_acs, bnb_relu;
     const float* bnb_mean; const float* bnb_invstd; const float* bnb_gamma; const float* bnb_beta; float* bnb_partials;
@@ -243,6 +250,56 @@ __device__ __forceinline__ void conv_epilogue(const ConvKP& p, const TileCoord& 
                     bsc[e] = p.bnb_gamma[nb0 + e] * bis[e]; bsh[e] = p.bnb_beta[nb0 + e] - bmu[e] * bsc[e];
                 }
         }
+        // Fast path (whole tile inside the grid, whole aligned channel pieces, no fold): 32-bit offsets, no per-piece bounds / mode
+        // tests, fully unrolled so that the LDS reads and (accumulate / BatchNorm-backward) loads of all pieces are in flight together.
+        // The general loop below spent ~70 instructions per 16-byte piece: the epilogue of a 9.66-GFLOP layer took 4.5 us of 19 us
+        // WITHOUT its stores (tools/k1_ablate.sh).
+        const bool fast_store = SALT_K1_FAST_STORE && full_tile && !p.fold_fused && !p.strip && y_vec && (n0 + BN <= p.Cout) && p.y_small;
+        if (fast_store) {
+            const int pc = tid % PPO, n = n0 + pc * VE;
+            const bool accum = p.accumulate != 0;
+            const T* yb = reinterpret_cast<const T*>(p.bnb_y);
+            const T* ab = reinterpret_cast<const T*>(p.bnb_a);
+#pragma unroll
+            for (int it = 0; it < BM * PPO / 256; ++it) {
+                const int m = it * (256 / PPO) + tid / PPO;
+                const int tx = m & ((1 << p.tw_log2) - 1);
+                const int ty = (m >> p.tw_log2) & ((1 << p.th_log2) - 1);
+                const int bl = m >> (p.tw_log2 + p.th_log2);
+                const unsigned pix = ((unsigned)(b0 + bl) * p.OHf + (oy0 + ty) * p.out_step + out_oy) * p.OWf + (ox0 + tx) * p.out_step + out_ox;
+                T* dst = yg + (pix * (unsigned)p.y_cs + n);
+                u32x4 stored = *reinterpret_cast<const u32x4*>(sO + m * PITCH + pc * VE);
+                if (accum) {
+                    float f[VE], o[VE];
+                    unpack16<T>(stored, f);
+                    unpack16<T>(*reinterpret_cast<const u32x4*>(dst), o);
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) f[e] += o[e];
+                    stored = pack16<T>(f);
+                }
+                *reinterpret_cast<u32x4*>(dst) = stored;
+                if (bnb) {                                         // host: out_step 1 (pix is the pixel index of bnb_y / bnb_a too)
+                    float g[VE], yc[VE];
+                    unpack16<T>(stored, g);
+                    unpack16<T>(*reinterpret_cast<const u32x4*>(yb + (pix * (unsigned)p.bnb_cs + n)), yc);
+                    if (p.bnb_a) {
+                        float av[VE];
+                        unpack16<T>(*reinterpret_cast<const u32x4*>(ab + (pix * (unsigned)p.bnb_acs + n)), av);
+#pragma unroll
+                        for (int e = 0; e < VE; ++e) {
+                            const float gg = (!p.bnb_relu || av[e] > 0.f) ? g[e] : 0.f;
+                            b1[e] += gg; b2[e] += gg * (yc[e] - bmu[e]) * bis[e];
+                        }
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < VE; ++e) {
+                            const float gg = (!p.bnb_relu || yc[e] * bsc[e] + bsh[e] > 0.f) ? g[e] : 0.f;
+                            b1[e] += gg; b2[e] += gg * (yc[e] - bmu[e]) * bis[e];
+                        }
+                    }
+                }
+            }
+        } else
         for (int q = tid; q < BM * PPO; q += 256) {
             const int m = q / PPO, pc = q - m * PPO;
             const int tx = m & ((1 << p.tw_log2) - 1);
@@ -299,7 +356,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvKP& p, const TileCoord& 
                     for (int e = 0; e < VE; ++e) f[e] += o[e];
                     stored = pack16<T>(f);
                 }
+#if defined(SALT_K1_DBG) && (SALT_K1_DBG & 8)
+                if (stored.x == 0x12345678u && stored.y == 0x9abcdef0u) *reinterpret_cast<u32x4*>(dst) = stored;   // ablation: staging without the stores
+#else
                 *reinterpret_cast<u32x4*>(dst) = stored;
+#endif
                 if (bnb) {                                         // host: bnb implies whole aligned pieces, out_step 1, no strip
                     float g[VE], yc[VE];
                     unpack16<T>(stored, g);
@@ -458,6 +519,16 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // compile-time ablations (tools/k1_ablate.sh): 1 return after the prologue, 2 no chunk loop, 4 no epilogue
+    if (SALT_K1_DBG & 1) {
+        int t = 0;
+#pragma unroll
+        for (int k = 0; k < MAXA; ++k) t += a_goff[k];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) t += pbase[i];
+        if (t == 0x7fffffff) reinterpret_cast<int*>(p.y)[0] = t;
+        return;
+    }
     const int nbp = p.ntaps * BN * 4;          // weight pieces per chunk
     constexpr int MAXBP = (9 * BN * 4 + 255) / 256;          // weight pieces per thread that fit the register prefetch (<= 9 taps)
 
@@ -605,7 +676,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
         } else {
             load_chunk(0);
         }
-        for (int c = 0; c < p.nchunk; ++c) {
+        for (int c = 0; c < ((SALT_K1_DBG & 2) ? 0 : p.nchunk); ++c) {
             __syncthreads();                    // fragment reads of chunk c-1 are done
 #pragma unroll
             for (int k = 0; k < MAXA; ++k)
@@ -653,6 +724,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
         }
     }
 
+    if (SALT_K1_DBG & 4) {
+        float tsum = 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) tsum += acc[i][j][r];
+        if (tsum == 123.456f) reinterpret_cast<float*>(p.y)[0] = tsum;
+        return;
+    }
     conv_epilogue<T, MI, NI, WM, WN>(p, TileCoord{m_tile, n_tile, oy0, ox0, b0, n0, out_oy, out_ox}, acc, smem);
 }
 
@@ -1432,6 +1514,10 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
         if (red_bytes > pl->lds) pl->lds = red_bytes;
     }
     k.fin.acc = nullptr; k.bnbf.acc = nullptr;
+    {
+        auto small = [](const salt_view& v) { return !v.p || (int64_t)v.B * v.H * v.W * v.cs < (int64_t)1 << 31; };
+        k.y_small = small(a->y) && small(a->bnb_y) && small(a->bnb_a);
+    }
     if (a->fin_acc) {
         if (a->stats || a->stats_part0 || a->strip) SALT_FAIL(SALT_E_BADARG, "conv: fin_acc excludes stats partials and fold mode");
         k.fin = BnFin{};
