@@ -9,6 +9,9 @@ import ctypes
 import os
 import re
 
+import torch  # noqa: F401  FIRST: libsaltnet_hip.so must bind to the HIP runtime torch ships (its libamdhip64), not load a second
+#                      copy from /opt/rocm - two runtimes in one process leave the later one without a device (hipErrorNoDevice)
+
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 HEADER = os.path.join(_ROOT, 'include', 'saltnet.h')
