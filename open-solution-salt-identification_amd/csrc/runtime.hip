@@ -20,6 +20,29 @@ void salt_set_error(const char* fmt, ...) {
 
 extern "C" const char* salt_last_error(void) { return g_err; }
 
+// A/B experiment (SALT_POLL=us): a host thread that polls the streams with hipStreamQuery every `us` microseconds while programs run.
+#include <thread>
+#include <atomic>
+#include <chrono>
+namespace {
+std::atomic<bool> g_poll_on{false};
+std::atomic<void*> g_poll_main{nullptr}, g_poll_side{nullptr};
+void salt_poll_thread(int us) {
+    for (;;) {
+        void* m = g_poll_main.load(); void* s2 = g_poll_side.load();
+        if (m) (void)hipStreamQuery((hipStream_t)m);
+        if (s2) (void)hipStreamQuery((hipStream_t)s2);
+        std::this_thread::sleep_for(std::chrono::microseconds(us));
+    }
+}
+void salt_poll_ensure(void* ms, void* ss) {
+    static const int us = getenv("SALT_POLL") ? atoi(getenv("SALT_POLL")) : 0;
+    if (us <= 0) return;
+    g_poll_main = ms; g_poll_side = ss;
+    if (!g_poll_on.exchange(true)) std::thread(salt_poll_thread, us).detach();
+}
+}  // namespace
+
 extern "C" int salt_abi_version(void) { return 17; }
 
 extern "C" int salt_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name_len) {
@@ -104,6 +127,7 @@ extern "C" int salt_program_run_streams_ex(const salt_program_entry* e, int begi
     if (!e || begin < 0 || end < begin) SALT_FAIL(SALT_E_BADARG, "program: bad range");
     if (g_events.ensure()) SALT_FAIL(SALT_E_BADARG, "hipEventCreate failed");
     hipStream_t ms = (hipStream_t)main_stream, ss = (hipStream_t)side_stream;
+    salt_poll_ensure(main_stream, side_stream);
     static const bool one_stream = getenv("SALT_ONE_STREAM") != nullptr;      // A/B: every entry on the main stream, in program order
     if (one_stream) {
         (void)hipEventRecord(g_events.ev[1], ss);                 // whatever the caller enqueued on the side stream before (weight packs)
@@ -114,7 +138,18 @@ extern "C" int salt_program_run_streams_ex(const salt_program_entry* e, int begi
     // Fork coalescing (SALT_FORK_EVERY = K > 1): side-stream entries are held back until K groups of them are pending, then issued
     // behind ONE fork.  A held entry only ever runs later than its program position, so its inputs are complete; every cross-queue
     // dependency costs the main queue ~10 us of dispatch stall (rocprofv3 timeline), a held entry costs the side stream its head start.
-    static const int fork_every = getenv("SALT_FORK_EVERY") ? atoi(getenv("SALT_FORK_EVERY")) : 8;
+    static const int fork_eager = getenv("SALT_FORK_EVERY") ? atoi(getenv("SALT_FORK_EVERY")) : 1;
+    static const int fork_graph = getenv("SALT_FORK_EVERY_GRAPH") ? atoi(getenv("SALT_FORK_EVERY_GRAPH")) : 8;
+    const int fork_every = g_capturing ? fork_graph : fork_eager;   // a cross-stream edge of a replayed graph stalls the main branch ~10 us, a live event does not
+    // SALT_FORK_PLAN="a,b,c": group counts of the first flushes of a range (then fork_every): A/B of the flush pattern
+    static int plan[16], nplan = -1;
+    if (nplan < 0) {
+        nplan = 0;
+        if (const char* e = getenv("SALT_FORK_PLAN")) {
+            while (*e && nplan < 16) { plan[nplan++] = atoi(e); while (*e && *e != ',') ++e; if (*e == ',') ++e; }
+        }
+    }
+    int nflush = 0;
     int pending[64], npending = 0, groups = 0;
     bool prev_side = false;
     auto flush = [&]() -> int {
@@ -129,7 +164,7 @@ extern "C" int salt_program_run_streams_ex(const salt_program_entry* e, int begi
             const int rc = e[j].fn(e[j].args, side_stream);
             if (rc) { char prev[400]; strncpy(prev, g_err, sizeof(prev) - 1); prev[sizeof(prev) - 1] = 0; salt_set_error("program entry %d failed (%d): %s", j, rc, prev); return rc; }
         }
-        npending = 0; groups = 0; side_used = true;
+        npending = 0; groups = 0; side_used = true; ++nflush;
         return 0;
     };
     for (int i = begin; i < end; ++i) {
@@ -141,7 +176,7 @@ extern "C" int salt_program_run_streams_ex(const salt_program_entry* e, int begi
                 continue;
             }
             if (prev_side) { ++groups; prev_side = false; }
-            if (groups >= fork_every || e[i].stream == 2 || e[i].stream == 3) { const int rc = flush(); if (rc) return rc; }
+            if (groups >= (nflush < nplan ? plan[nflush] : fork_every) || e[i].stream == 2 || e[i].stream == 3) { const int rc = flush(); if (rc) return rc; }
         }
         if ((e[i].stream == 2 && side_used) || e[i].stream == 3) {   // a main-stream entry that consumes side-stream results:
             (void)hipEventRecord(g_events.ev[1], ss);                 // 2 = produced inside this range, 3 = enqueued on the side

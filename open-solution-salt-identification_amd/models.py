@@ -102,10 +102,11 @@ class SegmentationModel(Model):
                                    model=self.model, **architecture_config['optimizer_params'])
         self.callbacks = callbacks_network(self.callbacks_config)
         self.dp = parallel.DataParallel.from_env()
-        # one-GPU training replays the whole step as a hipGraph (training_config['step_graph'] / SALT_STEP_GRAPH=0|1)
+        # opt-in: one-GPU training replays the whole step as a hipGraph (training_config['step_graph'] / SALT_STEP_GRAPH=1);
+        # the eager two-stream step is faster
         import os
         self._eager_done = set()
-        self.step_graph = bool(int(os.environ.get('SALT_STEP_GRAPH', '1' if (training_config or {}).get('step_graph', True) else '0')))
+        self.step_graph = bool(int(os.environ.get('SALT_STEP_GRAPH', '1' if (training_config or {}).get('step_graph', False) else '0')))
 
     # ------------------------------------------------------------------ reference surface
     def set_model(self):
