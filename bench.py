@@ -345,7 +345,7 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
     torch.cuda.set_device(local)
-    if world > 1 or os.environ.get('SALT_FORCE_DP_PATH') or os.environ.get('SALT_BENCH_INIT_PG'):
+    if world > 1 or os.environ.get('SALT_FORCE_DP_PATH'):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
         os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')

@@ -20,29 +20,6 @@ void salt_set_error(const char* fmt, ...) {
 
 extern "C" const char* salt_last_error(void) { return g_err; }
 
-// A/B experiment (SALT_POLL=us): a host thread that polls the streams with hipStreamQuery every `us` microseconds while programs run.
-#include <thread>
-#include <atomic>
-#include <chrono>
-namespace {
-std::atomic<bool> g_poll_on{false};
-std::atomic<void*> g_poll_main{nullptr}, g_poll_side{nullptr};
-void salt_poll_thread(int us) {
-    for (;;) {
-        void* m = g_poll_main.load(); void* s2 = g_poll_side.load();
-        if (m) (void)hipStreamQuery((hipStream_t)m);
-        if (s2) (void)hipStreamQuery((hipStream_t)s2);
-        std::this_thread::sleep_for(std::chrono::microseconds(us));
-    }
-}
-void salt_poll_ensure(void* ms, void* ss) {
-    static const int us = getenv("SALT_POLL") ? atoi(getenv("SALT_POLL")) : 0;
-    if (us <= 0) return;
-    g_poll_main = ms; g_poll_side = ss;
-    if (!g_poll_on.exchange(true)) std::thread(salt_poll_thread, us).detach();
-}
-}  // namespace
-
 extern "C" int salt_abi_version(void) { return 17; }
 
 extern "C" int salt_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name_len) {
@@ -127,7 +104,6 @@ extern "C" int salt_program_run_streams_ex(const salt_program_entry* e, int begi
     if (!e || begin < 0 || end < begin) SALT_FAIL(SALT_E_BADARG, "program: bad range");
     if (g_events.ensure()) SALT_FAIL(SALT_E_BADARG, "hipEventCreate failed");
     hipStream_t ms = (hipStream_t)main_stream, ss = (hipStream_t)side_stream;
-    salt_poll_ensure(main_stream, side_stream);
     static const bool one_stream = getenv("SALT_ONE_STREAM") != nullptr;      // A/B: every entry on the main stream, in program order
     if (one_stream) {
         (void)hipEventRecord(g_events.ev[1], ss);                 // whatever the caller enqueued on the side stream before (weight packs)

@@ -157,44 +157,6 @@ class DataParallel:
         if optimizer is not None:
             optimizer.grad_scale = 1.0 / self.world
         if not self._active():
-            seg = os.environ.get('SALT_BWD_SEGMENTS')           # A/B: the bucket plan's program ranges without any collective
-            if seg:
-                key = id(net)
-                if key not in self._plans:
-                    self._plans[key] = plan_buckets(net.g.grad_ready, eng.n_live, self.bucket_bytes)
-                pos, n_ops = 0, len(net.bwd)
-                for lo, hi, ridx in self._plans[key]:
-                    ridx = min(max(ridx, pos), n_ops)
-                    if ridx > pos:
-                        net.bwd.run(begin=pos, end=ridx, side=eng.side_stream, join=(seg == '2'))
-                        pos = ridx
-                    if seg == '6':
-                        import time
-                        t_end = time.perf_counter() + 150e-6
-                        while time.perf_counter() < t_end:
-                            pass
-                    if seg == '7':
-                        if self._comm_stream is None:
-                            self._comm_stream = torch.cuda.Stream()
-                        with torch.cuda.stream(self._comm_stream):
-                            self._comm_stream.wait_stream(eng.side_stream)
-                            eng.grads[lo:hi].mul_(1.0)
-                    if seg in ('3', '4'):
-                        ev, ev_side = torch.cuda.Event(), torch.cuda.Event()
-                        ev.record(torch.cuda.current_stream())
-                        ev_side.record(eng.side_stream)
-                        if seg == '4':
-                            if self._comm_stream is None:
-                                self._comm_stream = torch.cuda.Stream()
-                            self._comm_stream.wait_event(ev)
-                            self._comm_stream.wait_event(ev_side)
-                if pos < n_ops:
-                    net.bwd.run(begin=pos, end=n_ops, side=eng.side_stream)
-                elif seg != '2':
-                    torch.cuda.current_stream().wait_stream(eng.side_stream)
-                if seg in ('4', '7'):
-                    torch.cuda.current_stream().wait_stream(self._comm_stream)
-                return
             net.bwd.run(side=eng.side_stream)
             return
         key = id(net)
