@@ -2597,7 +2597,8 @@ int wgrad_plan(const salt_conv_wgrad_args* a, WgradKP* k, int* nsplit_out) {
     int ns = target_wgs / (k->a_blocks * k->b_blocks);
     // the stem (64 x 16 channels, launched on the MAIN stream at the very end of backward, nothing left to overlap with): finer
     // split.  NOT for the other single-block layers: their launches share the chip with the data-gradient chain, and 256 instead
-    // of 128 weight-gradient workgroups starved it (7.0 -> 8.5 ms per step)
+    // of 128 weight-gradient workgroups cost 6.17 -> 6.24 ms per step (and halving the tiles per split wherever a launch has fewer than
+    // 256 workgroups 6.17 -> 6.30)
     const int mt = (k->a_blocks * k->b_blocks == 1 && a->q.C <= 16 && min_tiles >= 2) ? min_tiles / 2 : min_tiles;
     if (ns > k->ntiles / mt) ns = k->ntiles / mt;
     if (ns < 1) ns = 1;
