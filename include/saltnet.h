@@ -395,6 +395,7 @@ typedef struct {              /* backward of a = relu?(bn(y) (+res)) in train mo
                               /* 2: the producer also finalized (salt_conv_args.bnb_fin): coef / dgamma / dbeta are ready, only the apply pass runs */
                               /* 3: the producer added the sums to fin_acc (salt_conv_args.bnb_acc without ticket): the apply pass finalizes them */
     double* fin_acc;          /* partials_ready == 0 and fin_acc != NULL: the reduction pass accumulates into [8][2][C] fp64 shards and its last block */
+    const float* da_bias;     /* NULL, or [B][C]: a per-image, per-channel constant added to da wherever it is read (partials_ready 0 only) */
     uint32_t* fin_ticket;     /* finalizes (no partials, no finalize launch); both zero before the first call, left zero (see salt_conv_args.fin).
                                * fin_ticket == NULL: no in-launch finalize - the apply pass finalizes the shards; the caller clears them */
 } salt_bn_bwd_args;
@@ -545,6 +546,8 @@ typedef struct {
     int accumulate;
     double* acc;              /* NULL, or [B][2C+1] fp64 ZEROED by the caller: the first pass adds its per-part sums there (atomics) and the
                                  FC backward reads them - no parts-reduction launch; partials unused */
+    int skip_bcast;           /* 1: dx is left WITHOUT the channel-SE term dgap[b][c]; the consumer of dx adds it on the fly
+                                 (salt_bn_bwd_args.da_bias = dgap) - one full pass over dx less */
 } salt_scse_bwd_args;
 int salt_scse_bwd(const salt_scse_bwd_args*, void* stream);
 

@@ -102,7 +102,8 @@ struct BnFin {
     const float* gamma; const float* beta; float* running_mean; float* running_var; int64_t* nbt;
     float momentum, eps; float* mean; float* invstd; float* scale; float* shift;
 };
-struct BnbFin { double* acc; unsigned* ticket; float* dgamma; float* dbeta; float* coef; int accumulate; double M; };
+struct BnbFin { double* acc; unsigned* ticket; float* dgamma; float* dbeta; float* coef; int accumulate; double M;
+                const float* da_bias; unsigned hw; };   // da_bias [B][C]: per-image, per-channel constant added to da on the fly (salt_bn_bwd_args.da_bias)
 // ---- in-launch BatchNorm finalize: sharded fp64 accumulators + arrival ticket ----------------------------------------------------
 // Every workgroup adds its tile's sums to the shard of its XCD (workgroup id % 8: 64 arrivals per address instead of 512) with
 // device-scope fp64 atomics, waits until they have been performed (vmcnt), and takes a ticket; the workgroup that draws the last ticket

@@ -405,9 +405,11 @@ extern "C" int salt_scse_bwd(const salt_scse_bwd_args* a, void* stream) {
         hipLaunchKernelGGL(se_fc_bwd_kernel, dim3(1), dim3(1024), fc_lds, st, a->partials, nparts, B, C, a->R, a->w1, a->w2, a->gap, a->hidden,
                            a->gate_c, a->g_w1, a->g_b1, a->g_w2, a->g_b2, a->g_ws, a->g_bs, a->dgap, 1.0f / (float)(a->x.H * a->x.W), a->acc);
         SALT_CHECK_LAUNCH();
-        const int64_t units = view_pixels(a->dx) * (C / VE);
-        const int blocks = (int)((units + 255) / 256 < 4096 ? (units + 255) / 256 : 4096);
-        hipLaunchKernelGGL(bcast_add_kernel<T>, dim3(blocks), dim3(256), 0, st, a->dx, a->dgap);
+        if (!a->skip_bcast) {                      // else: the consumer adds dgap[b][c] on the fly (salt_bn_bwd_args.da_bias)
+            const int64_t units = view_pixels(a->dx) * (C / VE);
+            const int blocks = (int)((units + 255) / 256 < 4096 ? (units + 255) / 256 : 4096);
+            hipLaunchKernelGGL(bcast_add_kernel<T>, dim3(blocks), dim3(256), 0, st, a->dx, a->dgap);
+        }
     })
     SALT_CHECK_LAUNCH();
     return SALT_OK;

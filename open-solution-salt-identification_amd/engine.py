@@ -431,6 +431,7 @@ class Graph:
             self.fwd.add('bn_finalize', stats=stats, stats_cnt=cnt, nparts=nparts, **fin)
         if res is not None and getattr(res, 'on_side', False):
             self.join()                          # the residual branch ran on the side stream
+        out.buf.bn_train_out = (out.c0, out.C)      # dL/d(out) is consumed by this layer's bn_bwd only: it may take a per-image bias (scse)
         sa = self.fwd.add('affine_act', dtype=self.dt, y=y.view(), scale=w['scale'].data_ptr(), shift=w['shift'].data_ptr(),
                           res=res.view() if res is not None else null_view(), relu=int(relu), a=out.view())
         if F is not None:                        # the producer only adds to the shards; this operator finalizes them
@@ -480,6 +481,12 @@ class Graph:
                           mean=w['mean'].data_ptr(), invstd=w['invstd'].data_ptr(), gamma=bn.weight.data_ptr(), beta=bn.bias.data_ptr(),
                           partials=partials, nparts=nparts, dgamma=gw, dbeta=gb, accumulate_param_grads=0,
                           coef=coef.data_ptr(), dy=y.gview(), dres=dres, accumulate_dres=acc_res, partials_ready=ready)
+        bias = getattr(out.buf, 'grad_bias', None)
+        if bias is not None:
+            if ready != 0:
+                raise SaltError('a per-image gradient bias needs the reduction pass of bn_bwd (the producer of dL/da is not a convolution)')
+            self.bwd.set_fields(s2, da_bias=bias.data_ptr())
+            out.buf.grad_bias = None
         if ready == 3:
             self._fin_slot('bwd', 8 * 2 * C, (producer, 'bnb_acc'), (s2, 'fin_acc'))
         elif ready == 2:
@@ -1012,5 +1019,11 @@ class Graph:
                                   dx=x.gview(), accumulate=acc)
                 if shards:
                     self._fin_slot('bwd', B * (2 * C + 1), (sb, 'acc'))
+                # x = relu(bn(conv)): its only gradient consumer is that layer's bn_bwd, which can add the channel-SE term dgap[b][c]
+                # wherever it reads dL/dx - the broadcast-add pass over dx (read + write of the whole tensor) disappears
+                if (getattr(x.buf, 'bn_train_out', None) == (x.c0, x.C) and acc == 0 and x.B * x.H * x.W < (1 << 31)
+                        and os.environ.get('SALT_SE_BIAS_FOLD', '1') != '0'):
+                    self.bwd.set_fields(sb, skip_bcast=1)
+                    x.buf.grad_bias = dgap
             self.tape.append(backward)
         return out
