@@ -103,7 +103,7 @@ struct BnFin {
     float momentum, eps; float* mean; float* invstd; float* scale; float* shift;
 };
 struct BnbFin { double* acc; unsigned* ticket; float* dgamma; float* dbeta; float* coef; int accumulate; double M;
-                const float* da_bias; unsigned hw; };   // da_bias [B][C]: per-image, per-channel constant added to da on the fly (salt_bn_bwd_args.da_bias)
+                const float* da_bias; unsigned hw; int hw_shift; };   // da_bias [B][C]: per-image, per-channel constant added to da on the fly (salt_bn_bwd_args.da_bias); image = pixel >> hw_shift (or / hw when hw_shift < 0)
 // ---- in-launch BatchNorm finalize: sharded fp64 accumulators + arrival ticket ----------------------------------------------------
 // Every workgroup adds its tile's sums to the shard of its XCD (workgroup id % 8: 64 arrivals per address instead of 512) with
 // device-scope fp64 atomics, waits until they have been performed (vmcnt), and takes a ticket; the workgroup that draws the last ticket
@@ -238,4 +238,8 @@ __device__ inline void fin_backward_consumer(const BnbFin& f, const float* gamma
             if (f.coef) { f.coef[c] = k0; f.coef[C + c] = k1; f.coef[2 * C + c] = k2; }
         }
     }
+}
+
+__device__ __forceinline__ unsigned bnb_image_of(const BnbFin& f, int64_t pix) {
+    return f.hw_shift >= 0 ? (unsigned)pix >> f.hw_shift : (unsigned)pix / f.hw;
 }

@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(salt_view da, salt_v
                     if (pix < p1) {
                         Unit<T, VEC>::ld((const T*)da.p + pix * da.cs + c0, g[u]);
                         if (fin.da_bias) {
-                            const float* bb = fin.da_bias + (size_t)((unsigned)pix / fin.hw) * C + c0;
+                            const float* bb = fin.da_bias + (size_t)bnb_image_of(fin, pix) * C + c0;
 #pragma unroll
                             for (int j = 0; j < N; ++j) g[u][j] += bb[j];
                         }
@@ -368,7 +368,7 @@ __global__ void bn_bwd_apply_kernel(salt_view da, salt_view a, salt_view y, int 
                 float g[N], yy[N], o[N], aa[N];
                 Unit<T, VEC>::ld((const T*)da.p + pix * da.cs + c0, g);
                 if (fin.da_bias) {
-                    const float* bb = fin.da_bias + (size_t)((unsigned)pix / fin.hw) * C + c0;
+                    const float* bb = fin.da_bias + (size_t)bnb_image_of(fin, pix) * C + c0;
 #pragma unroll
                     for (int j = 0; j < N; ++j) g[j] += bb[j];
                 }
@@ -403,7 +403,7 @@ __global__ void bn_bwd_apply_kernel(salt_view da, salt_view a, salt_view y, int 
         float g[N], yy[N], o[N], msk[N];
         Unit<T, VEC>::ld((const T*)da.p + pix * da.cs + c0, g);
         if (fin.da_bias) {
-            const float* bb = fin.da_bias + (size_t)((unsigned)pix / fin.hw) * C + c0;
+            const float* bb = fin.da_bias + (size_t)bnb_image_of(fin, pix) * C + c0;
 #pragma unroll
             for (int j = 0; j < N; ++j) g[j] += bb[j];
         }
@@ -928,7 +928,8 @@ extern "C" int salt_bn_bwd(const salt_bn_bwd_args* a, void* stream) {
         if (fin_apply && C > 4096) SALT_FAIL(SALT_E_BADARG, "bn_bwd: fin_acc supports <= 4096 channels");
         if (a->da_bias && (a->partials_ready || view_pixels(a->y) >= ((int64_t)1 << 31))) SALT_FAIL(SALT_E_BADARG, "bn_bwd: da_bias needs the reduction pass of this call (partials_ready 0)");
         const unsigned hw = (unsigned)(a->y.H * a->y.W);
-        const BnbFin fin{fin_here ? a->fin_acc : nullptr, a->fin_ticket, a->dgamma, a->dbeta, a->coef, a->accumulate_param_grads, (double)view_pixels(a->y), a->da_bias, hw};
+        const int hw_shift = (hw & (hw - 1)) == 0 ? ilog2_ceil((int)hw) : -1;
+        const BnbFin fin{fin_here ? a->fin_acc : nullptr, a->fin_ticket, a->dgamma, a->dbeta, a->coef, a->accumulate_param_grads, (double)view_pixels(a->y), a->da_bias, hw, hw_shift};
         if (!a->partials_ready) {
             if (v) hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, true>), dim3(nparts), dim3(256), lds, st, a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->gamma, a->beta, a->partials, per, fin);
             else hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, false>), dim3(nparts), dim3(256), lds, st, a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->gamma, a->beta, a->partials, per, fin);
@@ -944,13 +945,13 @@ extern "C" int salt_bn_bwd(const salt_bn_bwd_args* a, void* stream) {
         }
         const int64_t units = view_pixels(a->y) * cpv;
         if (fin_apply) {
-            const BnbFin fa{a->fin_acc, nullptr, a->dgamma, a->dbeta, a->coef, a->accumulate_param_grads, (double)view_pixels(a->y), a->da_bias, hw};
+            const BnbFin fa{a->fin_acc, nullptr, a->dgamma, a->dbeta, a->coef, a->accumulate_param_grads, (double)view_pixels(a->y), a->da_bias, hw, hw_shift};
             const size_t lds3 = (size_t)C * 3 * sizeof(float);
             hipEvent_t ev_ = salt_take_fork_event();
             if (v) hipExtLaunchKernelGGL((bn_bwd_apply_kernel<T, true, true>), dim3(ew_blocks(units)), dim3(256), lds3, st, nullptr, ev_, 0, a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->gamma, a->beta, nullptr, a->dy, a->dres, a->accumulate_dres, fa);
             else hipExtLaunchKernelGGL((bn_bwd_apply_kernel<T, false, true>), dim3(ew_blocks(units)), dim3(256), lds3, st, nullptr, ev_, 0, a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->gamma, a->beta, nullptr, a->dy, a->dres, a->accumulate_dres, fa);
         } else {
-            EW_LAUNCH_EV(bn_bwd_apply_kernel, T, v, units, st, salt_take_fork_event(), a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->gamma, a->beta, a->coef, a->dy, a->dres, a->accumulate_dres, BnbFin{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.0, a->da_bias, hw});
+            EW_LAUNCH_EV(bn_bwd_apply_kernel, T, v, units, st, salt_take_fork_event(), a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->gamma, a->beta, a->coef, a->dy, a->dres, a->accumulate_dres, BnbFin{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.0, a->da_bias, hw, hw_shift});
         }
     })
     SALT_CHECK_LAUNCH();
