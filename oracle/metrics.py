@@ -118,4 +118,6 @@ def tta_inverse(pred_chw, spec):
 
 def tta_aggregate(preds_chw, specs, method='mean'):
     stack = np.stack([tta_inverse(p, s) for p, s in zip(preds_chw, specs)], axis=-1)
+    if method == 'gmean':                              # scipy.stats.gmean (loaders.py:727-735): exp(mean(log x))
+        return np.exp(np.mean(np.log(stack), axis=-1))
     return {'mean': np.mean, 'max': np.max, 'min': np.min}[method](stack, axis=-1)

@@ -126,6 +126,61 @@ def test_predict_tta_end_to_end_vs_oracle():
         net.train(); I.predict_tta(net, X.to(DEV))
 
 
+@pytest.mark.parametrize('method', ['mean', 'max', 'min', 'gmean'])
+def test_predict_tta_tiles_rotation_and_aggregators_vs_oracle(method):
+    """The reference's TTA in its own order of operations (loaders.py:662-760, augmentation.py:143-163): flipud / fliplr / rot90 of
+    the RAW square tile, inference preprocessing of every variant, forward, inverse transform of the probability maps, aggregation by
+    mean / max / min / gmean - 16 variants with rotation - against the numpy restatement around the oracle network."""
+    from salt_amd import architectures as A, inference as I
+    from salt_amd.input_pipeline import DevicePreprocessor
+    from oracle import nets as ON, specs as OS, metrics as OM, inputs as OI
+    torch.manual_seed(3)
+    net = A.VanillaUNet(2, in_channels=1, base_filters=8, levels=3)
+    spec = OS.spec_vanilla_unet(2, 1, 8, 3)
+    sd = OS.init_state(spec, seed=2)
+    net.load_state_dict(sd)
+    net.to(DEV).eval()
+    r = np.random.RandomState(8)
+    img = r.rand(2, 101, 101).astype(np.float32)
+    pre = DevicePreprocessor(False, 1)
+    prob = I.predict_tta_tiles(net, pre, T(img).to(DEV), flip_ud=True, flip_lr=True, rotation=True, method=method).cpu().numpy()
+    specs = OM.tta_specs(True, True, True)
+    assert len(specs) == 16
+    for b in range(2):
+        preds = []
+        for sp in specs:
+            v = np.ascontiguousarray(OM.tta_transform(img[b][:, :, None], sp)[:, :, 0])
+            xv, _ = OI.preprocess(v[None], None, False, 1)
+            with torch.no_grad():
+                preds.append(OM.sigmoid(ON.vanilla_unet(sd, xv, False, levels=3)[0].numpy()))
+        ref = OM.tta_aggregate(preds, specs, method)
+        assert_close(prob[b], ref, 1e-4, 'tta %s probabilities' % method)
+
+
+@pytest.mark.parametrize('method', ['max', 'min', 'gmean'])
+def test_predict_tta_batch_aggregators_vs_oracle(method):
+    """predict_tta (flips of the preprocessed batch) with the non-default aggregators."""
+    from salt_amd import architectures as A, inference as I
+    from oracle import nets as ON, specs as OS, metrics as OM
+    torch.manual_seed(3)
+    net = A.VanillaUNet(2, in_channels=1, base_filters=8, levels=3)
+    spec = OS.spec_vanilla_unet(2, 1, 8, 3)
+    sd = OS.init_state(spec, seed=2)
+    net.load_state_dict(sd)
+    net.to(DEV).eval()
+    X = torch.randn(2, 1, 32, 48)
+    prob = I.predict_tta(net, X.to(DEV), True, True, depth_channels=False, method=method).cpu().numpy()
+    specs = OM.tta_specs(True, True)
+    for b in range(2):
+        preds = []
+        for sp in specs:
+            xv = OM.tta_transform(X[b].permute(1, 2, 0).numpy(), sp)
+            xv = torch.from_numpy(np.ascontiguousarray(xv)).permute(2, 0, 1)[None]
+            with torch.no_grad():
+                preds.append(OM.sigmoid(ON.vanilla_unet(sd, xv, False, levels=3)[0].numpy()))
+        assert_close(prob[b], OM.tta_aggregate(preds, specs, method), 1e-4, 'tta %s' % method)
+
+
 @pytest.mark.parametrize('train', [True, False])
 @pytest.mark.parametrize('channels', [1, 3])
 @pytest.mark.parametrize('as_u8', [False, True])
