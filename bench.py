@@ -2,7 +2,9 @@
 """bench.py — training images/s (+ val IoU) of the ResNet34 hypercolumn U-Net on synthetic 101x101 salt tiles.
 
     python bench.py --gpus N --steps K --warmup W [--dtype bf16|f32] [--workload r34_hyper|ternaus34|vanilla] [--batch 32]
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)
+    N > 1 works both ways: started by `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` (RANK / LOCAL_RANK / WORLD_SIZE in the environment), or as a plain
+    `python bench.py --gpus N`, which re-launches itself through torch.distributed.run (one rank per GPU, 127.0.0.1 rendezvous).
 
 A "step" is one `_fit_loop`-equivalent pass of the hot path (reference models.py:105-136) over one resident minibatch:
 pack weights -> forward -> Lovasz hinge -> backward (bucketed RCCL all-reduce on a side stream when N > 1) -> fused Adam.
@@ -113,14 +115,57 @@ def op_flops(name, s):
     return 0.0
 
 
+def _vb(v, es):
+    """bytes of one pass over the channels of a salt_view (0 for a NULL view)"""
+    return float(v.B) * v.H * v.W * v.C * es if v.p else 0.0
+
+
 def op_bytes(name, s, es):
-    """Algorithmic HBM bytes of one convolution launch: input pixels once, packed weights once, output once (twice when accumulating)."""
+    """Algorithmic HBM bytes of one operator launch from its argument struct: every operand tensor read once and every result written
+    once (convolutions: input pixels once, packed weights once, output once - twice when accumulating).  0 for operators without a rule."""
     if name == 'conv':
         return es * (s.x.B * s.x.H * s.x.W * s.x.C + s.ntaps * s.x.C * s.y.C + s.x.B * s.OH * s.OW * s.y.C * (2 if s.accumulate else 1))
+    if name == 'conv_wgrad':
+        return _vb(s.p, es) + _vb(s.q, es) + 4.0 * s.nsplit * s.ntaps * s.p.C * s.q.C
+    if name == 'wgrad_reduce':
+        return 4.0 * (s.nsplit + 1) * s.ntaps * s.Ca * s.Cb
+    if name == 'affine_act':
+        return _vb(s.y, es) + _vb(s.res, es) + _vb(s.a, es)
+    if name == 'bn_bwd':          # reduction pass (da, y[, a]) unless the producer carried the sums, then the apply pass (da, y[, a] -> dy[, dres])
+        rd = _vb(s.da, es) + _vb(s.y, es) + _vb(s.a, es)
+        return (1 if s.partials_ready else 2) * rd + _vb(s.dy, es) + _vb(s.dres, es) * (2 if s.accumulate_dres else 1)
+    if name == 'bilinear':
+        return _vb(s.x, es) * (2 if (s.backward and s.accumulate) else 1) + _vb(s.y, es)
+    if name in ('maxpool2', 'maxpool3s2', 'avgpool2'):
+        return _vb(s.x, es) + _vb(s.y, es)
+    if name in ('maxpool2_bwd', 'maxpool3s2_bwd'):
+        return _vb(s.x, es) + _vb(s.dy, es) + _vb(s.dx, es) * (2 if s.accumulate else 1)
+    if name == 'scse':            # statistics pass + apply pass over x, y written once
+        return 2 * _vb(s.x, es) + _vb(s.y, es)
+    if name == 'scse_bwd':        # (x, y, dy) read twice (sums, then apply), dx written
+        return 2 * (_vb(s.x, es) + _vb(s.y, es) + _vb(s.dy, es)) + _vb(s.dx, es) * (2 if s.accumulate else 1)
+    if name == 'head1x1':
+        return _vb(s.x, es) + 4.0 * s.x.B * s.x.H * s.x.W * s.Cout
+    if name == 'head1x1_bwd':
+        return _vb(s.x, es) + 4.0 * s.x.B * s.x.H * s.x.W * s.Cout + _vb(s.dx, es) * (2 if s.accumulate else 1)
+    if name == 'add':
+        return _vb(s.a, es) + _vb(s.b, es) + _vb(s.y, es) * (2 if s.accumulate else 1)
+    if name == 'relu_bwd':
+        return _vb(s.da, es) + _vb(s.a, es) + _vb(s.dy, es)
+    if name == 'lovasz_hinge':    # logits + targets read, gradient written (fp32 NCHW), 4 radix passes over (key, payload) pairs
+        return 0.0
     return 0.0
 
 
 PMC_FILE = 'profiles/r02_pmc_traffic.json'
+
+
+def pmc_commit():
+    """Commit the PMC file was measured at (recorded inside it by tools/pmc_traffic.py), so that `roofline.traffic` names its build."""
+    try:
+        return json.load(open(os.path.join(ROOT, PMC_FILE))).get('commit', 'unrecorded')
+    except (OSError, ValueError):
+        return None
 
 
 def pmc_traffic(kernel):
@@ -141,13 +186,14 @@ def pmc_traffic(kernel):
 
 CPU_LEG_THREADS = 16        # a fixed, modest thread count: GPU boxes advertise 256 logical CPUs but oversubscribing them makes
 CPU_LEG_BATCH = 8           # the torch CPU kernels orders of magnitude slower; SURVEY.md 8(d): batch 8, median of 10 steps after 2 warm-ups
-CPU_LEG_STEPS, CPU_LEG_WARMUP = 10, 2
+CPU_LEG_STEPS, CPU_LEG_WARMUP = int(os.environ.get('SALT_CPU_LEG_STEPS', '10')), int(os.environ.get('SALT_CPU_LEG_WARMUP', '2'))
 CPU_LEG_TIMEOUT_S = 150
 
 
-def cpu_baseline_leg(arch_name, loss_name, channels):
+def cpu_baseline_leg(arch_name, loss_name, channels, threads=0, batch=0):
     """Child process: time the oracle (oracle/, plain PyTorch CPU fp32) on a bounded sample of the same workload."""
-    torch.set_num_threads(CPU_LEG_THREADS)
+    threads = threads or CPU_LEG_THREADS
+    torch.set_num_threads(threads)
     from oracle import nets as ON, specs as OS, losses as OL
     spec = OS.SPECS[arch_name]() if arch_name != 'VanillaUNet' else OS.spec_vanilla_unet()
     sd = OS.init_state(spec, seed=0)
@@ -157,7 +203,7 @@ def cpu_baseline_leg(arch_name, loss_name, channels):
     params = [sd[k] for k in keys]
     m_ = [torch.zeros_like(p) for p in params]
     v_ = [torch.zeros_like(p) for p in params]
-    cb = CPU_LEG_BATCH
+    cb = batch or CPU_LEG_BATCH
     img, msk = synth_tiles(cb, seed=1234)
     xc, tc = preprocess(img, msk, True, channels)
     times = []
@@ -176,17 +222,18 @@ def cpu_baseline_leg(arch_name, loss_name, channels):
             break
     timed = times[CPU_LEG_WARMUP:]
     med = float(np.median(timed))
-    print(json.dumps({'value': round(cb / med, 2), 'unit': 'images/s', 'cores': CPU_LEG_THREADS, 'host_logical_cpus': os.cpu_count(), 'kind': 'port',
+    print(json.dumps({'value': round(cb / med, 2), 'unit': 'images/s', 'cores': threads, 'host_logical_cpus': os.cpu_count(), 'kind': 'port',
                       'sample': 'oracle (plain PyTorch CPU fp32, %d threads of the %d logical CPUs of this host) %s, %s loss, Adam; batch %d, '
                                 'median of %d steps after %d warm-ups' % (torch.get_num_threads(), os.cpu_count(), arch_name, loss_name, cb,
                                                                          len(timed), CPU_LEG_WARMUP)}))
 
 
-def cpu_baseline_subprocess(loss, arch_name):
+def cpu_baseline_subprocess(loss, arch_name, threads=0, batch=0):
     """Run the CPU leg in a child with a hard time limit so that the default bench run always finishes in minutes."""
     import subprocess
-    env = dict(os.environ, OMP_NUM_THREADS=str(CPU_LEG_THREADS), MKL_NUM_THREADS=str(CPU_LEG_THREADS))
-    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-leg', arch_name, '--loss', loss]
+    threads = min(threads or CPU_LEG_THREADS, os.cpu_count() or 1)
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+    cmd = [sys.executable, os.path.abspath(__file__), '--cpu-leg', arch_name, '--loss', loss, '--cpu-threads', str(threads), '--cpu-batch', str(batch or CPU_LEG_BATCH)]
     try:
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=CPU_LEG_TIMEOUT_S)
         line = [x for x in r.stdout.splitlines() if x.startswith('{')]
@@ -195,7 +242,7 @@ def cpu_baseline_subprocess(loss, arch_name):
         note = 'cpu leg failed: ' + (r.stderr.strip().splitlines() or ['?'])[-1][:200]
     except subprocess.TimeoutExpired:
         note = 'cpu leg exceeded %d s' % CPU_LEG_TIMEOUT_S
-    return {'value': None, 'unit': 'images/s', 'cores': CPU_LEG_THREADS, 'host_logical_cpus': os.cpu_count(), 'kind': 'port', 'sample': note}
+    return {'value': None, 'unit': 'images/s', 'cores': threads, 'host_logical_cpus': os.cpu_count(), 'kind': 'port', 'sample': note}
 
 
 WORKLOADS = {'r34_hyper': ('UNetResNet', 3, 'architectures.unet.UNetResNet(34, hypercolumn)'),
@@ -216,7 +263,10 @@ def conv_roofline(model, B, channels, dtype, loss, reps):
             for name, s, ms in prog.run_timed():
                 g = groups.setdefault(name, [0.0, 0.0, 0, 0.0])
                 g[0] += ms; g[1] += op_flops(name, s); g[2] += 1
-                g[3] += op_bytes(name, s, 2 if dtype == 'bf16' else 4)
+                try:
+                    g[3] += op_bytes(name, s, 2 if dtype == 'bf16' else 4)
+                except AttributeError:
+                    pass
     total_ms = sum(g[0] for g in groups.values()) / reps
     dn, (dms, dfl, dcnt, dby) = max(groups.items(), key=lambda kv: kv[1][0])
     peak = MFMA_PEAK_TFLOPS[dtype]
@@ -228,6 +278,21 @@ def conv_roofline(model, B, channels, dtype, loss, reps):
             'algorithmic_gflop_per_step': round(dfl / reps / 1e9, 2)}
     ops = {k: round(v[0] / reps, 3) for k, v in sorted(groups.items(), key=lambda kv: -kv[1][0])[:8]}
     side = sum(v[0] for k, v in groups.items() if k in ('conv_wgrad', 'wgrad_reduce', 'conv_first_wgrad', 'stem_grad_unfold')) / reps
+    # per kernel class: matrix kernels against the dense MFMA peak of the compute dtype, streaming kernels as
+    # algorithmic GB/s against the HBM peak; every launch timed alone with its own HIP event pair
+    by_class = {}
+    for k, (ms, fl, cnt, by) in sorted(groups.items(), key=lambda kv: -kv[1][0]):
+        if ms <= 0 or ms / reps < 0.02:
+            continue
+        e = {'launches_per_step': cnt // reps, 'ms_per_step': round(ms / reps, 3)}
+        if fl > 0:
+            e.update(bound='mfma', achieved=round(fl / (ms * 1e-3) / 1e12, 1), peak=peak, unit='TFLOP/s', frac=round(fl / (ms * 1e-3) / 1e12 / peak, 4))
+        elif by > 0:
+            e.update(bound='hbm', achieved=round(by / (ms * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBS, unit='GB/s', frac=round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+        else:
+            e.update(bound='latency', achieved=None, peak=None, unit=None, frac=None)
+        by_class[k] = e
+    roof['by_class'] = by_class
     return roof, ops, total_ms, side, sum(g[1] for g in groups.values()) / reps, dn
 
 
@@ -253,7 +318,7 @@ def train_config(workload, dtype, B, loss, steps, warmup, dev, rank=0, world=1, 
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    model.dp.measure = world > 1
+    model.dp.measure = model.dp._active()
     t0 = time.perf_counter()
     for i in range(steps):
         loss_v = model._fit_loop(list(batches[(warmup + i) % pool_batches]))
@@ -280,6 +345,7 @@ def extra_configs(dev, steps=12, warmup=4):
         net = model.model.engine().net((B, channels, 128, 128), True)
         net.x.copy_(batches[0][0]); net.target.copy_(batches[0][1])
         roof, _, _, _, fl, _ = conv_roofline(model, B, channels, dtype, 'lovasz', 1)
+        roof.pop('by_class', None)
         out[tag] = {'config': note, 'images_per_s': round(B * steps / elapsed, 1), 'ms_per_step': round(1e3 * elapsed / steps, 3), 'dtype': dtype,
                     'steps': steps, 'warmup': warmup, 'step_tflops': round(fl / (elapsed / steps) / 1e12, 1),
                     'conv_tflops': roof['achieved'], 'conv_frac_of_mfma_peak': roof['frac'], 'mfma_peak_tflops': roof['peak']}
@@ -298,7 +364,7 @@ def extra_configs(dev, steps=12, warmup=4):
     X = torch.randn(16, 3, 256, 256, device=dev)
 
     def step():
-        return I.crop_threshold(I.predict_tta(net, X, True, True), (202, 202), 0.5, cls=1)
+        return I.crop_threshold(I.predict_tta(net, X, True, True, depth_channels=False), (202, 202), 0.5, cls=1)
     step(); step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -322,6 +388,102 @@ def extra_configs(dev, steps=12, warmup=4):
     return out
 
 
+RCCL_LOG = '/tmp/salt_rccl_%d.log' % os.getpid()
+
+
+def init_rccl(rank):
+    """Bring up the RCCL process group.  RCCL prints a version banner on stdout when the first communicator is created; the contract
+    is ONE JSON line on stdout, so stdout is pointed at stderr while the process group and its communicator come up.  NCCL_DEBUG=INFO
+    goes to a per-process file; rccl_summary() quotes the lines that say which algorithm / protocol / channel count RCCL chose."""
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29511')
+    os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
+    if rank == 0 and 'NCCL_DEBUG' not in os.environ:
+        os.environ['NCCL_DEBUG'] = 'INFO'
+        os.environ.setdefault('NCCL_DEBUG_SUBSYS', 'INIT,GRAPH,TUNING')
+        os.environ['NCCL_DEBUG_FILE'] = RCCL_LOG
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        dist.init_process_group('nccl')
+        warm = torch.zeros(1 << 20, device='cuda')
+        dist.all_reduce(warm)
+        torch.cuda.synchronize()
+    finally:
+        sys.stdout.flush()
+        try:                                 # the banner sits in the C stdio buffer (fully buffered on a pipe): flush it to stderr
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
+def rccl_summary(limit=12):
+    """The NCCL_DEBUG=INFO lines that name RCCL's choices (rings / trees / channels / protocol / transport), echoed to stderr once
+    and returned for the JSON line, so a scaling run says WHICH collective ran over xGMI."""
+    import re
+    try:
+        lines = open(RCCL_LOG, errors='replace').read().splitlines()
+    except OSError:
+        return None
+    pat = re.compile(r'(Ring|Tree|Channel|channels|Algo|algo|Proto|proto|via P2P|via SHM|XGMI|xgmi|nranks|comm 0x)')
+    keep = [re.sub(r'^\S+:\d+:\d+ \[\d+\] ', '', ln) for ln in lines if pat.search(ln)]
+    out = []
+    for ln in keep:                           # one line per distinct message shape
+        key = re.sub(r'\d+', '#', ln)[:60]
+        if key not in [k for k, _ in out]:
+            out.append((key, ln[:200]))
+    out = [ln for _, ln in out[:limit]]
+    for ln in out:
+        sys.stderr.write('[rccl] ' + ln + '\n')
+    return out
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with no launcher in the environment: start N ranks of this script through torch.distributed.run
+    (the reference's nn.DataParallel needed no launcher, models.py:81-85; one process per GPU does).  Rank 0's JSON line is the
+    only thing the ranks write to stdout; the children's return code is ours."""
+    import socket
+    import subprocess
+    n = args.gpus
+    if not args.selftest_launch:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < n:
+            sys.stderr.write('bench.py: --gpus %d needs %d visible GPUs, this host shows %d (HIP_VISIBLE_DEVICES=%s); nothing was run\n'
+                             % (n, n, have, os.environ.get('HIP_VISIBLE_DEVICES', '<unset>')))
+            return 3
+    with socket.socket() as s_:                       # a free rendezvous port on the loopback interface
+        s_.bind(('127.0.0.1', 0))
+        port = s_.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')  # dmabuf IPC: RCCL's intra-node transport needs it on this driver
+    env.setdefault('OMP_NUM_THREADS', '8')
+    return subprocess.call(cmd, env=env)
+
+
+def selftest_launch_rank():
+    """Launcher self-test (tests/test_host_cpu.py): the ranks come up under gloo on CPU, agree on a MAX-reduced clock exactly as the
+    timed region does, and rank 0 prints the one JSON line.  No GPU, no model - it proves `bench.py --gpus N` starts N ranks."""
+    world, rank = int(os.environ['WORLD_SIZE']), int(os.environ['RANK'])
+    dist.init_process_group('gloo')
+    dist.barrier()
+    t0 = time.perf_counter()
+    x = torch.full((4,), float(rank + 1))
+    dist.all_reduce(x)
+    dist.barrier()
+    te = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(te, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({'metric': 'launcher self-test', 'n_gpus': world, 'ranks': dist.get_world_size(), 'backend': 'gloo',
+                          'allreduce_sum': float(x[0]), 'expected_sum': world * (world + 1) / 2.0, 'elapsed_s': float(te[0])}))
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -335,9 +497,17 @@ def main():
     ap.add_argument('--no-iou', action='store_true')
     ap.add_argument('--no-configs', action='store_true', help='skip the other BASELINE configurations (C1, fp32, C3 shape, C4)')
     ap.add_argument('--cpu-leg', default=None, help=argparse.SUPPRESS)       # child mode of the cpu_baseline leg
+    ap.add_argument('--cpu-threads', type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument('--cpu-batch', type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument('--selftest-launch', action='store_true', help=argparse.SUPPRESS)   # launcher self-test under gloo (no GPU)
     args = ap.parse_args()
     if args.cpu_leg:
-        cpu_baseline_leg(args.cpu_leg, args.loss, 1 if args.cpu_leg == 'VanillaUNet' else 3)
+        cpu_baseline_leg(args.cpu_leg, args.loss, 1 if args.cpu_leg == 'VanillaUNet' else 3, args.cpu_threads, args.cpu_batch)
+        return
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:]))
+    if args.selftest_launch:
+        selftest_launch_rank()
         return
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -346,29 +516,9 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
     torch.cuda.set_device(local)
     if world > 1 or os.environ.get('SALT_FORCE_DP_PATH'):
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29511')
-        os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
-        # RCCL prints a version banner on stdout when the first communicator is created; the contract is ONE JSON line
-        # on stdout, so stdout is pointed at stderr while the process group and its communicator come up
-        sys.stdout.flush()
-        saved = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            dist.init_process_group('nccl')
-            warm = torch.zeros(1, device='cuda')
-            dist.all_reduce(warm)
-            torch.cuda.synchronize()
-        finally:
-            sys.stdout.flush()
-            try:                                 # the banner sits in the C stdio buffer (fully buffered on a pipe): flush it to stderr
-                import ctypes
-                ctypes.CDLL(None).fflush(None)
-            except OSError:
-                pass
-            os.dup2(saved, 1)
-            os.close(saved)
-    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+        init_rccl(rank)
+    if world != args.gpus:
+        sys.exit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks' % (args.gpus, world))
     dev = torch.device('cuda', local)
 
     import salt_amd  # noqa: F401
@@ -390,6 +540,8 @@ def main():
         # after its last backward kernel (the collectives of the earlier buckets ran underneath backward)
         ex = model.dp.exposed_allreduce_ms()
         out['rccl_ranks'] = dist.get_world_size() if dist.is_initialized() else 1
+        if rank == 0:
+            out['rccl_info'] = rccl_summary()
         out['allreduce'] = {'buckets': len(list(model.dp._plans.values())[0]) if model.dp._plans else 0,
                             'gradient_bytes': int(model.model.engine().n_live * 4),
                             'exposed_allreduce_ms_per_step_rank0': round(ex, 4) if ex is not None else None}
@@ -402,7 +554,9 @@ def main():
         roof, ops, total_ms, side_ms, all_fl, dn = conv_roofline(model, B, channels, args.dtype, args.loss, 3)
         headline = args.dtype == 'bf16' and args.workload == 'r34_hyper' and B == 32
         roof['traffic'] = pmc_traffic({'conv': ('conv_mfma_kernel', 'conv_glds_kernel'), 'conv_wgrad': ('conv_wgrad_kernel',)}.get(dn, (dn,))) if headline else None
-        roof['traffic_unit'] = 'bytes per launch (rocprofv3 PMC FETCH_SIZE*2 + WRITE_SIZE, %s)' % PMC_FILE
+        roof['traffic_unit'] = ('bytes per launch (rocprofv3 PMC FETCH_SIZE*2 + WRITE_SIZE, separate --pmc passes; file %s measured at commit %s - '
+                                'PMC counters cannot be read inside the timed process)' % (PMC_FILE, pmc_commit()))
+        out['roofline_by_class'] = roof.pop('by_class')
         out['roofline'] = roof
         out['op_time_ms'] = ops
         out['op_time_serial_ms'] = round(total_ms, 3)          # every operator run back to back on ONE stream (no wgrad overlap)
@@ -424,11 +578,36 @@ def main():
         out['val_iou_note'] = ('mean IoU on 128 held-out synthetic tiles after %d training steps from random init (a smoke signal that the '
                                'step learns, not an accuracy result)' % (args.warmup + args.steps))
 
+    if rank == 0 and 'roofline_by_class' in out:           # the fused Adam + L2 kernel (28 bytes per parameter), timed after the evaluation
+        for name, _, ms in model.optimizer.prog.run_timed():
+            if name == 'adam' and ms > 0:
+                by = 28.0 * model.model.engine().n_live
+                out['roofline_by_class']['adam'] = {'launches_per_step': 1, 'ms_per_step': round(ms, 3), 'bound': 'hbm', 'achieved': round(by / (ms * 1e-3) / 1e9, 1),
+                                                    'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
     # ------------------------------------------------------------------ the other BASELINE configurations, same run (N = 1 only)
     if rank == 0 and world == 1 and not args.no_configs:
         del model, batches
         torch.cuda.empty_cache()
         out['configs'] = extra_configs(dev)
+        if not dist.is_initialized():
+            # the bucketed data-parallel step against a 1-rank RCCL communicator: what the N > 1 code path costs before any wire time
+            os.environ['SALT_FORCE_DP_PATH'] = '1'
+            try:
+                init_rccl(0)
+                m2, _, el2, _ = train_config(args.workload, args.dtype, B, args.loss, 12, 4, dev)
+                ex = m2.dp.exposed_allreduce_ms()
+                out['configs']['dp_path_1rank'] = {
+                    'config': 'the headline step through the bucketed all-reduce path (parallel.DataParallel.backward) with a 1-rank RCCL communicator',
+                    'images_per_s': round(B * 12 / el2, 1), 'ms_per_step': round(1e3 * el2 / 12, 3), 'steps': 12, 'warmup': 4,
+                    'buckets': len(list(m2.dp._plans.values())[0]) if m2.dp._plans else 0, 'rccl_info': rccl_summary(6),
+                    'exposed_allreduce_ms_per_step': round(ex, 4) if ex is not None else None}
+                del m2
+            except Exception as e:            # a missing RCCL transport on a 1-GPU box must not cost the headline line
+                out['configs']['dp_path_1rank'] = {'error': repr(e)[:200]}
+            finally:
+                os.environ.pop('SALT_FORCE_DP_PATH', None)
+            torch.cuda.empty_cache()
 
     # ------------------------------------------------------------------ CPU baseline: the oracle on the host cores (bounded sample)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -286,6 +286,7 @@ class HipNetwork(nn.Module):
 
     def _drop_engine(self):
         if self._engine is not None:
+            self._engine.release_step_graphs()
             for p in self.parameters():       # detach parameters from the flat buffers before they go away
                 p.data = p.data.clone()
                 p.grad = None

@@ -95,7 +95,7 @@ __device__ __attribute__((aligned(16))) unsigned int g_zero_piece[4] = {0u, 0u, 
 constexpr int MAXA = 9;     // halo pieces per thread: P_halo*4 <= 9*256 (6*256 for the 256-pixel tile: keeps its prefetch registers in budget)
 constexpr int maxa_for(int bm) { return bm >= 256 ? 6 : MAXA; }
 
-// Epilogue of one output tile, shared by conv_mfma_kernel and conv_mfma_persist_kernel.  C layout (32x32): col n = lane&31,
+// Epilogue of one output tile of conv_mfma_kernel.  C layout (32x32): col n = lane&31,
 // row m = (r&3) + 8*(r>>2) + 4*(lane>>5).  The accumulator tile goes through LDS (free after the main loop) so that the global stores
 // are whole 16-byte pieces of NHWC pixel rows (a wave writes full 128-B lines) instead of 2/4-byte scattered stores.
 struct TileCoord { int m_tile, n_tile, oy0, ox0, b0, n0, out_oy, out_ox; };

@@ -359,6 +359,9 @@ class Graph:
                 off, n = self.engine.grad_range(p)
                 self.grad_ready.append((off, n, len(self.bwd.ops)))
         self.tape = []
+        for b in getattr(self, '_bias_bufs', []):        # every folded channel-SE term must have met its bn_bwd, or x.grad is incomplete
+            if getattr(b, 'grad_bias', None) is not None:
+                raise SaltError('gradient bias of %s was never consumed (no BatchNorm backward read that slice)' % b.name)
         # The data-gradient weight packs of the step were enqueued on the side stream during forward (Engine.refresh): the FIRST
         # main-stream operator of the backward program joins the side stream - before any weight-gradient kernel is enqueued there,
         # so the join waits for the packs only.
@@ -483,9 +486,13 @@ class Graph:
                           coef=coef.data_ptr(), dy=y.gview(), dres=dres, accumulate_dres=acc_res, partials_ready=ready)
         bias = getattr(out.buf, 'grad_bias', None)
         if bias is not None:
+            # (c0, C, dgap): the scSE backward left the channel-SE term out of dL/d(out); THIS bn_bwd - the slice's only consumer - adds it
+            if (bias[0], bias[1]) != (out.c0, out.C):
+                raise SaltError('gradient bias of %s covers channels [%d, %d), this BatchNorm backward reads [%d, %d)'
+                                % (out.buf.name, bias[0], bias[0] + bias[1], out.c0, out.c0 + out.C))
             if ready != 0:
                 raise SaltError('a per-image gradient bias needs the reduction pass of bn_bwd (the producer of dL/da is not a convolution)')
-            self.bwd.set_fields(s2, da_bias=bias.data_ptr())
+            self.bwd.set_fields(s2, da_bias=bias[2].data_ptr())
             out.buf.grad_bias = None
         if ready == 3:
             self._fin_slot('bwd', 8 * 2 * C, (producer, 'bnb_acc'), (s2, 'fin_acc'))
@@ -1023,7 +1030,10 @@ class Graph:
                 # wherever it reads dL/dx - the broadcast-add pass over dx (read + write of the whole tensor) disappears
                 if (getattr(x.buf, 'bn_train_out', None) == (x.c0, x.C) and acc == 0 and x.B * x.H * x.W < (1 << 31)
                         and os.environ.get('SALT_SE_BIAS_FOLD', '1') != '0'):
+                    if getattr(x.buf, 'grad_bias', None) is not None:
+                        raise SaltError('two pending gradient biases on %s' % x.buf.name)
                     self.bwd.set_fields(sb, skip_bcast=1)
-                    x.buf.grad_bias = dgap
+                    x.buf.grad_bias = (x.c0, x.C, dgap)
+                    self._bias_bufs = getattr(self, '_bias_bufs', []) + [x.buf]
             self.tape.append(backward)
         return out

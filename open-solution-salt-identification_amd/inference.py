@@ -88,11 +88,21 @@ def _flip_input(X, ud, lr, depth_channels):
     return Y
 
 
-def predict_tta(net, X, flip_ud=False, flip_lr=True, variants_per_pass=None, depth_channels=True, method='mean'):
+def _looks_like_depth_channels(X):
+    """True when channel 1 of a 3-channel batch is the reference's depth ramp: constant along W and the same for every image
+    (utils.py:494-500) - an ordinary 3-channel (e.g. RGB-replicated) input is not, and must be flipped channel by channel."""
+    if X.dim() != 4 or X.shape[1] != 3:
+        return False
+    ramp = X[:, 1]
+    return bool(((ramp - ramp[:1, :, :1]).abs().max() <= 1e-6).item())
+
+
+def predict_tta(net, X, flip_ud=False, flip_lr=True, variants_per_pass=None, depth_channels=None, method='mean'):
     """Probabilities [B, C, H, W] of an eval-mode HipNetwork aggregated over the flip variants (reference default main.py:282-285:
     left-right only; BASELINE C4's "4-flip" is flip_ud=True, flip_lr=True).  ``depth_channels``: the input is the reference's
-    3-channel [gray, depth ramp, gray*ramp] batch (see _flip_input).  ``method``: 'mean' (default, neptune.yaml:80; one fused kernel)
-    or 'max' / 'min' / 'gmean' (loaders.py:727-735).
+    3-channel [gray, depth ramp, gray*ramp] batch, whose channels 1 / 2 an up-down flip must rebuild rather than flip (see
+    _flip_input); None (default) = decide from the data (channel 1 is a row ramp shared by the batch), True raises if it is not.
+    ``method``: 'mean' (default, neptune.yaml:80; one fused kernel) or 'max' / 'min' / 'gmean' (loaders.py:727-735).
 
     The variants are forwarded ``variants_per_pass`` at a time as one larger batch (default: all of them).  For bit-faithful
     handling of the asymmetric 13/14 edge pad use :func:`predict_tta_tiles`, which flips the raw tiles like the reference."""
@@ -101,6 +111,12 @@ def predict_tta(net, X, flip_ud=False, flip_lr=True, variants_per_pass=None, dep
     X = _f32c(X)
     B = X.shape[0]
     variants = tta_variants(flip_ud, flip_lr)
+    if flip_ud and depth_channels is not False:          # only an up-down flip touches the depth channels
+        is_ramp = _looks_like_depth_channels(X)
+        if depth_channels and not is_ramp:
+            raise SaltError('predict_tta(depth_channels=True): channel 1 of the batch is not a row ramp (utils.py:494-500); pass '
+                            'depth_channels=False for an ordinary 3-channel input')
+        depth_channels = is_ramp
     per = len(variants) if not variants_per_pass else int(variants_per_pass)
     outs = []
     with torch.no_grad():

@@ -11,6 +11,8 @@ parameter buffers), the optimizer is one fused Adam kernel, ``_fit_loop`` runs f
 -> (bucketed RCCL all-reduce overlapped with backward) -> Adam without touching torch autograd, and
 ``nn.DataParallel`` (models.py:81-85) is replaced by one process per GPU (parallel.py).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -104,8 +106,6 @@ class SegmentationModel(Model):
         self.dp = parallel.DataParallel.from_env()
         # opt-in: one-GPU training replays the whole step as a hipGraph (training_config['step_graph'] / SALT_STEP_GRAPH=1);
         # the eager two-stream step is faster
-        import os
-        self._eager_done = set()
         self.step_graph = bool(int(os.environ.get('SALT_STEP_GRAPH', '1' if (training_config or {}).get('step_graph', False) else '0')))
 
     # ------------------------------------------------------------------ reference surface
@@ -181,7 +181,8 @@ class SegmentationModel(Model):
 
     def _fused_step(self, X, target, kind, weight):
         eng = self.model.engine(X.device)
-        if self.step_graph and not self.dp._active() and (id(eng), tuple(X.shape), kind) in self._eager_done:
+        # 'first step of a shape ran eagerly' is remembered ON the engine (a rebuilt engine starts empty - no recycled id() can skip it)
+        if self.step_graph and not self.dp._active() and (tuple(X.shape), kind) in eng.eager_done:
             # the whole step (pack, forward, loss, backward, Adam; both streams) replayed as ONE hipGraph launch (the first step of
             # a shape runs eagerly: lazy one-time work - kernel attributes, workspace allocation - must not fall into the capture)
             net = eng.net(tuple(X.shape), True)
@@ -196,7 +197,7 @@ class SegmentationModel(Model):
         net.target.copy_(target[:, :K])
         net.loss_program(kind, weight).run()
         self.dp.backward(eng, net, self.optimizer)
-        self._eager_done.add((id(eng), tuple(X.shape), kind))
+        eng.eager_done.add((tuple(X.shape), kind))
         return net.loss[0].clone()
 
     def transform(self, datagen, validation_datagen=None, *args, **kwargs):

@@ -100,7 +100,7 @@ class Engine:
         self._folded_version = None
         self.world = 1
         self.side_stream = torch.cuda.Stream(device=device)     # weight-gradient kernels overlap the data-gradient chain
-        self._step_graphs = {}
+        self.eager_done = set()          # (shape, loss kind) whose first training step already ran eagerly (models.SegmentationModel._fused_step)
 
     # ------------------------------------------------------------------ flat parameter storage
     def _flatten(self):
@@ -293,10 +293,15 @@ class Engine:
         """Capture pack -> forward (two streams) -> data-gradient packs -> loss -> backward (two streams) -> Adam of one compiled
         instance into a hipGraph (cached); replaying it is one launch instead of ~490.  Everything the step touches is static
         device memory; the learning rate / bias corrections live in the optimizer's device `hyper` vector (adam_tick)."""
-        key = (id(net), kind, float(loss_scale), id(optimizer))
-        g = self._step_graphs.get(key)
-        if g is not None:
-            return g
+        # the cache lives ON the compiled instance (which this engine owns) and holds the optimizer object itself: a rebuilt engine /
+        # net / optimizer can never alias a stale executable through a recycled id()
+        cache = net.__dict__.setdefault('_step_graphs', {})
+        key = (kind, float(loss_scale))
+        hit = cache.get(key)
+        if hit is not None and hit[0] is optimizer:
+            return hit[1]
+        if hit is not None:
+            lib.salt_graph_destroy(hit[1])
         if getattr(self, '_pack_batched_n', -1) != len(self._pack_ops):
             self._build_pack_batch()
         optimizer._bind()
@@ -312,8 +317,8 @@ class Engine:
                 net.fwd.run(stream=st, side=self.side_stream)
                 if len(self._pack_batched_bwd):
                     # fork: the data-gradient packs run on the side stream under the loss kernel; backward's first operator joins
-                    lib.salt_program_run_streams_ex(ctypes.cast(self._pack_fork_entries(), ctypes.c_void_p), 0, 1, ctypes.c_void_p(st.cuda_stream),
-                                                    ctypes.c_void_p(self.side_stream.cuda_stream), 0)
+                    _abi.check(lib.salt_program_run_streams_ex(ctypes.cast(self._pack_fork_entries(), ctypes.c_void_p), 0, 1, ctypes.c_void_p(st.cuda_stream),
+                                                               ctypes.c_void_p(self.side_stream.cuda_stream), 0), 'pack_fork')
                 loss_prog.run(stream=st)
                 net.bwd.run(stream=st, side=self.side_stream)
                 optimizer.prog.run(stream=st)
@@ -321,8 +326,14 @@ class Engine:
                 rc = lib.salt_graph_end(ctypes.c_void_p(st.cuda_stream), ctypes.byref(exec_))
             _abi.check(rc, 'graph_end')
         torch.cuda.synchronize()
-        self._step_graphs[key] = exec_
+        cache[key] = (optimizer, exec_)
         return exec_
+
+    def release_step_graphs(self):
+        """Destroy the captured step executables of every compiled instance (called when the engine is dropped)."""
+        for net in self.nets.values():
+            for _, ex in net.__dict__.pop('_step_graphs', {}).values():
+                lib.salt_graph_destroy(ex)
 
     def _pack_fork_entries(self):
         """The data-gradient pack launch as a one-entry program tagged for the side stream (the executor forks with an event)."""

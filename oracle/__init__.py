@@ -5,7 +5,7 @@ reference's U-Net training/inference path (neptune-ai/open-solution-salt-identif
 It exists so that the hand-written HIP kernels can be checked against something that runs
 everywhere, including the GPU box where /root/reference does not exist.
 
-Rules (enforced by tests/test_layout_rules.py):
+Rules (enforced by tests/test_host_cpu.py::test_product_never_imports_the_oracle_or_reads_the_reference):
   * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it;
   * the product package never imports it and never falls back to it.
 

@@ -21,3 +21,16 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if 'gpu' in it.keywords:
             it.add_marker(skip)
+
+
+DETERMINISTIC_ENV = {'SALT_BN_FIN': '0', 'SALT_SE_SHARDS': '0'}
+
+
+@pytest.fixture
+def deterministic_sums(monkeypatch):
+    """Bit-for-bit comparisons of two runs need sums whose ORDER is fixed.  The default step (SALT_BN_FIN=2 / SALT_SE_SHARDS=1) adds the
+    BatchNorm and SE statistics with fp64 atomics - reproducible in practice, not by construction; SALT_BN_FIN=0 /
+    SALT_SE_SHARDS=0 selects the per-tile partials + fixed-order finalize protocol, which is (README: deterministic training)."""
+    for k, v in DETERMINISTIC_ENV.items():
+        monkeypatch.setenv(k, v)
+    return dict(DETERMINISTIC_ENV)

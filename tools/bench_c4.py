@@ -32,7 +32,7 @@ crop = (202, 202) if args.size == 256 else (101, 101)
 
 
 def step():
-    prob = I.predict_tta(net, X, True, True)
+    prob = I.predict_tta(net, X, True, True, depth_channels=False)
     return I.crop_threshold(prob, crop, 0.5, cls=1)
 
 
