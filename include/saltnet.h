@@ -144,6 +144,11 @@ typedef struct {
 int salt_conv(const salt_conv_args*, void* stream);
 /* number of stats partials a launch with these args writes (host sizes the workspace with it) */
 int salt_conv_stats_parts(const salt_conv_args*);
+/* which kernel salt_conv runs these arguments on: 1..5 conv_mfma_kernel tile configs, 6..8 conv_glds_kernel, 9 conv_ws_kernel (the
+ * weight-stationary multi-tile kernel of the 3x3 layers with <= 64 channels: bf16, Cin in {32, 64}, Cout in {32, 64}, output grid a
+ * multiple of 16 x 16).  `cfg` & 0xff: 0 = heuristic, 1..8 = that config, 9 = conv_ws_kernel wherever it applies (else heuristic);
+ * with 9, cfg >> 8 caps the workgroups per XCD (0 = one per CU). */
+int salt_conv_kernel_id(const salt_conv_args*);
 
 /* weight gradient of the same family:
  *   dW[t][a][b] = sum_{pixels p of P} P[p, a] * Q[pad(p*q_step + tap[t]), b]

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(PKG)
 INC = os.path.join(ROOT, 'include')
 OBJ = os.path.join(HERE, '_obj')
 LIB = os.path.join(PKG, 'libsaltnet_hip.so')
-SOURCES = ['runtime.hip', 'conv_mfma.hip', 'conv_small.hip', 'elementwise.hip', 'se.hip', 'loss.hip', 'input.hip']
+SOURCES = ['runtime.hip', 'conv_mfma.hip', 'conv_ws.hip', 'conv_small.hip', 'elementwise.hip', 'se.hip', 'loss.hip', 'input.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + INC, '-I' + HERE, '-Wno-unused-value']
 
 
@@ -57,7 +57,7 @@ def build(force=False, verbose=True):
     if force:
         for f in os.listdir(OBJ):
             os.remove(os.path.join(OBJ, f))
-    with ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         results = list(ex.map(_compile, SOURCES))
     objs = [o for o, _ in results]
     if any(ch for _, ch in results) or not os.path.exists(LIB):

@@ -66,6 +66,11 @@ hipEvent_t salt_take_fork_event();
 #define SALT_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { \
     salt_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_)); return (int)e_; } } while (0)
 
+// conv_ws.hip: the weight-stationary multi-tile kernel of the <= 64-channel 3x3 layers; salt_conv tries it first
+bool conv_ws_eligible(const salt_conv_args* a);
+int conv_ws_tiles(const salt_conv_args* a);
+int conv_ws_launch(const salt_conv_args* a, hipStream_t st);
+
 static inline int ilog2_ceil(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline bool view_ok(const salt_view& v) { return v.p && v.B > 0 && v.H > 0 && v.W > 0 && v.C > 0 && v.cs >= v.C; }

@@ -1,0 +1,194 @@
+"""conv_ws_kernel (csrc/conv_ws.hip), the weight-stationary multi-tile kernel of the 3x3 layers with <= 64 channels - torchvision
+BasicBlock convs of ResNet34 layer1 (architectures/encoders.py:6-45), Conv2dBnRelu of the shallow DecoderBlocks
+(architectures/base.py:7-37) and their data gradients - through the C-ABI against torch CPU fp32 and against conv_mfma_kernel on
+the same launch.  cfg = 9 | cap << 8 asks for the kernel wherever it applies and caps the workgroups per XCD, so that small tensors
+walk the whole pipeline: several tiles per workgroup, both wave groups, the halo DMA issued from the epilogue, the aliased
+transposition slices of the 64 -> 64 variant."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from helpers import assert_close
+
+pytestmark = pytest.mark.gpu
+TOLBF = 4e-2
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def _force_cfg(g, cfg):
+    orig = g._conv_launch
+
+    def launch(*args, **kw):
+        kw.setdefault('cfg', cfg)
+        return orig(*args, **kw)
+    g._conv_launch = launch
+    orig_parts = g._conv_parts
+    g._conv_parts = lambda *a_, **k_: orig_parts(*a_, cfg=cfg, **k_)
+
+
+def _kernel_ids(prog):
+    from salt_amd._abi import lib
+    return [lib.salt_conv_kernel_id(ctypes.byref(s)) for name, _, s in prog.ops if name == 'conv']
+
+
+# B, Cin, H, W, Cout, workgroups per XCD (0: one per tile, up to one per CU)
+WS_CASES = [
+    (2, 64, 32, 32, 64, 0),      # 8 tiles, 8 workgroups: one tile each (group 1 idles)
+    (1, 64, 64, 64, 64, 1),      # 16 tiles over 8 workgroups: 2-tile pipelines, both groups, no mid-kernel DMA (the C2 layer1 regime)
+    (3, 64, 64, 32, 64, 1),      # 24 tiles: 3 per workgroup - the epilogue issues the next halo into its own transposition slices
+    (5, 64, 32, 64, 32, 1),      # 64 -> 32 (DecoderBlock dec1.conv1), 5 tiles per workgroup; its data gradient is the 32 -> 64 variant
+    (5, 32, 32, 64, 64, 1),      # 32 -> 64 (dec1.conv2), data gradient 64 -> 32
+    (2, 64, 48, 80, 64, 2),      # 30 tiles, 16 workgroups: uneven tile counts (2 and 1) inside one XCD range
+]
+
+
+@pytest.mark.parametrize('case', WS_CASES)
+@pytest.mark.parametrize('replicate', [False, True])
+def test_ws_conv_bn_relu_train_vs_torch(case, replicate):
+    """conv (+ bias) -> train-mode BN -> ReLU, bf16: forward (statistics through the fp64 shards), data gradient, weight / BN gradients.
+    replicate = the reference's top/right replicate padding (base.py:21-27): the forward launch clamps its halo rows."""
+    from gpu_harness import BlockRun
+    B, Cin, H, W, Cout, cap = case
+    cfg = 9 | (cap << 8)
+    conv = nn.Conv2d(Cin, Cout, 3, 1, 0 if replicate else 1, bias=True)
+    bn = nn.BatchNorm2d(Cout)
+    mod = nn.Sequential(conv, bn)
+    with torch.no_grad():
+        conv.weight.copy_(_rand(conv.weight.shape, 1, (2.0 / (Cin * 9)) ** 0.5)); conv.bias.copy_(0.1 * _rand((Cout,), 6))
+        bn.weight.copy_(1 + 0.1 * _rand((Cout,), 2)); bn.bias.copy_(0.1 * _rand((Cout,), 3))
+    x = _rand((B, Cin, H, W), 4).bfloat16().float()
+
+    def emit(g, a):
+        _force_cfg(g, cfg)
+        return g.conv(a, conv, bn, relu=True, replicate=replicate)
+
+    mod.train()
+    run = BlockRun(mod, [x], emit, train=True, dtype='bf16')
+    assert _kernel_ids(run.g.fwd) == [9]
+    if not replicate:
+        assert _kernel_ids(run.g.bwd) == [9]                      # the plain data gradient; the replicate one is the fused-fold launch
+    y = run.forward()
+    ref_conv, ref_bn = nn.Conv2d(Cin, Cout, 3, 1, 0 if replicate else 1, bias=True), nn.BatchNorm2d(Cout)
+    with torch.no_grad():
+        ref_conv.weight.copy_(conv.weight.detach().cpu().bfloat16().float()); ref_conv.bias.copy_(conv.bias.detach().cpu())
+        ref_bn.weight.copy_(bn.weight.detach().cpu()); ref_bn.bias.copy_(bn.bias.detach().cpu())
+    xr = x.clone().requires_grad_(True)
+    xin = F.pad(xr, (0, 2, 2, 0), mode='replicate') if replicate else xr
+    yr = F.relu(ref_bn(ref_conv(xin)))
+    assert_close(y, yr, TOLBF, 'y')
+    assert_close(bn.running_mean.cpu(), ref_bn.running_mean, TOLBF, 'running_mean')
+    assert_close(bn.running_var.cpu(), ref_bn.running_var, TOLBF, 'running_var')
+    gy = _rand(tuple(yr.shape), 5)
+    yr.backward(gy)
+    gx, grads = run.backward(gy.to('cuda:0'))
+    for name, got, want in [('dgrad', gx[0], xr.grad), ('wgrad', grads['0.weight'], ref_conv.weight.grad)]:
+        l2 = float((got.double() - want.double()).norm() / want.double().norm())
+        assert l2 <= TOLBF, '%s: rel-L2 %.3e' % (name, l2)
+    assert_close(grads['1.weight'], ref_bn.weight.grad, 3 * TOLBF, 'dgamma')
+    assert_close(grads['1.bias'], ref_bn.bias.grad, 3 * TOLBF, 'dbeta')
+    y2 = run.forward()                                             # the program is re-runnable (shards cleared by its head)
+    assert float((y2.float() - y.float()).abs().max()) <= 1e-6 * float(y.float().abs().max())
+
+
+@pytest.mark.parametrize('case', [(1, 64, 32, 32, 64, 64, 1), (3, 64, 64, 32, 64, 64, 1), (2, 32, 64, 64, 64, 32, 1), (2, 64, 32, 64, 32, 64, 1)])
+def test_ws_equals_conv_mfma_kernel_on_a_residual_block(case):
+    """A BasicBlock-shaped chain (conv-BN-ReLU, conv-BN, + identity, ReLU) in train mode, once on conv_ws_kernel and once on
+    conv_mfma_kernel: forward statistics, (+)= data gradients, the BatchNorm-backward sums carried by the second layer's data gradient
+    (with the residual's ReLU mask read from the block output) - results of the two kernels on the same launches agree to bf16
+    rounding of single values (they sum in different orders), and both match torch."""
+    from gpu_harness import BlockRun
+    B, Cin, H, W, Cmid, Cout, cap = case
+    res_ok = Cin == Cout
+    outs = {}
+    for tag, cfg in (('ws', 9 | (cap << 8)), ('mfma', 2)):
+        c1, b1, c2, b2 = nn.Conv2d(Cin, Cmid, 3, 1, 1, bias=False), nn.BatchNorm2d(Cmid), nn.Conv2d(Cmid, Cout, 3, 1, 1, bias=False), nn.BatchNorm2d(Cout)
+        mod = nn.Sequential(c1, b1, c2, b2)
+        with torch.no_grad():
+            c1.weight.copy_(_rand(c1.weight.shape, 11, (2.0 / (Cin * 9)) ** 0.5)); c2.weight.copy_(_rand(c2.weight.shape, 12, (2.0 / (Cmid * 9)) ** 0.5))
+            for i, b in enumerate((b1, b2)):
+                b.weight.copy_(1 + 0.1 * _rand(b.weight.shape, 13 + i)); b.bias.copy_(0.1 * _rand(b.bias.shape, 15 + i))
+        x = _rand((B, Cin, H, W), 17).bfloat16().float()
+
+        def emit(g, a):
+            _force_cfg(g, cfg)
+            # a leading 1x1-free identity consumer keeps `a` a plain activation; the block: a -> conv1 -> conv2 (+ a)
+            h = g.conv(a, c1, b1, relu=True)
+            return g.conv(h, c2, b2, relu=True, res=a if res_ok else None)
+
+        mod.train()
+        run = BlockRun(mod, [x], emit, train=True, dtype='bf16')
+        ids_f, ids_b = _kernel_ids(run.g.fwd), _kernel_ids(run.g.bwd)
+        if tag == 'ws':
+            assert ids_f == [9, 9] and ids_b == [9, 9], (ids_f, ids_b)
+            ready = [int(st.partials_ready) for name, _, st in run.g.bwd.ops if name == 'bn_bwd']
+            assert ready == [0, 3], ready          # layer 1's BatchNorm-backward sums came from layer 2's data-gradient launch
+        else:
+            assert 9 not in ids_f + ids_b
+        y = run.forward()
+        gy = _rand(tuple(y.shape), 18)
+        gx, grads = run.backward(gy.to('cuda:0'))
+        outs[tag] = (y, gx[0], grads, {k: v.detach().cpu().clone() for k, v in mod.state_dict().items()})
+    # the two kernels against each other
+    y_w, y_m = outs['ws'][0], outs['mfma'][0]
+    assert_close(y_w, y_m, 1e-2, 'forward ws vs mfma')
+    l2 = float((outs['ws'][1].double() - outs['mfma'][1].double()).norm() / outs['mfma'][1].double().norm())
+    assert l2 < 1e-2, 'dgrad ws vs mfma rel-L2 %.3e' % l2
+    for k in outs['ws'][2]:
+        a, b = outs['ws'][2][k].double(), outs['mfma'][2][k].double()
+        assert float((a - b).norm() / (b.norm() + 1e-12)) < 2e-2, k
+    for k in outs['ws'][3]:
+        if 'running' in k:
+            assert_close(outs['ws'][3][k], outs['mfma'][3][k], 1e-3, k)
+    # and against torch CPU fp32 (weights rounded to bf16 as the kernels see them)
+    c1r, b1r, c2r, b2r = nn.Conv2d(Cin, Cmid, 3, 1, 1, bias=False), nn.BatchNorm2d(Cmid), nn.Conv2d(Cmid, Cout, 3, 1, 1, bias=False), nn.BatchNorm2d(Cout)
+    with torch.no_grad():
+        c1r.weight.copy_(_rand(c1r.weight.shape, 11, (2.0 / (Cin * 9)) ** 0.5).bfloat16().float())
+        c2r.weight.copy_(_rand(c2r.weight.shape, 12, (2.0 / (Cmid * 9)) ** 0.5).bfloat16().float())
+        for i, b in enumerate((b1r, b2r)):
+            b.weight.copy_(1 + 0.1 * _rand(b.weight.shape, 13 + i)); b.bias.copy_(0.1 * _rand(b.bias.shape, 15 + i))
+    xr = _rand((B, Cin, H, W), 17).bfloat16().float().requires_grad_(True)
+    hr = F.relu(b1r(c1r(xr)))
+    yr = b2r(c2r(hr))
+    yr = F.relu(yr + xr) if res_ok else F.relu(yr)
+    assert_close(y_w, yr, 2 * TOLBF, 'forward vs torch')
+    yr.backward(_rand(tuple(yr.shape), 18))
+    l2 = float((outs['ws'][1].double() - xr.grad.double()).norm() / xr.grad.double().norm())
+    assert l2 < 2 * TOLBF, 'dgrad vs torch rel-L2 %.3e' % l2
+
+
+@pytest.mark.parametrize('case', [(2, 64, 32, 32, 64, 1), (4, 64, 32, 32, 32, 1), (4, 32, 32, 32, 64, 1)])
+def test_ws_eval_folded_bn_relu_vs_torch(case):
+    """eval mode: bias + folded BatchNorm + ReLU in the epilogue (salt_conv_args.bias / scale / shift / relu)."""
+    from gpu_harness import BlockRun
+    B, Cin, H, W, Cout, cap = case
+    conv, bn = nn.Conv2d(Cin, Cout, 3, 1, 1, bias=True), nn.BatchNorm2d(Cout)
+    mod = nn.Sequential(conv, bn)
+    with torch.no_grad():
+        conv.weight.copy_(_rand(conv.weight.shape, 1, (2.0 / (Cin * 9)) ** 0.5)); conv.bias.copy_(0.1 * _rand((Cout,), 6))
+        bn.weight.copy_(1 + 0.1 * _rand((Cout,), 2)); bn.bias.copy_(0.1 * _rand((Cout,), 3))
+        bn.running_mean.copy_(0.2 * _rand((Cout,), 7)); bn.running_var.copy_(1 + 0.3 * _rand((Cout,), 8).abs())
+    x = _rand((B, Cin, H, W), 4).bfloat16().float()
+
+    def emit(g, a):
+        _force_cfg(g, 9 | (cap << 8))
+        return g.conv(a, conv, bn, relu=True)
+
+    mod.eval()
+    run = BlockRun(mod, [x], emit, train=False, dtype='bf16')
+    assert _kernel_ids(run.g.fwd) == [9]
+    y = run.forward()
+    rc, rb = nn.Conv2d(Cin, Cout, 3, 1, 1, bias=True), nn.BatchNorm2d(Cout)
+    rc.load_state_dict({k: v.detach().cpu() for k, v in conv.state_dict().items()}); rb.load_state_dict({k: v.detach().cpu() for k, v in bn.state_dict().items()})
+    with torch.no_grad():
+        rc.weight.copy_(rc.weight.bfloat16().float())
+    rb.eval()
+    with torch.no_grad():
+        yr = F.relu(rb(rc(x)))
+    assert_close(y, yr, TOLBF, 'eval y')
