@@ -14,16 +14,19 @@
 //   * The 8 waves are TWO groups of 4.  A group alternates between two roles, one phase each, and the groups run in antiphase:
 //       MMA(tile k): 4 waves x (64 pixels x all output channels), MI x NI = 2 x 2 register blocking (one ds_read_b128 per MFMA),
 //                    all 9 taps x all chunks straight through - no barrier inside: operands are fully resident;
-//       EPI(tile k): the same waves, one phase later, with the tile still in their accumulators: BatchNorm statistics from the
-//                    registers, bf16 rounding, transposition of the wave's own 64 x Cout block through a WAVE-PRIVATE LDS region
-//                    (no cross-wave dependency, hence no barrier), whole 128-byte NHWC pixel rows to HBM, (+)= / BatchNorm-backward
-//                    sums for data gradients, and the LDS-DMA of the halo of tile k+2 into the buffer tile k just released.
+//       EPI(tile k): the same waves, one phase later, with the tile still in their accumulators - and NO trip through LDS: the MFMA
+//                    operands are swapped (A = weights, B = pixels), so a lane holds, for ONE pixel, 4 x 4 consecutive output
+//                    channels per 32 x 32 block; v_cvt_pk_bf16_f32 + v_permlane32_swap pair the two half-waves into whole 16-byte
+//                    pieces of the NHWC pixel row, which go straight to HBM ((+)= and the BatchNorm-backward operand tiles are
+//                    16-byte loads at the same addresses); then the LDS-DMA of the halo of tile k+2 into the buffer tile k released.
 //     So the epilogue + next-tile load of one group hide under the MFMAs of the other; each SIMD hosts one wave of either group.
-//     ONE raw s_barrier per phase (counted vmcnt, never __syncthreads: DMA stays in flight across it).
-//   * 64 -> 64 leaves no LDS for a separate transposition buffer: a wave transposes inside the slice of ITS group's halo buffer
-//     that its OWN next-tile DMA pieces will overwrite (contiguous piece ownership), and issues those pieces only after its reads.
-//   * Per-workgroup sums (BatchNorm forward statistics, BatchNorm-backward sums) are carried in registers across all tiles of the
-//     workgroup and leave as ONE set of fp64 shard atomics per workgroup (salt_conv_args.fin_acc / bnb_acc without ticket).
+//     ONE raw s_barrier per phase (never __syncthreads inside the loop: DMA stays in flight across a phase).
+//   * Per-channel sums (BatchNorm forward statistics, BatchNorm-backward sums) are per-LANE fp32 accumulators over all tiles of the
+//     workgroup (a lane's pixels differ, its channel set does not); ONE halving butterfly over the 32 lanes at kernel end, an 8-wave
+//     merge through LDS, and ONE set of fp64 shard atomics per workgroup (salt_conv_args.fin_acc / bnb_acc without ticket).
+//   * First version of this kernel (kept in git history, profiles/r03_ws_clocks_v1.txt): lane = channel, transposition of the tile
+//     through wave-private LDS slices.  In-kernel clocks: epilogue 16.7 k cycles per 256 x 64 tile against 7.2 k for its MFMAs
+//     (register spills around 64 ds_write_b16 + the store loop) - 25 us per 64 -> 64 @64x64 launch against 17.7 for conv_mfma_kernel.
 //
 // Scope (host: conv_ws_eligible): bf16, 9 taps inside a 3 x 3 window, unit steps, Cin in {32, 64}, Cout in {32, 64}, output grid a
 // multiple of 16 x 16 and equal to y, zero or replicate (clamp) padding, bias / folded BN / ReLU / accumulate / statistics shards /
@@ -54,7 +57,7 @@ struct WsKP {
 
 __device__ __attribute__((aligned(16))) unsigned int g_ws_zero[4] = {0u, 0u, 0u, 0u};
 #if SALT_WS_CLK
-__device__ unsigned long long g_ws_clk[256 * 32];
+__device__ unsigned long long g_ws_clk[256 * 48];
 #endif
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -69,7 +72,22 @@ template <int N> __device__ __forceinline__ void ws_wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
 }
 
-template <int NCH, int NI>
+// One step of the halving butterfly that sums per-lane values over the 32 lanes of a half-wave: exchange with lane ^ (1 << S); a lane
+// whose bit S is clear keeps the lower half of its N values, else the upper half, and adds the partner's copy of the half it keeps.
+// After steps 0 .. 3 on 16 values (and a plain xor-16 add) v[0] of lane l holds the total of value index
+// 8 b0 + 4 b1 + 2 b2 + b3 (b = bits of l & 31).
+template <int N, int S> __device__ __forceinline__ void ws_halve(float* v, int l31) {
+    const bool up = (l31 >> S) & 1;
+#pragma unroll
+    for (int i = 0; i < N / 2; ++i) {
+        const float keep = up ? v[i + N / 2] : v[i], give = up ? v[i] : v[i + N / 2];
+        v[i] = keep + __shfl_xor(give, 1 << S);
+    }
+}
+
+// MODE 0: bias / folded BN / ReLU / (+)=;  1: + train-mode BatchNorm statistics of the result;  2: (+)= and the BatchNorm-backward
+// sums of the stored gradient (salt_conv_args.bnb_*)
+template <int NCH, int NI, int MODE>
 __global__ __launch_bounds__(512) void conv_ws_kernel(WsKP p) {
     typedef bf16_t T;
     constexpr int BN = 32 * NI, NT = 9, MI = 2;
@@ -78,16 +96,9 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsKP p) {
     constexpr int WP = NCH * NT * BN / 16;             // weight pieces
     constexpr int NSW = (WP + 7) / 8;                  // weight DMA instructions per wave (8 waves)
     constexpr int NSH = (HP + 3) / 4;                  // halo DMA instructions per wave and tile (4 waves of a group)
-    constexpr bool ALIAS = (NCH == 2 && NI == 2);      // no room for a separate transposition buffer
     constexpr int W_BYTES = WP * 1024, H_BYTES = HP * 1024, HC_BYTES = HPC * 1024;
-    constexpr int PITCHB = BN * 2 + 16;                // staged pixel row: BN bf16 + 16 bytes (bank spread)
-    constexpr int STG_WAVE = 64 * PITCHB;
-    constexpr int OFF_H = W_BYTES, OFF_STG = OFF_H + 2 * H_BYTES;
-    constexpr int OFF_DUMMY = ALIAS ? OFF_STG : OFF_STG + 4 * STG_WAVE;
-    constexpr int OFF_BNB = OFF_DUMMY + 1024;          // [4][BN] floats: mean, invstd, gamma * invstd, beta - mean * gamma * invstd
-    constexpr int PPO = BN / 8;                        // 16-byte pieces per output pixel row
-    constexpr int NPC = 64 * PPO / 64;                 // pieces per lane of a wave's 64 x BN block (= PPO)
-    static_assert(!ALIAS || (HP == 42 && STG_WAVE <= 10 * 1024), "aliased transposition slices");
+    constexpr int OFF_H = W_BYTES, OFF_DUMMY = OFF_H + 2 * H_BYTES;
+    constexpr int OFF_CONST = OFF_DUMMY + 1024;        // [4][BN] floats: MODE 0 / 1 bias, scale, shift; MODE 2 mean, invstd, gamma invstd, beta - mean gamma invstd
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -109,8 +120,8 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsKP p) {
         c.ox0 = tx << 4; c.oy0 = (r % p.tiles_y) << 4; c.b = r / p.tiles_y; return c;
     };
 #if SALT_WS_CLK
-    unsigned long long clk[16]; int nclk = 0;
-    auto stamp = [&]() { if (nclk < 16) clk[nclk++] = __builtin_readcyclecounter(); };
+    unsigned long long clk[24]; int nclk = 0;
+    auto stamp = [&]() { if (nclk < 24) clk[nclk++] = __builtin_readcyclecounter(); };
 #else
     auto stamp = [&]() {};
 #endif
@@ -132,9 +143,6 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsKP p) {
             dma(src, real ? q * 1024 : OFF_DUMMY);
         }
     };
-    // halo piece owned by slot i of wave wm: ALIAS - a contiguous range (11, 11, 10, 10 pieces), so that the wave's transposition
-    // slice is exactly what its own DMA overwrites; otherwise round-robin
-    const int a_start = wm * 10 + (wm < 2 ? wm : 2), a_cnt = wm < 2 ? 11 : 10;
     auto issue_halo = [&](const TC& c, int g) {
         int ln = lane;
         asm volatile("" : "+v"(ln));             // keeps the per-piece index math INSIDE the tile loop: hoisted to kernel entry it is spilled around the MFMA phases
@@ -143,8 +151,8 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsKP p) {
         const bool clamp = p.pad_mode != 0;
 #pragma unroll
         for (int i = 0; i < NSH; ++i) {
-            const int pidx = ALIAS ? a_start + i : wm + 4 * i;
-            const bool real = ALIAS ? i < a_cnt : pidx < HP;
+            const int pidx = wm + 4 * i;                                       // round-robin over the group's 4 waves
+            const bool real = pidx < HP;
             const int ch = (NCH > 1 && pidx >= HPC) ? 1 : 0;
             const int row = (pidx - ch * HPC) * 16 + (ln >> 2);
             const int hy = (int)__umulhi((unsigned)row, 238609295u);          // row / 18 for row < 2^16 (2^32 / 18 + 1)
@@ -159,18 +167,30 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsKP p) {
         }
     };
 
-    // ---- prologue: the weights (all waves), then each group's first halo tile
+    // ---- prologue: the weights (all waves), then each group's first halo tile; per-channel epilogue constants into LDS
     issue_weights();
     if (grp < n_my) issue_halo(coords(tile_of(grp)), grp);
+    if (tid < BN) {
+        float* sc = reinterpret_cast<float*>(smem + OFF_CONST);
+        if (MODE == 2) {
+            if (p.bnb_acc) {
+                const float mu = p.bnb_mean[tid], is = p.bnb_invstd[tid], k = p.bnb_gamma[tid] * is;
+                sc[tid] = mu; sc[BN + tid] = is; sc[2 * BN + tid] = k; sc[3 * BN + tid] = p.bnb_beta[tid] - mu * k;
+            }
+        } else {
+            sc[tid] = p.bias ? p.bias[tid] : 0.f; sc[BN + tid] = p.scale ? p.scale[tid] : 1.f; sc[2 * BN + tid] = p.shift ? p.shift[tid] : 0.f;
+        }
+    }                                                                      // (read after the first phase barrier at the earliest)
 
-    // ---- fragment addressing: the lane's halo pixel per M sub-tile is tile invariant; the 18 + 18 A addresses derived from it are
-    // recomputed at the head of every MFMA phase (kept live across the epilogue they were spilled to scratch)
+    // ---- fragment addressing: the lane's halo pixel per M sub-tile is tile invariant
     int pbase[MI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = wm * 64 + i * 32 + ws_perm(l31);
         pbase[i] = (m >> 4) * 18 + (m & 15);
     }
+    // acc[i][j]: D = W X^T of pixel sub-tile i, channel block j: lane = pixel ws_perm(l31) of the sub-tile, register r = channel
+    // 32 j + (r & 3) + 8 (r >> 2) + 4 khalf
     f32x16 acc[MI][NI];
     struct Frag { u32x4 a[MI], b[NI]; };
     auto mma_tile = [&](int g) {
@@ -179,7 +199,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsKP p) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             int pb = pbase[i];
-            asm volatile("" : "+v"(pb));                                     // not hoistable: see above
+            asm volatile("" : "+v"(pb));                                     // recomputed per tile: kept live across the epilogue these 36 addresses were spilled
 #pragma unroll
             for (int t = 0; t < NT; ++t) a_addr[t][i] = ws_swz(pb + p.tap_off[t], khalf);
         }
@@ -202,157 +222,157 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsKP p) {
 #pragma unroll
             for (int j = 0; j < NI; ++j) f.b[j] = *reinterpret_cast<const u32x4*>(smem + (c * NT + t) * (BN * 64) + (b_addr[j] ^ hx));
         };
-        auto mma_frag = [&](const Frag& f) {
+        auto mma_frag = [&](const Frag& f) {                                 // operands swapped: rows of D = output channels
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.a[i]), __builtin_bit_cast(bf16x8, f.b[j]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.b[j]), __builtin_bit_cast(bf16x8, f.a[i]), acc[i][j], 0, 0, 0);
         };
+        // fragment ring of 3 stages: the reads of stage s + 2 are issued before the MFMAs of stage s.  One wave per SIMD feeds the matrix
+        // pipe here (its partner on the SIMD is in the epilogue role), so nobody else covers its LDS latency: with a 2-stage ring the
+        // phase ran at 64 % of the MFMA rate alone on the CU (in-kernel clocks, profiles/r03_ws_clocks_v1.txt)
         constexpr int NST = NCH * NT * 2;
-        Frag f0, f1;
-        load_frag(0, f0);
-        __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
+        Frag f[3];
+        load_frag(0, f[0]);
+        load_frag(1, f[1]);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * (MI + NI), 0);
 #pragma unroll
-        for (int s = 0; s < NST; s += 2) {
-            load_frag(s + 1, f1);
-            mma_frag(f0);
-            __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);         // the reads of stage s+1 ...
-            __builtin_amdgcn_sched_group_barrier(0x008, MI * NI, 0);         // ... then the MFMAs of stage s
-            if (s + 2 < NST) load_frag(s + 2, f0);
-            mma_frag(f1);
+        for (int s = 0; s < NST; ++s) {
+            if (s + 2 < NST) load_frag(s + 2, f[(s + 2) % 3]);
+            mma_frag(f[s % 3]);
             if (s + 2 < NST) __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, MI * NI, 0);
         }
     };
 
-    // ---- per-lane epilogue constants and per-workgroup running sums
-    const bool want_stats = p.fin_acc != nullptr;
-    const bool bnb = p.bnb_acc != nullptr;
+    // ---- running sums over all tiles of the workgroup.  Per tile a lane gathers, per channel block j, 16 per-lane values per statistic
+    // (MODE 1: sum / sum of squares of the result per channel register r; MODE 2: sum(g m) / sum(g m xhat) per channel (gp, e) of the
+    // lane's two pieces), runs TWO halving steps over its lane quad (DPP, no LDS) and adds the 4 survivors here; the other 3 steps run
+    // once at kernel end.  (All 32 values per statistic carried in registers across the MFMA phases were spilled.)
+    float rs0[NI][4], rs1[NI][4];
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { rs0[j][e] = 0.f; rs1[j][e] = 0.f; }
     const bool has_affine = p.bias || p.scale || p.shift || p.relu;
-    float ep_bias[NI], ep_sc[NI], ep_sh[NI];
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int n = j * 32 + l31;
-        ep_bias[j] = p.bias ? p.bias[n] : 0.f; ep_sc[j] = p.scale ? p.scale[n] : 1.f; ep_sh[j] = p.shift ? p.shift[n] : 0.f;
-    }
-    double st_s[NI], st_q[NI];
-#pragma unroll
-    for (int j = 0; j < NI; ++j) { st_s[j] = 0.0; st_q[j] = 0.0; }
-    const int pc = lane % PPO, prow = lane / PPO;                          // this lane's channel piece / first pixel row of its pieces
-    float b1[8], b2[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { b1[e] = 0.f; b2[e] = 0.f; }
-    if (bnb && tid < BN) {                                                 // BatchNorm constants of the layer whose backward sums ride along
-        float* sb = reinterpret_cast<float*>(smem + OFF_BNB);
-        const float mu = p.bnb_mean[tid], is = p.bnb_invstd[tid], sc = p.bnb_gamma[tid] * is;
-        sb[tid] = mu; sb[BN + tid] = is; sb[2 * BN + tid] = sc; sb[3 * BN + tid] = p.bnb_beta[tid] - mu * sc;
-    }                                                                      // (read after the first phase barrier at the earliest)
+    const bool sums = (MODE == 1 && p.fin_acc) || (MODE == 2 && p.bnb_acc);
 
     // epilogue of the tile in `acc` (computed by this wave one phase ago); issues the halo DMA of `next` (if any) into buffer g
     auto epilogue = [&](const TC& c, int g, bool has_next, const TC& next) {
-        unsigned char* stg = smem + (ALIAS ? OFF_H + g * H_BYTES + a_start * 1024 : OFF_STG + wm * STG_WAVE);
-        // global element offsets of this lane's pieces: piece it = pixel rows it * (64 / PPO) + prow of the wave's 64 pixels
-        unsigned goff[NPC];
+        const float* cst = reinterpret_cast<const float*>(smem + OFF_CONST);
+        unsigned pix[MI];
 #pragma unroll
-        for (int it = 0; it < NPC; ++it) {
-            const int m = wm * 64 + it * (64 / PPO) + prow;
-            goff[it] = (unsigned)((c.b * p.OH + c.oy0 + (m >> 4)) * p.OW + c.ox0 + (m & 15));
+        for (int i = 0; i < MI; ++i) {
+            const int m = wm * 64 + i * 32 + ws_perm(l31);
+            pix[i] = (unsigned)((c.b * p.OH + c.oy0 + (m >> 4)) * p.OW + c.ox0 + (m & 15));
         }
-        // affine / ReLU (eval, or the convolution bias), statistics of the fp32 values, bf16 transposition through the wave's slice
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-            float ssum = 0.f;
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = acc[i][j][r];
-                    if (has_affine) {
-                        v = (v + ep_bias[j]) * ep_sc[j] + ep_sh[j];
-                        if (p.relu) v = fmaxf(v, 0.f);
-                        acc[i][j][r] = v;
-                    }
-                    ssum += v;
-                    const int ml = i * 32 + ws_perm((r & 3) + 8 * (r >> 2) + 4 * khalf);
-                    *reinterpret_cast<T*>(stg + ml * PITCHB + (j * 32 + l31) * 2) = f2bf(v);
-                }
-            if (want_stats) {
-                const float s = ssum + __shfl_xor(ssum, 32);
-                const float mean = s * (1.f / 64.f);
-                float m2 = 0.f;
+            // operand tiles of the (+)= / BatchNorm-backward epilogue: 16-byte pieces at this lane's store addresses
+            u32x4 oldv[MI][2], yv[MI][2], av[MI][2];
+            if (MODE != 1 && p.accumulate) {
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) { const float d = acc[i][j][r] - mean; m2 += d * d; }
-                m2 += __shfl_xor(m2, 32);
-                st_s[j] += (double)s;
-                st_q[j] += (double)m2 + (double)s * (double)s * (1.0 / 64.0);
+                    for (int gp = 0; gp < 2; ++gp)
+                        oldv[i][gp] = *reinterpret_cast<const u32x4*>(p.y + (pix[i] * (unsigned)p.y_cs + 8 * khalf + 32 * j + 16 * gp));
             }
-        }
-        // the accumulators are dead from here.  Two batches of NPC / 2 pieces (bounds the live registers): operand loads of the (+)= /
-        // BatchNorm-backward epilogue, staged pieces, sums, stores
-        float bmu[8], bis[8], bsc[8], bsh[8];
-        if (bnb) {
-            const float* sb = reinterpret_cast<const float*>(smem + OFF_BNB) + pc * 8;
+            if (MODE == 2 && p.bnb_acc) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { bmu[e] = sb[e]; bis[e] = sb[BN + e]; bsc[e] = sb[2 * BN + e]; bsh[e] = sb[3 * BN + e]; }
-        }
-        constexpr int HB = NPC / 2;
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            u32x4 oldv[HB], yv[HB], av[HB], sv[HB];
-            if (p.accumulate) {
-#pragma unroll
-                for (int u = 0; u < HB; ++u) oldv[u] = *reinterpret_cast<const u32x4*>(p.y + (goff[h * HB + u] * (unsigned)p.y_cs + pc * 8));
+                    for (int gp = 0; gp < 2; ++gp) {
+                        yv[i][gp] = *reinterpret_cast<const u32x4*>(p.bnb_y + (pix[i] * (unsigned)p.bnb_cs + 8 * khalf + 32 * j + 16 * gp));
+                        if (p.bnb_a) av[i][gp] = *reinterpret_cast<const u32x4*>(p.bnb_a + (pix[i] * (unsigned)p.bnb_acs + 8 * khalf + 32 * j + 16 * gp));
+                    }
             }
-            if (bnb) {
+            float t0[16], t1[16];
 #pragma unroll
-                for (int u = 0; u < HB; ++u) yv[u] = *reinterpret_cast<const u32x4*>(p.bnb_y + (goff[h * HB + u] * (unsigned)p.bnb_cs + pc * 8));
-                if (p.bnb_a) {
+            for (int e = 0; e < 16; ++e) { t0[e] = 0.f; t1[e] = 0.f; }
 #pragma unroll
-                    for (int u = 0; u < HB; ++u) av[u] = *reinterpret_cast<const u32x4*>(p.bnb_a + (goff[h * HB + u] * (unsigned)p.bnb_acs + pc * 8));
-                }
-            }
+            for (int i = 0; i < MI; ++i) {
+                const unsigned yo = pix[i] * (unsigned)p.y_cs + 8 * khalf + 32 * j;     // + 16 gp: this lane's piece gp of block j
+                float v[16];
 #pragma unroll
-            for (int u = 0; u < HB; ++u) sv[u] = *reinterpret_cast<const u32x4*>(stg + ((h * HB + u) * (64 / PPO) + prow) * PITCHB + pc * 16);
+                for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r];
+                if (MODE != 2 && has_affine) {
 #pragma unroll
-            for (int u = 0; u < HB; ++u) {
-                u32x4 stored = sv[u];
-                if (p.accumulate) {
-                    float f[8], o[8];
-                    unpack16<T>(stored, f); unpack16<T>(oldv[u], o);
+                    for (int q = 0; q < 4; ++q) {                                   // 4 consecutive channels 32 j + 8 q + 4 khalf ..
+                        const int ch0 = 32 * j + 8 * q + 4 * khalf;
+                        const f32x4 bi = *reinterpret_cast<const f32x4*>(cst + ch0), sc = *reinterpret_cast<const f32x4*>(cst + BN + ch0),
+                                    sh = *reinterpret_cast<const f32x4*>(cst + 2 * BN + ch0);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) f[e] += o[e];
-                    stored = pack16<T>(f);
-                }
-                *reinterpret_cast<u32x4*>(p.y + (goff[h * HB + u] * (unsigned)p.y_cs + pc * 8)) = stored;
-                if (bnb) {
-                    float gq[8], yc[8];
-                    unpack16<T>(stored, gq); unpack16<T>(yv[u], yc);
-                    if (p.bnb_a) {
-                        float a8[8];
-                        unpack16<T>(av[u], a8);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const float gg = (!p.bnb_relu || a8[e] > 0.f) ? gq[e] : 0.f;
-                            b1[e] += gg; b2[e] += gg * (yc[e] - bmu[e]) * bis[e];
+                        for (int e = 0; e < 4; ++e) {
+                            float t = (v[4 * q + e] + bi[e]) * sc[e] + sh[e];
+                            if (p.relu) t = fmaxf(t, 0.f);
+                            v[4 * q + e] = t;
                         }
-                    } else {
+                    }
+                }
+                if (MODE == 1) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const float gg = (!p.bnb_relu || yc[e] * bsc[e] + bsh[e] > 0.f) ? gq[e] : 0.f;
-                            b1[e] += gg; b2[e] += gg * (yc[e] - bmu[e]) * bis[e];
+                    for (int r = 0; r < 16; ++r) { t0[r] += v[r]; t1[r] += v[r] * v[r]; }
+                }
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    // channel groups 2 gp (registers 8 gp .. 8 gp + 3) and 2 gp + 1 of both half-waves -> one 16-byte piece per lane:
+                    // lanes 0-31 channels 32 j + 16 gp + 0..7, lanes 32-63 channels 32 j + 16 gp + 8..15 of the same pixel
+                    const unsigned ax = f2bf_pk(v[8 * gp + 0], v[8 * gp + 1]), ay = f2bf_pk(v[8 * gp + 2], v[8 * gp + 3]);
+                    const unsigned bx = f2bf_pk(v[8 * gp + 4], v[8 * gp + 5]), by = f2bf_pk(v[8 * gp + 6], v[8 * gp + 7]);
+                    const auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+                    const auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+                    u32x4 stored = {rx[0], ry[0], rx[1], ry[1]};
+                    if (MODE != 1 && p.accumulate) {
+                        float f8[8], o8[8];
+                        unpack16<T>(stored, f8); unpack16<T>(oldv[i][gp], o8);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) f8[e] += o8[e];
+                        stored = pack16<T>(f8);
+                    }
+                    *reinterpret_cast<u32x4*>(p.y + (yo + 16 * gp)) = stored;
+                    if (MODE == 2 && p.bnb_acc) {
+                        const int ch0 = 32 * j + 16 * gp + 8 * khalf;
+                        float mu[8], is[8], gq[8], yc[8];
+                        *reinterpret_cast<f32x4*>(mu) = *reinterpret_cast<const f32x4*>(cst + ch0);
+                        *reinterpret_cast<f32x4*>(mu + 4) = *reinterpret_cast<const f32x4*>(cst + ch0 + 4);
+                        *reinterpret_cast<f32x4*>(is) = *reinterpret_cast<const f32x4*>(cst + BN + ch0);
+                        *reinterpret_cast<f32x4*>(is + 4) = *reinterpret_cast<const f32x4*>(cst + BN + ch0 + 4);
+                        unpack16<T>(stored, gq); unpack16<T>(yv[i][gp], yc);
+                        if (p.bnb_a) {                                              // residual layer: the mask is the sign of the block output
+                            float a8[8];
+                            unpack16<T>(av[i][gp], a8);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float gg = (!p.bnb_relu || a8[e] > 0.f) ? gq[e] : 0.f;
+                                t0[gp * 8 + e] += gg; t1[gp * 8 + e] += gg * (yc[e] - mu[e]) * is[e];
+                            }
+                        } else {
+                            float ks[8], sh[8];
+                            *reinterpret_cast<f32x4*>(ks) = *reinterpret_cast<const f32x4*>(cst + 2 * BN + ch0);
+                            *reinterpret_cast<f32x4*>(ks + 4) = *reinterpret_cast<const f32x4*>(cst + 2 * BN + ch0 + 4);
+                            *reinterpret_cast<f32x4*>(sh) = *reinterpret_cast<const f32x4*>(cst + 3 * BN + ch0);
+                            *reinterpret_cast<f32x4*>(sh + 4) = *reinterpret_cast<const f32x4*>(cst + 3 * BN + ch0 + 4);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float gg = (!p.bnb_relu || yc[e] * ks[e] + sh[e] > 0.f) ? gq[e] : 0.f;
+                                t0[gp * 8 + e] += gg; t1[gp * 8 + e] += gg * (yc[e] - mu[e]) * is[e];
+                            }
                         }
                     }
                 }
             }
+            if (MODE != 0 && sums) {
+                ws_halve<16, 0>(t0, l31); ws_halve<8, 1>(t0, l31);
+                ws_halve<16, 0>(t1, l31); ws_halve<8, 1>(t1, l31);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { rs0[j][e] += t0[e]; rs1[j][e] += t1[e]; }
+            }
         }
+        stamp();
         if (has_next) {
-            // the halo of this group's next tile goes into the buffer the group released at the phase barrier - LAST, so that the wave's
-            // reads of its transposition slice (ALIAS: a slice of that very buffer) have returned and the plain vmcnt(0) in front of the
-            // next phase barrier covers it whatever else (stores, compiler scratch traffic) shares the counter
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // the halo of this group's next tile goes into the buffer the group released at the phase barrier - LAST, so that the
+            // plain vmcnt(0) in front of the next phase barrier covers it whatever else shares the counter
             __builtin_amdgcn_sched_barrier(0);
             issue_halo(next, g);
         }
@@ -364,7 +384,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsKP p) {
         const int g_mma = k & 1;
         if (k == 0) { if (grp == 0 || n_my < 2) ws_wait_vm<0>(); else ws_wait_vm<NSH>(); }   // weights (+ tile 0) landed; group 1's own tile may fly on
         else if (grp == g_mma && k < n_my) ws_wait_vm<0>();                  // this group's halo tile k (prologue / its previous epilogue) landed
-        asm volatile("" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   // (k == 0: the epilogue constants written above)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         stamp();
@@ -380,52 +400,46 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsKP p) {
     }
 
     // ---- per-workgroup sums -> fp64 shard atomics (the weights region is free: every MFMA phase ended before the last barrier)
-    if (want_stats || bnb) {
+    if (MODE != 0 && sums) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const int C = BN;
-        if (want_stats) {
-            double* red = reinterpret_cast<double*>(smem);                  // [8 waves][BN][2]
-            if (khalf == 0) {
+        float* red = reinterpret_cast<float*>(smem);                        // [8 waves][2][BN]
+        // the remaining butterfly steps: value index 8 b0 + 4 b1 + 2 b2 + b3 of block j.  MODE 1: index = channel register r;
+        // MODE 2: index = 8 gp + e
+        const int idx = 8 * (l31 & 1) + 4 * ((l31 >> 1) & 1) + 2 * ((l31 >> 2) & 1) + ((l31 >> 3) & 1);
 #pragma unroll
-                for (int j = 0; j < NI; ++j) { red[(wave * BN + j * 32 + l31) * 2] = st_s[j]; red[(wave * BN + j * 32 + l31) * 2 + 1] = st_q[j]; }
-            }
-            __syncthreads();
-            if (tid < 2 * BN) {
-                const int st = tid / BN, n = tid - st * BN;
-                double t = 0.0;
-#pragma unroll
-                for (int w = 0; w < 8; ++w) t += red[(w * BN + n) * 2 + st];
-                double* a = p.fin_acc + (blockIdx.x & 7) * (2 * C + 1);
-                fin_add(a + st * C + n, t);
-                if (tid == 0) fin_add(a + 2 * C, (double)n_my * 256.0);
-            }
-            __syncthreads();
+        for (int j = 0; j < NI; ++j) {
+            ws_halve<4, 2>(rs0[j], l31); ws_halve<2, 3>(rs0[j], l31);
+            ws_halve<4, 2>(rs1[j], l31); ws_halve<2, 3>(rs1[j], l31);
+            const float s0 = rs0[j][0] + __shfl_xor(rs0[j][0], 16), s1 = rs1[j][0] + __shfl_xor(rs1[j][0], 16);
+            const int ch = MODE == 1 ? 32 * j + (idx & 3) + 8 * (idx >> 2) + 4 * khalf : 32 * j + 16 * (idx >> 3) + 8 * khalf + (idx & 7);
+            red[(wave * 2 + 0) * BN + ch] = s0;                             // (lanes l and l ^ 16 write the same value)
+            red[(wave * 2 + 1) * BN + ch] = s1;
         }
-        if (bnb) {
-            float* red = reinterpret_cast<float*>(smem);                    // [8 waves][64 / PPO rows][BN][2]
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int st = tid / BN, n = tid - st * BN;
+            double t = 0.0;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                red[((wave * (64 / PPO) + prow) * BN + pc * 8 + e) * 2] = b1[e];
-                red[((wave * (64 / PPO) + prow) * BN + pc * 8 + e) * 2 + 1] = b2[e];
-            }
-            __syncthreads();
-            if (tid < 2 * BN) {
-                const int st = tid / BN, n = tid - st * BN;
-                float t = 0.f;
-                for (int r = 0; r < 8 * (64 / PPO); ++r) t += red[(r * BN + n) * 2 + st];
-                fin_add(p.bnb_acc + ((blockIdx.x & 7) * 2 + st) * C + n, (double)t);
+            for (int w = 0; w < 8; ++w) t += (double)red[(w * 2 + st) * BN + n];
+            if (MODE == 1) {
+                double* a = p.fin_acc + (blockIdx.x & 7) * (2 * BN + 1);
+                fin_add(a + st * BN + n, t);
+                if (tid == 0) fin_add(a + 2 * BN, (double)n_my * 256.0);
+            } else {
+                fin_add(p.bnb_acc + ((blockIdx.x & 7) * 2 + st) * BN + n, t);
             }
         }
     }
 #if SALT_WS_CLK
     stamp();
     if (lane == 0 && (wave == 0 || wave == 4) && blockIdx.x < 256) {
-        unsigned long long* o = g_ws_clk + (blockIdx.x * 2 + grp) * 16;
-        for (int i = 0; i < 16; ++i) o[i] = i < nclk ? clk[i] : 0ull;
+        unsigned long long* o = g_ws_clk + (blockIdx.x * 2 + grp) * 24;
+        for (int i = 0; i < 24; ++i) o[i] = i < nclk ? clk[i] : 0ull;
     }
 #endif
 }
+
 
 int ws_cus() {
     static int cus = 0;
@@ -437,13 +451,12 @@ int ws_cus() {
     return cus;
 }
 
-template <int NCH, int NI>
-int ws_launch(const WsKP& k, hipStream_t st) {
+template <int NCH, int NI, int MODE>
+int ws_launch_mode(const WsKP& k, hipStream_t st) {
     constexpr int BN = 32 * NI, HP = NCH * 21, WP = NCH * 9 * BN / 16;
-    constexpr bool ALIAS = (NCH == 2 && NI == 2);
-    constexpr int LDS = WP * 1024 + 2 * HP * 1024 + (ALIAS ? 0 : 4 * 64 * (BN * 2 + 16)) + 1024 + 4 * BN * 4;
-    static_assert(LDS <= 160 * 1024, "LDS budget");
-    auto kern = conv_ws_kernel<NCH, NI>;
+    constexpr int LDS = WP * 1024 + 2 * HP * 1024 + 1024 + 4 * BN * 4;
+    static_assert(LDS <= 160 * 1024 && 8 * 2 * BN * 4 <= WP * 1024, "LDS budget");
+    auto kern = conv_ws_kernel<NCH, NI, MODE>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -453,6 +466,13 @@ int ws_launch(const WsKP& k, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3((unsigned)(k.wg_per_xcd * 8)), dim3(512), LDS, st, k);
     SALT_CHECK_LAUNCH();
     return SALT_OK;
+}
+
+template <int NCH, int NI>
+int ws_launch(const WsKP& k, hipStream_t st) {
+    if (k.fin_acc) return ws_launch_mode<NCH, NI, 1>(k, st);
+    if (k.bnb_acc) return ws_launch_mode<NCH, NI, 2>(k, st);
+    return ws_launch_mode<NCH, NI, 0>(k, st);
 }
 
 }  // namespace
@@ -530,7 +550,7 @@ int conv_ws_launch(const salt_conv_args* a, hipStream_t st) {
 
 extern "C" int salt_debug_ws_clk(unsigned long long* host_out, int n) {
 #if SALT_WS_CLK
-    if (n > 256 * 32) n = 256 * 32;
+    if (n > 256 * 48) n = 256 * 48;
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_ws_clk), (size_t)n * sizeof(unsigned long long));
 #else
     (void)host_out; (void)n;

@@ -1,6 +1,5 @@
 #!/bin/bash
-# Build an A/B variant of the library with extra compiler flags: tools/build_variant.sh <name> <flags...>
-#   -> open-solution-salt-identification_amd/csrc/_variants/libsaltnet_hip.<name>.so   (run with SALT_LIB=<that path>)
+# Build an A/B variant of the library whose conv_ws.hip is compiled with extra flags: tools/build_variant_ws.sh <name> <flags...>
 set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
@@ -8,7 +7,7 @@ C=open-solution-salt-identification_amd/csrc
 mkdir -p $C/_variants/obj_$name
 objs=""
 for f in runtime conv_mfma conv_ws conv_small elementwise se loss input; do
-  if [ $f = conv_mfma ]; then
+  if [ $f = conv_ws ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -I$C -Wno-unused-value "$@" -c $C/$f.hip -o $C/_variants/obj_$name/$f.o
     objs="$objs $C/_variants/obj_$name/$f.o"
   else
