@@ -70,6 +70,9 @@ hipEvent_t salt_take_fork_event();
 bool conv_ws_eligible(const salt_conv_args* a);
 int conv_ws_tiles(const salt_conv_args* a);
 int conv_ws_launch(const salt_conv_args* a, hipStream_t st);
+// conv_ws.hip: the loader-specialised streaming kernel of the deeper 3x3 layers (conv_ls_variant: 0 = not applicable, else channel blocks of 32 NI)
+int conv_ls_variant(const salt_conv_args* a);
+int conv_ls_launch(const salt_conv_args* a, hipStream_t st);
 
 static inline int ilog2_ceil(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

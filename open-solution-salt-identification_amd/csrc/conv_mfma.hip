@@ -1386,10 +1386,10 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
     const bool v2_ok = a->dtype == SALT_BF16 && a->in_step == 1 && (a->ntaps == 9 || a->ntaps == 4) && a->x.C % 32 == 0 &&
                        a->x.cs % 8 == 0 && (reinterpret_cast<uintptr_t>(a->x.p) & 15) == 0;
     // ---- tile config heuristic (overridable for tests/tuning)
-    int id = (a->cfg & 0xff) == 9 ? 0 : a->cfg;   // 9 = "conv_ws_kernel where it applies" (conv_ws.hip): the heuristic decides for the rest
+    int id = ((a->cfg & 0xff) == 9 || (a->cfg & 0xff) == 10) ? 0 : a->cfg;   // 9 = "conv_ws_kernel where it applies" (conv_ws.hip): the heuristic decides for the rest
     if (id >= 6 && !v2_ok) id = 0;            // a forced conv_glds config applies where the kernel does (tests force one config per graph)
     if (id == 2 && vt > 1) id = 1;            // 256-pixel tiles x 4 virtual taps exceed the halo-piece budget
-    if (id == 0 && v2_ok && v2_env && (a->cfg == 0 || (a->cfg & 0xff) == 9)) {
+    if (id == 0 && v2_ok && v2_env && (a->cfg == 0 || (a->cfg & 0xff) == 9 || (a->cfg & 0xff) == 10)) {
         if (v2_env >= 6) id = v2_env;
         else {
             // measured (tools/v2_sweep.sh, tools/v2_ablate.sh): the LDS-DMA kernel wins where conv_mfma_kernel's 128x32 tiles cannot
@@ -2669,6 +2669,7 @@ extern "C" int salt_conv(const salt_conv_args* a, void* stream) {
             SALT_FAIL(SALT_E_BADARG, "conv: fold mode needs OH/OW = y.H/y.W + pads, out_step 1, no stats, 16-byte aligned strip");
     }
     if (conv_ws_eligible(a)) return conv_ws_launch(a, (hipStream_t)stream);      // the plan above validated the arguments
+    if (conv_ls_variant(a)) return conv_ls_launch(a, (hipStream_t)stream);
     if (a->dtype == SALT_F32) return launch_T<float>(pl, (hipStream_t)stream);
     if (a->dtype == SALT_BF16) return launch_T<bf16_t>(pl, (hipStream_t)stream);
     SALT_FAIL(SALT_E_BADARG, "conv: dtype %d", a->dtype);
@@ -2676,7 +2677,7 @@ extern "C" int salt_conv(const salt_conv_args* a, void* stream) {
 
 extern "C" int salt_conv_stats_parts(const salt_conv_args* a) {
     Plan pl;
-    if (conv_ws_eligible(a)) return conv_ws_tiles(a);
+    if (conv_ws_eligible(a) || conv_ls_variant(a)) return conv_ws_tiles(a);
     if (make_plan(a, &pl)) return -1;
     return pl.parts;
 }
@@ -2684,7 +2685,7 @@ extern "C" int salt_conv_stats_parts(const salt_conv_args* a) {
 extern "C" int salt_conv_kernel_id(const salt_conv_args* a) {
     Plan pl;
     if (make_plan(a, &pl)) return -1;
-    return conv_ws_eligible(a) ? 9 : pl.cfg.id;
+    return conv_ws_eligible(a) ? 9 : (conv_ls_variant(a) ? 10 : pl.cfg.id);
 }
 
 extern "C" int64_t salt_packed_weight_elems(int dtype, int ntaps, int n, int c) {

@@ -38,6 +38,22 @@ def _kernel_ids(prog):
     return [lib.salt_conv_kernel_id(ctypes.byref(s)) for name, _, s in prog.ops if name == 'conv']
 
 
+def _ls(cap, ni):
+    """cfg word that asks for conv_ls_kernel (id 10) with `cap` workgroups per XCD and 32 * ni output channels per item"""
+    return 10 | (cap << 8) | (ni << 16)
+
+
+# conv_ls_kernel (loader-specialised streaming kernel, K = 9 Cin too large for resident weights): B, Cin, H, W, Cout, cfg
+LS_CASES = [
+    (1, 128, 32, 32, 128, _ls(4, 1)),    # 4 tiles x 4 channel blocks, one item per workgroup, 4 chunks through the 4-deep ring
+    (2, 128, 64, 32, 64, _ls(2, 1)),     # 16 tiles, 2 channel blocks, 2 items per workgroup: the chunk stream runs across items
+    (2, 128, 32, 64, 128, _ls(2, 2)),    # 64 channels per item (2-deep ring), 2 items per workgroup
+    (1, 256, 16, 16, 64, _ls(2, 1)),     # 8 chunks per item, a single tile: most XCDs have no item
+    (1, 64, 16, 32, 32, _ls(1, 1)),      # fewer chunks (2) than the ring's prefetch depth (3)
+    (3, 96, 32, 32, 96, _ls(3, 1)),      # 3 chunks, 3 channel blocks
+    (2, 320, 32, 16, 64, _ls(1, 2)),     # 10 chunks, 64 channels per item (the final convolution's shape, scaled down)
+]
+
 # B, Cin, H, W, Cout, workgroups per XCD (0: one per tile, up to one per CU)
 WS_CASES = [
     (2, 64, 32, 32, 64, 0),      # 8 tiles, 8 workgroups: one tile each (group 1 idles)
@@ -49,14 +65,14 @@ WS_CASES = [
 ]
 
 
-@pytest.mark.parametrize('case', WS_CASES)
+@pytest.mark.parametrize('case', [('ws',) + c[:5] + (9 | (c[5] << 8),) for c in WS_CASES] + [('ls',) + c for c in LS_CASES])
 @pytest.mark.parametrize('replicate', [False, True])
 def test_ws_conv_bn_relu_train_vs_torch(case, replicate):
     """conv (+ bias) -> train-mode BN -> ReLU, bf16: forward (statistics through the fp64 shards), data gradient, weight / BN gradients.
     replicate = the reference's top/right replicate padding (base.py:21-27): the forward launch clamps its halo rows."""
     from gpu_harness import BlockRun
-    B, Cin, H, W, Cout, cap = case
-    cfg = 9 | (cap << 8)
+    kind, B, Cin, H, W, Cout, cfg = case
+    kid = 9 if kind == 'ws' else 10
     conv = nn.Conv2d(Cin, Cout, 3, 1, 0 if replicate else 1, bias=True)
     bn = nn.BatchNorm2d(Cout)
     mod = nn.Sequential(conv, bn)
@@ -71,9 +87,12 @@ def test_ws_conv_bn_relu_train_vs_torch(case, replicate):
 
     mod.train()
     run = BlockRun(mod, [x], emit, train=True, dtype='bf16')
-    assert _kernel_ids(run.g.fwd) == [9]
+    assert _kernel_ids(run.g.fwd) == [kid]
     if not replicate:
-        assert _kernel_ids(run.g.bwd) == [9]                      # the plain data gradient; the replicate one is the fused-fold launch
+        # the plain data gradient (the replicate one is the fused-fold launch); its channel counts are swapped, so a conv_ws forward
+        # with Cout = 32 has a conv_ws data gradient too, and a conv_ls layer a conv_ls (or, at Cout = 32 < 64 input channels, conv_mfma) one
+        ids = _kernel_ids(run.g.bwd)
+        assert ids == [kid] or (kind == 'ls' and Cout < 64), ids
     y = run.forward()
     ref_conv, ref_bn = nn.Conv2d(Cin, Cout, 3, 1, 0 if replicate else 1, bias=True), nn.BatchNorm2d(Cout)
     with torch.no_grad():
@@ -97,17 +116,20 @@ def test_ws_conv_bn_relu_train_vs_torch(case, replicate):
     assert float((y2.float() - y.float()).abs().max()) <= 1e-6 * float(y.float().abs().max())
 
 
-@pytest.mark.parametrize('case', [(1, 64, 32, 32, 64, 64, 1), (3, 64, 64, 32, 64, 64, 1), (2, 32, 64, 64, 64, 32, 1), (2, 64, 32, 64, 32, 64, 1)])
+@pytest.mark.parametrize('case', [(1, 64, 32, 32, 64, 64, 9 | (1 << 8)), (3, 64, 64, 32, 64, 64, 9 | (1 << 8)), (2, 32, 64, 64, 64, 32, 9 | (1 << 8)),
+                                  (2, 64, 32, 64, 32, 64, 9 | (1 << 8)), (2, 128, 32, 32, 128, 128, _ls(2, 1)), (1, 128, 32, 64, 128, 128, _ls(1, 2)),
+                                  (2, 256, 16, 32, 128, 256, _ls(4, 1))])
 def test_ws_equals_conv_mfma_kernel_on_a_residual_block(case):
     """A BasicBlock-shaped chain (conv-BN-ReLU, conv-BN, + identity, ReLU) in train mode, once on conv_ws_kernel and once on
     conv_mfma_kernel: forward statistics, (+)= data gradients, the BatchNorm-backward sums carried by the second layer's data gradient
     (with the residual's ReLU mask read from the block output) - results of the two kernels on the same launches agree to bf16
     rounding of single values (they sum in different orders), and both match torch."""
     from gpu_harness import BlockRun
-    B, Cin, H, W, Cmid, Cout, cap = case
+    B, Cin, H, W, Cmid, Cout, cfg_new = case
+    kid = cfg_new & 0xff
     res_ok = Cin == Cout
     outs = {}
-    for tag, cfg in (('ws', 9 | (cap << 8)), ('mfma', 2)):
+    for tag, cfg in (('ws', cfg_new), ('mfma', 2)):
         c1, b1, c2, b2 = nn.Conv2d(Cin, Cmid, 3, 1, 1, bias=False), nn.BatchNorm2d(Cmid), nn.Conv2d(Cmid, Cout, 3, 1, 1, bias=False), nn.BatchNorm2d(Cout)
         mod = nn.Sequential(c1, b1, c2, b2)
         with torch.no_grad():
@@ -126,11 +148,11 @@ def test_ws_equals_conv_mfma_kernel_on_a_residual_block(case):
         run = BlockRun(mod, [x], emit, train=True, dtype='bf16')
         ids_f, ids_b = _kernel_ids(run.g.fwd), _kernel_ids(run.g.bwd)
         if tag == 'ws':
-            assert ids_f == [9, 9] and ids_b == [9, 9], (ids_f, ids_b)
+            assert ids_f == [kid, kid] and ids_b == [kid, kid], (ids_f, ids_b)
             ready = [int(st.partials_ready) for name, _, st in run.g.bwd.ops if name == 'bn_bwd']
             assert ready == [0, 3], ready          # layer 1's BatchNorm-backward sums came from layer 2's data-gradient launch
         else:
-            assert 9 not in ids_f + ids_b
+            assert 9 not in ids_f + ids_b and 10 not in ids_f + ids_b
         y = run.forward()
         gy = _rand(tuple(y.shape), 18)
         gx, grads = run.backward(gy.to('cuda:0'))
@@ -163,11 +185,12 @@ def test_ws_equals_conv_mfma_kernel_on_a_residual_block(case):
     assert l2 < 2 * TOLBF, 'dgrad vs torch rel-L2 %.3e' % l2
 
 
-@pytest.mark.parametrize('case', [(2, 64, 32, 32, 64, 1), (4, 64, 32, 32, 32, 1), (4, 32, 32, 32, 64, 1)])
+@pytest.mark.parametrize('case', [(2, 64, 32, 32, 64, 9 | (1 << 8)), (4, 64, 32, 32, 32, 9 | (1 << 8)), (4, 32, 32, 32, 64, 9 | (1 << 8)),
+                                  (2, 128, 32, 32, 96, _ls(3, 1)), (2, 192, 32, 32, 128, _ls(2, 2))])
 def test_ws_eval_folded_bn_relu_vs_torch(case):
     """eval mode: bias + folded BatchNorm + ReLU in the epilogue (salt_conv_args.bias / scale / shift / relu)."""
     from gpu_harness import BlockRun
-    B, Cin, H, W, Cout, cap = case
+    B, Cin, H, W, Cout, cfg = case
     conv, bn = nn.Conv2d(Cin, Cout, 3, 1, 1, bias=True), nn.BatchNorm2d(Cout)
     mod = nn.Sequential(conv, bn)
     with torch.no_grad():
@@ -177,12 +200,12 @@ def test_ws_eval_folded_bn_relu_vs_torch(case):
     x = _rand((B, Cin, H, W), 4).bfloat16().float()
 
     def emit(g, a):
-        _force_cfg(g, 9 | (cap << 8))
+        _force_cfg(g, cfg)
         return g.conv(a, conv, bn, relu=True)
 
     mod.eval()
     run = BlockRun(mod, [x], emit, train=False, dtype='bf16')
-    assert _kernel_ids(run.g.fwd) == [9]
+    assert _kernel_ids(run.g.fwd) == [cfg & 0xff]
     y = run.forward()
     rc, rb = nn.Conv2d(Cin, Cout, 3, 1, 1, bias=True), nn.BatchNorm2d(Cout)
     rc.load_state_dict({k: v.detach().cpu() for k, v in conv.state_dict().items()}); rb.load_state_dict({k: v.detach().cpu() for k, v in bn.state_dict().items()})
