@@ -2676,8 +2676,9 @@ extern "C" int salt_conv(const salt_conv_args* a, void* stream) {
 }
 
 extern "C" int salt_conv_stats_parts(const salt_conv_args* a) {
+    // always conv_mfma_kernel's tile count: the per-tile partials protocols (SALT_BN_FIN=0: stats / bnb_partials) run on that kernel
+    // only, and the engine sizes their workspaces BEFORE it sets those fields - conv_ws / conv_ls (shard protocols) never use the count
     Plan pl;
-    if (conv_ws_eligible(a) || conv_ls_variant(a)) return conv_ws_tiles(a);
     if (make_plan(a, &pl)) return -1;
     return pl.parts;
 }

@@ -44,8 +44,10 @@ namespace {
 struct WsKP {
     const bf16_t* x; const bf16_t* w; bf16_t* y;
     const float* bias; const float* scale; const float* shift;
-    int B, H, W, x_cs, y_cs, OH, OW;
-    int tiles_x, tiles_y, ntiles, per_xcd, wg_per_xcd;
+    int B, H, W, x_cs, y_cs, OH, OW;     // x is [B,H,W,*]; OH x OW: the launch's output grid (the extended grid of a fused fold)
+    int yH, yW, fold_top, ox_shift;      // y is [B,yH,yW,*]: grid row oy -> y row oy - fold_top; tile columns start at -ox_shift
+    int Cout, n_tiles, slots;            // channel blocks of 32 NI; workgroup j of an XCD: block j % n_tiles, every `slots`-th tile
+    int tiles_x, tiles_y, ntiles, per_xcd;
     int min_dy, min_dx, pad_mode;
     int tap_off[9];
     int relu, accumulate;
@@ -67,6 +69,8 @@ __device__ __forceinline__ int ws_swz(int row, int slot) { return row * 64 + (((
 // MFMA row -> pixel of a 32-pixel (2 image rows x 16) block such that every 16-lane group of a ds_read_b128 covers 16 CONSECUTIVE
 // pixels of one image row (conflict-free for the 18-pixel halo pitch; see conv_glds_kernel)
 __device__ __forceinline__ int ws_perm(int m) { return (int)((0x73261540u >> ((m >> 2) * 4)) & 0xfu) * 4 + (m & 3); }
+
+__device__ __forceinline__ int ws_perm_inv(int q) { return (int)((0x74216530u >> ((q >> 2) * 4)) & 0xfu) * 4 + (q & 3); }      // ws_perm(ws_perm_inv(q)) == q
 
 template <int N> __device__ __forceinline__ void ws_wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
@@ -98,41 +102,53 @@ struct WsEpi {
     int y_cs, bnb_cs, bnb_acs, relu, accumulate, bnb_relu;
     bool has_affine, sums;
 };
+// Per-lane geometry of the wave tile: which of the lane's two pixels are stored (ragged grids, pad-ring pixels of a fused fold), and
+// - FOLD, the data gradient of a replicate-padded convolution on the extended grid (salt_conv_args.fold_top / fold_right = 2, tile
+// columns right-aligned) - where the pad-ring values it must add come from.  The ring pixels a pixel folds share its WAVE: the two
+// ring columns are tile columns 14 / 15 of the edge pixel's own row, the two ring rows are rows 0 / 1 of the wave that holds image
+// row 0 in row 2.  So the fold is a lane permutation (ds_bpermute) of fp32 accumulators: first columns 14, 15 onto column 13 in every
+// row (ring rows included), then rows 0, 1 (sub-tile 0) onto row 2 (sub-tile 1) - which also carries the corner.
+struct WsLaneGeo {
+    bool valid[2];
+    bool do_right, do_top;        // wave-uniform: the tile is in the last tile column / this wave holds image row 0 and the pad rows
+    bool fr_on, ft_on;            // this lane's pixel takes the right / (sub-tile 1 only) the top fold
+    int fr_src0, fr_src1;         // lanes of tile columns 14 / 15 of this lane's row (same sub-tile)
+    int ft_src0, ft_src1;         // lanes of rows 0 / 1 of this lane's column in sub-tile 0
+};
 
-template <int NI, int MODE>
-__device__ __forceinline__ void ws_epilogue_tile(const WsEpi& p, f32x16 (&acc)[2][NI], const unsigned (&pix)[2], int n0, const float* cst,
-                                                 float (&rs0)[NI][4], float (&rs1)[NI][4], int khalf, int l31) {
+template <int NI, int MODE, bool FOLD>
+__device__ __forceinline__ void ws_epilogue_tile(const WsEpi& p, f32x16 (&acc)[2][NI], const unsigned (&pix)[2], const WsLaneGeo& geo, int n0,
+                                                 const float* cst, float (&rs0)[NI][4], float (&rs1)[NI][4], int khalf, int l31) {
     typedef bf16_t T;
     constexpr int MI = 2, BN = 32 * NI;
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         // operand tiles of the (+)= / BatchNorm-backward epilogue: 16-byte pieces at this lane's store addresses
         u32x4 oldv[MI][2], yv[MI][2], av[MI][2];
-        if (MODE != 1 && p.accumulate) {
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
+        auto load_operands = [&](int i) {                                       // i is a constant after unrolling
+            if (!geo.valid[i]) return;
+            if (MODE != 1 && p.accumulate) {
 #pragma unroll
                 for (int gp = 0; gp < 2; ++gp)
                     oldv[i][gp] = *reinterpret_cast<const u32x4*>(p.y + (pix[i] * (unsigned)p.y_cs + n0 + 8 * khalf + 32 * j + 16 * gp));
-        }
-        if (MODE == 2 && p.sums) {
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
+            }
+            if (MODE == 2 && p.sums) {
 #pragma unroll
                 for (int gp = 0; gp < 2; ++gp) {
                     yv[i][gp] = *reinterpret_cast<const u32x4*>(p.bnb_y + (pix[i] * (unsigned)p.bnb_cs + n0 + 8 * khalf + 32 * j + 16 * gp));
                     if (p.bnb_a) av[i][gp] = *reinterpret_cast<const u32x4*>(p.bnb_a + (pix[i] * (unsigned)p.bnb_acs + n0 + 8 * khalf + 32 * j + 16 * gp));
                 }
+            }
+        };
+        if (!FOLD) {                                                            // (FOLD holds both sub-tiles in fp32 across the lane
+#pragma unroll                                                                  //  permutation: its operands are requested per sub-tile below)
+            for (int i = 0; i < MI; ++i) load_operands(i);
         }
-        float t0[16], t1[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { t0[e] = 0.f; t1[e] = 0.f; }
+        float v[MI][16];
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-            const unsigned yo = pix[i] * (unsigned)p.y_cs + n0 + 8 * khalf + 32 * j;     // + 16 gp: this lane's piece gp of block j
-            float v[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r];
+            for (int r = 0; r < 16; ++r) v[i][r] = acc[i][j][r];
             if (MODE != 2 && p.has_affine) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {                                   // 4 consecutive channels 32 j + 8 q + 4 khalf ..
@@ -141,25 +157,55 @@ __device__ __forceinline__ void ws_epilogue_tile(const WsEpi& p, f32x16 (&acc)[2
                                 sh = *reinterpret_cast<const f32x4*>(cst + 2 * BN + ch0);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float t = (v[4 * q + e] + bi[e]) * sc[e] + sh[e];
+                        float t = (v[i][4 * q + e] + bi[e]) * sc[e] + sh[e];
                         if (p.relu) t = fmaxf(t, 0.f);
-                        v[4 * q + e] = t;
+                        v[i][4 * q + e] = t;
                     }
                 }
             }
+        }
+        if (FOLD) {
+            // (a ds_bpermute costs the wave ~45 cycles here: only the tiles / waves that hold pad-ring pixels run them - in-kernel
+            // clocks, profiles/r03_ws_clocks.txt: 12.4 k cycles per tile epilogue with the permutations unconditional, 3.7 k without)
+            const int hb = khalf << 5;                                          // the source lane holds the same channels: same half-wave
+            if (geo.do_right) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float add = __shfl(v[i][r], hb + geo.fr_src0) + __shfl(v[i][r], hb + geo.fr_src1);
+                        if (geo.fr_on) v[i][r] += add;
+                    }
+            }
+            if (geo.do_top) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float add = __shfl(v[0][r], hb + geo.ft_src0) + __shfl(v[0][r], hb + geo.ft_src1);
+                    if (geo.ft_on) v[1][r] += add;
+                }
+            }
+        }
+        float t0[16], t1[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { t0[e] = 0.f; t1[e] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const unsigned yo = pix[i] * (unsigned)p.y_cs + n0 + 8 * khalf + 32 * j;     // + 16 gp: this lane's piece gp of block j
+            if (FOLD) load_operands(i);
             if (MODE == 1) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { t0[r] += v[r]; t1[r] += v[r] * v[r]; }
+                for (int r = 0; r < 16; ++r) { t0[r] += v[i][r]; t1[r] += v[i][r] * v[i][r]; }      // (host: MODE 1 launches have whole tiles only)
             }
 #pragma unroll
             for (int gp = 0; gp < 2; ++gp) {
                 // channel groups 2 gp (registers 8 gp .. 8 gp + 3) and 2 gp + 1 of both half-waves -> one 16-byte piece per lane:
                 // lanes 0-31 channels 32 j + 16 gp + 0..7, lanes 32-63 channels 32 j + 16 gp + 8..15 of the same pixel
-                const unsigned ax = f2bf_pk(v[8 * gp + 0], v[8 * gp + 1]), ay = f2bf_pk(v[8 * gp + 2], v[8 * gp + 3]);
-                const unsigned bx = f2bf_pk(v[8 * gp + 4], v[8 * gp + 5]), by = f2bf_pk(v[8 * gp + 6], v[8 * gp + 7]);
+                const unsigned ax = f2bf_pk(v[i][8 * gp + 0], v[i][8 * gp + 1]), ay = f2bf_pk(v[i][8 * gp + 2], v[i][8 * gp + 3]);
+                const unsigned bx = f2bf_pk(v[i][8 * gp + 4], v[i][8 * gp + 5]), by = f2bf_pk(v[i][8 * gp + 6], v[i][8 * gp + 7]);
                 const auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
                 const auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
                 u32x4 stored = {rx[0], ry[0], rx[1], ry[1]};
+                if (!geo.valid[i]) continue;                                    // (after the swap: its partner lane may be valid)
                 if (MODE != 1 && p.accumulate) {
                     float f8[8], o8[8];
                     unpack16<T>(stored, f8); unpack16<T>(oldv[i][gp], o8);
@@ -246,7 +292,7 @@ __device__ __forceinline__ void ws_sums_flush(float (&rs0)[NI][4], float (&rs1)[
 }
 
 // MODE: see ws_epilogue_tile
-template <int NCH, int NI, int MODE>
+template <int NCH, int NI, int MODE, bool FOLD>
 __global__ __launch_bounds__(512) void conv_ws_kernel(WsKP p) {
     typedef bf16_t T;
     constexpr int BN = 32 * NI, NT = 9, MI = 2;
@@ -265,22 +311,24 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsKP p) {
     const int grp = wave >> 2, wm = wave & 3;
     const int khalf = lane >> 5, l31 = lane & 31;
 
-    // ---- tiles of this workgroup: XCD x (= block id % 8, where consecutive block ids go) owns a contiguous range of tiles, so that
-    // neighbouring tiles share their halo rows through that XCD's L2
+    // ---- tiles of this workgroup: XCD x (= block id % 8, where consecutive block ids go) owns a contiguous range of pixel tiles, so
+    // that neighbouring tiles share their halo rows through that XCD's L2; its workgroup j keeps the weights of channel block
+    // j % n_tiles resident and walks every `slots`-th tile of the range
     const int xcd = blockIdx.x & 7, jwg = blockIdx.x >> 3;
+    const int nt = jwg % p.n_tiles, slot = jwg / p.n_tiles, n0 = nt * BN;
     const int t_lo = xcd * p.per_xcd;
     const int t_hi = min(t_lo + p.per_xcd, p.ntiles);
-    const int n_my = (t_lo + jwg < t_hi) ? (t_hi - t_lo - jwg + p.wg_per_xcd - 1) / p.wg_per_xcd : 0;
+    const int n_my = (t_lo + slot < t_hi) ? (t_hi - t_lo - slot + p.slots - 1) / p.slots : 0;
     if (n_my <= 0) return;
-    auto tile_of = [&](int k) { return t_lo + jwg + k * p.wg_per_xcd; };
+    auto tile_of = [&](int k) { return t_lo + slot + k * p.slots; };
     struct TC { int b, oy0, ox0; };
     auto coords = [&](int t) {
         TC c; const int tx = t % p.tiles_x; const int r = t / p.tiles_x;
-        c.ox0 = tx << 4; c.oy0 = (r % p.tiles_y) << 4; c.b = r / p.tiles_y; return c;
+        c.ox0 = (tx << 4) - p.ox_shift; c.oy0 = (r % p.tiles_y) << 4; c.b = r / p.tiles_y; return c;
     };
 #if SALT_WS_CLK
     unsigned long long clk[24]; int nclk = 0;
-    auto stamp = [&]() { if (nclk < 24) clk[nclk++] = __builtin_readcyclecounter(); };
+    auto stamp = [&]() { if (nclk < 22) clk[nclk++] = __builtin_readcyclecounter(); };
 #else
     auto stamp = [&]() {};
 #endif
@@ -294,11 +342,12 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsKP p) {
     auto issue_weights = [&]() {
 #pragma unroll
         for (int i = 0; i < NSW; ++i) {
-            const int q = wave + 8 * i;                                   // piece q = packed weight rows 16 q .. 16 q + 15
+            const int q = wave + 8 * i;                                   // piece q = rows 16 q .. 16 q + 15 of this block's [chunk][tap][BN] rows
             const bool real = q < WP;
             const int R = q * 16 + (lane >> 2);
-            const int slot = (lane ^ (R >> 2)) & 3;
-            const unsigned char* src = real ? reinterpret_cast<const unsigned char*>(p.w + (R * 32 + slot * 8)) : zp;
+            const int ct = R / BN, n = R - ct * BN;                       // (chunk, tap) and channel of the row inside the packed [chunk][tap][Cout][32]
+            const int cslot = (lane ^ (R >> 2)) & 3;
+            const unsigned char* src = real ? reinterpret_cast<const unsigned char*>(p.w + ((ct * p.Cout + n0 + n) * 32 + cslot * 8)) : zp;
             dma(src, real ? q * 1024 : OFF_DUMMY);
         }
     };
@@ -333,11 +382,11 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsKP p) {
         float* sc = reinterpret_cast<float*>(smem + OFF_CONST);
         if (MODE == 2) {
             if (p.bnb_acc) {
-                const float mu = p.bnb_mean[tid], is = p.bnb_invstd[tid], k = p.bnb_gamma[tid] * is;
-                sc[tid] = mu; sc[BN + tid] = is; sc[2 * BN + tid] = k; sc[3 * BN + tid] = p.bnb_beta[tid] - mu * k;
+                const float mu = p.bnb_mean[n0 + tid], is = p.bnb_invstd[n0 + tid], k = p.bnb_gamma[n0 + tid] * is;
+                sc[tid] = mu; sc[BN + tid] = is; sc[2 * BN + tid] = k; sc[3 * BN + tid] = p.bnb_beta[n0 + tid] - mu * k;
             }
         } else {
-            sc[tid] = p.bias ? p.bias[tid] : 0.f; sc[BN + tid] = p.scale ? p.scale[tid] : 1.f; sc[2 * BN + tid] = p.shift ? p.shift[tid] : 0.f;
+            sc[tid] = p.bias ? p.bias[n0 + tid] : 0.f; sc[BN + tid] = p.scale ? p.scale[n0 + tid] : 1.f; sc[2 * BN + tid] = p.shift ? p.shift[n0 + tid] : 0.f;
         }
     }                                                                      // (read after the first phase barrier at the earliest)
 
@@ -418,12 +467,25 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsKP p) {
     // epilogue of the tile in `acc` (computed by this wave one phase ago); issues the halo DMA of `next` (if any) into buffer g
     auto epilogue = [&](const TC& c, int g, bool has_next, const TC& next) {
         unsigned pix[MI];
+        WsLaneGeo geo = {{true, true}, false, false, false, false, 0, 0, 0, 0};
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int m = wm * 64 + i * 32 + ws_perm(l31);
-            pix[i] = (unsigned)((c.b * p.OH + c.oy0 + (m >> 4)) * p.OW + c.ox0 + (m & 15));
+            const int oy = c.oy0 + (m >> 4), ox = c.ox0 + (m & 15);
+            const int iy = oy - p.fold_top;                                   // y row (pad-ring rows of a fused fold: < 0, never stored)
+            geo.valid[i] = ((unsigned)iy < (unsigned)p.yH) & ((unsigned)ox < (unsigned)p.yW);
+            pix[i] = (unsigned)((c.b * p.yH + iy) * p.yW + ox);
         }
-        ws_epilogue_tile<NI, MODE>(ep, acc, pix, 0, reinterpret_cast<const float*>(smem + OFF_CONST), rs0, rs1, khalf, l31);
+        if (FOLD) {
+            const int q = ws_perm(l31), rs = q >> 4, col = q & 15;             // the lane's row (0 | 1) inside a sub-tile and its tile column
+            geo.fr_src0 = ws_perm_inv(rs * 16 + 14); geo.fr_src1 = ws_perm_inv(rs * 16 + 15);
+            geo.ft_src0 = ws_perm_inv(col); geo.ft_src1 = ws_perm_inv(16 + col);
+            geo.do_right = c.ox0 + 16 == p.OW;                                 // the last tile column holds the pad columns (tile columns 14, 15)
+            geo.do_top = wm == 0 && c.oy0 == 0;                                // wave 0 of the first tile row holds the pad rows (rows 0, 1)
+            geo.fr_on = col == 13 && geo.do_right;                             // image column yW - 1
+            geo.ft_on = rs == 0 && geo.do_top;                                 // (sub-tile 1) image row 0 = grid row 2
+        }
+        ws_epilogue_tile<NI, MODE, FOLD>(ep, acc, pix, geo, n0, reinterpret_cast<const float*>(smem + OFF_CONST), rs0, rs1, khalf, l31);
         stamp();
         if (has_next) {
             // the halo of this group's next tile goes into the buffer the group released at the phase barrier - LAST, so that the
@@ -458,13 +520,15 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsKP p) {
     if (MODE != 0 && sums) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        ws_sums_flush<NI, MODE, 8>(rs0, rs1, true, wave, reinterpret_cast<float*>(smem), 0, BN, p.fin_acc, p.bnb_acc, (double)n_my * 256.0, khalf, l31);
+        ws_sums_flush<NI, MODE, 8>(rs0, rs1, true, wave, reinterpret_cast<float*>(smem), n0, p.Cout, p.fin_acc, p.bnb_acc,
+                                   nt == 0 ? (double)n_my * 256.0 : 0.0, khalf, l31);
     }
 #if SALT_WS_CLK
-    stamp();
     if (lane == 0 && (wave == 0 || wave == 4) && blockIdx.x < 256) {
         unsigned long long* o = g_ws_clk + (blockIdx.x * 2 + grp) * 24;
-        for (int i = 0; i < 24; ++i) o[i] = i < nclk ? clk[i] : 0ull;
+        for (int i = 0; i < 22; ++i) o[i] = i < nclk ? clk[i] : 0ull;
+        o[22] = (unsigned long long)n_my;                        // tiles of this workgroup
+        o[23] = __builtin_readcyclecounter();                    // kernel end
     }
 #endif
 }
@@ -480,30 +544,30 @@ int ws_cus() {
     return cus;
 }
 
-template <int NCH, int NI, int MODE>
+template <int NCH, int NI, int MODE, bool FOLD>
 int ws_launch_mode(const WsKP& k, hipStream_t st) {
     constexpr int BN = 32 * NI, HP = NCH * 21, WP = NCH * 9 * BN / 16;
     constexpr int LDS = WP * 1024 + 2 * HP * 1024 + 1024 + 4 * BN * 4;
     static_assert(LDS <= 160 * 1024 && 8 * 2 * BN * 4 <= WP * 1024, "LDS budget");
-    auto kern = conv_ws_kernel<NCH, NI, MODE>;
+    auto kern = conv_ws_kernel<NCH, NI, MODE, FOLD>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) SALT_FAIL((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(k.wg_per_xcd * 8)), dim3(512), LDS, st, k);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(k.slots * k.n_tiles * 8)), dim3(512), LDS, st, k);
     SALT_CHECK_LAUNCH();
     return SALT_OK;
 }
 
 template <int NCH, int NI>
 int ws_launch(const WsKP& k, hipStream_t st) {
-    if (k.fin_acc) return ws_launch_mode<NCH, NI, 1>(k, st);
-    if (k.bnb_acc) return ws_launch_mode<NCH, NI, 2>(k, st);
-    return ws_launch_mode<NCH, NI, 0>(k, st);
+    const bool fold = k.fold_top != 0;
+    if (k.fin_acc) return ws_launch_mode<NCH, NI, 1, false>(k, st);
+    if (k.bnb_acc) return fold ? ws_launch_mode<NCH, NI, 2, true>(k, st) : ws_launch_mode<NCH, NI, 2, false>(k, st);
+    return fold ? ws_launch_mode<NCH, NI, 0, true>(k, st) : ws_launch_mode<NCH, NI, 0, false>(k, st);
 }
-
 
 // ------------------------------------------------------------------------------------------ conv_ls_kernel
 // Loader-specialised streaming kernel for the 3x3 layers whose weights do NOT fit in LDS (K = 9 Cin >= 1152: ResNet34 layer2 / layer3
@@ -731,7 +795,8 @@ __global__ __launch_bounds__(512) void conv_ls_kernel(LsKP p) {
                 const int m = wm * 64 + i * 32 + ws_perm(l31);
                 pix[i] = (unsigned)((cc.b * p.OH + cc.oy0 + (m >> 4)) * p.OW + cc.ox0 + (m & 15));
             }
-            ws_epilogue_tile<NI, MODE>(ep, acc, pix, n0, reinterpret_cast<const float*>(smem + OFF_CONST), rs0, rs1, khalf, l31);
+            const WsLaneGeo geo = {{true, true}, false, false, false, false, 0, 0, 0, 0};
+            ws_epilogue_tile<NI, MODE, false>(ep, acc, pix, geo, n0, reinterpret_cast<const float*>(smem + OFF_CONST), rs0, rs1, khalf, l31);
         }
     }
     if (MODE != 0 && sums) {
@@ -772,6 +837,8 @@ int ls_launch(const LsKP& k, int wgs, hipStream_t st) {
 // cfg & 0xff == 9 asks for this kernel wherever it applies, whatever the tile count (tests); cfg >> 8 (if non-zero) caps the
 // workgroups per XCD, so that small test tensors exercise the multi-tile pipeline.  A launch it does not apply to falls back to
 // conv_mfma_kernel's own heuristic; salt_conv_kernel_id tells which kernel a launch gets.
+int conv_ws_tiles(const salt_conv_args* a);
+
 bool conv_ws_eligible(const salt_conv_args* a) {
     static const int env = getenv("SALT_CONV_WS") ? atoi(getenv("SALT_CONV_WS")) : 1;
     if (!a || a->dtype != SALT_BF16) return false;
@@ -779,12 +846,21 @@ bool conv_ws_eligible(const salt_conv_args* a) {
     if (a->cfg != 0 && !asked) return false;
     if (!asked && !env) return false;
     if (a->ntaps != 9 || a->in_step != 1 || a->out_step != 1 || a->out_oy || a->out_ox || a->nphase > 1) return false;
-    if (a->strip || a->fold_top || a->fold_bottom || a->fold_left || a->fold_right) return false;
+    // plain launches, or the FUSED fold of a 3x3 replicate-padded convolution's data gradient (two pad rows on top, two columns right)
+    const bool fold = !a->strip && (a->fold_top || a->fold_right);
+    if (a->strip || a->fold_bottom || a->fold_left) return false;
+    if (fold && (a->fold_top != 2 || a->fold_right != 2 || a->fin_acc || a->OH != a->y.H + 2 || a->OW != a->y.W + 2)) return false;
+    // the extended grid is tiled 16 x 16 from its top-right corner: on a 34 x 34 grid that is 9 tiles for 4 tiles of image - measured
+    // slower than conv_mfma_kernel's fused fold below 64 x 64 (profiles/r03_ws_clocks.txt)
+    if (fold && !asked && (a->y.H < 64 || a->y.W < 64)) return false;
+    if (!fold && (a->OH != a->y.H || a->OW != a->y.W)) return false;
     if (a->stats || a->fin_ticket || a->bnb_partials || a->bnb_ticket) return false;
     const int Cin = a->x.C, Cout = a->y.C;
-    if (!((Cin == 64 && (Cout == 64 || Cout == 32)) || (Cin == 32 && Cout == 64))) return false;
+    // all taps x all input channels of ONE block of 32 | 64 output channels stay in LDS: Cin <= 64
+    if (!((Cin == 64 && (Cout % 64 == 0 || Cout == 32)) || (Cin == 32 && Cout % 64 == 0))) return false;
     if (a->x.cs % 8 || a->y.cs % 8 || ((reinterpret_cast<uintptr_t>(a->x.p) | reinterpret_cast<uintptr_t>(a->y.p) | reinterpret_cast<uintptr_t>(a->w)) & 15)) return false;
-    if (a->OH != a->y.H || a->OW != a->y.W || a->OH % 16 || a->OW % 16 || a->x.B != a->y.B) return false;
+    if (a->x.B != a->y.B) return false;
+    if (a->fin_acc && (a->OH % 16 || a->OW % 16)) return false;           // forward statistics: whole tiles only (no per-pixel mask there)
     int min_dy = 1 << 30, max_dy = -(1 << 30), min_dx = 1 << 30, max_dx = -(1 << 30);
     for (int t = 0; t < 9; ++t) {
         min_dy = a->tap_dy[t] < min_dy ? a->tap_dy[t] : min_dy; max_dy = a->tap_dy[t] > max_dy ? a->tap_dy[t] : max_dy;
@@ -800,20 +876,26 @@ bool conv_ws_eligible(const salt_conv_args* a) {
                            (reinterpret_cast<uintptr_t>(a->bnb_a.p) & 15))) return false;
         if (a->fin_acc) return false;
     }
-    const int64_t ntiles = (int64_t)a->x.B * (a->OH / 16) * (a->OW / 16);
-    // a launch must give most CUs at least one tile; below that the per-CU weight load has nothing to amortise over
-    if (!asked && ntiles < ws_cus() / 2) return false;
+    const int bn = Cout % 64 == 0 ? 64 : 32;
+    if (Cout / bn > ws_cus() / 8) return false;
+    const int64_t nitems = (int64_t)conv_ws_tiles(a) * (Cout / bn);
+    // a launch must give most CUs at least one item; below that the per-CU weight load has nothing to amortise over
+    if (!asked && nitems < ws_cus() / 2) return false;
     return true;
 }
 
-int conv_ws_tiles(const salt_conv_args* a) { return a->x.B * (a->OH / 16) * (a->OW / 16); }
+int conv_ws_tiles(const salt_conv_args* a) { return a->x.B * cdiv(a->OH, 16) * cdiv(a->OW, 16); }
 
 int conv_ws_launch(const salt_conv_args* a, hipStream_t st) {
     WsKP k;
     k.x = reinterpret_cast<const bf16_t*>(a->x.p); k.w = reinterpret_cast<const bf16_t*>(a->w); k.y = reinterpret_cast<bf16_t*>(a->y.p);
     k.bias = a->bias; k.scale = a->scale; k.shift = a->shift;
     k.B = a->x.B; k.H = a->x.H; k.W = a->x.W; k.x_cs = a->x.cs; k.y_cs = a->y.cs; k.OH = a->OH; k.OW = a->OW;
-    k.tiles_x = a->OW / 16; k.tiles_y = a->OH / 16; k.ntiles = k.B * k.tiles_x * k.tiles_y;
+    k.yH = a->y.H; k.yW = a->y.W; k.fold_top = a->fold_top;
+    k.tiles_x = cdiv(a->OW, 16); k.tiles_y = cdiv(a->OH, 16); k.ntiles = k.B * k.tiles_x * k.tiles_y;
+    // fused fold: tile columns are RIGHT-aligned with the extended grid, so that the two pad columns share a tile (and a wave) with the
+    // last image column; rows start at 0: the two pad rows share the first tile row's first wave with image row 0
+    k.ox_shift = a->fold_right ? k.tiles_x * 16 - a->OW : 0;
     int min_dy = 1 << 30, min_dx = 1 << 30;
     for (int t = 0; t < 9; ++t) { min_dy = a->tap_dy[t] < min_dy ? a->tap_dy[t] : min_dy; min_dx = a->tap_dx[t] < min_dx ? a->tap_dx[t] : min_dx; }
     k.min_dy = min_dy; k.min_dx = min_dx; k.pad_mode = a->pad_mode;
@@ -824,17 +906,18 @@ int conv_ws_launch(const salt_conv_args* a, hipStream_t st) {
     k.bnb_mean = a->bnb_mean; k.bnb_invstd = a->bnb_invstd; k.bnb_gamma = a->bnb_gamma; k.bnb_beta = a->bnb_beta;
     k.fin_acc = a->fin_acc; k.bnb_acc = a->bnb_acc;
     if (!a->bnb_acc) { k.bnb_y = nullptr; k.bnb_a = nullptr; }
-    const int cus = ws_cus();
-    k.per_xcd = cdiv(k.ntiles, 8);
-    int wpx = cus / 8;                                   // workgroups per XCD: one per CU, fewer when the launch has fewer tiles
-    if (wpx > k.per_xcd) wpx = k.per_xcd;
+    const int Cin = a->x.C, Cout = a->y.C, bn = Cout % 64 == 0 ? 64 : 32;
+    k.Cout = Cout; k.n_tiles = Cout / bn;
+    int wpx = ws_cus() / 8;                              // workgroups per XCD: one per CU, fewer when the launch has fewer items
     const int cap = (a->cfg >> 8) & 0xff;
-    if ((a->cfg & 0xff) == 9 && cap && wpx > cap) wpx = cap;
-    k.wg_per_xcd = wpx;
-    const int Cin = a->x.C, Cout = a->y.C;
-    if (Cin == 64 && Cout == 64) return ws_launch<2, 2>(k, st);
-    if (Cin == 64 && Cout == 32) return ws_launch<2, 1>(k, st);
-    if (Cin == 32 && Cout == 64) return ws_launch<1, 2>(k, st);
+    if ((a->cfg & 0xff) == 9 && cap && wpx > cap) wpx = cap > k.n_tiles ? cap : k.n_tiles;
+    k.per_xcd = cdiv(k.ntiles, 8);
+    k.slots = wpx / k.n_tiles;
+    if (k.slots > k.per_xcd) k.slots = k.per_xcd;
+    if (k.slots < 1) SALT_FAIL(SALT_E_UNSUPPORTED, "conv_ws: %d channel blocks for %d workgroups per XCD", k.n_tiles, wpx);
+    if (Cin == 64 && bn == 64) return ws_launch<2, 2>(k, st);
+    if (Cin == 64 && bn == 32) return ws_launch<2, 1>(k, st);
+    if (Cin == 32 && bn == 64) return ws_launch<1, 2>(k, st);
     SALT_FAIL(SALT_E_BADARG, "conv_ws: channels %d -> %d", Cin, Cout);
 }
 

@@ -62,6 +62,8 @@ WS_CASES = [
     (5, 64, 32, 64, 32, 1),      # 64 -> 32 (DecoderBlock dec1.conv1), 5 tiles per workgroup; its data gradient is the 32 -> 64 variant
     (5, 32, 32, 64, 64, 1),      # 32 -> 64 (dec1.conv2), data gradient 64 -> 32
     (2, 64, 48, 80, 64, 2),      # 30 tiles, 16 workgroups: uneven tile counts (2 and 1) inside one XCD range
+    (2, 64, 32, 32, 128, 2),     # two channel blocks of 64 (each workgroup keeps ONE block's weights): the shape of dec2.conv1's data gradient
+    (1, 64, 32, 64, 320, 5),     # five channel blocks: the final convolution's data gradient (64 -> 320), scaled down
 ]
 
 
@@ -88,11 +90,14 @@ def test_ws_conv_bn_relu_train_vs_torch(case, replicate):
     mod.train()
     run = BlockRun(mod, [x], emit, train=True, dtype='bf16')
     assert _kernel_ids(run.g.fwd) == [kid]
-    if not replicate:
-        # the plain data gradient (the replicate one is the fused-fold launch); its channel counts are swapped, so a conv_ws forward
-        # with Cout = 32 has a conv_ws data gradient too, and a conv_ls layer a conv_ls (or, at Cout = 32 < 64 input channels, conv_mfma) one
-        ids = _kernel_ids(run.g.bwd)
-        assert ids == [kid] or (kind == 'ls' and Cout < 64), ids
+    # the data gradient swaps the channel counts.  conv_ws also runs the FUSED-fold data gradient of the replicate-padded layer (extended
+    # 34 x 34 ... grids: ragged tiles, pad ring folded onto the edge pixels by lane permutation); conv_ls only plain ones with >= 64
+    # input channels (= Cout here)
+    ids = _kernel_ids(run.g.bwd)
+    if kind == 'ws':
+        assert ids == [9] or Cout > 64, ids
+    elif not replicate:
+        assert ids == [10] or Cout < 64, ids
     y = run.forward()
     ref_conv, ref_bn = nn.Conv2d(Cin, Cout, 3, 1, 0 if replicate else 1, bias=True), nn.BatchNorm2d(Cout)
     with torch.no_grad():
@@ -186,7 +191,8 @@ def test_ws_equals_conv_mfma_kernel_on_a_residual_block(case):
 
 
 @pytest.mark.parametrize('case', [(2, 64, 32, 32, 64, 9 | (1 << 8)), (4, 64, 32, 32, 32, 9 | (1 << 8)), (4, 32, 32, 32, 64, 9 | (1 << 8)),
-                                  (2, 128, 32, 32, 96, _ls(3, 1)), (2, 192, 32, 32, 128, _ls(2, 2))])
+                                  (2, 128, 32, 32, 96, _ls(3, 1)), (2, 192, 32, 32, 128, _ls(2, 2)),
+                                  (3, 64, 40, 24, 64, 9 | (1 << 8)), (2, 64, 101, 101, 64, 9 | (2 << 8)), (2, 32, 20, 50, 128, 9 | (2 << 8))])   # ragged grids
 def test_ws_eval_folded_bn_relu_vs_torch(case):
     """eval mode: bias + folded BatchNorm + ReLU in the epilogue (salt_conv_args.bias / scale / shift / relu)."""
     from gpu_harness import BlockRun

@@ -16,15 +16,16 @@ from salt_amd.engine import Graph
 from salt_amd.runtime import Engine
 
 B, Cin, H, W, Cout = [int(v) for v in sys.argv[1].split(',')]
-train = len(sys.argv) > 2 and sys.argv[2] == 'train'
-conv = nn.Conv2d(Cin, Cout, 3, 1, 1, bias=False)
+mode = sys.argv[2] if len(sys.argv) > 2 else 'eval'
+train = mode in ('train', 'dgrad_rep')
+conv = nn.Conv2d(Cin, Cout, 3, 1, 0 if mode == 'dgrad_rep' else 1, bias=False)
 bn = nn.BatchNorm2d(Cout)
 mod = nn.Sequential(conv, bn).to('cuda:0')
 eng = Engine(mod, torch.device('cuda:0'), 'bf16')
 g = Graph(eng, train)
 x = g.new_act(B, H, W, Cin, 'x')
 x.buf.t.normal_()
-y = g.conv(x, conv, bn if train else None, relu=False)
+y = g.conv(x, conv, bn if train else None, relu=False, replicate=(mode == 'dgrad_rep'))
 if train:
     g.build_backward()
 g.finalize(); eng.refresh(train)
@@ -35,6 +36,11 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record(); g.fwd.run(side=eng.side_stream); e1.record()
 torch.cuda.synchronize()
 print('program wall %.1f us (%d ops)' % (e0.elapsed_time(e1) * 1e3, len(g.fwd.ops)))
+if mode == 'dgrad_rep':                     # the data gradient of the replicate-padded layer (fused fold) is the last conv_ws launch
+    y.buf.grad().normal_()
+    for name, st, ms in g.bwd.run_timed():
+        print('  bwd %-14s %8.1f us' % (name, ms * 1e3))
+    torch.cuda.synchronize()
 NS = 24
 buf = (ctypes.c_ulonglong * (256 * 2 * NS))()
 lib.salt_debug_ws_clk.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -45,7 +51,9 @@ for grp in (0, 1):
     st = a[:, grp, :]
     valid = st[:, 0] > 0
     st = st[valid]
-    n = int((st[0] > 0).sum())
+    n = int((st[0, :22] > 0).sum())
+    tot = st[:, 23] - st[:, 0]
+    print('  kernel entry -> end: median %.0f max %.0f cycles; tiles per workgroup %d..%d' % (np.median(tot), tot.max(), st[:, 22].min(), st[:, 22].max()))
     print('group %d: %d workgroups, %d stamps' % (grp, st.shape[0], n))
     t0 = st[:, 0].min()
     print('  stamps in program order: entry, then per phase k: after the barrier, [epilogue role: before its halo DMA issue], after the role\'s work; end')
