@@ -24,6 +24,12 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# RCCL reads its NCCL_DEBUG* variables once, when librccl initialises its logger: set them before torch is imported (round 2 set them
+# next to init_process_group and the file never appeared).  %p = pid, one file per rank; rccl_summary() quotes rank 0's.
+if 'NCCL_DEBUG' not in os.environ and __name__ == '__main__':
+    os.environ['NCCL_DEBUG'] = 'INFO'
+    os.environ.setdefault('NCCL_DEBUG_SUBSYS', 'INIT,GRAPH,TUNING')
+    os.environ['NCCL_DEBUG_FILE'] = '/tmp/salt_rccl_%p.log'
 
 import numpy as np
 import torch
@@ -69,8 +75,9 @@ def preprocess(img, mask, train, channels):
     x = torch.from_numpy(img)[:, None]
     m = torch.from_numpy(mask)[:, None]
     if train:
-        x = torch.nn.functional.interpolate(x, size=(102, 102), mode='bilinear', align_corners=False)
-        m = (torch.nn.functional.interpolate(m, size=(102, 102), mode='nearest') > 0.5).float()
+        # iaa.Scale's default in the reference's imgaug 0.2.5 is cubic (cv2.INTER_CUBIC), on the uint8 tile and the uint8 mask alike
+        x = torch.clamp(torch.floor(torch.nn.functional.interpolate(x, size=(102, 102), mode='bicubic', align_corners=False) * 255 + 0.5), 0, 255) / 255
+        m = torch.clamp(torch.floor(torch.nn.functional.interpolate(m, size=(102, 102), mode='bicubic', align_corners=False) + 0.5), 0, 1)
         pad = (13, 13, 13, 13)
     else:
         pad = (14, 13, 13, 14)                      # (left, right, top, bottom)
@@ -157,7 +164,7 @@ def op_bytes(name, s, es):
     return 0.0
 
 
-PMC_FILE = 'profiles/r02_pmc_traffic.json'
+PMC_FILE = 'profiles/r03_pmc_traffic.json'
 
 
 def pmc_commit():
@@ -171,7 +178,7 @@ def pmc_commit():
 def pmc_traffic(kernel):
     """HBM bytes per launch, averaged over the kernels named in the tuple `kernel`, from the committed rocprofv3 --pmc passes (PMC_FILE;
     tools/pmc_traffic.sh regenerates it - PMC counters cannot be read from inside the timed process).  None when the file is absent."""
-    for path in (os.path.join(ROOT, PMC_FILE), os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')):
+    for path in (os.path.join(ROOT, PMC_FILE), os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')):
         try:
             ks = json.load(open(path))['kernels']
             sel = [v for k, v in ks.items() if k in kernel]
@@ -271,7 +278,7 @@ def conv_roofline(model, B, channels, dtype, loss, reps):
     dn, (dms, dfl, dcnt, dby) = max(groups.items(), key=lambda kv: kv[1][0])
     peak = MFMA_PEAK_TFLOPS[dtype]
     ach = dfl / (dms * 1e-3) / 1e12 if dms > 0 else 0.0
-    kern = {'conv': 'conv_mfma_kernel + conv_glds_kernel (fwd + dgrad launches)', 'conv_wgrad': 'conv_wgrad_kernel'}.get(dn, dn)
+    kern = {'conv': 'conv_ws_kernel + conv_ls_kernel + conv_mfma_kernel + conv_glds_kernel (fwd + dgrad launches)', 'conv_wgrad': 'conv_wgrad_kernel'}.get(dn, dn)
     roof = {'kernel': kern, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
             'algorithmic_bytes_per_launch': round(dby / dcnt) if dcnt else None, 'launches_per_step': dcnt // reps,
             'avg_launch_us': round(1e3 * dms / dcnt, 2), 'share_of_step': round(dms / reps / total_ms, 3),
@@ -398,10 +405,6 @@ def init_rccl(rank):
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29511')
     os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
-    if rank == 0 and 'NCCL_DEBUG' not in os.environ:
-        os.environ['NCCL_DEBUG'] = 'INFO'
-        os.environ.setdefault('NCCL_DEBUG_SUBSYS', 'INIT,GRAPH,TUNING')
-        os.environ['NCCL_DEBUG_FILE'] = RCCL_LOG
     sys.stdout.flush()
     saved = os.dup(1)
     os.dup2(2, 1)
@@ -553,7 +556,7 @@ def main():
         net.x.copy_(batches[0][0]); net.target.copy_(batches[0][1])
         roof, ops, total_ms, side_ms, all_fl, dn = conv_roofline(model, B, channels, args.dtype, args.loss, 3)
         headline = args.dtype == 'bf16' and args.workload == 'r34_hyper' and B == 32
-        roof['traffic'] = pmc_traffic({'conv': ('conv_mfma_kernel', 'conv_glds_kernel'), 'conv_wgrad': ('conv_wgrad_kernel',)}.get(dn, (dn,))) if headline else None
+        roof['traffic'] = pmc_traffic({'conv': ('conv_ws_kernel', 'conv_ls_kernel', 'conv_mfma_kernel', 'conv_glds_kernel'), 'conv_wgrad': ('conv_wgrad_kernel',)}.get(dn, (dn,))) if headline else None
         roof['traffic_unit'] = ('bytes per launch (rocprofv3 PMC FETCH_SIZE*2 + WRITE_SIZE, separate --pmc passes; file %s measured at commit %s - '
                                 'PMC counters cannot be read inside the timed process)' % (PMC_FILE, pmc_commit()))
         out['roofline_by_class'] = roof.pop('by_class')

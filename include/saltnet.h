@@ -57,7 +57,7 @@ const char* salt_last_error(void);          /* text for the last non-zero return
  * data-gradients (same kernel, transposed packed weights, mirrored taps).
  *   out[b, oy*out_step+out_oy, ox*out_step+out_ox, n] (+)= epi( sum_t sum_c
  *        X[b, pad(oy*in_step + tap_dy[t]), pad(ox*in_step + tap_dx[t]), c] * Wp[t][n][c] )
- *   epi(v) = relu?( (v + bias[n]) * scale[n] + shift[n] )        (each part optional)
+ *   epi(v) = relu?( (v + bias[n]) * scale[n] + shift[n] )        (each part optional; + res before the ReLU: see `res` below)
  * Wp is the packed layout produced by salt_pack_conv_weight: [ceil(Cin/KC)][ntaps][Cout][KC],
  * KC = 64 bytes of channels (16 f32 / 32 bf16), zero padded.
  * stats (optional): per output-tile-wave partial (sum, M2 about the partial's own mean, count) of
@@ -140,6 +140,24 @@ typedef struct {
     const void* bnb_fin;
     double* bnb_acc;          /* [8][2 * Cout] */
     uint32_t* bnb_ticket;
+    /* Residual epilogue (eval-mode torchvision BasicBlock / Bottleneck, out = relu(bn(conv(a)) + identity), architectures/encoders.py:6-45):
+     * res.p != NULL: y = relu?( round_to_dtype((v + bias) * scale + shift) + res ), res a [B,OH,OW,Cout] view - the values a separate
+     * salt_affine_act(y, res, relu) pass over the stored convolution output would produce, bit for bit, without that pass.  Plain
+     * full-grid launches only (out_step 1, no fold / strip / statistics / accumulate). */
+    salt_view res;
+    /* Input transform: the PRODUCER's BatchNorm apply + ReLU folded into this launch's loader (the measured alternative to the
+     * separate salt_affine_act pass between a convolution and its single consumer, architectures/base.py:29-37, unet_models.py:21-30;
+     * DESIGN 10 has the numbers).  in_scale != NULL or in_fin_acc != NULL: every in-range input element becomes
+     * x' = round_to_dtype(relu?(x * in_scale[c] + in_shift[c])) - the value salt_affine_act would have stored - between the global
+     * load and the LDS store; zero padding stays zero.  in_fin_acc: the [8][2 Cin + 1] fp64 shards of the producer's statistics
+     * (salt_conv_args.fin_acc without a ticket) are finalized in every workgroup's prologue with in_fin (the producer layer's const
+     * salt_bn_finalize_args*), workgroup 0 stores mean / invstd / scale / shift / running statistics: in_scale / in_shift are ignored.
+     * bf16, 9 taps, whole aligned 16-byte pieces; runs on conv_mfma_kernel's register-staged loader (never the LDS-DMA kernels). */
+    const float* in_scale;    /* [Cin] */
+    const float* in_shift;
+    int in_relu;
+    const void* in_fin;
+    const double* in_fin_acc;
 } salt_conv_args;
 int salt_conv(const salt_conv_args*, void* stream);
 /* number of stats partials a launch with these args writes (host sizes the workspace with it) */
@@ -448,7 +466,7 @@ typedef struct {              /* nn.AvgPool2d(2,2) (unet.py:62); bwd: dx = dy/4 
 } salt_avgpool2_args;
 int salt_avgpool2(const salt_avgpool2_args*, void* stream);
 
-typedef struct {              /* bilinear xR, align_corners=False (base.py:70, unet.py:103-106 on torch 2.10) */
+typedef struct {              /* bilinear xR (nn.Upsample / F.upsample(mode='bilinear'), base.py:70, unet.py:103-106) */
     int dtype;
     salt_view x;              /* low resolution  [B,H,W,C] */
     salt_view y;              /* high resolution [B,H*R,W*R,C] */
@@ -456,8 +474,25 @@ typedef struct {              /* bilinear xR, align_corners=False (base.py:70, u
     int backward;             /* 0: y = up(x);  1: x (+)= up^T(y) */
     int accumulate;
     void* tmp;                /* backward, R >= 4: workspace of B*(H*R)*W*roundup(C) elements for the separable adjoint, or NULL */
+    int align_corners;        /* 0: src = (dst + 0.5) / R - 0.5 clamped at 0 (torch >= 0.4 default: what the oracle / goldens executed);
+                               * 1: src = dst * (H - 1) / (R H - 1) - how torch 0.3.1, the reference's pinned version (environment.yml:17),
+                               * evaluated the same call: use it for checkpoints trained in the reference's own environment */
 } salt_bilinear_args;
 int salt_bilinear(const salt_bilinear_args*, void* stream);
+
+/* Hypercolumn rows (architectures/unet.py:101-107: torch.cat of the decoder maps up-sampled x2 / x4 / x8 / x16): ONE pass writes the
+ * nlev up-sampled levels of every output pixel next to each other - channels [c0 + k*C, c0 + (k+1)*C) of y's pixel row from x[k] at
+ * factor R[k] - instead of one salt_bilinear launch per level into a channel slice (128-byte pieces at the row pitch; at the C4 size
+ * that streams a 2.7 GB buffer four times at 0.6 TB/s).  Same arithmetic per value as salt_bilinear: bit-identical. */
+typedef struct {
+    int dtype;
+    int nlev;                 /* 1..4 */
+    salt_view x[4];           /* [B, H / R[k], W / R[k], C] */
+    int R[4];
+    salt_view y;              /* [B, H, W, *] view whose channels [c0, c0 + nlev*C) are written (y.C = nlev*C, y.p at channel c0) */
+    int align_corners;
+} salt_hyper_rows_args;
+int salt_hyper_rows(const salt_hyper_rows_args*, void* stream);
 
 typedef struct {              /* adjoint of replicate padding: fold an extended grad back (base.py:21-27) */
     int dtype;
@@ -652,7 +687,7 @@ typedef struct {              /* x_out[b] = flip(x[b]) for NCHW fp32 batches (TT
 int salt_flip(const salt_flip_args*, void* stream);
 
 /* ------------------------------------------------------------------ on-device input pipeline
- * gray tile -> [bilinear resize] -> edge pad -> Normalize -> AddDepthChannels; mask -> nearest resize -> pad -> one-hot
+ * gray tile -> [resize: cubic | bilinear] -> edge pad -> Normalize -> AddDepthChannels; mask -> [resize] -> pad -> one-hot
  * (loaders.py:603-612,763-769; augmentation.py:79-96,247-284; utils.py:494-500).  Normalisation divides by std exactly as
  * torchvision ((g - mean) / std is evaluated as (g - mean) * (1 / std), agreement 1 ulp). */
 typedef struct {
@@ -673,6 +708,10 @@ typedef struct {
     float std[3];
     float* x;                 /* out fp32 NCHW [B,channels,H,W] */
     float* target;            /* out fp32 NCHW [B,2,H,W] one-hot {background, salt}; required when mask != NULL */
+    int interpolation;        /* of the resize.  1: cubic - cv2.INTER_CUBIC as imgaug 0.2.5's iaa.Scale default (augmentation.py:79-85 passes no
+                               * interpolation; environment.yml:15-16): Keys kernel a = -0.75, half-pixel centres, replicated border; a uint8
+                               * tile is rounded back to the uint8 grid with saturation (cv2's uint8 output) and the {0,1} mask goes through the
+                               * same resize, then round-half-up.  0: bilinear, half-pixel centres, nearest for the mask (rounds 1 - 2 default) */
 } salt_preprocess_args;
 int salt_preprocess(const salt_preprocess_args*, void* stream);
 

@@ -265,6 +265,10 @@ class HipNetwork(nn.Module):
     """Base of the callable networks: owns the Engine, dispatches forward to the compiled HIP program."""
 
     compute_dtype = os.environ.get('SALT_DTYPE', 'f32')
+    # nn.Upsample / F.upsample(mode='bilinear') (base.py:70, unet.py:103-106).  False: torch >= 0.4 semantics, what the oracle and the
+    # goldens executed (torch 2.10).  True: how torch 0.3.1 - the version the reference pins, environment.yml:17 - evaluated the very
+    # same calls; a checkpoint TRAINED in the reference's environment saw these features, so evaluate / fine-tune it with True
+    align_corners = False
 
     def __init__(self):
         super().__init__()
@@ -281,6 +285,13 @@ class HipNetwork(nn.Module):
     def set_compute_dtype(self, dtype):
         if dtype != self.compute_dtype:
             self.compute_dtype = dtype
+            self._drop_engine()
+        return self
+
+    def set_align_corners(self, flag):
+        flag = bool(flag)
+        if flag != self.align_corners:
+            self.align_corners = flag
             self._drop_engine()
         return self
 
@@ -379,7 +390,9 @@ class UNetResNet(HipNetwork):
         # the hypercolumn up-samplings only feed the final convolution: each one goes to the side stream as soon as its decoder
         # level exists and overlaps the remaining decoder levels; the final convolution joins
         def hyper_up(x, R, k):
-            if self.use_hypercolumn:
+            # SALT_EXP_VHYPER_SKIP: TIMING experiment - the step without the four up-sampling launches and their adjoints is
+            # the upper bound of what a loader that interpolates on the fly ("virtual hypercolumn") could save; the values are wrong
+            if self.use_hypercolumn and not os.environ.get('SALT_EXP_VHYPER_SKIP'):
                 with g.side():
                     g.upsample(x, R, out=hyper.slice(k * d, d))
         d5 = self.dec5.emit(g, c, e5, cat=cat5)

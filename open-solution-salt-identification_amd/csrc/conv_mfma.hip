@@ -53,7 +53,11 @@ struct ConvKP {
     // BatchNorm-backward sums of the stored tile (saltnet.h, salt_conv_args.bnb_*); bnb_partials == nullptr: off
     const void* bnb_y; const void* bnb_a; int bnb_cs, bnb_acs, bnb_relu;
     const float* bnb_mean; const float* bnb_invstd; const float* bnb_gamma; const float* bnb_beta; float* bnb_partials;
+    const void* res; int res_cs;     // residual epilogue (salt_conv_args.res): y = relu?(stored + res); nullptr: off
     BnFin fin; BnbFin bnbf;          // in-launch BatchNorm finalize (saltnet.h, salt_conv_args.fin / bnb_fin; common.h); acc == nullptr: off
+    // input transform (salt_conv_args.in_*): x' = relu?(x * in_scale[c] + in_shift[c]) applied by the loader between the global load and
+    // the LDS store; in_fin.acc != nullptr: the coefficients are finalized from the producer's statistics shards in the prologue
+    const float* in_scale; const float* in_shift; int in_relu, in_tab_off; BnFin in_fin;
 };
 
 template <typename T> struct Mma;
@@ -165,7 +169,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKP& p, const TileCoord& 
                     float v = acc[i][j][r];
                     if constexpr (AFF) {
                         v = (v + bias) * sc + sh;
-                        if (p.relu) v = fmaxf(v, 0.f);
+                        if (p.relu && !p.res) v = fmaxf(v, 0.f);           // with a residual the ReLU follows the add (store loop)
                         acc[i][j][r] = v;
                     }
                     if constexpr (ST) { if ((vmask[i] >> r) & 1u) ssum[j] += v; }
@@ -277,6 +281,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvKP& p, const TileCoord& 
                     for (int e = 0; e < VE; ++e) f[e] += o[e];
                     stored = pack16<T>(f);
                 }
+                if (p.res) {                                       // host: out_step 1, full grid - pix is the residual's pixel index too
+                    float f[VE], o[VE];
+                    unpack16<T>(stored, f);
+                    unpack16<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.res) + (pix * (unsigned)p.res_cs + n)), o);
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) { f[e] += o[e]; if (p.relu) f[e] = fmaxf(f[e], 0.f); }
+                    stored = pack16<T>(f);
+                }
                 *reinterpret_cast<u32x4*>(dst) = stored;
                 if (bnb) {                                         // host: out_step 1 (pix is the pixel index of bnb_y / bnb_a too)
                     float g[VE], yc[VE];
@@ -356,6 +368,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvKP& p, const TileCoord& 
                     for (int e = 0; e < VE; ++e) f[e] += o[e];
                     stored = pack16<T>(f);
                 }
+                if (p.res) {                                       // host: res implies whole aligned pieces, out_step 1, full grid, no fold
+                    float f[VE], o[VE];
+                    unpack16<T>(stored, f);
+                    unpack16<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.res) + (((int64_t)b * p.OHf + oy) * p.OWf + ox) * p.res_cs + n), o);
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) { f[e] += o[e]; if (p.relu) f[e] = fmaxf(f[e], 0.f); }
+                    stored = pack16<T>(f);
+                }
 #if defined(SALT_K1_DBG) && (SALT_K1_DBG & 8)
                 if (stored.x == 0x12345678u && stored.y == 0x9abcdef0u) *reinterpret_cast<u32x4*>(dst) = stored;   // ablation: staging without the stores
 #else
@@ -425,7 +445,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKP& p, const TileCoord& 
 // per thread): the global loads of chunk c+1 are not issued in one burst after the barrier - where the 8-12 waves of a CU queue up
 // behind its 64 B/clk address path and nobody feeds the matrix cores (in-kernel clocks on 256->256 @32x32: 0.98 us of load issue
 // per 0.94 us of MFMAs) - but one piece per (tap, k-step) stage between the MFMAs, branch-free (masked pieces read g_zero_piece).
-template <typename T, int MI, int NI, int WM, int WN, int NT, int MAXA_T = 0>
+template <typename T, int MI, int NI, int WM, int WN, int NT, int MAXA_T = 0, bool INA = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
     constexpr int BN = 32 * NI * WN;
     constexpr int KCE = 64 / (int)sizeof(T);
@@ -462,6 +482,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
     const T* xg = reinterpret_cast<const T*>(p.x);
     const T* wg = reinterpret_cast<const T*>(p.w) + w_off;
     const bool x_vec = ((p.x_cs % VE) == 0) && ((reinterpret_cast<uintptr_t>(p.x) & 15) == 0);
+    // ---- input transform table [2][Cin] behind the staging buffers (INA: bf16, whole 16-byte pieces - checked by the host)
+    float* in_tab = reinterpret_cast<float*>(smem + p.in_tab_off);
+    if constexpr (INA) {
+        if (p.in_fin.acc) fin_forward_consumer(p.in_fin, p.Cin, in_tab, in_tab + p.Cin, blockIdx.x == 0);
+        else for (int c = tid; c < p.Cin; c += 256) { in_tab[c] = p.in_scale[c]; in_tab[p.Cin + c] = p.in_shift[c]; }
+    }
 
     // ---- per-thread halo staging pieces (fixed for the whole chunk loop); offsets are relative to image b0 (fit 32 bits)
     constexpr bool ILV = MAXA_T > 0;
@@ -677,7 +703,30 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
             load_chunk(0);
         }
         for (int c = 0; c < ((SALT_K1_DBG & 2) ? 0 : p.nchunk); ++c) {
-            __syncthreads();                    // fragment reads of chunk c-1 are done
+            __syncthreads();                    // fragment reads of chunk c-1 are done (c == 0: the input transform table is complete)
+            if constexpr (INA) {
+                const int ch0 = c * KCE + (tid & 3) * VE;
+                if (ch0 < p.Cin) {
+                    float sc[8], sh[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { sc[j] = in_tab[ch0 + j]; sh[j] = in_tab[p.Cin + ch0 + j]; }
+#pragma unroll
+                    for (int k = 0; k < MAXA; ++k) {
+                        if (k < npa && a_goff[k] >= 0) {
+                            unsigned o[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const unsigned wv = ra[k][j];
+                                float lo = __uint_as_float(wv << 16) * sc[2 * j] + sh[2 * j];
+                                float hi = __uint_as_float(wv & 0xffff0000u) * sc[2 * j + 1] + sh[2 * j + 1];
+                                if (p.in_relu) { lo = fmaxf(lo, 0.f); hi = fmaxf(hi, 0.f); }
+                                o[j] = f2bf_pk(lo, hi);
+                            }
+                            ra[k] = u32x4{o[0], o[1], o[2], o[3]};
+                        }
+                    }
+                }
+            }
 #pragma unroll
             for (int k = 0; k < MAXA; ++k)
                 if (k < npa && a_goff[k] != -2) *reinterpret_cast<u32x4*>(sA + lds_lane + k * (RPP * 64)) = ra[k];
@@ -1144,7 +1193,7 @@ __global__ __launch_bounds__(512, 2) void conv_glds_kernel(ConvKP p) {
                 float v = fin[o][r];
                 if (has_affine) {
                     v = (v + bias) * sc + sh;
-                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.relu && !p.res) v = fmaxf(v, 0.f);
                     fin[o][r] = v;
                 }
                 if (want_stats && ((vmask[o] >> r) & 1u)) ssum[o] += v;
@@ -1226,6 +1275,14 @@ __global__ __launch_bounds__(512, 2) void conv_glds_kernel(ConvKP p) {
                     unpack16<T>(*reinterpret_cast<const u32x4*>(dst), o);
 #pragma unroll
                     for (int e = 0; e < VE; ++e) f[e] += o[e];
+                    stored = pack16<T>(f);
+                }
+                if (p.res) {
+                    float f[VE], o[VE];
+                    unpack16<T>(stored, f);
+                    unpack16<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.res) + (((int64_t)b * p.OHf + oy) * p.OWf + ox) * p.res_cs + n), o);
+#pragma unroll
+                    for (int e = 0; e < VE; ++e) { f[e] += o[e]; if (p.relu) f[e] = fmaxf(f[e], 0.f); }
                     stored = pack16<T>(f);
                 }
                 *reinterpret_cast<u32x4*>(dst) = stored;
@@ -1383,8 +1440,9 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
     // 64-byte channel chunks.  Decided from the geometry only (salt_conv_stats_parts plans with the same rule before the epilogue
     // fields are known).
     static const int v2_env = getenv("SALT_CONV_V2") ? atoi(getenv("SALT_CONV_V2")) : 1;     // 0: off, N >= 6: force config N
+    const bool in_tf = a->in_scale || a->in_fin_acc;            // the input transform lives in conv_mfma_kernel's register-staged loader
     const bool v2_ok = a->dtype == SALT_BF16 && a->in_step == 1 && (a->ntaps == 9 || a->ntaps == 4) && a->x.C % 32 == 0 &&
-                       a->x.cs % 8 == 0 && (reinterpret_cast<uintptr_t>(a->x.p) & 15) == 0;
+                       a->x.cs % 8 == 0 && (reinterpret_cast<uintptr_t>(a->x.p) & 15) == 0 && !in_tf;
     // ---- tile config heuristic (overridable for tests/tuning)
     int id = ((a->cfg & 0xff) == 9 || (a->cfg & 0xff) == 10) ? 0 : a->cfg;   // 9 = "conv_ws_kernel where it applies" (conv_ws.hip): the heuristic decides for the rest
     if (id >= 6 && !v2_ok) id = 0;            // a forced conv_glds config applies where the kernel does (tests force one config per graph)
@@ -1416,7 +1474,7 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
     const TileCfg* cfg = nullptr;
     for (const auto& c : kCfgs) if (c.id == id) cfg = &c;
     if (!cfg) SALT_FAIL(SALT_E_BADARG, "conv: unknown cfg %d", id);
-    for (int attempt = 0; attempt < 2; ++attempt) {
+    for (int attempt = 0; attempt < 4; ++attempt) {
         const int BM = 32 * cfg->MI * cfg->WM;
         ConvKP& k = pl->kp;
         k.tw_log2 = ilog2_ceil(a->OW) < 4 ? ilog2_ceil(a->OW) : 4;
@@ -1434,12 +1492,15 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
             k.nbuf = 3 * buf + 8192 <= 160 * 1024 ? 3 : 2;
             if (cdiv(phalo, 16) > v2_namax(BM) || 2 * buf + 8192 > 160 * 1024) {
                 if (attempt == 0 && cfg->id != 8) { for (const auto& c : kCfgs) if (c.id == 8) cfg = &c; continue; }
+                // tiny maps (4 x 4 and below: a 128-pixel tile is 8+ images, each with its own halo ring): conv_mfma_kernel's tiles
+                // (round 3: a ResNet50 at 64 x 64 in bf16 failed here instead of falling back)
+                if (a->cfg < 6) { for (const auto& c : kCfgs) if (c.id == 4) cfg = &c; continue; }
                 SALT_FAIL(SALT_E_UNSUPPORTED, "conv: halo tile of %d pixels too large for the LDS ring", phalo);
             }
             break;
         }
         if (phalo * 4 > maxa_for(BM) * 256) {
-            if (attempt == 0 && cfg->id != 5) { for (const auto& c : kCfgs) if (c.id == 5) cfg = &c; continue; }
+            if (cfg->id != 5) { for (const auto& c : kCfgs) if (c.id == 5) cfg = &c; continue; }
             SALT_FAIL(SALT_E_UNSUPPORTED, "conv: halo tile of %d pixels too large", phalo);
         }
         break;
@@ -1513,10 +1574,35 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
         const size_t red_bytes = (size_t)((cfg->KS > 0 ? 512 : 256) / (BN / ve)) * BN * 2 * sizeof(float) + 16;
         if (red_bytes > pl->lds) pl->lds = red_bytes;
     }
+    k.res = a->res.p; k.res_cs = a->res.cs;
+    if (a->res.p) {
+        const int ve = a->dtype == SALT_F32 ? 4 : 8;
+        if (a->strip || fold_fused || a->stats || a->fin_acc || a->bnb_partials || a->bnb_acc || a->accumulate || a->out_step != 1 || a->out_oy || a->out_ox ||
+            k.nphase > 1 || a->OH != a->y.H || a->OW != a->y.W)
+            SALT_FAIL(SALT_E_BADARG, "conv: the residual epilogue needs a plain full-grid launch");
+        if (!view_ok(a->res) || a->res.B != a->y.B || a->res.H != a->y.H || a->res.W != a->y.W || a->res.C != a->y.C)
+            SALT_FAIL(SALT_E_BADARG, "conv: res shape");
+        if (Cout % ve || a->y.cs % ve || a->res.cs % ve || ((reinterpret_cast<uintptr_t>(a->y.p) | reinterpret_cast<uintptr_t>(a->res.p)) & 15))
+            SALT_FAIL(SALT_E_BADARG, "conv: the residual epilogue needs 16-byte aligned whole channel pieces");
+    }
     k.fin.acc = nullptr; k.bnbf.acc = nullptr;
+    k.in_scale = a->in_scale; k.in_shift = a->in_shift; k.in_relu = a->in_relu; k.in_tab_off = 0; k.in_fin = BnFin{};
+    if (in_tf) {
+        if (a->dtype != SALT_BF16 || a->ntaps != 9 || vt != 1 || cfg->KS > 0 || cfg->MI * cfg->WM == 2)
+            SALT_FAIL(SALT_E_UNSUPPORTED, "conv: the input transform needs a 9-tap bf16 launch with 128- or 256-pixel tiles");
+        if (a->in_fin_acc) {
+            const salt_bn_finalize_args* f = static_cast<const salt_bn_finalize_args*>(a->in_fin);
+            if (!f || f->C != a->x.C || !f->gamma || !f->beta || !f->mean || !f->invstd || !f->scale || !f->shift)
+                SALT_FAIL(SALT_E_BADARG, "conv: in_fin_acc needs the complete salt_bn_finalize arguments of the producer");
+            k.in_fin = BnFin{const_cast<double*>(a->in_fin_acc), nullptr, f->gamma, f->beta, f->running_mean, f->running_var, f->num_batches_tracked,
+                             f->momentum, f->eps, f->mean, f->invstd, f->scale, f->shift};
+        } else if (!a->in_shift) SALT_FAIL(SALT_E_BADARG, "conv: in_scale without in_shift");
+        k.in_tab_off = (int)((pl->lds + 15) & ~(size_t)15);
+        pl->lds = (size_t)k.in_tab_off + (size_t)2 * a->x.C * sizeof(float);
+    }
     {
         auto small = [](const salt_view& v) { return !v.p || (int64_t)v.B * v.H * v.W * v.cs < (int64_t)1 << 31; };
-        k.y_small = small(a->y) && small(a->bnb_y) && small(a->bnb_a);
+        k.y_small = small(a->y) && small(a->bnb_y) && small(a->bnb_a) && small(a->res);
     }
     if (a->fin_acc) {
         if (a->stats || a->stats_part0 || a->strip) SALT_FAIL(SALT_E_BADARG, "conv: fin_acc excludes stats partials and fold mode");
@@ -1545,9 +1631,9 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
     return SALT_OK;
 }
 
-template <typename T, int MI, int NI, int WM, int WN, int NT, int MAXA_T = 0>
+template <typename T, int MI, int NI, int WM, int WN, int NT, int MAXA_T = 0, bool INA = false>
 int launch_cfg_nt(const Plan& pl, hipStream_t st) {
-    auto kern = conv_mfma_kernel<T, MI, NI, WM, WN, NT, MAXA_T>;
+    auto kern = conv_mfma_kernel<T, MI, NI, WM, WN, NT, MAXA_T, INA>;
     static bool attr_set = false;
     if (pl.lds > 64 * 1024 && !attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1566,6 +1652,15 @@ int launch_cfg(const Plan& pl, hipStream_t st) {
         const ConvKP& k = pl.kp;
         const int npa = (k.nb * k.hh * k.hw * k.vt * 4 + 255) >> 8;
         const bool ok = !ilv_off && k.x_cs % 8 == 0 && k.Cin % 8 == 0 && (reinterpret_cast<uintptr_t>(k.x) & 15) == 0;
+        if (k.in_scale || k.in_fin.acc) {                                  // input transform: the interleaved 9-tap loader only
+            if (!ok || k.ntaps != 9 || k.vt != 1) SALT_FAIL(SALT_E_UNSUPPORTED, "conv: the input transform needs a 9-tap bf16 launch over aligned 16-byte pieces");
+            if constexpr (MI * WM == 8) { if (npa <= 6) return launch_cfg_nt<T, MI, NI, WM, WN, 9, 6, true>(pl, st); }
+            else {
+                if (npa <= 3) return launch_cfg_nt<T, MI, NI, WM, WN, 9, 3, true>(pl, st);
+                return launch_cfg_nt<T, MI, NI, WM, WN, 9, 9, true>(pl, st);
+            }
+            SALT_FAIL(SALT_E_UNSUPPORTED, "conv: the input transform does not fit this tile's loader");
+        }
         if (ok && k.ntaps == 9) {
             if constexpr (MI * WM == 8) { if (npa <= 6) return launch_cfg_nt<T, MI, NI, WM, WN, 9, 6>(pl, st); }
             else {
@@ -1575,6 +1670,7 @@ int launch_cfg(const Plan& pl, hipStream_t st) {
         }
         if constexpr (MI * WM != 8) { if (ok && k.ntaps == 4) return launch_cfg_nt<T, MI, NI, WM, WN, 4, 9>(pl, st); }
     }
+    if (pl.kp.in_scale || pl.kp.in_fin.acc) SALT_FAIL(SALT_E_UNSUPPORTED, "conv: the input transform needs bf16 tiles of 128 or 256 pixels");
     if (pl.kp.ntaps == 9) return launch_cfg_nt<T, MI, NI, WM, WN, 9>(pl, st);
     if (pl.kp.ntaps == 4) return launch_cfg_nt<T, MI, NI, WM, WN, 4>(pl, st);      // 1x1 with 4 virtual taps, ConvT k4 output phases
     return launch_cfg_nt<T, MI, NI, WM, WN, 0>(pl, st);
@@ -1700,9 +1796,14 @@ struct WgradKP {
     int tiles_y, tiles_x, ntiles, nsplit;
     int a_blocks, b_blocks;
     int bmp;                        // pixels per K tile (64 | 128)
+    int atomic;                     // SALT_WGRAD_ATOMIC=1 (A/B): every split ADDS into slab 0 with global_atomic_add_f32 instead of writing its own slab
 };
 
-template <typename T> struct WRow { static constexpr int BYTES = 64 * (int)sizeof(T); };   // 64 channels per pixel row
+template <typename T> struct WRow { static constexpr int BYTES = 64 * (int)sizeof(T); };
+__device__ __forceinline__ void slab_put4(float* dst, const f32x4& v, bool atomic) {
+    if (atomic) { unsafeAtomicAdd(dst, v.x); unsafeAtomicAdd(dst + 1, v.y); unsafeAtomicAdd(dst + 2, v.z); unsafeAtomicAdd(dst + 3, v.w); }
+    else *reinterpret_cast<f32x4*>(dst) = v;
+}   // 64 channels per pixel row
 
 template <typename T, int NT>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradKP p) {
@@ -1928,8 +2029,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradKP p) {
             for (int r = 0; r < 16; ++r) {
                 const int a = a0 + wa * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
                 const int b = c0 + wb * 32 + l31;
-                if (a < p.Ca && b < p.Cb)
-                    p.partials[(((int64_t)split * p.ntaps + t) * p.Ca + a) * p.Cb + b] = acc[t][r];
+                if (a < p.Ca && b < p.Cb) {
+                    float* d = p.partials + (((int64_t)(p.atomic ? 0 : split) * p.ntaps + t) * p.Ca + a) * p.Cb + b;
+                    if (p.atomic) unsafeAtomicAdd(d, acc[t][r]); else *d = acc[t][r];
+                }
             }
         }
     }
@@ -2151,11 +2254,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_fast_kernel(WgradKP p) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         if (t < p.ntaps && a < p.Ca) {
-            float* row = p.partials + (((int64_t)split * p.ntaps + t) * p.Ca + a) * p.Cb;
+            float* row = p.partials + (((int64_t)(p.atomic ? 0 : split) * p.ntaps + t) * p.Ca + a) * p.Cb;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int b = c0 + wb * 32 + 8 * g + 4 * khalf;
-                if (b < p.Cb) *reinterpret_cast<f32x4*>(row + b) = f32x4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+                if (b < p.Cb) slab_put4(row + b, f32x4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]}, p.atomic != 0);
             }
         }
     }
@@ -2343,11 +2446,11 @@ __global__ __launch_bounds__(512) void conv_wgrad_fast8_kernel(WgradKP p) {
 #pragma unroll
     for (int tl = 0; tl < NTA; ++tl) {
         if (tl < cnt && a < p.Ca) {
-            float* row = p.partials + (((int64_t)split * p.ntaps + grp * 5 + tl) * p.Ca + a) * p.Cb;
+            float* row = p.partials + (((int64_t)(p.atomic ? 0 : split) * p.ntaps + grp * 5 + tl) * p.Ca + a) * p.Cb;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int b = c0 + wb * 32 + 8 * g + 4 * khalf;
-                if (b < p.Cb) *reinterpret_cast<f32x4*>(row + b) = f32x4{acc[tl][4 * g], acc[tl][4 * g + 1], acc[tl][4 * g + 2], acc[tl][4 * g + 3]};
+                if (b < p.Cb) slab_put4(row + b, f32x4{acc[tl][4 * g], acc[tl][4 * g + 1], acc[tl][4 * g + 2], acc[tl][4 * g + 3]}, p.atomic != 0);
             }
         }
     }
@@ -2546,11 +2649,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_fast32_kernel(WgradKP p) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         if (t < p.ntaps && a < p.Ca) {
-            float* row = p.partials + (((int64_t)split * p.ntaps + t) * p.Ca + a) * p.Cb;
+            float* row = p.partials + (((int64_t)(p.atomic ? 0 : split) * p.ntaps + t) * p.Ca + a) * p.Cb;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int b = c0 + wb * 32 + 8 * g + 4 * khalf;
-                if (b < p.Cb) *reinterpret_cast<f32x4*>(row + b) = f32x4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+                if (b < p.Cb) slab_put4(row + b, f32x4{acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]}, p.atomic != 0);
             }
         }
     }
@@ -2668,8 +2771,9 @@ extern "C" int salt_conv(const salt_conv_args* a, void* stream) {
             (reinterpret_cast<uintptr_t>(a->strip) & 15))
             SALT_FAIL(SALT_E_BADARG, "conv: fold mode needs OH/OW = y.H/y.W + pads, out_step 1, no stats, 16-byte aligned strip");
     }
-    if (conv_ws_eligible(a)) return conv_ws_launch(a, (hipStream_t)stream);      // the plan above validated the arguments
-    if (conv_ls_variant(a)) return conv_ls_launch(a, (hipStream_t)stream);
+    const bool in_tf = a->in_scale || a->in_fin_acc;                              // input transform: conv_mfma_kernel only
+    if (!in_tf && conv_ws_eligible(a)) return conv_ws_launch(a, (hipStream_t)stream);      // the plan above validated the arguments
+    if (!in_tf && conv_ls_variant(a)) return conv_ls_launch(a, (hipStream_t)stream);
     if (a->dtype == SALT_F32) return launch_T<float>(pl, (hipStream_t)stream);
     if (a->dtype == SALT_BF16) return launch_T<bf16_t>(pl, (hipStream_t)stream);
     SALT_FAIL(SALT_E_BADARG, "conv: dtype %d", a->dtype);
@@ -2686,6 +2790,7 @@ extern "C" int salt_conv_stats_parts(const salt_conv_args* a) {
 extern "C" int salt_conv_kernel_id(const salt_conv_args* a) {
     Plan pl;
     if (make_plan(a, &pl)) return -1;
+    if (a->in_scale || a->in_fin_acc) return pl.cfg.id;
     return conv_ws_eligible(a) ? 9 : (conv_ls_variant(a) ? 10 : pl.cfg.id);
 }
 
@@ -2811,6 +2916,14 @@ extern "C" int salt_conv_wgrad(const salt_conv_wgrad_args* a, void* stream) {
     if (rc) return rc;
     if (!a->partials) SALT_FAIL(SALT_E_BADARG, "wgrad: partials workspace missing");
     if (a->nsplit != ns) SALT_FAIL(SALT_E_BADARG, "wgrad: nsplit %d, expected %d", a->nsplit, ns);
+    // A/B switch: the splits add into ONE slab with global_atomic_add_f32 (zeroed here, in stream order) instead of
+    // writing nsplit slabs that salt_wgrad_reduce sums.  Not bit-reproducible; off by default.
+    static const bool atomic = getenv("SALT_WGRAD_ATOMIC") != nullptr;
+    k.atomic = atomic && ns > 1;
+    if (k.atomic) {
+        hipError_t e = hipMemsetAsync(a->partials, 0, (size_t)a->ntaps * k.Ca * k.Cb * sizeof(float), (hipStream_t)stream);
+        if (e != hipSuccess) SALT_FAIL((int)e, "hipMemsetAsync: %s", hipGetErrorString(e));
+    }
     if (a->dtype == SALT_F32) return launch_wgrad<float>(k, (hipStream_t)stream);
     if (a->dtype == SALT_BF16) return launch_wgrad<bf16_t>(k, (hipStream_t)stream);
     SALT_FAIL(SALT_E_BADARG, "wgrad: dtype");
@@ -2823,6 +2936,8 @@ extern "C" int salt_wgrad_reduce(const salt_wgrad_reduce_args* a, void* stream) 
     p.KH = a->KH; p.KW = a->KW; p.accumulate = a->accumulate;
     for (int t = 0; t < a->ntaps; ++t) { p.tap_kh[t] = a->tap_kh[t]; p.tap_kw[t] = a->tap_kw[t]; }
     const int64_t slab = (int64_t)a->ntaps * a->Ca * a->Cb;
+    static const bool atomic = getenv("SALT_WGRAD_ATOMIC") != nullptr;
+    if (atomic && p.nsplit > 1) p.nsplit = 1;                      // salt_conv_wgrad added every split into slab 0
     static const bool rows_reduce = getenv("SALT_WGRAD_REDUCE_ROWS") != nullptr;
     if (!rows_reduce && a->nsplit <= 8) hipLaunchKernelGGL(wgrad_reduce8_kernel, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((slab + 63) / 64)), dim3(256), 0, (hipStream_t)stream, p);

@@ -55,6 +55,7 @@ struct WsKP {
     const float* bnb_mean; const float* bnb_invstd; const float* bnb_gamma; const float* bnb_beta;
     double* fin_acc;             // [8][2 Cout + 1] forward statistics shards (nullptr: off)
     double* bnb_acc;             // [8][2][Cout] BatchNorm-backward shards (nullptr: off)
+    const bf16_t* res; int res_cs;   // residual epilogue (salt_conv_args.res), MODE 0 only
 };
 
 __device__ __attribute__((aligned(16))) unsigned int g_ws_zero[4] = {0u, 0u, 0u, 0u};
@@ -101,6 +102,7 @@ struct WsEpi {
     bf16_t* y; const bf16_t* bnb_y; const bf16_t* bnb_a;
     int y_cs, bnb_cs, bnb_acs, relu, accumulate, bnb_relu;
     bool has_affine, sums;
+    const bf16_t* res; int res_cs;        // MODE 0 residual epilogue (salt_conv_args.res): y = relu?(bf16(affine) + res)
 };
 // Per-lane geometry of the wave tile: which of the lane's two pixels are stored (ragged grids, pad-ring pixels of a fused fold), and
 // - FOLD, the data gradient of a replicate-padded convolution on the extended grid (salt_conv_args.fold_top / fold_right = 2, tile
@@ -132,6 +134,11 @@ __device__ __forceinline__ void ws_epilogue_tile(const WsEpi& p, f32x16 (&acc)[2
                 for (int gp = 0; gp < 2; ++gp)
                     oldv[i][gp] = *reinterpret_cast<const u32x4*>(p.y + (pix[i] * (unsigned)p.y_cs + n0 + 8 * khalf + 32 * j + 16 * gp));
             }
+            if (MODE == 0 && p.res) {                                           // (host: never together with accumulate)
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp)
+                    oldv[i][gp] = *reinterpret_cast<const u32x4*>(p.res + (pix[i] * (unsigned)p.res_cs + n0 + 8 * khalf + 32 * j + 16 * gp));
+            }
             if (MODE == 2 && p.sums) {
 #pragma unroll
                 for (int gp = 0; gp < 2; ++gp) {
@@ -158,7 +165,7 @@ __device__ __forceinline__ void ws_epilogue_tile(const WsEpi& p, f32x16 (&acc)[2
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         float t = (v[i][4 * q + e] + bi[e]) * sc[e] + sh[e];
-                        if (p.relu) t = fmaxf(t, 0.f);
+                        if (p.relu && !(MODE == 0 && p.res)) t = fmaxf(t, 0.f);  // with a residual the ReLU follows the add
                         v[i][4 * q + e] = t;
                     }
                 }
@@ -211,6 +218,13 @@ __device__ __forceinline__ void ws_epilogue_tile(const WsEpi& p, f32x16 (&acc)[2
                     unpack16<T>(stored, f8); unpack16<T>(oldv[i][gp], o8);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) f8[e] += o8[e];
+                    stored = pack16<T>(f8);
+                }
+                if (MODE == 0 && p.res) {
+                    float f8[8], o8[8];
+                    unpack16<T>(stored, f8); unpack16<T>(oldv[i][gp], o8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { f8[e] += o8[e]; if (p.relu) f8[e] = fmaxf(f8[e], 0.f); }
                     stored = pack16<T>(f8);
                 }
                 *reinterpret_cast<u32x4*>(p.y + (yo + 16 * gp)) = stored;
@@ -462,7 +476,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsKP p) {
         for (int e = 0; e < 4; ++e) { rs0[j][e] = 0.f; rs1[j][e] = 0.f; }
     const bool sums = (MODE == 1 && p.fin_acc) || (MODE == 2 && p.bnb_acc);
     const WsEpi ep = {p.y, p.bnb_y, p.bnb_a, p.y_cs, p.bnb_cs, p.bnb_acs, p.relu, p.accumulate, p.bnb_relu,
-                      p.bias || p.scale || p.shift || p.relu, sums};
+                      p.bias || p.scale || p.shift || p.relu, sums, p.res, p.res_cs};
 
     // epilogue of the tile in `acc` (computed by this wave one phase ago); issues the halo DMA of `next` (if any) into buffer g
     auto epilogue = [&](const TC& c, int g, bool has_next, const TC& next) {
@@ -594,6 +608,7 @@ struct LsKP {
     const bf16_t* bnb_y; const bf16_t* bnb_a; int bnb_cs, bnb_acs, bnb_relu;
     const float* bnb_mean; const float* bnb_invstd; const float* bnb_gamma; const float* bnb_beta;
     double* fin_acc; double* bnb_acc;
+    const bf16_t* res; int res_cs;
 };
 
 template <int NI, int MODE>
@@ -727,7 +742,7 @@ __global__ __launch_bounds__(512) void conv_ls_kernel(LsKP p) {
             pbase[i] = (m >> 4) * 18 + (m & 15);
         }
         const WsEpi ep = {p.y, p.bnb_y, p.bnb_a, p.y_cs, p.bnb_cs, p.bnb_acs, p.relu, p.accumulate, p.bnb_relu,
-                          p.bias || p.scale || p.shift || p.relu, sums};
+                          p.bias || p.scale || p.shift || p.relu, sums, p.res, p.res_cs};
         struct Frag { u32x4 a[MI], b[NI]; };
         int g = 0;
 #pragma unroll 1
@@ -868,7 +883,8 @@ bool conv_ws_eligible(const salt_conv_args* a) {
     }
     if (max_dy - min_dy != 2 || max_dx - min_dx != 2) return false;
     auto small = [](const salt_view& v) { return !v.p || (int64_t)v.B * v.H * v.W * v.cs < (int64_t)1 << 31; };
-    if (!small(a->x) || !small(a->y) || !small(a->bnb_y) || !small(a->bnb_a)) return false;
+    if (!small(a->x) || !small(a->y) || !small(a->bnb_y) || !small(a->bnb_a) || !small(a->res)) return false;
+    if (a->res.p && (a->res.cs % 8 || (reinterpret_cast<uintptr_t>(a->res.p) & 15) || a->accumulate || a->fin_acc || a->bnb_acc || fold)) return false;
     if (a->bnb_acc) {
         if (!view_ok(a->bnb_y) || a->bnb_y.B != a->y.B || a->bnb_y.H != a->y.H || a->bnb_y.W != a->y.W || a->bnb_y.C != Cout || a->bnb_y.cs % 8 ||
             (reinterpret_cast<uintptr_t>(a->bnb_y.p) & 15) || !a->bnb_mean || !a->bnb_invstd || !a->bnb_gamma || !a->bnb_beta) return false;
@@ -905,6 +921,7 @@ int conv_ws_launch(const salt_conv_args* a, hipStream_t st) {
     k.bnb_cs = a->bnb_y.cs; k.bnb_acs = a->bnb_a.cs; k.bnb_relu = a->bnb_relu;
     k.bnb_mean = a->bnb_mean; k.bnb_invstd = a->bnb_invstd; k.bnb_gamma = a->bnb_gamma; k.bnb_beta = a->bnb_beta;
     k.fin_acc = a->fin_acc; k.bnb_acc = a->bnb_acc;
+    k.res = reinterpret_cast<const bf16_t*>(a->res.p); k.res_cs = a->res.cs;
     if (!a->bnb_acc) { k.bnb_y = nullptr; k.bnb_a = nullptr; }
     const int Cin = a->x.C, Cout = a->y.C, bn = Cout % 64 == 0 ? 64 : 32;
     k.Cout = Cout; k.n_tiles = Cout / bn;
@@ -939,7 +956,8 @@ static int ls_common_ok(const salt_conv_args* a) {
     }
     if (max_dy - min_dy != 2 || max_dx - min_dx != 2) return 0;
     auto small = [](const salt_view& v) { return !v.p || (int64_t)v.B * v.H * v.W * v.cs < (int64_t)1 << 31; };
-    if (!small(a->x) || !small(a->y) || !small(a->bnb_y) || !small(a->bnb_a)) return 0;
+    if (!small(a->x) || !small(a->y) || !small(a->bnb_y) || !small(a->bnb_a) || !small(a->res)) return 0;
+    if (a->res.p && (a->res.cs % 8 || (reinterpret_cast<uintptr_t>(a->res.p) & 15) || a->accumulate || a->fin_acc || a->bnb_acc)) return 0;
     if (a->bnb_acc) {
         if (!view_ok(a->bnb_y) || a->bnb_y.B != a->y.B || a->bnb_y.H != a->y.H || a->bnb_y.W != a->y.W || a->bnb_y.C != Cout || a->bnb_y.cs % 8 ||
             (reinterpret_cast<uintptr_t>(a->bnb_y.p) & 15) || !a->bnb_mean || !a->bnb_invstd || !a->bnb_gamma || !a->bnb_beta) return 0;
@@ -987,6 +1005,7 @@ int conv_ls_launch(const salt_conv_args* a, hipStream_t st) {
     k.bnb_cs = a->bnb_y.cs; k.bnb_acs = a->bnb_a.cs; k.bnb_relu = a->bnb_relu;
     k.bnb_mean = a->bnb_mean; k.bnb_invstd = a->bnb_invstd; k.bnb_gamma = a->bnb_gamma; k.bnb_beta = a->bnb_beta;
     k.fin_acc = a->fin_acc; k.bnb_acc = a->bnb_acc;
+    k.res = reinterpret_cast<const bf16_t*>(a->res.p); k.res_cs = a->res.cs;
     if (!a->bnb_acc) { k.bnb_y = nullptr; k.bnb_a = nullptr; }
     int wpx = ws_cus() / 8;
     const int cap = (a->cfg >> 8) & 0xff;

@@ -647,17 +647,19 @@ __global__ void avgpool2_kernel(salt_view x, salt_view y, int backward, int accu
     }
 }
 
-// ---------------------------------------------------------------- bilinear xR (align_corners=False)
-__device__ __forceinline__ void bil_src(int d, int R, int n, int& i0, int& i1, float& lam) {
-    float s = ((float)d + 0.5f) * (1.0f / (float)R) - 0.5f;
-    s = s < 0.f ? 0.f : s;
+// ---------------------------------------------------------------- bilinear xR (AC = 0: align_corners=False, AC = 1: True; saltnet.h)
+__device__ __forceinline__ void bil_src(int d, int R, int n, int ac, int& i0, int& i1, float& lam) {
+    float s;
+    if (ac) s = n > 1 ? (float)d * ((float)(n - 1) / (float)(R * n - 1)) : 0.f;      // torch area_pixel_compute_scale, align_corners=True
+    else { s = ((float)d + 0.5f) * (1.0f / (float)R) - 0.5f; s = s < 0.f ? 0.f : s; }
     i0 = (int)s;
+    i0 = i0 < n - 1 ? i0 : n - 1;
     i1 = i0 + 1 < n ? i0 + 1 : n - 1;
     lam = s - (float)i0;
 }
 
 template <typename T, bool VEC>
-__global__ void bilinear_fwd_kernel(salt_view x, salt_view y, int R) {
+__global__ void bilinear_fwd_kernel(salt_view x, salt_view y, int R, int ac) {
     constexpr int N = Unit<T, VEC>::N;
     const int cpv = x.C / N;
     const int64_t units = (int64_t)y.B * y.H * y.W * cpv;
@@ -665,8 +667,8 @@ __global__ void bilinear_fwd_kernel(salt_view x, salt_view y, int R) {
         int64_t pix = u / cpv; const int c0 = (int)(u - pix * cpv) * N;
         const int ox = (int)(pix % y.W); int64_t r = pix / y.W; const int oy = (int)(r % y.H); const int b = (int)(r / y.H);
         int y0, y1, x0, x1; float ly, lx;
-        bil_src(oy, R, x.H, y0, y1, ly);
-        bil_src(ox, R, x.W, x0, x1, lx);
+        bil_src(oy, R, x.H, ac, y0, y1, ly);
+        bil_src(ox, R, x.W, ac, x0, x1, lx);
         const T* base = (const T*)x.p + (int64_t)b * x.H * x.W * x.cs + c0;
         float a[N], bq[N], c[N], d[N], o[N];
         Unit<T, VEC>::ld(base + ((int64_t)y0 * x.W + x0) * x.cs, a);
@@ -680,10 +682,39 @@ __global__ void bilinear_fwd_kernel(salt_view x, salt_view y, int R) {
     }
 }
 
+// all levels of the hypercolumn in one pass: unit = (pixel, level, channel piece), so consecutive lanes write consecutive bytes of a pixel row
+struct HyperKP { salt_view x[4]; int R[4]; salt_view y; int nlev, ac; };
+template <typename T, bool VEC>
+__global__ void hyper_rows_kernel(HyperKP p) {
+    constexpr int N = Unit<T, VEC>::N;
+    const int cpl = p.x[0].C / N, upp = cpl * p.nlev;
+    const int64_t units = (int64_t)p.y.B * p.y.H * p.y.W * upp;
+    for (int64_t u = blockIdx.x * 256LL + threadIdx.x; u < units; u += gridDim.x * 256LL) {
+        int64_t pix = u / upp; const int r_ = (int)(u - pix * upp);
+        const int lev = r_ / cpl, c0 = (r_ - lev * cpl) * N;
+        const salt_view& x = p.x[lev];
+        const int R = p.R[lev];
+        const int ox = (int)(pix % p.y.W); int64_t r = pix / p.y.W; const int oy = (int)(r % p.y.H); const int b = (int)(r / p.y.H);
+        int y0, y1, x0, x1; float ly, lx;
+        bil_src(oy, R, x.H, p.ac, y0, y1, ly);
+        bil_src(ox, R, x.W, p.ac, x0, x1, lx);
+        const T* base = (const T*)x.p + (int64_t)b * x.H * x.W * x.cs + c0;
+        float a[N], bq[N], c[N], d[N], o[N];
+        Unit<T, VEC>::ld(base + ((int64_t)y0 * x.W + x0) * x.cs, a);
+        Unit<T, VEC>::ld(base + ((int64_t)y0 * x.W + x1) * x.cs, bq);
+        Unit<T, VEC>::ld(base + ((int64_t)y1 * x.W + x0) * x.cs, c);
+        Unit<T, VEC>::ld(base + ((int64_t)y1 * x.W + x1) * x.cs, d);
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+            o[j] = (1.f - ly) * ((1.f - lx) * a[j] + lx * bq[j]) + ly * ((1.f - lx) * c[j] + lx * d[j]);
+        Unit<T, VEC>::st((T*)p.y.p + pix * p.y.cs + lev * x.C + c0, o);
+    }
+}
+
 // adjoint as a gather over the (<= 2R x 2R) outputs that reference each input pixel: deterministic.
 // X_ONLY / Y_ONLY variants make it separable (two passes through a [B,OH,W,C] fp32-free temp of dtype T) for large R.
 template <typename T, bool VEC, int MODE>      // MODE 0: full 2-D, 1: x only (y.H == x.H), 2: y only (y.W == x.W)
-__global__ void bilinear_bwd_kernel(salt_view x, salt_view y, int R, int accumulate) {
+__global__ void bilinear_bwd_kernel(salt_view x, salt_view y, int R, int accumulate, int ac) {
     constexpr int N = Unit<T, VEC>::N;
     const int cpv = x.C / N;
     const int64_t units = (int64_t)x.B * x.H * x.W * cpv;
@@ -692,6 +723,13 @@ __global__ void bilinear_bwd_kernel(salt_view x, salt_view y, int R, int accumul
         const int ix = (int)(pix % x.W); int64_t r = pix / x.W; const int iy = (int)(r % x.H); const int b = (int)(r / x.H);
         int oy_lo = max(0, R * iy - R / 2), oy_hi = min(y.H - 1, R * iy + (3 * R) / 2 - 1);
         int ox_lo = max(0, R * ix - R / 2), ox_hi = min(y.W - 1, R * ix + (3 * R) / 2 - 1);
+        if (ac) {                                     // outputs with src = d (n - 1) / (R n - 1) in (i - 1, i + 1): d in ((i - 1) q, (i + 1) q),
+            // q = (R n - 1) / (n - 1) > R; integer floor / ceil of the ends, one more on each side for the fp32 rounding of src
+            // (a superset: zero weights are skipped below)
+            const int qy = max(x.H - 1, 1), qx = max(x.W - 1, 1);
+            oy_lo = max(0, (max(iy - 1, 0) * (y.H - 1)) / qy - 1); oy_hi = min(y.H - 1, ((iy + 1) * (y.H - 1) + qy - 1) / qy + 1);
+            ox_lo = max(0, (max(ix - 1, 0) * (y.W - 1)) / qx - 1); ox_hi = min(y.W - 1, ((ix + 1) * (y.W - 1) + qx - 1) / qx + 1);
+        }
         if (MODE == 1) { oy_lo = iy; oy_hi = iy; }
         if (MODE == 2) { ox_lo = ix; ox_hi = ix; }
         float o[N];
@@ -702,7 +740,7 @@ __global__ void bilinear_bwd_kernel(salt_view x, salt_view y, int R, int accumul
             float wy = 1.f;
             if (MODE != 1) {
                 int y0, y1; float ly;
-                bil_src(oy, R, x.H, y0, y1, ly);
+                bil_src(oy, R, x.H, ac, y0, y1, ly);
                 wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
                 if (wy == 0.f) continue;
             }
@@ -710,7 +748,7 @@ __global__ void bilinear_bwd_kernel(salt_view x, salt_view y, int R, int accumul
                 float w = wy;
                 if (MODE != 2) {
                     int x0, x1; float lx;
-                    bil_src(ox, R, x.W, x0, x1, lx);
+                    bil_src(ox, R, x.W, ac, x0, x1, lx);
                     w = wy * ((x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f));
                     if (w == 0.f) continue;
                 }
@@ -1045,23 +1083,45 @@ extern "C" int salt_bilinear(const salt_bilinear_args* a, void* stream) {
         const bool v = vec_ok(a->x, ve) && vec_ok(a->y, ve);
         if (!a->backward) {
             const int64_t units = view_pixels(a->y) * (a->y.C / (v ? ve : 1));
-            EW_LAUNCH(bilinear_fwd_kernel, T, v, units, (hipStream_t)stream, a->x, a->y, a->R);
+            EW_LAUNCH(bilinear_fwd_kernel, T, v, units, (hipStream_t)stream, a->x, a->y, a->R, a->align_corners);
         } else {
             const int64_t units = view_pixels(a->x) * (a->x.C / (v ? ve : 1));
             if (a->R >= 4 && a->tmp) {
                 // separable: x-pass into tmp [B, OH, W, C] (same dtype, contiguous), then y-pass into x
                 salt_view t = a->x; t.p = a->tmp; t.H = a->y.H; t.cs = ((a->x.C + ve - 1) / ve) * ve;
                 const int64_t tunits = view_pixels(t) * (a->x.C / (v ? ve : 1));
-                if (v) hipLaunchKernelGGL((bilinear_bwd_kernel<T, true, 1>), dim3(ew_blocks(tunits)), dim3(256), 0, (hipStream_t)stream, t, a->y, a->R, 0);
-                else hipLaunchKernelGGL((bilinear_bwd_kernel<T, false, 1>), dim3(ew_blocks(tunits)), dim3(256), 0, (hipStream_t)stream, t, a->y, a->R, 0);
+                if (v) hipLaunchKernelGGL((bilinear_bwd_kernel<T, true, 1>), dim3(ew_blocks(tunits)), dim3(256), 0, (hipStream_t)stream, t, a->y, a->R, 0, a->align_corners);
+                else hipLaunchKernelGGL((bilinear_bwd_kernel<T, false, 1>), dim3(ew_blocks(tunits)), dim3(256), 0, (hipStream_t)stream, t, a->y, a->R, 0, a->align_corners);
                 SALT_CHECK_LAUNCH();
-                if (v) hipLaunchKernelGGL((bilinear_bwd_kernel<T, true, 2>), dim3(ew_blocks(units)), dim3(256), 0, (hipStream_t)stream, a->x, t, a->R, a->accumulate);
-                else hipLaunchKernelGGL((bilinear_bwd_kernel<T, false, 2>), dim3(ew_blocks(units)), dim3(256), 0, (hipStream_t)stream, a->x, t, a->R, a->accumulate);
+                if (v) hipLaunchKernelGGL((bilinear_bwd_kernel<T, true, 2>), dim3(ew_blocks(units)), dim3(256), 0, (hipStream_t)stream, a->x, t, a->R, a->accumulate, a->align_corners);
+                else hipLaunchKernelGGL((bilinear_bwd_kernel<T, false, 2>), dim3(ew_blocks(units)), dim3(256), 0, (hipStream_t)stream, a->x, t, a->R, a->accumulate, a->align_corners);
             } else {
-                if (v) hipLaunchKernelGGL((bilinear_bwd_kernel<T, true, 0>), dim3(ew_blocks(units)), dim3(256), 0, (hipStream_t)stream, a->x, a->y, a->R, a->accumulate);
-                else hipLaunchKernelGGL((bilinear_bwd_kernel<T, false, 0>), dim3(ew_blocks(units)), dim3(256), 0, (hipStream_t)stream, a->x, a->y, a->R, a->accumulate);
+                if (v) hipLaunchKernelGGL((bilinear_bwd_kernel<T, true, 0>), dim3(ew_blocks(units)), dim3(256), 0, (hipStream_t)stream, a->x, a->y, a->R, a->accumulate, a->align_corners);
+                else hipLaunchKernelGGL((bilinear_bwd_kernel<T, false, 0>), dim3(ew_blocks(units)), dim3(256), 0, (hipStream_t)stream, a->x, a->y, a->R, a->accumulate, a->align_corners);
             }
         }
+    })
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}
+
+extern "C" int salt_hyper_rows(const salt_hyper_rows_args* a, void* stream) {
+    if (!a || a->nlev < 1 || a->nlev > 4 || !view_ok(a->y)) SALT_FAIL(SALT_E_BADARG, "hyper_rows: bad args");
+    HyperKP k;
+    k.y = a->y; k.nlev = a->nlev; k.ac = a->align_corners;
+    for (int i = 0; i < 4; ++i) { k.x[i] = a->x[i < a->nlev ? i : 0]; k.R[i] = a->R[i < a->nlev ? i : 0]; }
+    for (int i = 0; i < a->nlev; ++i) {
+        const salt_view& x = a->x[i];
+        if (!view_ok(x) || a->R[i] < 1 || a->y.H != x.H * a->R[i] || a->y.W != x.W * a->R[i] || x.B != a->y.B || x.C != a->x[0].C)
+            SALT_FAIL(SALT_E_BADARG, "hyper_rows: level %d does not match the output grid", i);
+    }
+    if (a->y.C != a->nlev * a->x[0].C) SALT_FAIL(SALT_E_BADARG, "hyper_rows: y.C must be nlev * C");
+    SALT_DISPATCH_DTYPE(a->dtype, T, {
+        const int ve = Elem<T>::VE;
+        bool v = vec_ok(a->y, ve) && a->x[0].C % ve == 0;
+        for (int i = 0; i < a->nlev; ++i) v = v && vec_ok(a->x[i], ve);
+        const int64_t units = view_pixels(a->y) * (a->y.C / (v ? ve : 1));
+        EW_LAUNCH(hyper_rows_kernel, T, v, units, (hipStream_t)stream, k);
     })
     SALT_CHECK_LAUNCH();
     return SALT_OK;

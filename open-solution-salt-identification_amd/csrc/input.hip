@@ -3,7 +3,7 @@
 // What the reference does per image on the CPU with PIL / imgaug / torchvision (loaders.py:603-612, augmentation.py:79-96,
 // 247-284, utils.py:494-500, loaders.py:763-769) is one pass here:
 //   gray tile [h, w] (uint8 or float in [0,1])
-//     -> optional bilinear resize to [rh, rw] (half-pixel centres, as torch's align_corners=False)      train: 101 -> 102
+//     -> optional resize to [rh, rw]: cubic (cv2.INTER_CUBIC, imgaug's iaa.Scale default) or bilinear     train: 101 -> 102
 //     -> edge (replicate) pad: `top` rows / `left` columns, rest to [H, W]                                train: 13; inference 13/14
 //     -> Grayscale(3) + ToTensor + Normalize(mean, std) per channel
 //     -> AddDepthChannels: ch1 := linspace(0, 1, H)[row], ch2 := ch0 * ch1                                (3-channel mode)
@@ -14,13 +14,23 @@ namespace {
 
 struct PreKP {
     const void* img; const unsigned char* mask; float* x; float* target;
-    int img_is_u8, B, h, w, rh, rw, top, left, H, W, channels;
+    int img_is_u8, B, h, w, rh, rw, top, left, H, W, channels, cubic;
     float mean[3], inv_std[3];
 };
 
 __device__ __forceinline__ float src_index(int dst, float scale) {      // torch area_pixel_compute_source_index, align_corners=False
     const float s = scale * ((float)dst + 0.5f) - 0.5f;
     return s < 0.f ? 0.f : s;
+}
+
+// cv2.INTER_CUBIC / imgaug 0.2.5 iaa.Scale default: Keys cubic convolution, a = -0.75, taps at floor(s) - 1 .. floor(s) + 2 of the
+// half-pixel-centred source coordinate s = (dst + 0.5) * in / out - 0.5, indices clamped to the image (BORDER_REPLICATE)
+__device__ __forceinline__ void cubic_w(float t, float (&w)[4]) {
+    const float A = -0.75f;
+    w[0] = ((A * (t + 1.f) - 5.f * A) * (t + 1.f) + 8.f * A) * (t + 1.f) - 4.f * A;
+    w[1] = ((A + 2.f) * t - (A + 3.f)) * t * t + 1.f;
+    w[2] = ((A + 2.f) * (1.f - t) - (A + 3.f)) * (1.f - t) * (1.f - t) + 1.f;
+    w[3] = 1.f - w[0] - w[1] - w[2];
 }
 
 __global__ void preprocess_kernel(PreKP p) {
@@ -33,9 +43,31 @@ __global__ void preprocess_kernel(PreKP p) {
             const int64_t o = ((int64_t)b * p.h + yy) * p.w + xx;
             return p.img_is_u8 ? (float)reinterpret_cast<const unsigned char*>(p.img)[o] * (1.f / 255.f) : reinterpret_cast<const float*>(p.img)[o];
         };
-        float g;
+        float g, mres = -1.f;                                 // mres >= 0: the mask value out of the cubic resize
         if (p.rh == p.h && p.rw == p.w) {
             g = px(ry, rx);
+        } else if (p.cubic) {
+            const float fy = ((float)ry + 0.5f) * sy - 0.5f, fx = ((float)rx + 0.5f) * sx - 0.5f;
+            const float y0f = floorf(fy), x0f = floorf(fx);
+            float wy[4], wx[4];
+            cubic_w(fy - y0f, wy); cubic_w(fx - x0f, wx);
+            const int y0 = (int)y0f - 1, x0 = (int)x0f - 1;
+            float acc = 0.f, macc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int yy = min(max(y0 + i, 0), p.h - 1);
+                float row = 0.f, mrow = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int xx = min(max(x0 + j, 0), p.w - 1);
+                    row += wx[j] * px(yy, xx);
+                    if (p.mask) mrow += wx[j] * (p.mask[((int64_t)b * p.h + yy) * p.w + xx] ? 1.f : 0.f);
+                }
+                acc += wy[i] * row; macc += wy[i] * mrow;
+            }
+            // the reference resizes uint8 images: cv2 writes saturate_cast<uchar>(round(value)) - back onto the uint8 grid
+            g = p.img_is_u8 ? fminf(fmaxf(floorf(acc * 255.f + 0.5f), 0.f), 255.f) * (1.f / 255.f) : acc;
+            mres = fminf(fmaxf(floorf(macc + 0.5f), 0.f), 1.f);
         } else {
             const float fy = src_index(ry, sy), fx = src_index(rx, sx);
             const int y0 = (int)fy, x0 = (int)fx;
@@ -57,7 +89,7 @@ __global__ void preprocess_kernel(PreKP p) {
             // nearest: torch 'nearest' picks floor(dst * in / out)
             const int my = p.rh == p.h ? ry : min((int)floorf((float)ry * sy), p.h - 1);
             const int mx = p.rw == p.w ? rx : min((int)floorf((float)rx * sx), p.w - 1);
-            const float m = p.mask[((int64_t)b * p.h + my) * p.w + mx] ? 1.f : 0.f;
+            const float m = mres >= 0.f ? mres : (p.mask[((int64_t)b * p.h + my) * p.w + mx] ? 1.f : 0.f);
             float* to = p.target + (int64_t)b * 2 * hw + (int64_t)Y * p.W + X;
             to[0] = 1.f - m;
             to[hw] = m;
@@ -75,7 +107,8 @@ extern "C" int salt_preprocess(const salt_preprocess_args* a, void* stream) {
     p.img = a->img; p.mask = a->mask; p.x = a->x; p.target = a->target;
     p.img_is_u8 = a->img_is_u8; p.B = a->B; p.h = a->h; p.w = a->w;
     p.rh = a->resize_h > 0 ? a->resize_h : a->h; p.rw = a->resize_w > 0 ? a->resize_w : a->w;
-    p.top = a->top; p.left = a->left; p.H = a->H; p.W = a->W; p.channels = a->channels;
+    p.top = a->top; p.left = a->left; p.H = a->H; p.W = a->W; p.channels = a->channels; p.cubic = a->interpolation == 1;
+    if (a->interpolation != 0 && a->interpolation != 1) SALT_FAIL(SALT_E_BADARG, "preprocess: interpolation %d (0 bilinear | 1 cubic)", a->interpolation);
     if (p.top + p.rh > p.H || p.left + p.rw > p.W) SALT_FAIL(SALT_E_BADARG, "preprocess: resized tile + pad offset exceeds the output");
     for (int c = 0; c < 3; ++c) {
         if (a->std[c] <= 0.f) SALT_FAIL(SALT_E_BADARG, "preprocess: std must be positive");

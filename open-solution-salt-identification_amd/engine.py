@@ -181,6 +181,7 @@ class Buffer:
         self.grad_t = None
         self.grad_init = np.zeros(self.Ct, dtype=bool)
         self.grad_writers = []         # one entry per gradient writer in backward-program order: [c0, C, conv-args struct | None]
+        self.reads = 0                 # views handed out (SALT_EXP_BN_FOLD: an activation nobody else reads need not be materialised)
 
     def grad(self):
         if self.grad_t is None:
@@ -209,6 +210,7 @@ class Act:
         return v
 
     def view(self):
+        self.buf.reads += 1
         return self._view(self.buf.t)
 
     def gview(self):
@@ -340,6 +342,7 @@ class Graph:
         self._fin_bytes[which] = off + _round_up(ndoubles * 8, 64)
         for st, field in targets:
             self._fin_patches.append((st, field, which, off))
+        return off
 
     def _gp(self, param):
         """Gradient pointer of a parameter; remembers that the current backward closure finalises it."""
@@ -350,6 +353,7 @@ class Graph:
         """Emit the backward program (reverse tape order).  Also records, per parameter, the program position
         after which its gradient is final (parallel.plan_buckets turns that into all-reduce buckets)."""
         self.grad_ready = []
+        self._resolve_lazies()
         if self.train and self._fin_mode() == 2 and 'bwd' not in self._fin_zero:
             self._fin_zero['bwd'] = self.bwd.add('zero', p=1, bytes=0)
         for fn in reversed(self.tape):
@@ -372,6 +376,27 @@ class Graph:
                     break
                 if st == 1:
                     raise SaltError('backward program starts with a side-stream operator')
+
+    def _resolve_lazies(self):
+        """SALT_EXP_BN_FOLD: drop the affine_act of every conv -> BN -> ReLU output whose only forward reader is ONE convolution that
+        applies the transform in its loader; every other candidate goes back to reading the materialised activation."""
+        drop = []
+        for buf in getattr(self, '_lazies', []):
+            lz = buf.lazy
+            if len(lz['users']) == 1 and buf.reads == lz['reads0']:
+                lz['dropped'] = True
+                drop.append(next(i for i, (_, _, st) in enumerate(self.fwd.ops) if st is lz['sa']))
+            else:
+                for st in lz['users']:
+                    fill(st, x=Act(buf).view(), in_fin=None, in_relu=0)
+                    self._fin_patches = [q for q in self._fin_patches if q[0] is not st or q[1] != 'in_fin_acc']
+        for i in sorted(drop, reverse=True):
+            if self.fwd.streams[i] != 0:
+                raise SaltError('a dropped affine_act carried a stream join')
+            del self.fwd.ops[i]
+            del self.fwd.streams[i]
+        self._lazies = []
+        self.n_folded = len(drop)
 
     # ------------------------------------------------------------------ helpers
     def _es(self):
@@ -439,7 +464,13 @@ class Graph:
                           res=res.view() if res is not None else null_view(), relu=int(relu), a=out.view())
         if F is not None:                        # the producer only adds to the shards; this operator finalizes them
             self.fwd.set_fields(sa, fin=ctypes.addressof(F))
-            self._fin_slot('fwd', 8 * (2 * bn.num_features + 1), (producer, 'fin_acc'), (sa, 'fin_acc'))
+            off = self._fin_slot('fwd', 8 * (2 * bn.num_features + 1), (producer, 'fin_acc'), (sa, 'fin_acc'))
+            if (os.environ.get('SALT_EXP_BN_FOLD') and res is None and relu and self.dtype == 'bf16' and out.c0 == 0 and out.C == out.buf.C
+                    and self.fwd.streams[-1] == 0):
+                # measurement switch: if the ONLY forward reader of `out` turns out to be one 3x3 convolution, that launch
+                # applies this BatchNorm + ReLU in its loader (salt_conv_args.in_*) and this affine_act is dropped (build_backward)
+                out.buf.lazy = dict(y=y, F=F, sa=sa, off=off, reads0=out.buf.reads, users=[], dropped=False)
+                self._lazies = getattr(self, '_lazies', []) + [out.buf]
         return w
 
     def _bn_train_bwd(self, y, bn, relu, res, out, w):
@@ -533,13 +564,31 @@ class Graph:
         assert (out.B, out.H, out.W, out.C) == (x.B, OH, OW, Cout), name
         y = None
         w = None
+        lz = getattr(x.buf, 'lazy', None) if (self.train and x.c0 == 0 and x.C == x.buf.C and len(taps) == 9 and stride == 1) else None
         if bn is not None and self.train:
             y = self.new_act(x.B, OH, OW, Cout, name + '.y')
-            nparts = self._conv_parts(x.view(), td, stride, y.view(), OH, OW)
-            if self._fin_on():
+            if lz is not None and self._fin_on():
+                # candidate for the loader fold: read the producer's raw output and transform it on the way into LDS
+                nparts = self._conv_parts(lz['y'].view(), td, stride, y.view(), OH, OW)
+                S = fill(STRUCTS['salt_conv_args'](), dtype=self.dt, x=lz['y'].view(), w=1, ntaps=9, tap_dy=[t[0] for t in td], tap_dx=[t[1] for t in td],
+                         in_step=1, pad_mode=pad_mode, y=y.view(), OH=OH, OW=OW, out_step=1, in_fin=ctypes.addressof(lz['F']), in_fin_acc=8, in_relu=1)
+                if lib.salt_conv_kernel_id(ctypes.byref(S)) in (1, 2, 3, 4):
+                    prod = self._conv_launch(self.fwd, lz['y'].view(), pk.data_ptr(), td, stride, pad_mode, y.view(), OH, OW, bias=bias,
+                                             in_fin=ctypes.addressof(lz['F']), in_relu=1)
+                    self._fin_patches.append((prod, 'in_fin_acc', 'fwd', lz['off']))
+                    lz['users'].append(prod)
+                else:
+                    lz = None
+                    prod = self._conv_launch(self.fwd, x.view(), pk.data_ptr(), td, stride, pad_mode, y.view(), OH, OW, bias=bias)
+                w = self._bn_train_fwd(y, bn, relu, res, out, nparts, None, None, producer=prod)
+            elif self._fin_on():
+                lz = None
+                nparts = self._conv_parts(x.view(), td, stride, y.view(), OH, OW)
                 prod = self._conv_launch(self.fwd, x.view(), pk.data_ptr(), td, stride, pad_mode, y.view(), OH, OW, bias=bias)
                 w = self._bn_train_fwd(y, bn, relu, res, out, nparts, None, None, producer=prod)
             else:
+                lz = None
+                nparts = self._conv_parts(x.view(), td, stride, y.view(), OH, OW)
                 stats, cnt = Scratch('stats' + self._scratch_sfx, 4 * lib.salt_bn_stats_floats(nparts, Cout)), Scratch('stats_cnt' + self._scratch_sfx, nparts * 4)
                 self._conv_launch(self.fwd, x.view(), pk.data_ptr(), td, stride, pad_mode, y.view(), OH, OW, bias=bias, stats=stats, stats_cnt=cnt)
                 w = self._bn_train_fwd(y, bn, relu, res, out, nparts, stats, cnt)
@@ -548,6 +597,13 @@ class Graph:
             if res is None:
                 self._conv_launch(self.fwd, x.view(), pk.data_ptr(), td, stride, pad_mode, out.view(), OH, OW, bias=bias,
                                   scale=w['scale'].data_ptr(), shift=w['shift'].data_ptr(), relu=int(relu))
+            elif Cout % self.ve == 0 and not os.environ.get('SALT_NO_RES_FOLD'):
+                # eval-mode residual block: folded BN + identity add + ReLU all in the convolution's epilogue (salt_conv_args.res) - the
+                # same values as the separate affine_act pass below, bit for bit, without its launch and its trip over `out`
+                if getattr(res, 'on_side', False):
+                    self.join()
+                self._conv_launch(self.fwd, x.view(), pk.data_ptr(), td, stride, pad_mode, out.view(), OH, OW, bias=bias,
+                                  scale=w['scale'].data_ptr(), shift=w['shift'].data_ptr(), relu=int(relu), res=res.view())
             else:
                 self._conv_launch(self.fwd, x.view(), pk.data_ptr(), td, stride, pad_mode, out.view(), OH, OW, bias=bias,
                                   scale=w['scale'].data_ptr(), shift=w['shift'].data_ptr(), relu=0)
@@ -571,7 +627,12 @@ class Graph:
                     if relu:
                         self.bwd.add('relu_bwd', dtype=self.dt, da=out.gview(), a=out.view(), dy=out.gview(), accumulate=0)
                 # weight gradient: P = dY (a = cout), Q = X (b = cin)
-                self._wgrad(dy.gview(), x.view(), td, tk, stride, pad_mode, conv.weight, KH, KW)
+                xq = x
+                if lz is not None and lz['dropped']:
+                    # SALT_EXP_BN_FOLD is a TIMING experiment: the activation was never materialised and the weight-gradient kernels
+                    # (LDS-DMA loaders) cannot transform their operand, so they read the producer's RAW output - wrong weight gradients
+                    xq = lz['y']
+                self._wgrad(dy.gview(), xq.view(), td, tk, stride, pad_mode, conv.weight, KH, KW)
                 # data gradient
                 if x.buf.name != '__input__':
                     self._dgrad(conv, x, dy, taps, stride, replicate, KH, KW)
@@ -966,12 +1027,13 @@ class Graph:
     def upsample(self, x, R, out=None, name=''):
         if out is None:
             out = self.new_act(x.B, x.H * R, x.W * R, x.C, name)
-        self.fwd.add('bilinear', dtype=self.dt, x=x.view(), y=out.view(), R=R, backward=0, accumulate=0)
+        ac = int(bool(getattr(getattr(self.engine, 'module', None), 'align_corners', False)))      # HipNetwork.set_align_corners
+        self.fwd.add('bilinear', dtype=self.dt, x=x.view(), y=out.view(), R=R, backward=0, accumulate=0, align_corners=ac)
         if self.train:
             def backward():
                 acc = x.grad_state()
                 tmp = Scratch('bilinear', x.B * out.H * x.W * _round_up(x.C, self.ve) * self._es()) if R >= 4 else None
-                self.bwd.add('bilinear', dtype=self.dt, x=x.gview(), y=out.gview(), R=R, backward=1, accumulate=acc, tmp=tmp)
+                self.bwd.add('bilinear', dtype=self.dt, x=x.gview(), y=out.gview(), R=R, backward=1, accumulate=acc, tmp=tmp, align_corners=ac)
             self.tape.append(backward)
         return out
 

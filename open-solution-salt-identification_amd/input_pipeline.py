@@ -4,7 +4,7 @@ The reference prepares every tile on the CPU with PIL / imgaug / torchvision and
 (loaders.py:603-612, augmentation.py:79-96,247-284, utils.py:494-500, loaders.py:763-769).  Here the raw 101x101 gray tiles
 (uint8, 10 KB each) are copied once and one kernel produces the network's input batch and the one-hot target:
 
-    train      resize 101 -> 102 (bilinear) + edge-pad 13 on every side -> 128        (neptune.yaml:22-26)
+    train      resize 101 -> 102 (cubic: imgaug 0.2.5's iaa.Scale default; or bilinear) + edge-pad 13 on every side -> 128   (neptune.yaml:22-26)
     inference  edge-pad to the next multiple of 64 with the reference's split: top 13 / bottom 14, left 14 / right 13
     both       Grayscale(3) + ToTensor + Normalize(ImageNet) + AddDepthChannels; mask -> {background, salt} one-hot
 
@@ -31,7 +31,13 @@ def pad_split(size, divisor=64):
 class DevicePreprocessor:
     """Callable: (images [B,h,w] uint8|float, masks [B,h,w] or None) on the GPU -> (X [B,C,H,W], target [B,2,H,W] | None)."""
 
-    def __init__(self, train, channels=3, resize=102, pad=13, divisor=64, mean=MEAN, std=STD):
+    def __init__(self, train, channels=3, resize=102, pad=13, divisor=64, mean=MEAN, std=STD, interpolation='cubic'):
+        """``interpolation`` of the train-branch resize: 'cubic' (default) is what the reference executes - augmentation.py:79-85 calls
+        ``iaa.Scale({...})`` without an interpolation argument and imgaug 0.2.5 (environment.yml:15) defaults to 'cubic' =
+        cv2.INTER_CUBIC, applied to the uint8 tile AND the uint8 {0,1} mask; 'bilinear' is rounds 1-2 of this build."""
+        if interpolation not in ('cubic', 'bilinear'):
+            raise SaltError('DevicePreprocessor: interpolation %r (cubic | bilinear)' % (interpolation,))
+        self.interpolation = interpolation
         self.train, self.channels, self.resize, self.pad, self.divisor = bool(train), int(channels), resize, pad, divisor
         self.mean, self.std = tuple(mean), tuple(std)
 
@@ -62,6 +68,6 @@ class DevicePreprocessor:
         s = S()
         fill(s, img=images.data_ptr(), img_is_u8=int(images.dtype == torch.uint8), mask=mptr, B=B, h=h, w=w, resize_h=rh, resize_w=rw,
              top=top, left=left, H=H, W=W, channels=self.channels, mean=list(self.mean), std=list(self.std), x=x.data_ptr(),
-             target=target.data_ptr() if target is not None else None)
+             target=target.data_ptr() if target is not None else None, interpolation=1 if self.interpolation == 'cubic' else 0)
         check(fn(ctypes.byref(s), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'preprocess')
         return x, target

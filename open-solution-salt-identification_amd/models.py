@@ -115,6 +115,8 @@ class SegmentationModel(Model):
         self.model = config['model'](num_classes=mp['out_channels'], **config['model_config'])
         if 'compute_dtype' in mp:
             self.model.set_compute_dtype(mp['compute_dtype'])
+        if 'align_corners' in mp:            # True: bilinear up-sampling as torch 0.3.1 (the reference's pinned version) evaluated it
+            self.model.set_align_corners(mp['align_corners'])
         self._initialize_model_weights = lambda: None
 
     def set_loss(self):
@@ -227,6 +229,10 @@ class SegmentationModel(Model):
         return {'{}_prediction'.format(name): get_list_of_image_predictions(outs) for name, outs in outputs.items()}
 
     def load(self, filepath):
+        """Reference checkpoints ('module.'-prefixed keys, models.py:196-208).  Which bilinear semantics the loaded weights get is the
+        network's ``align_corners`` (architecture_config['model_params']['align_corners'], default False = torch >= 0.4, the oracle's):
+        a checkpoint trained in the reference's own environment (torch 0.3.1) expects True - nothing in the file says which, so the
+        caller states it."""
         self.model.eval()
         sd = torch.load(filepath, map_location='cpu')
         sd = {(k[len('module.'):] if k.startswith('module.') else k): v for k, v in sd.items()}

@@ -114,9 +114,12 @@ def deconv_conv2d_bn_relu(sd, p, x, train, use_relu=True, use_batch_norm=True):
     return _st(y) if (use_batch_norm or use_relu) else y
 
 
+ALIGN_CORNERS = False     # tests flip it to restate torch 0.3.1's evaluation of the same nn.Upsample call (version drift)
+
+
 def upsample_bilinear(x, scale):
     """nn.Upsample(mode='bilinear') as executed by torch 2.10 (align_corners=False)."""
-    return _st(F.interpolate(x, scale_factor=scale, mode='bilinear', align_corners=False))
+    return _st(F.interpolate(x, scale_factor=scale, mode='bilinear', align_corners=ALIGN_CORNERS))
 
 
 def decoder_block_v1(sd, p, x, train):

@@ -6,9 +6,17 @@ Restates, with plain torch CPU ops:
   * resize_pad_seq (augmentation.py:79-85, neptune.yaml:22-26): resize 101 -> 102, edge-pad 13 -> 128            (train)
   * pad_to_fit_net / InferencePad (augmentation.py:93-96, 247-284) with get_crop_pad_sequence (utils.py:308-313)  (inference)
 
-Parity note: imgaug / cv2 are absent from the image, so the interpolation kernel of `iaa.Scale` cannot be executed here;
-the restatement uses bilinear with half-pixel centres for the tile and nearest for the mask ("parity unpinned" for the
-101 -> 102 resize only; the pad geometry, normalisation and depth channels are pinned by golden F10 / the reference source).
+Parity note (the 101 -> 102 resize only; pad geometry, normalisation and depth channels are pinned by golden F10 / the reference source):
+`augmentation.py:79-85` calls `iaa.Scale({'height': ..., 'width': ...})` with no interpolation argument; the pinned imgaug==0.2.5
+(environment.yml:15) declares `Scale(size, interpolation="cubic", ...)` and resizes with `cv2.resize(..., interpolation=cv2.INTER_CUBIC)`
+(opencv_python==3.4.0.12), on the uint8 tile and - through the same `augment_image` call, loaders.py:137-139 + utils.py:343-344 - on the
+uint8 {0,1} mask.  imgaug / cv2 are absent from this image, so that kernel cannot be executed here: PARITY UNPINNED, restated from the
+public definition of INTER_CUBIC (Keys cubic convolution with a = -0.75, half-pixel centres, BORDER_REPLICATE taps, uint8 output =
+saturate_cast(round(v))).  `torch.nn.functional.interpolate(mode='bicubic', align_corners=False)` implements the same definition
+(A = -0.75, clamped taps) and serves as the executable restatement; `cubic_weights` below is the hand-checkable form
+(KAT: t = 0.5 -> [-0.09375, 0.59375, 0.59375, -0.09375], tests/test_oracle_golden.py).  cv2's uint8 path evaluates the separable
+filter in 11-bit fixed point, so its result can differ from this float restatement by 1 LSB (1/255) on isolated pixels.
+interpolation='bilinear' keeps rounds 1-2's restatement (bilinear for the tile, nearest for the mask).
 """
 import numpy as np
 import torch
@@ -24,14 +32,51 @@ def crop_pad_sequence(vertical, horizontal):                  # utils.py:308-313
     return top, right, vertical - top, horizontal - right
 
 
-def preprocess(img, mask, train, channels, resize=102, pad=13, divisor=64):
-    """img: float [B,h,w] in [0,1]; mask: {0,1} [B,h,w] or None -> (X [B,channels,H,W], target [B,2,H,W] | None)."""
+def cubic_weights(t, a=-0.75):
+    """The four Keys cubic-convolution tap weights (taps floor(s) - 1 .. floor(s) + 2) at fraction t, as cv2.INTER_CUBIC defines them."""
+    w0 = ((a * (t + 1) - 5 * a) * (t + 1) + 8 * a) * (t + 1) - 4 * a
+    w1 = ((a + 2) * t - (a + 3)) * t * t + 1
+    w2 = ((a + 2) * (1 - t) - (a + 3)) * (1 - t) * (1 - t) + 1
+    return [w0, w1, w2, 1 - w0 - w1 - w2]
+
+
+def resize_cubic_numpy(img, oh, ow):
+    """Direct (loop) evaluation of the cubic resize of ONE [h, w] float image - the slow, hand-checkable twin of the torch call below."""
+    img = np.asarray(img, dtype=np.float64)
+    h, w = img.shape
+    out = np.zeros((oh, ow))
+    for oy in range(oh):
+        fy = (oy + 0.5) * h / oh - 0.5
+        y0 = int(np.floor(fy)); wy = cubic_weights(fy - y0)
+        for ox in range(ow):
+            fx = (ox + 0.5) * w / ow - 0.5
+            x0 = int(np.floor(fx)); wx = cubic_weights(fx - x0)
+            v = 0.0
+            for i in range(4):
+                yy = min(max(y0 - 1 + i, 0), h - 1)
+                for j in range(4):
+                    xx = min(max(x0 - 1 + j, 0), w - 1)
+                    v += wy[i] * wx[j] * img[yy, xx]
+            out[oy, ox] = v
+    return out
+
+
+def preprocess(img, mask, train, channels, resize=102, pad=13, divisor=64, interpolation='cubic', uint8_grid=True):
+    """img: float [B,h,w] in [0,1]; mask: {0,1} [B,h,w] or None -> (X [B,channels,H,W], target [B,2,H,W] | None).
+    uint8_grid: the tile is a uint8 image / 255 (the reference's case): the cubic resize rounds back onto that grid like cv2's uint8 output."""
     x = torch.as_tensor(img, dtype=torch.float32)[:, None]
     m = None if mask is None else torch.as_tensor(mask, dtype=torch.float32)[:, None]
-    if train:
+    if train and interpolation == 'cubic':
+        x = F.interpolate(x, size=(resize, resize), mode='bicubic', align_corners=False)
+        if uint8_grid:
+            x = torch.clamp(torch.floor(x * 255.0 + 0.5), 0, 255) / 255.0
+        if m is not None:
+            m = torch.clamp(torch.floor(F.interpolate(m, size=(resize, resize), mode='bicubic', align_corners=False) + 0.5), 0, 1)
+    elif train:
         x = F.interpolate(x, size=(resize, resize), mode='bilinear', align_corners=False)
         if m is not None:
             m = (F.interpolate(m, size=(resize, resize), mode='nearest') > 0.5).float()
+    if train:
         pads = (pad, pad, pad, pad)                           # (left, right, top, bottom)
     else:
         h, w = x.shape[2:]

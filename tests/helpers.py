@@ -30,6 +30,22 @@ def state_from_fixture(fx, canonical=None):
     return sd
 
 
+def record_parity(name, **values):
+    """SALT_PARITY_COUNTS=<file.json>: the parity tests of the BASELINE configs append their decision counts (mask pixels that differ from
+    the oracle, totals, agreement) to that file - tools/r03_evidence.sh commits it as profiles/rNN_parity_counts.json."""
+    path = os.environ.get('SALT_PARITY_COUNTS')
+    if not path:
+        return
+    import json
+    doc = {}
+    if os.path.exists(path):
+        with open(path) as f:
+            doc = json.load(f)
+    doc[name] = {k: (float(v) if isinstance(v, float) else int(v) if isinstance(v, (int, np.integer)) else v) for k, v in values.items()}
+    with open(path, 'w') as f:
+        json.dump(doc, f, indent=1, sort_keys=True)
+
+
 def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)

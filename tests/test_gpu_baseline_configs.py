@@ -79,6 +79,11 @@ def test_c4_r152_tta_pipeline_bf16_full_shape():
     assert agree >= agree_emu - 0.01, (agree, agree_emu)
     # every disagreeing mask pixel has a reference probability within the measured bf16 error of the threshold
     dis = mask[0].cpu().numpy().astype(bool) != ref_mask
+    from helpers import record_parity
+    record_parity('C4_r152_tta_bf16_crop_threshold_masks', config='[16,3,256,256] bf16, 4-flip TTA mean, crop 202, > 0.5; image 0 vs fp32 oracle pipeline',
+                  decisions=int(dis.size), differ=int(dis.sum()), agreement=agree, agreement_emulated_bf16_storage=agree_emu,
+                  prob_error_mean=float(err.mean()), prob_error_max=float(err.max()),
+                  max_ref_distance_to_threshold_at_differing=float(np.abs(ref_crop - 0.5)[dis].max()) if dis.any() else 0.0)
     assert not dis.any() or float(np.abs(ref_crop - 0.5)[dis].max()) <= float(err.max()) + 1e-6
 
 

@@ -221,3 +221,40 @@ def test_ws_eval_folded_bn_relu_vs_torch(case):
     with torch.no_grad():
         yr = F.relu(rb(rc(x)))
     assert_close(y, yr, TOLBF, 'eval y')
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 32, 32, 64), (2, 32, 32, 48, 96), (1, 128, 16, 16, 128)])
+def test_bn_apply_in_consumer_loader_forward_is_bit_identical(shape, monkeypatch):
+    """salt_conv_args.in_fin / in_fin_acc / in_relu (the SALT_EXP_BN_FOLD measurement switch): conv -> BN -> ReLU -> conv ->
+    BN -> ReLU (DecoderBlock, architectures/base.py:29-37) with the first BatchNorm + ReLU applied by the SECOND convolution's loader
+    instead of a salt_affine_act pass.  The forward values (block output, both layers' running statistics) must equal the separate-pass
+    program bit for bit; the affine_act of layer 1 must be gone from the program."""
+    from gpu_harness import BlockRun
+    B, Cin, H, W, C = shape
+    c1, b1, c2, b2 = nn.Conv2d(Cin, C, 3, 1, 1, bias=False), nn.BatchNorm2d(C), nn.Conv2d(C, C, 3, 1, 1, bias=False), nn.BatchNorm2d(C)
+    mod = nn.Sequential(c1, b1, c2, b2)
+    with torch.no_grad():
+        c1.weight.copy_(_rand(c1.weight.shape, 1, (2.0 / (Cin * 9)) ** 0.5)); c2.weight.copy_(_rand(c2.weight.shape, 2, (2.0 / (C * 9)) ** 0.5))
+        b1.weight.copy_(1 + 0.1 * _rand((C,), 3)); b1.bias.copy_(0.1 * _rand((C,), 4))
+    x = _rand((B, Cin, H, W), 5).bfloat16().float()
+    outs = {}
+    for fold in ('', '1'):
+        if fold:
+            monkeypatch.setenv('SALT_EXP_BN_FOLD', '1')
+        else:
+            monkeypatch.delenv('SALT_EXP_BN_FOLD', raising=False)
+        for m in (b1, b2):
+            m.reset_running_stats()
+        mod.train()
+        def emit(g, a):
+            _force_cfg(g, 1)                   # the same conv_mfma_kernel tiles (128 pixels x 64 channels) in both programs
+            return g.conv(g.conv(a, c1, b1, relu=True), c2, b2, relu=True)
+        run = BlockRun(mod, [x], emit, train=True, dtype='bf16')
+        assert _kernel_ids(run.g.fwd) == [1, 1]
+        n_aff = sum(1 for name, _, _ in run.g.fwd.ops if name == 'affine_act')
+        assert n_aff == (1 if fold else 2), n_aff
+        assert getattr(run.g, 'n_folded', 0) == (1 if fold else 0)
+        y = run.forward()
+        outs[fold] = (y.clone(), b1.running_mean.clone(), b1.running_var.clone(), b2.running_mean.clone(), b2.running_var.clone())
+    for a, b in zip(outs[''], outs['1']):
+        assert torch.equal(a.cpu(), b.cpu())

@@ -235,6 +235,13 @@ def test_bf16_whole_network_vs_fp32_oracle_c2_shape():
     print('bf16 C2: eval logits relL2 %.3e (mask agreement %.5f) | train logits relL2 HIP %.3e / emulated bf16 storage %.3e | BCE+Dice %.5f '
           'vs %.5f | Lovasz %.5f vs %.5f | gradient cosine HIP %.4f / emulated %.4f' % (e_eval, agree, e_train, e_train_emu,
                                                                                       float(metrics['sum']), loss_r, float(lv), lv_r, cos, cos_emu))
+    from helpers import record_parity
+    mis = (y[:, 1] > 0) != (yr[:, 1] > 0)
+    record_parity('C2_r34_hypercolumn_bf16_eval_masks', config='[32,3,128,128] bf16 HIP vs fp32 oracle.nets.unet_resnet, logit[1] > 0',
+                  decisions=int(mis.numel()), differ=int(mis.sum()), agreement=agree, eval_logits_rel_l2=e_eval,
+                  max_abs_ref_logit_at_differing=float(yr[:, 1][mis].abs().max()) if bool(mis.any()) else 0.0,
+                  train_logits_rel_l2_hip=e_train, train_logits_rel_l2_emulated_bf16_storage=e_train_emu, gradient_cosine_hip=float(cos),
+                  gradient_cosine_emulated=cos_emu)
     assert e_eval < 3e-2, e_eval                                          # measured 1e-2: ~55 bf16 roundings of 2^-9 each
     assert agree > 0.995, agree                                           # masks differ only where |logit| is within bf16 noise of 0
     assert abs(float(metrics['sum']) - loss_r) < 1e-2 * max(1.0, abs(loss_r)) and abs(float(lv) - lv_r) < 1e-2 * max(1.0, abs(lv_r))

@@ -184,8 +184,10 @@ def test_predict_tta_batch_aggregators_vs_oracle(method):
 @pytest.mark.parametrize('train', [True, False])
 @pytest.mark.parametrize('channels', [1, 3])
 @pytest.mark.parametrize('as_u8', [False, True])
-def test_device_input_pipeline_vs_oracle(train, channels, as_u8):
-    """f-1: resize + edge-pad + normalise + depth channels + one-hot target in one kernel vs the CPU restatement."""
+def test_device_input_pipeline_vs_oracle(train, channels, as_u8, interpolation='cubic'):
+    """f-1: resize + edge-pad + normalise + depth channels + one-hot target in one kernel vs the CPU restatement.  The resize kernel
+    restated is cv2.INTER_CUBIC - imgaug 0.2.5's iaa.Scale default, which augmentation.py:79-85 gets by passing no interpolation
+    (oracle/inputs.py: unpinned by the reference, imgaug / cv2 absent; pinned to the public definition by its own KATs)."""
     from salt_amd.input_pipeline import DevicePreprocessor
     from oracle import inputs as OI
     r = np.random.RandomState(4)
@@ -197,15 +199,83 @@ def test_device_input_pipeline_vs_oracle(train, channels, as_u8):
         dev_img = T(u8).to(DEV)
     else:
         dev_img = T(img).to(DEV)
-    msk = (r.rand(B, h, w) > 0.5).astype(np.uint8)
-    msk[0] = 0
-    X, Tg = DevicePreprocessor(train, channels)(dev_img, T(msk).to(DEV))
-    Xr, Tr = OI.preprocess(img, msk, train, channels)
+    msk = np.zeros((B, h, w), np.uint8)                                     # blobs, not salt-and-pepper: what a salt mask looks like
+    yy, xx = np.mgrid[0:h, 0:w]
+    for b in range(1, B):
+        msk[b] = (((yy - r.uniform(0, h)) / r.uniform(10, 60)) ** 2 + ((xx - r.uniform(0, w)) / r.uniform(10, 60)) ** 2 <= 1).astype(np.uint8)
+    pre = DevicePreprocessor(train, channels, interpolation=interpolation)
+    X, Tg = pre(dev_img, T(msk).to(DEV))
+    Xr, Tr = OI.preprocess(img, msk, train, channels, interpolation=interpolation, uint8_grid=as_u8)
     assert tuple(X.shape) == tuple(Xr.shape) == (B, channels, 128, 128)
-    assert_close(X.cpu(), Xr, 2e-6, 'input batch')
+    if train and interpolation == 'cubic' and as_u8:
+        # both sides round the cubic value onto the uint8 grid; float summation order may move a value across a rounding boundary:
+        # at most one grid step (1 / 255 / std), on a vanishing fraction of the pixels
+        d = (X.cpu() - Xr)[:, 0].abs()
+        assert float(d.max()) <= 1.0 / 255 / 0.229 + 1e-5, float(d.max())
+        assert float((d > 1e-5).float().mean()) < 1e-3, float((d > 1e-5).float().mean())
+    else:
+        assert_close(X.cpu(), Xr, 2e-5 if (train and interpolation == 'cubic') else 2e-6, 'input batch')
     assert torch.equal(Tg.cpu(), Tr)                                         # one-hot target: exact
-    X2, T2 = DevicePreprocessor(train, channels)(dev_img)                    # inference batches carry no target
+    X2, T2 = pre(dev_img)                                                    # inference batches carry no target
     assert T2 is None and torch.equal(X2, X)
+
+
+@pytest.mark.parametrize('as_u8', [True, False])
+def test_device_input_pipeline_bilinear_mode(as_u8):
+    """interpolation='bilinear': rounds 1-2's train-branch resize (bilinear tile, nearest mask), kept selectable."""
+    test_device_input_pipeline_vs_oracle(True, 3, as_u8, interpolation='bilinear')
+
+
+@pytest.mark.parametrize('R', [2, 4, 8, 16])
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_bilinear_align_corners_vs_torch(R, dtype):
+    """salt_bilinear_args.align_corners = 1: nn.Upsample(mode='bilinear') as torch 0.3.1 - the reference's pinned version - evaluated
+    it (base.py:70, unet.py:103-106): forward and the adjoint against torch's align_corners=True autograd."""
+    from gpu_harness import BlockRun
+    from torch import nn
+    g = torch.Generator().manual_seed(R)
+    x = torch.randn(2, 16, 5, 7, generator=g)
+    if dtype == 'bf16':
+        x = x.bfloat16().float()
+    dummy = nn.Linear(1, 1)
+    dummy.align_corners = True
+    run = BlockRun(dummy, [x], lambda gr, a: gr.upsample(a, R), train=True, dtype=dtype)
+    assert [int(s.align_corners) for name, _, s in run.g.fwd.ops if name == 'bilinear'] == [1]
+    y = run.forward()
+    xr = x.clone().requires_grad_(True)
+    yr = torch.nn.functional.interpolate(xr, scale_factor=R, mode='bilinear', align_corners=True)
+    tol = 2e-6 if dtype == 'f32' else 1e-2
+    assert_close(y, yr, tol, 'up x%d align_corners' % R)
+    gy = torch.randn(*yr.shape, generator=g)
+    yr.backward(gy)
+    gx, _ = run.backward(gy.to(DEV))
+    assert_close(gx[0], xr.grad, 1e-5 if dtype == 'f32' else 2e-2, 'adjoint x%d align_corners' % R)
+
+
+def test_network_align_corners_switch_vs_oracle():
+    """HipNetwork.set_align_corners(True) - how a checkpoint trained under torch 0.3.1 saw its decoder / hypercolumn features: eval logits
+    of the ResNet34 hypercolumn U-Net against the oracle with the same switch; the default (False) is what the goldens pin."""
+    from salt_amd import architectures as A
+    from oracle import nets as ON, specs as OS, blocks as OB
+    spec = OS.SPECS['UNetResNet'](with_fc=True)
+    sd = OS.init_state(spec, seed=3)
+    net = A.UNetResNet(34, 2, use_hypercolumn=True, dropout_2d=0.0, pretrained=False)
+    net.load_state_dict({k: sd[k] for k in net.state_dict() if k in sd}, strict=False)
+    x = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(1))
+    outs = {}
+    for ac in (False, True):
+        net.set_align_corners(ac)
+        net.to(DEV).eval()
+        with torch.no_grad():
+            outs[ac] = net(x.to(DEV)).float().cpu()
+        OB.ALIGN_CORNERS = ac
+        try:
+            with torch.no_grad():
+                ref = ON.unet_resnet({k: v for k, v in sd.items()}, x, False)
+        finally:
+            OB.ALIGN_CORNERS = False
+        assert_close(outs[ac], ref, 1e-3, 'eval logits align_corners=%s' % ac)
+    assert float((outs[True] - outs[False]).abs().max()) > 1e-3               # the switch is not a no-op
 
 
 def test_device_input_pipeline_other_sizes():
@@ -218,9 +288,9 @@ def test_device_input_pipeline_other_sizes():
     assert tuple(X.shape) == (2, 3, 256, 256)
     assert_close(X.cpu(), Xr, 2e-6, 'inference pad 202 -> 256')
     X, Tg = DevicePreprocessor(True, 3, resize=204, pad=26)(T(img).to(DEV), T((img > 0.5).astype(np.uint8)).to(DEV))
-    Xr, Tr = OI.preprocess(img, (img > 0.5).astype(np.uint8), True, 3, resize=204, pad=26)
+    Xr, Tr = OI.preprocess(img, (img > 0.5).astype(np.uint8), True, 3, resize=204, pad=26, uint8_grid=False)     # float tiles: no uint8 rounding
     assert tuple(X.shape) == (2, 3, 256, 256)
-    assert_close(X.cpu(), Xr, 2e-6, 'train resize 202 -> 204 + pad 26')
+    assert_close(X.cpu(), Xr, 2e-5, 'train cubic resize 202 -> 204 + pad 26')
     assert torch.equal(Tg.cpu(), Tr)
 
 

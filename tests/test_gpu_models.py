@@ -230,6 +230,10 @@ def test_vanilla_unet_matches_oracle_c1_shape():
     mis = (y[:, 1] > 0) != (yr[:, 1] > 0)
     n_mis = int(mis.sum())
     print('C1 mask: %d of %d decisions differ from the oracle' % (n_mis, mis.numel()))
+    from helpers import record_parity
+    record_parity('C1_vanilla_unet_fp32_eval_masks', config='[32,1,128,128] fp32, logit[1] > 0 vs oracle.nets.vanilla_unet', decisions=int(mis.numel()),
+                  differ=n_mis, max_abs_ref_logit_at_differing=float(yr[:, 1][mis].abs().max()) if n_mis else 0.0,
+                  max_abs_logit_error=float((y - yr).abs().max()))
     if n_mis:
         assert n_mis <= 2 and float(yr[:, 1][mis].abs().max()) < 2e-6 * float(yr.abs().max()), (n_mis, float(yr[:, 1][mis].abs().max()))
     net.train()
@@ -375,3 +379,57 @@ def test_cpu_tensor_is_rejected_loudly():
     net = A.VanillaUNet(2, 1, 16, 2)
     with pytest.raises(SaltError):
         net(torch.zeros(1, 1, 16, 16))
+
+
+@pytest.mark.parametrize('depth,dtype,shape', [(34, 'f32', (2, 3, 64, 64)), (34, 'bf16', (32, 3, 128, 128)), (50, 'bf16', (2, 3, 64, 64)), (50, 'f32', (2, 3, 64, 64))])
+def test_eval_residual_epilogue_is_bit_identical_to_the_separate_pass(depth, dtype, shape, monkeypatch):
+    """Eval-mode BasicBlock / Bottleneck (torchvision layout via architectures/encoders.py:6-45): out = relu(bn(conv(a)) + identity).
+    The folded form (salt_conv_args.res: BN affine, identity add and ReLU in the convolution's epilogue - conv_mfma_kernel for the
+    1x1 / small launches, conv_ws_kernel / conv_ls_kernel at the [32,3,128,128] shape) must give the logits of the unfused form
+    (convolution, then salt_affine_act over its stored output) bit for bit."""
+    from salt_amd import architectures as A
+    outs = {}
+    for fold in (True, False):
+        if fold:
+            monkeypatch.delenv('SALT_NO_RES_FOLD', raising=False)
+        else:
+            monkeypatch.setenv('SALT_NO_RES_FOLD', '1')
+        torch.manual_seed(5)
+        net = A.UNetResNet(depth, 2, use_hypercolumn=True, dropout_2d=0.0, pretrained=False)
+        with torch.no_grad():
+            for m in net.modules():                      # non-trivial running statistics
+                if isinstance(m, torch.nn.BatchNorm2d):
+                    m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5)
+        net.set_compute_dtype(dtype)
+        net.to(DEV).eval()
+        g = torch.Generator().manual_seed(3)
+        x = torch.randn(*shape, generator=g)
+        with torch.no_grad():
+            outs[fold] = net(x.to(DEV)).float().cpu()
+        prog = net.engine().net(tuple(shape), False).fwd
+        n_aff = sum(1 for name, _, s_ in prog.ops if name == 'affine_act' and s_.res.p)
+        n_res = sum(1 for name, _, s_ in prog.ops if name == 'conv' and s_.res.p)
+        nblocks = {34: 16, 50: 16}[depth]
+        assert (n_res, n_aff) == ((nblocks, 0) if fold else (0, nblocks)), (n_res, n_aff)
+    assert torch.isfinite(outs[True]).all()
+    assert torch.equal(outs[True], outs[False])
+
+
+def test_segmentation_model_transform_values_match_reference_golden():
+    """SegmentationModel.transform (models.py:138-147 -> _transform 150-177): the probabilities handed to the post-processing are
+    sigmoid(eval logits) of the reference's own forward (golden F8, architectures.unet.UNetResNet(34, hypercolumn)) - a VALUE check of
+    the boundary function, not only its shapes."""
+    from salt_amd.models import SegmentationModel
+    fx = golden('F8_unet_resnet34_hyper')
+    arch = {'model_params': {'architecture': 'UNetResNet', 'out_channels': 2, 'activation': 'sigmoid'},
+            'optimizer_params': {'lr': 1e-4}, 'regularizer_params': {'regularize': True, 'weight_decay_conv2d': 1e-4}}
+    m = SegmentationModel(arch, {'epochs': 1}, {})
+    _fill_closed_form(m.model)
+    x = T(fx['x'])
+    out = m.transform(([x[:1], x[1:]], 2))['mask_prediction']
+    ref = 1.0 / (1.0 + np.exp(-fx['eval_logits'].astype(np.float64)))
+    assert len(out) == x.shape[0]
+    for i, pr in enumerate(out):
+        assert pr.shape == ref[i].shape and pr.dtype == np.float32
+        assert float(np.abs(pr - ref[i]).max()) <= 1e-4, float(np.abs(pr - ref[i]).max())      # 1e-3 relative on logits -> <= 2.5e-4 on sigmoid
+        assert np.array_equal(pr[1] > 0.5, fx['eval_mask'][i].astype(bool))

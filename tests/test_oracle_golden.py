@@ -239,3 +239,42 @@ def test_tta_post_metric():
     b = e.copy(); b[1:3] = 1
     assert OM.iou_single(e, e) == 1.0 and OM.iou_single(a, e) == 0.0 and OM.iou_single(e, a) == 0.0
     assert abs(OM.iou_single(a, b) - 5 / 15) < 1e-12
+
+
+def test_cubic_resize_restatement_kats():
+    """f-1 train-branch resize (augmentation.py:79-85 -> imgaug 0.2.5 iaa.Scale default 'cubic' -> cv2.INTER_CUBIC): imgaug / cv2 are
+    absent, so the oracle restates the public definition; these known answers pin THAT restatement (hand arithmetic):
+    Keys weights with a = -0.75 at t = 0 -> [0, 1, 0, 0], t = 0.5 -> [-3/32, 19/32, 19/32, -3/32], sum 1 everywhere; a constant image
+    stays constant; the direct loop form equals the executable torch form on 101 -> 102."""
+    from oracle import inputs as OI
+    assert np.allclose(OI.cubic_weights(0.0), [0, 1, 0, 0])
+    assert np.allclose(OI.cubic_weights(0.5), [-0.09375, 0.59375, 0.59375, -0.09375])
+    assert np.allclose(OI.cubic_weights(0.25), [-0.10546875, 0.87890625, 0.26171875, -0.03515625])
+    for t in np.linspace(0, 1, 7):
+        assert abs(sum(OI.cubic_weights(t)) - 1) < 1e-12
+    r = np.random.RandomState(0)
+    img = r.rand(13, 11)
+    a = OI.resize_cubic_numpy(img, 14, 12)
+    b = torch.nn.functional.interpolate(torch.from_numpy(img)[None, None], size=(14, 12), mode='bicubic', align_corners=False)[0, 0].numpy()
+    assert np.abs(a - b).max() < 1e-12
+    assert np.allclose(OI.resize_cubic_numpy(np.full((5, 5), 0.3), 6, 6), 0.3)
+    # a step edge: the cubic overshoots (negative lobes) - which the uint8 path saturates, and the mask path rounds back to {0, 1}
+    step = np.zeros((1, 8, 8), np.float32); step[:, :, 4:] = 1.0
+    X, Tm = OI.preprocess(step, step.astype(np.uint8), True, 1, resize=9, pad=0)
+    assert set(np.unique(Tm.numpy()).tolist()) <= {0.0, 1.0}
+    assert float(Tm[0, 1].sum()) > 0 and float(Tm[0, 0].sum()) > 0
+    g = X[0, 0].numpy() * 0.229 + 0.485
+    assert g.min() >= -1e-6 and g.max() <= 1 + 1e-6                         # saturated onto [0, 255] / 255
+
+
+def test_align_corners_restatement_kat():
+    """torch 0.3.1 evaluated nn.Upsample(mode='bilinear') with src = dst (H - 1) / (R H - 1): [0, 1] x2 -> [0, 1/3, 2/3, 1]
+    (the torch >= 0.4 default gives [0, 0.25, 0.75, 1])."""
+    from oracle import blocks as OB
+    x = torch.tensor([0.0, 1.0]).view(1, 1, 1, 2).repeat(1, 1, 2, 1)
+    assert torch.allclose(OB.upsample_bilinear(x, 2)[0, 0, 0], torch.tensor([0, 0.25, 0.75, 1.0]))
+    OB.ALIGN_CORNERS = True
+    try:
+        assert torch.allclose(OB.upsample_bilinear(x, 2)[0, 0, 0], torch.tensor([0, 1 / 3, 2 / 3, 1.0]))
+    finally:
+        OB.ALIGN_CORNERS = False

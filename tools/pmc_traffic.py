@@ -5,6 +5,7 @@ Counter units and corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / W
 tallies the 128-byte requests of wide coalesced reads at 64 bytes, so read bytes = FETCH_SIZE * 1024 * 2.  WRITE_SIZE is
 uncalibrated in the guide; the Adam kernel (reads 4 and writes 3 fp32 arrays of known length) is printed as a calibration row."""
 import json
+import os
 import sqlite3
 import sys
 from collections import defaultdict
@@ -25,7 +26,7 @@ def per_kernel(path, counter):
     agg = defaultdict(lambda: [0, 0.0])
     for name, _, v in rows[lo:hi]:
         k = name.replace('_ZN12_GLOBAL__N_1', '').replace('.kd', '')
-        for base in ('conv_mfma_kernel', 'conv_glds_kernel', 'conv_wgrad_kernel', 'bn_bwd_reduce', 'bn_bwd_apply', 'bn_bwd_finalize', 'bn_finalize', 'affine_act',
+        for base in ('conv_ws_kernel', 'conv_ls_kernel', 'conv_mfma_kernel', 'conv_glds_kernel', 'conv_wgrad_kernel', 'bn_bwd_reduce', 'bn_bwd_apply', 'bn_bwd_finalize', 'bn_finalize', 'affine_act',
                      'wgrad_reduce', 'adam_kernel', 'pad_fold', 'lovasz', 'bilinear_fwd', 'bilinear_bwd', 'pack_batched', 'head1x1', 'scse', 'se_'):
             if base in k:
                 k = base
@@ -40,6 +41,7 @@ def main(fetch_db, write_db):
     sw, w = per_kernel(write_db, 'WRITE_SIZE')
     out = {'source': 'rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) over bench.py bf16 r34_hyper batch 32',
            'corrections': 'bytes_read = FETCH_SIZE KiB * 1024 * 2 (gfx950 wide-read correction); bytes_written = WRITE_SIZE KiB * 1024',
+           'commit': os.environ.get('SALT_COMMIT', 'unrecorded'),      # the gpurun snapshot has no .git: the caller passes `git rev-parse --short HEAD` (+dirty)
            'steps': sf, 'kernels': {}}
     tot_r = tot_w = 0.0
     for k in sorted(set(f) | set(w), key=lambda k: -(f.get(k, [0, 0])[1] * 2 + w.get(k, [0, 0])[1])):
