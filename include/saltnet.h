@@ -158,6 +158,16 @@ typedef struct {
     int in_relu;
     const void* in_fin;
     const double* in_fin_acc;
+    /* Planar y: y_plane != 0 (elements): y is stored as C / y.cs dense planes [B,H,W,y.cs] - channel c of pixel q at
+     * y.p + (c / y.cs) * y_plane + q * y.cs + c % y.cs - instead of channel-interleaved rows (y.cs < y.C is legal only here).  The
+     * gradient of the 320-channel hypercolumn (architectures/unet.py:101-107) is kept this way: the five consumers (the up-sampling
+     * adjoints, the scSE backward of dec1) each read ONE dense 64-channel plane instead of 128-byte pieces at a 640-byte pitch.
+     * conv_ws_kernel only (y.cs == 64 = its channel block); salt_conv fails for any other launch, salt_conv_kernel_id returns -1. */
+    int64_t y_plane;
+    /* Planar x, the same layout on the input side: channel c of pixel q at x.p + (c / x.cs) * x_plane + q * x.cs + c % x.cs.  The
+     * forward convolution over the hypercolumn reads its 32-channel chunks from the five level planes.  conv_ls_kernel only
+     * (x.cs == 64: two chunks per plane). */
+    int64_t x_plane;
 } salt_conv_args;
 int salt_conv(const salt_conv_args*, void* stream);
 /* number of stats partials a launch with these args writes (host sizes the workspace with it) */
@@ -186,6 +196,7 @@ typedef struct {
     int pad_mode;
     float* partials;
     int nsplit;               /* as returned by salt_conv_wgrad_nsplit */
+    int64_t q_plane;          /* != 0: q is planar (salt_conv_args.y_plane layout), q.cs == 64 = the kernels' b-block: block bb reads plane bb */
 } salt_conv_wgrad_args;
 int salt_conv_wgrad(const salt_conv_wgrad_args*, void* stream);
 int salt_conv_wgrad_nsplit(const salt_conv_wgrad_args*);

@@ -385,14 +385,23 @@ class UNetResNet(HipNetwork):
         e5 = emit_blocks(g, enc.layer4, e4, out=cat5.slice(b // 2, 512 * exp))
         c = self.center[1].emit(g, self.center[0].emit(g, e5))
         c = g.avgpool2(c, name='center.pool')
+        # SALT_HYPER_ROWS (default 0; 1: eval, 2: train too): ONE salt_hyper_rows pass writes the four up-sampled levels of every pixel row
+        # instead of four launches into channel slices - measured SLOWER on both streams, kept selectable
+        rows_mode = int(os.environ.get('SALT_HYPER_ROWS', '0'))
+        fused_rows = self.use_hypercolumn and (rows_mode == 2 or (rows_mode == 1 and not g.train))
         if self.use_hypercolumn:
-            hyper = g.new_act(B, H, W, 5 * d, 'hypercolumn')
+            # PLANAR hypercolumn where the kernels allow it (bf16, conv_ls / conv_ws eligible): five dense [B,H,W,64] planes instead of
+            # 320-channel rows.  Every producer (dec1's scSE, the four up-samplings) and every gradient consumer then streams ONE dense
+            # tensor instead of 128-byte pieces at a 640-byte pitch (0.6 TB/s at the C4 size); the final convolution, its data gradient
+            # and its weight gradient address the planes themselves (salt_conv_args.x_plane / y_plane, salt_conv_wgrad_args.q_plane)
+            planes = d if (not fused_rows and g.planar_ok(B, H, W, 5 * d, d, self.final[0].conv)) else 0
+            hyper = g.new_act(B, H, W, 5 * d, 'hypercolumn', planes=planes)
         # the hypercolumn up-samplings only feed the final convolution: each one goes to the side stream as soon as its decoder
         # level exists and overlaps the remaining decoder levels; the final convolution joins
         def hyper_up(x, R, k):
             # SALT_EXP_VHYPER_SKIP: TIMING experiment - the step without the four up-sampling launches and their adjoints is
             # the upper bound of what a loader that interpolates on the fly ("virtual hypercolumn") could save; the values are wrong
-            if self.use_hypercolumn and not os.environ.get('SALT_EXP_VHYPER_SKIP'):
+            if self.use_hypercolumn and not fused_rows and not os.environ.get('SALT_EXP_VHYPER_SKIP'):
                 with g.side():
                     g.upsample(x, R, out=hyper.slice(k * d, d))
         d5 = self.dec5.emit(g, c, e5, cat=cat5)
@@ -403,6 +412,9 @@ class UNetResNet(HipNetwork):
         hyper_up(d3, 4, 2)
         d2 = self.dec2.emit(g, d3, e2, cat=cat2)
         hyper_up(d2, 2, 1)
+        if fused_rows and not os.environ.get('SALT_EXP_VHYPER_SKIP'):
+            with g.side():
+                g.hyper_rows([d2, d3, d4, d5], [2, 4, 8, 16], hyper.slice(d, 4 * d))
         if self.use_hypercolumn:
             d1 = self.dec1.emit(g, d2, None, out=hyper.slice(0, d))
             g.join()

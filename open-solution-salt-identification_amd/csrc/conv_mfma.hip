@@ -1409,7 +1409,13 @@ struct Plan {
 
 int make_plan(const salt_conv_args* a, Plan* pl) {
     if (!a) SALT_FAIL(SALT_E_BADARG, "null args");
-    if (!view_ok(a->x) || !view_ok(a->y) || !a->w) SALT_FAIL(SALT_E_BADARG, "conv: bad view");
+    {
+        salt_view yv = a->y, xv = a->x;
+        if (a->y_plane) yv.cs = yv.C;            // planar y (conv_ws_kernel only): y.cs is the plane's channel count, checked there
+        if (a->x_plane) xv.cs = xv.C;            // planar x (conv_ls_kernel only)
+        if (!view_ok(xv) || !view_ok(yv) || !a->w) SALT_FAIL(SALT_E_BADARG, "conv: bad view");
+        if (a->y_plane < 0 || a->x_plane < 0) SALT_FAIL(SALT_E_BADARG, "conv: x_plane / y_plane");
+    }
     if (a->ntaps < 1 || a->ntaps > SALT_MAX_TAPS) SALT_FAIL(SALT_E_BADARG, "conv: ntaps %d", a->ntaps);
     if (a->in_step < 1 || a->in_step > 2 || a->out_step < 1 || a->out_step > 2) SALT_FAIL(SALT_E_BADARG, "conv: steps");
     if (a->OH < 1 || a->OW < 1) SALT_FAIL(SALT_E_BADARG, "conv: empty output grid");
@@ -1796,6 +1802,7 @@ struct WgradKP {
     int tiles_y, tiles_x, ntiles, nsplit;
     int a_blocks, b_blocks;
     int bmp;                        // pixels per K tile (64 | 128)
+    long long q_plane;              // salt_conv_wgrad_args.q_plane: b-block bb reads the dense plane Q + bb * q_plane (0: channel-interleaved rows)
     int atomic;                     // SALT_WGRAD_ATOMIC=1 (A/B): every split ADDS into slab 0 with global_atomic_add_f32 instead of writing its own slab
 };
 
@@ -1825,7 +1832,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradKP p) {
     const int a0 = ab * 64, c0 = bb * 64;
     const int hhw = p.hh * p.hw, phalo = p.nb * hhw;
     const T* Pg = reinterpret_cast<const T*>(p.P);
-    const T* Qg = reinterpret_cast<const T*>(p.Q);
+    const T* Qg = reinterpret_cast<const T*>(p.Q) + (p.q_plane ? (long long)bb * p.q_plane - c0 : 0);   // planar Q: channel c0 + j of block bb is element j of plane bb
     const bool p_vec = ((p.p_cs % VE) == 0) && ((reinterpret_cast<uintptr_t>(p.P) & 15) == 0);
     const bool q_vec = ((p.q_cs % VE) == 0) && ((reinterpret_cast<uintptr_t>(p.Q) & 15) == 0);
 
@@ -2075,7 +2082,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_fast_kernel(WgradKP p) {
     const int a0 = ab * 64, c0 = bb * 64;
     const int hhw = p.hh * p.hw, phalo = p.nb * hhw;
     const T* Pg = reinterpret_cast<const T*>(p.P);
-    const T* Qg = reinterpret_cast<const T*>(p.Q);
+    const T* Qg = reinterpret_cast<const T*>(p.Q) + (p.q_plane ? (long long)bb * p.q_plane - c0 : 0);   // planar Q: channel c0 + j of block bb is element j of plane bb
     const T* zp = reinterpret_cast<const T*>(g_zero_piece);
 
     f32x16 acc[NT];
@@ -2290,7 +2297,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_fast8_kernel(WgradKP p) {
     const int a0 = ab * 64, c0 = bb * 64;
     const int hhw = p.hh * p.hw, phalo = p.nb * hhw;
     const T* Pg = reinterpret_cast<const T*>(p.P);
-    const T* Qg = reinterpret_cast<const T*>(p.Q);
+    const T* Qg = reinterpret_cast<const T*>(p.Q) + (p.q_plane ? (long long)bb * p.q_plane - c0 : 0);   // planar Q: channel c0 + j of block bb is element j of plane bb
     const T* zp = reinterpret_cast<const T*>(g_zero_piece);
 
     f32x16 acc[NTA];
@@ -2487,7 +2494,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_fast32_kernel(WgradKP p) {
     const int a0 = ab * 64, c0 = bb * 64;
     const int hhw = p.hh * p.hw, phalo = p.nb * hhw;
     const T* Pg = reinterpret_cast<const T*>(p.P);
-    const T* Qg = reinterpret_cast<const T*>(p.Q);
+    const T* Qg = reinterpret_cast<const T*>(p.Q) + (p.q_plane ? (long long)bb * p.q_plane - c0 : 0);   // planar Q: channel c0 + j of block bb is element j of plane bb
     const T* zp = reinterpret_cast<const T*>(g_zero_piece);
 
     f32x16 acc[NT];
@@ -2660,7 +2667,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_fast32_kernel(WgradKP p) {
 }
 
 int wgrad_plan(const salt_conv_wgrad_args* a, WgradKP* k, int* nsplit_out) {
-    if (!a || !view_ok(a->p) || !view_ok(a->q)) SALT_FAIL(SALT_E_BADARG, "wgrad: bad view");
+    if (!a) SALT_FAIL(SALT_E_BADARG, "wgrad: null args");
+    {
+        salt_view qv = a->q;
+        if (a->q_plane) {                         // planar q: planes of one 64-channel b-block
+            if (a->q.cs != 64 || a->q.C % 64 || a->q_plane % 8 || a->q_plane < (int64_t)a->q.B * a->q.H * a->q.W * 64)
+                SALT_FAIL(SALT_E_BADARG, "wgrad: q_plane needs dense planes of 64 channels");
+            qv.cs = qv.C;
+        }
+        if (!view_ok(a->p) || !view_ok(qv)) SALT_FAIL(SALT_E_BADARG, "wgrad: bad view");
+    }
     if (a->ntaps < 1 || a->ntaps > 9) SALT_FAIL(SALT_E_BADARG, "wgrad: ntaps %d (max 9 per launch)", a->ntaps);
     if (a->p.B != a->q.B) SALT_FAIL(SALT_E_BADARG, "wgrad: batch mismatch");
     int min_dy = 1 << 30, max_dy = -(1 << 30), min_dx = 1 << 30, max_dx = -(1 << 30);
@@ -2682,6 +2698,7 @@ int wgrad_plan(const salt_conv_wgrad_args* a, WgradKP* k, int* nsplit_out) {
         if ((size_t)(bmp + k->nb * k->hh * k->hw) * rowb <= 80 * 1024) break;     // keep >= 2 workgroups per CU
     }
     k->P = a->p.p; k->Q = a->q.p; k->partials = a->partials;
+    k->q_plane = a->q_plane;
     k->B = a->p.B; k->PH = a->p.H; k->PW = a->p.W; k->Ca = a->p.C; k->p_cs = a->p.cs;
     k->QH = a->q.H; k->QW = a->q.W; k->Cb = a->q.C; k->q_cs = a->q.cs;
     k->ntaps = a->ntaps; k->q_step = a->q_step; k->pad_mode = a->pad_mode; k->min_dy = min_dy; k->min_dx = min_dx;
@@ -2773,7 +2790,9 @@ extern "C" int salt_conv(const salt_conv_args* a, void* stream) {
     }
     const bool in_tf = a->in_scale || a->in_fin_acc;                              // input transform: conv_mfma_kernel only
     if (!in_tf && conv_ws_eligible(a)) return conv_ws_launch(a, (hipStream_t)stream);      // the plan above validated the arguments
+    if (a->y_plane) SALT_FAIL(SALT_E_UNSUPPORTED, "conv: planar y (y_plane) is written by conv_ws_kernel only and this launch is not eligible for it");
     if (!in_tf && conv_ls_variant(a)) return conv_ls_launch(a, (hipStream_t)stream);
+    if (a->x_plane) SALT_FAIL(SALT_E_UNSUPPORTED, "conv: planar x (x_plane) is read by conv_ls_kernel only and this launch is not eligible for it");
     if (a->dtype == SALT_F32) return launch_T<float>(pl, (hipStream_t)stream);
     if (a->dtype == SALT_BF16) return launch_T<bf16_t>(pl, (hipStream_t)stream);
     SALT_FAIL(SALT_E_BADARG, "conv: dtype %d", a->dtype);
@@ -2791,6 +2810,8 @@ extern "C" int salt_conv_kernel_id(const salt_conv_args* a) {
     Plan pl;
     if (make_plan(a, &pl)) return -1;
     if (a->in_scale || a->in_fin_acc) return pl.cfg.id;
+    if (a->y_plane) return conv_ws_eligible(a) ? 9 : -1;
+    if (a->x_plane) return conv_ls_variant(a) ? 10 : -1;
     return conv_ws_eligible(a) ? 9 : (conv_ls_variant(a) ? 10 : pl.cfg.id);
 }
 

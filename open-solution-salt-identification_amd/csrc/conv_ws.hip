@@ -24,7 +24,7 @@
 //   * Per-channel sums (BatchNorm forward statistics, BatchNorm-backward sums) are per-LANE fp32 accumulators over all tiles of the
 //     workgroup (a lane's pixels differ, its channel set does not); ONE halving butterfly over the 32 lanes at kernel end, an 8-wave
 //     merge through LDS, and ONE set of fp64 shard atomics per workgroup (salt_conv_args.fin_acc / bnb_acc without ticket).
-//   * First version of this kernel (kept in git history, profiles/r03_ws_clocks_v1.txt): lane = channel, transposition of the tile
+//   * First version of this kernel (kept in git history, profiles/r03_ws_clocks.txt): lane = channel, transposition of the tile
 //     through wave-private LDS slices.  In-kernel clocks: epilogue 16.7 k cycles per 256 x 64 tile against 7.2 k for its MFMAs
 //     (register spills around 64 ds_write_b16 + the store loop) - 25 us per 64 -> 64 @64x64 launch against 17.7 for conv_mfma_kernel.
 //
@@ -56,6 +56,7 @@ struct WsKP {
     double* fin_acc;             // [8][2 Cout + 1] forward statistics shards (nullptr: off)
     double* bnb_acc;             // [8][2][Cout] BatchNorm-backward shards (nullptr: off)
     const bf16_t* res; int res_cs;   // residual epilogue (salt_conv_args.res), MODE 0 only
+    long long y_plane;               // salt_conv_args.y_plane: channel block b of y is the dense plane y + b * y_plane (0: channel-interleaved rows)
 };
 
 __device__ __attribute__((aligned(16))) unsigned int g_ws_zero[4] = {0u, 0u, 0u, 0u};
@@ -453,7 +454,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsKP p) {
         };
         // fragment ring of 3 stages: the reads of stage s + 2 are issued before the MFMAs of stage s.  One wave per SIMD feeds the matrix
         // pipe here (its partner on the SIMD is in the epilogue role), so nobody else covers its LDS latency: with a 2-stage ring the
-        // phase ran at 64 % of the MFMA rate alone on the CU (in-kernel clocks, profiles/r03_ws_clocks_v1.txt)
+        // phase ran at 64 % of the MFMA rate alone on the CU (in-kernel clocks, profiles/r03_ws_clocks.txt)
         constexpr int NST = NCH * NT * 2;
         Frag f[3];
         load_frag(0, f[0]);
@@ -475,7 +476,8 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(WsKP p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { rs0[j][e] = 0.f; rs1[j][e] = 0.f; }
     const bool sums = (MODE == 1 && p.fin_acc) || (MODE == 2 && p.bnb_acc);
-    const WsEpi ep = {p.y, p.bnb_y, p.bnb_a, p.y_cs, p.bnb_cs, p.bnb_acs, p.relu, p.accumulate, p.bnb_relu,
+    // planar y (y_plane != 0): the epilogue addresses y + pixel * y_cs + n0 + ...; with planes of BN channels that is plane nt at offset 0
+    const WsEpi ep = {p.y_plane ? p.y + ((long long)nt * p.y_plane - n0) : p.y, p.bnb_y, p.bnb_a, p.y_cs, p.bnb_cs, p.bnb_acs, p.relu, p.accumulate, p.bnb_relu,
                       p.bias || p.scale || p.shift || p.relu, sums, p.res, p.res_cs};
 
     // epilogue of the tile in `acc` (computed by this wave one phase ago); issues the halo DMA of `next` (if any) into buffer g
@@ -609,6 +611,7 @@ struct LsKP {
     const float* bnb_mean; const float* bnb_invstd; const float* bnb_gamma; const float* bnb_beta;
     double* fin_acc; double* bnb_acc;
     const bf16_t* res; int res_cs;
+    long long x_plane;               // salt_conv_args.x_plane: chunk c is the half (c & 1) of the dense 64-channel plane x + (c >> 1) * x_plane
 };
 
 template <int NI, int MODE>
@@ -711,12 +714,13 @@ __global__ __launch_bounds__(512) void conv_ls_kernel(LsKP p) {
             if (live && ic == 0) item_offsets(ik);
             const int buf = (ig % D) * CH_BYTES;
             const T* wc = p.w + (int64_t)ic * NT * p.Cout * 32;
+            const T* xc = xb + (p.x_plane ? (long long)(ic >> 1) * p.x_plane + (ic & 1) * 32 : (long long)ic * 32);   // wave-uniform
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
                 const int pi = wm + 4 * i;
                 const void* src = zp;
                 int dst = OFF_DUMMY;
-                if (live && pi < HPC) { if (h_off[i] >= 0) src = xb + (h_off[i] + ic * 32); dst = buf + pi * 1024; }
+                if (live && pi < HPC) { if (h_off[i] >= 0) src = xc + h_off[i]; dst = buf + pi * 1024; }
                 else if (live && pi < PC) { src = wc + w_rel[i]; dst = buf + pi * 1024; }
                 dma(src, dst);
             }
@@ -871,6 +875,9 @@ bool conv_ws_eligible(const salt_conv_args* a) {
     if (!fold && (a->OH != a->y.H || a->OW != a->y.W)) return false;
     if (a->stats || a->fin_ticket || a->bnb_partials || a->bnb_ticket) return false;
     const int Cin = a->x.C, Cout = a->y.C;
+    if (a->x_plane) return false;
+    // planar y: planes of exactly one channel block (64 channels)
+    if (a->y_plane && (a->y.cs != 64 || Cout % 64 || a->y_plane < (int64_t)a->y.B * a->y.H * a->y.W * 64 || a->y_plane % 8 || a->bnb_acc || a->res.p)) return false;
     // all taps x all input channels of ONE block of 32 | 64 output channels stay in LDS: Cin <= 64
     if (!((Cin == 64 && (Cout % 64 == 0 || Cout == 32)) || (Cin == 32 && Cout % 64 == 0))) return false;
     if (a->x.cs % 8 || a->y.cs % 8 || ((reinterpret_cast<uintptr_t>(a->x.p) | reinterpret_cast<uintptr_t>(a->y.p) | reinterpret_cast<uintptr_t>(a->w)) & 15)) return false;
@@ -922,6 +929,7 @@ int conv_ws_launch(const salt_conv_args* a, hipStream_t st) {
     k.bnb_mean = a->bnb_mean; k.bnb_invstd = a->bnb_invstd; k.bnb_gamma = a->bnb_gamma; k.bnb_beta = a->bnb_beta;
     k.fin_acc = a->fin_acc; k.bnb_acc = a->bnb_acc;
     k.res = reinterpret_cast<const bf16_t*>(a->res.p); k.res_cs = a->res.cs;
+    k.y_plane = a->y_plane;
     if (!a->bnb_acc) { k.bnb_y = nullptr; k.bnb_a = nullptr; }
     const int Cin = a->x.C, Cout = a->y.C, bn = Cout % 64 == 0 ? 64 : 32;
     k.Cout = Cout; k.n_tiles = Cout / bn;
@@ -947,6 +955,8 @@ static int ls_common_ok(const salt_conv_args* a) {
     if (a->stats || a->fin_ticket || a->bnb_partials || a->bnb_ticket) return 0;
     const int Cin = a->x.C, Cout = a->y.C;
     if (Cin % 32 || Cin < 64 || Cout % 32) return 0;
+    if (a->y_plane) return 0;
+    if (a->x_plane && (a->x.cs != 64 || Cin % 64 || a->x_plane % 8 || a->x_plane < (int64_t)a->x.B * a->x.H * a->x.W * 64)) return 0;
     if (a->x.cs % 8 || a->y.cs % 8 || ((reinterpret_cast<uintptr_t>(a->x.p) | reinterpret_cast<uintptr_t>(a->y.p) | reinterpret_cast<uintptr_t>(a->w)) & 15)) return 0;
     if (a->OH != a->y.H || a->OW != a->y.W || a->OH % 16 || a->OW % 16 || a->x.B != a->y.B) return 0;
     int min_dy = 1 << 30, max_dy = -(1 << 30), min_dx = 1 << 30, max_dx = -(1 << 30);
@@ -1006,6 +1016,7 @@ int conv_ls_launch(const salt_conv_args* a, hipStream_t st) {
     k.bnb_mean = a->bnb_mean; k.bnb_invstd = a->bnb_invstd; k.bnb_gamma = a->bnb_gamma; k.bnb_beta = a->bnb_beta;
     k.fin_acc = a->fin_acc; k.bnb_acc = a->bnb_acc;
     k.res = reinterpret_cast<const bf16_t*>(a->res.p); k.res_cs = a->res.cs;
+    k.x_plane = a->x_plane;
     if (!a->bnb_acc) { k.bnb_y = nullptr; k.bnb_a = nullptr; }
     int wpx = ws_cus() / 8;
     const int cap = (a->cfg >> 8) & 0xff;

@@ -30,6 +30,12 @@ inline int ew_blocks(int64_t units) {
     int64_t b = (units + 255) / 256; return (int)(b < 1 ? 1 : (b > cap ? cap : b));
 }
 
+#ifndef SALT_BNB_UNITS
+#define SALT_BNB_UNITS 1          // units per thread in flight in bn_bwd_apply_kernel (2 and 4 measured slower)
+#endif
+#ifndef SALT_AFF_UNITS
+#define SALT_AFF_UNITS 2          // ... in affine_act_kernel
+#endif
 #define EW_LAUNCH(KERN, T, allvec, units, stream, ...) \
     do { if (allvec) hipLaunchKernelGGL((KERN<T, true>), dim3(ew_blocks(units)), dim3(256), 0, stream, __VA_ARGS__); \
          else hipLaunchKernelGGL((KERN<T, false>), dim3(ew_blocks(units)), dim3(256), 0, stream, __VA_ARGS__); } while (0)
@@ -49,7 +55,7 @@ inline int ew_blocks(int64_t units) {
 // FIN: scale / shift are not read from memory - every workgroup finalizes the producer's fp64 statistics shards itself
 // (fin_forward_consumer, common.h) into LDS; workgroup 0 stores mean / invstd / scale / shift / running statistics.
 template <typename T, bool VEC, int U = 2, bool FIN = false>
-__global__ void affine_act_kernel(salt_view y, const float* scale, const float* shift, salt_view res, int relu, salt_view a, BnFin fin) {
+__global__ __launch_bounds__(256) void affine_act_kernel(salt_view y, const float* scale, const float* shift, salt_view res, int relu, salt_view a, BnFin fin) {
     constexpr int N = Unit<T, VEC>::N;
     const int cpv = y.C / N;
     const int64_t units = (int64_t)y.B * y.H * y.W * cpv;
@@ -334,7 +340,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* parti
 // FIN: coef is not read from memory - every workgroup finalizes the fp64 shards of the BatchNorm-backward sums itself
 // (fin_backward_consumer) into LDS; workgroup 0 stores dgamma / dbeta / coef.
 template <typename T, bool VEC, bool FIN = false>
-__global__ void bn_bwd_apply_kernel(salt_view da, salt_view a, salt_view y, int relu, const float* mean, const float* invstd,
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(salt_view da, salt_view a, salt_view y, int relu, const float* mean, const float* invstd,
                                     const float* gamma, const float* beta, const float* coef, salt_view dy, salt_view dres, int acc_dres, BnbFin fin) {
     constexpr int N = Unit<T, VEC>::N;
     const int C = y.C, cpv = C / N;
@@ -352,47 +358,66 @@ __global__ void bn_bwd_apply_kernel(salt_view da, salt_view a, salt_view y, int 
             const int64_t u0 = blockIdx.x * 256LL + threadIdx.x;
             const int c0 = (int)(u0 % cpv) * N;
             const bool from_y = relu && a.p == nullptr;
-            float mu[N], is[N], k0[N], k1[N], k2[N], sc[N], sh[N], ga[N], be[N];
+            // Six per-channel vectors stay live in the loop: A, D, E with  dy = A gg + D (y - mean) + E  (= k (gg - c1 - xhat c2) with the
+            // products folded), mean, and scale / shift of the forward pass for the ReLU mask (the SAME expression affine_act evaluated, so
+            // the mask is the forward decision).  Round 2 kept nine (118 VGPRs, 4 waves per SIMD).
+            float mu[N], A[N], D[N], E[N], sc[N], sh[N];
             const float* gptr = from_y ? gamma : mean;             // valid addresses either way: every load below is unconditional,
             const float* bptr = from_y ? beta : mean;              // so all of them are in flight together (one latency, not N)
-#pragma unroll
-            for (int j = 0; j < N; ++j) {
-                mu[j] = mean[c0 + j]; is[j] = invstd[c0 + j];
-                k0[j] = coef[c0 + j]; k1[j] = coef[C + c0 + j]; k2[j] = coef[2 * C + c0 + j];
-                ga[j] = gptr[c0 + j]; be[j] = bptr[c0 + j];
-            }
-#pragma unroll
-            for (int j = 0; j < N; ++j) { sc[j] = ga[j] * is[j]; sh[j] = be[j] - mu[j] * sc[j]; }
-            for (int64_t u = u0; u < units; u += stride_) {
-                const int64_t pix = u / cpv;
-                float g[N], yy[N], o[N], aa[N];
-                Unit<T, VEC>::ld((const T*)da.p + pix * da.cs + c0, g);
-                if (fin.da_bias) {
-                    const float* bb = fin.da_bias + (size_t)bnb_image_of(fin, pix) * C + c0;
-#pragma unroll
-                    for (int j = 0; j < N; ++j) g[j] += bb[j];
-                }
-                Unit<T, VEC>::ld((const T*)y.p + pix * y.cs + c0, yy);
-#pragma unroll
-                for (int j = 0; j < N; ++j) aa[j] = 1.f;
-                if (relu && !from_y) Unit<T, VEC>::ld((const T*)a.p + pix * a.cs + c0, aa);
+            {
+                float is[N], k0[N], k1[N], k2[N], ga[N], be[N];
 #pragma unroll
                 for (int j = 0; j < N; ++j) {
-                    const float pre = from_y ? yy[j] * sc[j] + sh[j] : aa[j];
-                    const float gg = (!relu || pre > 0.f) ? g[j] : 0.f;
-                    g[j] = gg;
-                    const float xh = (yy[j] - mu[j]) * is[j];
-                    o[j] = k0[j] * (gg - k1[j] - xh * k2[j]);
+                    mu[j] = mean[c0 + j]; is[j] = invstd[c0 + j];
+                    k0[j] = coef[c0 + j]; k1[j] = coef[C + c0 + j]; k2[j] = coef[2 * C + c0 + j];
+                    ga[j] = gptr[c0 + j]; be[j] = bptr[c0 + j];
                 }
-                Unit<T, VEC>::st((T*)dy.p + pix * dy.cs + c0, o);
-                if (dres.p) {
-                    if (acc_dres) {
-                        float old[N];
-                        Unit<T, VEC>::ld((const T*)dres.p + pix * dres.cs + c0, old);
 #pragma unroll
-                        for (int j = 0; j < N; ++j) g[j] += old[j];
+                for (int j = 0; j < N; ++j) {
+                    sc[j] = ga[j] * is[j]; sh[j] = be[j] - mu[j] * sc[j];
+                    A[j] = k0[j]; D[j] = -(k0[j] * k2[j]) * is[j]; E[j] = -(k0[j] * k1[j]);
+                }
+            }
+            // UB units per thread in flight: all loads of an iteration are issued before the first is used (one unit per iteration was a
+            // chain of units / threads dependent round trips: 2.8 TB/s on a 67 MB tensor)
+            constexpr int UB = SALT_BNB_UNITS;
+            for (int64_t u = u0; u < units; u += UB * stride_) {
+                int64_t pix[UB];
+                float g[UB][N], yy[UB][N], aa[UB][N], old[UB][N];
+#pragma unroll
+                for (int i = 0; i < UB; ++i) {
+                    const int64_t ui = u + i * stride_;
+                    pix[i] = (ui < units ? ui : u) / cpv;                  // past the end: unit 0 again, never stored
+                    Unit<T, VEC>::ld((const T*)da.p + pix[i] * da.cs + c0, g[i]);
+                    Unit<T, VEC>::ld((const T*)y.p + pix[i] * y.cs + c0, yy[i]);
+                    if (relu && !from_y) Unit<T, VEC>::ld((const T*)a.p + pix[i] * a.cs + c0, aa[i]);
+                    if (dres.p && acc_dres) Unit<T, VEC>::ld((const T*)dres.p + pix[i] * dres.cs + c0, old[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < UB; ++i) {
+                    float o[N];
+                    if (fin.da_bias) {
+                        const float* bb = fin.da_bias + (size_t)bnb_image_of(fin, pix[i]) * C + c0;
+#pragma unroll
+                        for (int j = 0; j < N; ++j) g[i][j] += bb[j];
                     }
-                    Unit<T, VEC>::st((T*)dres.p + pix * dres.cs + c0, g);
+#pragma unroll
+                    for (int j = 0; j < N; ++j) {
+                        const float pre = from_y ? yy[i][j] * sc[j] + sh[j] : ((relu && !from_y) ? aa[i][j] : 1.f);
+                        const float gg = (!relu || pre > 0.f) ? g[i][j] : 0.f;
+                        g[i][j] = gg;
+                        o[j] = A[j] * gg + (D[j] * (yy[i][j] - mu[j]) + E[j]);
+                    }
+                    if (i == 0 || u + i * stride_ < units) {
+                        Unit<T, VEC>::st((T*)dy.p + pix[i] * dy.cs + c0, o);
+                        if (dres.p) {
+                            if (acc_dres) {
+#pragma unroll
+                                for (int j = 0; j < N; ++j) g[i][j] += old[i][j];
+                            }
+                            Unit<T, VEC>::st((T*)dres.p + pix[i] * dres.cs + c0, g[i]);
+                        }
+                    }
                 }
             }
             return;
@@ -658,27 +683,57 @@ __device__ __forceinline__ void bil_src(int d, int R, int n, int ac, int& i0, in
     lam = s - (float)i0;
 }
 
-template <typename T, bool VEC>
-__global__ void bilinear_fwd_kernel(salt_view x, salt_view y, int R, int ac) {
+// U output units per thread in flight: the 4 U gathers of an iteration are issued before any of them is used.  (One unit per
+// iteration was a chain of ~16 dependent memory round trips per thread: 33 us for a 67 MB level, whatever the write pitch - round 3.)
+// the interpolation itself, with the contractions pinned (bilinear_fwd_kernel and hyper_rows_kernel must agree bit for bit)
+__device__ __forceinline__ float bil_mix(float ly, float lx, float a, float b, float c, float d) {
+    const float top = __fmaf_rn(lx, b, __fmul_rn(1.f - lx, a));
+    const float bot = __fmaf_rn(lx, d, __fmul_rn(1.f - lx, c));
+    return __fmaf_rn(ly, bot, __fmul_rn(1.f - ly, top));
+}
+
+template <typename T, bool VEC, int U = 4>
+__global__ __launch_bounds__(256) void bilinear_fwd_kernel(salt_view x, salt_view y, int R, int ac) {
     constexpr int N = Unit<T, VEC>::N;
-    const int cpv = x.C / N;
+    const unsigned cpv = x.C / N;
     const int64_t units = (int64_t)y.B * y.H * y.W * cpv;
-    for (int64_t u = blockIdx.x * 256LL + threadIdx.x; u < units; u += gridDim.x * 256LL) {
-        int64_t pix = u / cpv; const int c0 = (int)(u - pix * cpv) * N;
-        const int ox = (int)(pix % y.W); int64_t r = pix / y.W; const int oy = (int)(r % y.H); const int b = (int)(r / y.H);
-        int y0, y1, x0, x1; float ly, lx;
-        bil_src(oy, R, x.H, ac, y0, y1, ly);
-        bil_src(ox, R, x.W, ac, x0, x1, lx);
-        const T* base = (const T*)x.p + (int64_t)b * x.H * x.W * x.cs + c0;
-        float a[N], bq[N], c[N], d[N], o[N];
-        Unit<T, VEC>::ld(base + ((int64_t)y0 * x.W + x0) * x.cs, a);
-        Unit<T, VEC>::ld(base + ((int64_t)y0 * x.W + x1) * x.cs, bq);
-        Unit<T, VEC>::ld(base + ((int64_t)y1 * x.W + x0) * x.cs, c);
-        Unit<T, VEC>::ld(base + ((int64_t)y1 * x.W + x1) * x.cs, d);
+    const int64_t stride = gridDim.x * 256LL;
+    for (int64_t u0 = blockIdx.x * 256LL + threadIdx.x; u0 < units; u0 += U * stride) {
+        float a[U][N], bq[U][N], c[U][N], d[U][N], ly[U], lx[U];
+        int64_t dsto[U];
 #pragma unroll
-        for (int j = 0; j < N; ++j)
-            o[j] = (1.f - ly) * ((1.f - lx) * a[j] + lx * bq[j]) + ly * ((1.f - lx) * c[j] + lx * d[j]);
-        Unit<T, VEC>::st((T*)y.p + pix * y.cs + c0, o);
+        for (int i = 0; i < U; ++i) {
+            const int64_t ui = u0 + i * stride;
+            const int64_t uu = ui < units ? ui : u0;                   // past the end: recompute unit 0 of the thread, never stored
+            int64_t pix; unsigned c0;
+            int ox, oy, b;
+            if (units < (1LL << 31)) {                                   // (wave-uniform) 32-bit index arithmetic
+                const unsigned q = (unsigned)uu / cpv; c0 = ((unsigned)uu - q * cpv) * N;
+                const unsigned r = q / (unsigned)y.W; ox = (int)(q - r * (unsigned)y.W);
+                b = (int)(r / (unsigned)y.H); oy = (int)(r - (unsigned)b * (unsigned)y.H);
+                pix = q;
+            } else {
+                pix = uu / cpv; c0 = (unsigned)(uu - pix * cpv) * N;
+                ox = (int)(pix % y.W); const int64_t r = pix / y.W; oy = (int)(r % y.H); b = (int)(r / y.H);
+            }
+            int y0, y1, x0, x1;
+            bil_src(oy, R, x.H, ac, y0, y1, ly[i]);
+            bil_src(ox, R, x.W, ac, x0, x1, lx[i]);
+            const T* base = (const T*)x.p + (int64_t)b * x.H * x.W * x.cs + c0;
+            Unit<T, VEC>::ld(base + ((int64_t)y0 * x.W + x0) * x.cs, a[i]);
+            Unit<T, VEC>::ld(base + ((int64_t)y0 * x.W + x1) * x.cs, bq[i]);
+            Unit<T, VEC>::ld(base + ((int64_t)y1 * x.W + x0) * x.cs, c[i]);
+            Unit<T, VEC>::ld(base + ((int64_t)y1 * x.W + x1) * x.cs, d[i]);
+            dsto[i] = pix * y.cs + c0;
+        }
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            float o[N];
+#pragma unroll
+            for (int j = 0; j < N; ++j)
+                o[j] = bil_mix(ly[i], lx[i], a[i][j], bq[i][j], c[i][j], d[i][j]);
+            if (i == 0 || u0 + i * stride < units) Unit<T, VEC>::st((T*)y.p + dsto[i], o);
+        }
     }
 }
 
@@ -706,7 +761,7 @@ __global__ void hyper_rows_kernel(HyperKP p) {
         Unit<T, VEC>::ld(base + ((int64_t)y1 * x.W + x1) * x.cs, d);
 #pragma unroll
         for (int j = 0; j < N; ++j)
-            o[j] = (1.f - ly) * ((1.f - lx) * a[j] + lx * bq[j]) + ly * ((1.f - lx) * c[j] + lx * d[j]);
+            o[j] = bil_mix(ly, lx, a[j], bq[j], c[j], d[j]);
         Unit<T, VEC>::st((T*)p.y.p + pix * p.y.cs + lev * x.C + c0, o);
     }
 }
@@ -736,26 +791,55 @@ __global__ void bilinear_bwd_kernel(salt_view x, salt_view y, int R, int accumul
 #pragma unroll
         for (int j = 0; j < N; ++j) o[j] = 0.f;
         const T* base = (const T*)y.p + (int64_t)b * y.H * y.W * y.cs + c0;
-        for (int oy = oy_lo; oy <= oy_hi; ++oy) {
-            float wy = 1.f;
-            if (MODE != 1) {
-                int y0, y1; float ly;
-                bil_src(oy, R, x.H, ac, y0, y1, ly);
-                wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+        // one-dimensional weight of output o on input i (0 when o does not reference i)
+        auto wgt = [&](int o_, int n, int i_) -> float {
+            int i0, i1; float l;
+            bil_src(o_, R, n, ac, i0, i1, l);
+            return (i0 == i_ ? 1.f - l : 0.f) + (i1 == i_ ? l : 0.f);
+        };
+        // The gathers are issued in batches of G before any is used (same summation order and the same skipped zero-weight terms as the
+        // one-at-a-time loop this replaces, which was a chain of up to (2R)^2 dependent memory round trips per thread).
+        constexpr int G = 4;
+        if (MODE == 0) {
+            for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+                const float wy = wgt(oy, x.H, iy);
                 if (wy == 0.f) continue;
-            }
-            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-                float w = wy;
-                if (MODE != 2) {
-                    int x0, x1; float lx;
-                    bil_src(ox, R, x.W, ac, x0, x1, lx);
-                    w = wy * ((x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f));
-                    if (w == 0.f) continue;
-                }
-                float g[N];
-                Unit<T, VEC>::ld(base + ((int64_t)oy * y.W + ox) * y.cs, g);
+                for (int ox = ox_lo; ox <= ox_hi; ox += G) {
+                    float g[G][N], w[G];
 #pragma unroll
-                for (int j = 0; j < N; ++j) o[j] += w * g[j];
+                    for (int k = 0; k < G; ++k) {
+                        const int oxk = min(ox + k, ox_hi);
+                        w[k] = ox + k <= ox_hi ? wy * wgt(oxk, x.W, ix) : 0.f;
+                        Unit<T, VEC>::ld(base + ((int64_t)oy * y.W + oxk) * y.cs, g[k]);
+                    }
+#pragma unroll
+                    for (int k = 0; k < G; ++k)
+                        if (w[k] != 0.f) {
+#pragma unroll
+                            for (int j = 0; j < N; ++j) o[j] += w[k] * g[k][j];
+                        }
+                }
+            }
+        } else {
+            // separable passes: one line of outputs along x (MODE 1) or y (MODE 2)
+            const int lo = MODE == 1 ? ox_lo : oy_lo, hi = MODE == 1 ? ox_hi : oy_hi;
+            const int n = MODE == 1 ? x.W : x.H, ii = MODE == 1 ? ix : iy;
+            const int64_t line = MODE == 1 ? (int64_t)iy * y.W * y.cs : (int64_t)ix * y.cs;     // MODE 1: oy == iy;  MODE 2: ox == ix
+            const int64_t step = MODE == 1 ? (int64_t)y.cs : (int64_t)y.W * y.cs;
+            for (int q = lo; q <= hi; q += G) {
+                float g[G][N], w[G];
+#pragma unroll
+                for (int k = 0; k < G; ++k) {
+                    const int qk = min(q + k, hi);
+                    w[k] = q + k <= hi ? wgt(qk, n, ii) : 0.f;
+                    Unit<T, VEC>::ld(base + line + qk * step, g[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < G; ++k)
+                    if (w[k] != 0.f) {
+#pragma unroll
+                        for (int j = 0; j < N; ++j) o[j] += w[k] * g[k][j];
+                    }
             }
         }
         T* dst = (T*)x.p + pix * x.cs + c0;
@@ -886,10 +970,10 @@ extern "C" int salt_affine_act(const salt_affine_act_args* a, void* stream) {
             const BnFin fin{const_cast<double*>(a->fin_acc), nullptr, f->gamma, f->beta, f->running_mean, f->running_var, f->num_batches_tracked,
                             f->momentum, f->eps, f->mean, f->invstd, f->scale, f->shift};
             const size_t lds = (size_t)a->y.C * 2 * sizeof(float);
-            if (v) hipLaunchKernelGGL((affine_act_kernel<T, true, 2, true>), dim3(ew_blocks(units)), dim3(256), lds, (hipStream_t)stream, a->y, nullptr, nullptr, a->res, a->relu, a->a, fin);
-            else hipLaunchKernelGGL((affine_act_kernel<T, false, 2, true>), dim3(ew_blocks(units)), dim3(256), lds, (hipStream_t)stream, a->y, nullptr, nullptr, a->res, a->relu, a->a, fin);
+            if (v) hipLaunchKernelGGL((affine_act_kernel<T, true, SALT_AFF_UNITS, true>), dim3(ew_blocks(units)), dim3(256), lds, (hipStream_t)stream, a->y, nullptr, nullptr, a->res, a->relu, a->a, fin);
+            else hipLaunchKernelGGL((affine_act_kernel<T, false, SALT_AFF_UNITS, true>), dim3(ew_blocks(units)), dim3(256), lds, (hipStream_t)stream, a->y, nullptr, nullptr, a->res, a->relu, a->a, fin);
         } else {
-            EW_LAUNCH_U(affine_act_kernel, T, v, 2, units, (hipStream_t)stream, a->y, a->scale, a->shift, a->res, a->relu, a->a, BnFin{});
+            EW_LAUNCH_U(affine_act_kernel, T, v, SALT_AFF_UNITS, units, (hipStream_t)stream, a->y, a->scale, a->shift, a->res, a->relu, a->a, BnFin{});
         }
     })
     SALT_CHECK_LAUNCH();

@@ -284,6 +284,7 @@ extern "C" int salt_abi_struct_sizes(int* out, int n) {
     (int)sizeof(salt_maxpool2_bwd_args),
     (int)sizeof(salt_avgpool2_args),
     (int)sizeof(salt_bilinear_args),
+    (int)sizeof(salt_hyper_rows_args),
     (int)sizeof(salt_pad_fold_args),
     (int)sizeof(salt_pad_fold_strip_args),
     (int)sizeof(salt_add_args),

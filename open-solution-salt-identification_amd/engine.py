@@ -171,21 +171,32 @@ def _stream_ptr(stream):
 
 
 class Buffer:
-    """NHWC storage [B,H,W,Ct] (+ lazily allocated gradient storage of the same geometry)."""
+    """NHWC storage [B,H,W,Ct] (+ lazily allocated gradient storage of the same geometry).  ``planes`` > 0: PLANAR storage
+    [C / planes][B,H,W,planes] for both - every channel slice of `planes` channels is a dense tensor of its own, and a launch that takes
+    the whole buffer names the plane stride (salt_conv_args.x_plane / y_plane, salt_conv_wgrad_args.q_plane)."""
 
-    def __init__(self, graph, B, H, W, C, name=''):
+    def __init__(self, graph, B, H, W, C, name='', planes=0):
         self.g, self.B, self.H, self.W, self.C = graph, B, H, W, C
         self.Ct = _round_up(C, graph.ve)
         self.name = name
-        self.t = graph.alloc((B, H, W, self.Ct), graph.tdtype)
+        self.planes = planes
+        if planes and (C % planes or planes % graph.ve):
+            raise SaltError('planar buffer %s: %d channels in planes of %d' % (name, C, planes))
+        self.t = graph.alloc(self._shape(), graph.tdtype)
         self.grad_t = None
         self.grad_init = np.zeros(self.Ct, dtype=bool)
         self.grad_writers = []         # one entry per gradient writer in backward-program order: [c0, C, conv-args struct | None]
         self.reads = 0                 # views handed out (SALT_EXP_BN_FOLD: an activation nobody else reads need not be materialised)
 
+    def _shape(self):
+        return (self.C // self.planes, self.B, self.H, self.W, self.planes) if self.planes else (self.B, self.H, self.W, self.Ct)
+
+    def plane_elems(self):
+        return self.B * self.H * self.W * self.planes
+
     def grad(self):
         if self.grad_t is None:
-            self.grad_t = self.g.alloc((self.B, self.H, self.W, self.Ct), self.g.tdtype)
+            self.grad_t = self.g.alloc(self._shape(), self.g.tdtype)
         return self.grad_t
 
 
@@ -205,9 +216,22 @@ class Act:
 
     def _view(self, t):
         v = STRUCTS['salt_view']()
+        pc = self.buf.planes
+        if pc:
+            # one dense plane, or the whole buffer (cs < C: only a launch that also names the plane stride may take it)
+            whole = self.c0 == 0 and self.C == self.buf.C
+            if self.c0 % pc or not (self.C == pc or whole):
+                raise SaltError('planar buffer %s: slice [%d, %d) is not one plane of %d channels' % (self.buf.name, self.c0, self.c0 + self.C, pc))
+            v.p = t.data_ptr() + (self.c0 // pc) * self.buf.plane_elems() * t.element_size()
+            v.B, v.H, v.W, v.C, v.cs = self.buf.B, self.buf.H, self.buf.W, self.C, pc
+            return v
         v.p = t.data_ptr() + self.c0 * t.element_size()
         v.B, v.H, v.W, v.C, v.cs = self.buf.B, self.buf.H, self.buf.W, self.C, self.buf.Ct
         return v
+
+    def plane_stride(self):
+        """plane stride (elements) a launch over the WHOLE planar buffer passes as x_plane / y_plane / q_plane; 0 for ordinary buffers"""
+        return self.buf.plane_elems() if (self.buf.planes and self.C != self.buf.planes) else 0
 
     def view(self):
         self.buf.reads += 1
@@ -230,12 +254,17 @@ class Act:
     def grad_ready(self):
         return bool(self.buf.grad_init[self.c0:self.c0 + self.C].all())
 
+    def _nhwc(self, t):
+        if self.buf.planes:
+            t = t.permute(1, 2, 3, 0, 4).reshape(self.buf.B, self.buf.H, self.buf.W, self.buf.C)
+        return t[..., self.c0:self.c0 + self.C]
+
     def tensor(self):
-        """NHWC torch view [B,H,W,C] of the activation (tests / debugging)."""
-        return self.buf.t[..., self.c0:self.c0 + self.C]
+        """NHWC torch view [B,H,W,C] of the activation (tests / debugging; a copy for planar buffers)."""
+        return self._nhwc(self.buf.t)
 
     def grad_tensor(self):
-        return self.buf.grad()[..., self.c0:self.c0 + self.C]
+        return self._nhwc(self.buf.grad())
 
 
 def null_view():
@@ -288,8 +317,8 @@ class Graph:
         self.bytes += t.numel() * t.element_size()
         return t
 
-    def new_act(self, B, H, W, C, name=''):
-        return Act(Buffer(self, B, H, W, C, name))
+    def new_act(self, B, H, W, C, name='', planes=0):
+        return Act(Buffer(self, B, H, W, C, name, planes))
 
     # ------------------------------------------------------------------ forward branches on the side stream
     def side(self):
@@ -377,6 +406,35 @@ class Graph:
                 if st == 1:
                     raise SaltError('backward program starts with a side-stream operator')
 
+    def planar_ok(self, B, H, W, C, pc, conv):
+        """Can a [B,H,W,C] buffer that feeds ONE replicate-padded 3x3 convolution (the hypercolumn -> final Conv2dBnRelu,
+        architectures/unet.py:101-109) be stored as C / pc dense planes?  Yes iff the library runs the forward launch on conv_ls_kernel
+        (x_plane) and, in train mode, the data gradient on conv_ws_kernel (y_plane) and accepts q_plane for the weight gradient."""
+        if self.dtype != 'bf16' or os.environ.get('SALT_NO_PLANAR') or C % pc or pc % self.ve:
+            return False
+        if self.train and self._fin_mode() != 2:
+            return False                               # the per-tile partials protocols run on conv_mfma_kernel only
+        Cout, _, KH, KW = conv.weight.shape
+        if (KH, KW) != (3, 3):
+            return False
+        d = 1 << 20                                     # stand-in pointer (the probes only plan, nothing is launched)
+        td = [(kh - (KH - 1), kw) for kh in range(KH) for kw in range(KW)]
+        xv, yv, plane = shaped_view(d, B, H, W, C, pc), shaped_view(d, B, H, W, Cout), B * H * W * pc
+        S = fill(STRUCTS['salt_conv_args'](), dtype=self.dt, x=xv, w=d, ntaps=9, tap_dy=[t[0] for t in td], tap_dx=[t[1] for t in td], in_step=1,
+                 pad_mode=1, y=yv, OH=H, OW=W, out_step=1, x_plane=plane)
+        if lib.salt_conv_kernel_id(ctypes.byref(S)) != 10:
+            return False
+        if not self.train:
+            return True
+        tg = [(-t[0] - (KH - 1), -t[1]) for t in td]
+        S = fill(STRUCTS['salt_conv_args'](), dtype=self.dt, x=yv, w=d, ntaps=9, tap_dy=[t[0] for t in tg], tap_dx=[t[1] for t in tg], in_step=1,
+                 pad_mode=0, y=xv, OH=H + KH - 1, OW=W + KW - 1, out_step=1, fold_top=KH - 1, fold_right=KW - 1, y_plane=plane)
+        if lib.salt_conv_kernel_id(ctypes.byref(S)) != 9:
+            return False
+        Wg = fill(STRUCTS['salt_conv_wgrad_args'](), dtype=self.dt, p=yv, q=xv, ntaps=9, tap_dy=[t[0] for t in td], tap_dx=[t[1] for t in td],
+                  q_step=1, pad_mode=1, q_plane=plane)
+        return lib.salt_conv_wgrad_nsplit(ctypes.byref(Wg)) >= 1
+
     def _resolve_lazies(self):
         """SALT_EXP_BN_FOLD: drop the affine_act of every conv -> BN -> ReLU output whose only forward reader is ONE convolution that
         applies the transform in its loader; every other candidate goes back to reading the materialised activation."""
@@ -410,12 +468,24 @@ class Graph:
                   stats_part0=part0, cfg=cfg)
         stream = fold.pop('stream', None)
         kw.update(fold)
+        kw.update(self._plane_args(x_view, y_view))
         return prog.add('conv', stream=stream, **kw)
+
+    @staticmethod
+    def _plane_args(x_view, y_view):
+        """A view over a whole PLANAR buffer has cs < C (Act._view): the launch must name the plane stride (salt_conv_args.x_plane /
+        y_plane; the library fails if its kernel for these arguments cannot address planes)."""
+        kw = {}
+        if not isinstance(y_view, tuple) and 0 < y_view.cs < y_view.C:
+            kw['y_plane'] = y_view.B * y_view.H * y_view.W * y_view.cs
+        if not isinstance(x_view, tuple) and 0 < x_view.cs < x_view.C:
+            kw['x_plane'] = x_view.B * x_view.H * x_view.W * x_view.cs
+        return kw
 
     def _conv_parts(self, x_view, taps_dydx, in_step, y_view, OH, OW, cfg=0):
         S = STRUCTS['salt_conv_args']()
         fill(S, dtype=self.dt, x=x_view, w=1, ntaps=len(taps_dydx), tap_dy=[t[0] for t in taps_dydx], tap_dx=[t[1] for t in taps_dydx],
-             in_step=in_step, pad_mode=0, y=y_view, OH=OH, OW=OW, out_step=1, cfg=cfg)
+             in_step=in_step, pad_mode=0, y=y_view, OH=OH, OW=OW, out_step=1, cfg=cfg, **self._plane_args(x_view, y_view))
         n = lib.salt_conv_stats_parts(ctypes.byref(S))
         if n < 0:
             raise SaltError('conv plan failed: ' + lib.salt_last_error().decode())
@@ -647,14 +717,15 @@ class Graph:
         for i in range(0, len(taps_dydx), 9 if len(taps_dydx) != 16 else 4):
             chunk = list(range(i, min(i + (9 if len(taps_dydx) != 16 else 4), len(taps_dydx))))
             S = STRUCTS['salt_conv_wgrad_args']()
+            qp = q_view.B * q_view.H * q_view.W * q_view.cs if 0 < q_view.cs < q_view.C else 0       # planar Q (Act._view of a whole planar buffer)
             fill(S, dtype=self.dt, p=p_view, q=q_view, ntaps=len(chunk), tap_dy=[taps_dydx[j][0] for j in chunk],
-                 tap_dx=[taps_dydx[j][1] for j in chunk], q_step=q_step, pad_mode=pad_mode)
+                 tap_dx=[taps_dydx[j][1] for j in chunk], q_step=q_step, pad_mode=pad_mode, q_plane=qp)
             ns = lib.salt_conv_wgrad_nsplit(ctypes.byref(S))
             if ns < 0:
                 raise SaltError('wgrad plan failed: ' + lib.salt_last_error().decode())
             nbytes = ns * len(chunk) * Ca * Cb * 4
             self.bwd.add('conv_wgrad', stream=1, dtype=self.dt, p=p_view, q=q_view, ntaps=len(chunk), tap_dy=[taps_dydx[j][0] for j in chunk],
-                         tap_dx=[taps_dydx[j][1] for j in chunk], q_step=q_step, pad_mode=pad_mode, partials=Scratch('wgrad', nbytes), nsplit=ns)
+                         tap_dx=[taps_dydx[j][1] for j in chunk], q_step=q_step, pad_mode=pad_mode, partials=Scratch('wgrad', nbytes), nsplit=ns, q_plane=qp)
             self.bwd.add('wgrad_reduce', stream=1, partials=Scratch('wgrad', nbytes), nsplit=ns, ntaps=len(chunk), Ca=Ca, Cb=Cb, KH=KH, KW=KW,
                          tap_kh=[taps_khkw[j][0] for j in chunk], tap_kw=[taps_khkw[j][1] for j in chunk], grad=gw, accumulate=0)
             first = False
@@ -688,7 +759,8 @@ class Graph:
                 # gradient) the launch can carry the BatchNorm-backward sums of x's producer
                 s = self._conv_launch(self.bwd, dy.gview(), pk.data_ptr(), td, 1, 0, x.gview(), Hp, Wp, accumulate=acc,
                                       fold_top=top, fold_right=right, stream=self._bwd_pack_tag())
-                x.buf.grad_writers[-1][2] = s
+                if not x.plane_stride():               # (a planar dL/dx has one dense consumer per plane: nothing to ride along)
+                    x.buf.grad_writers[-1][2] = s
                 return
             # strip fold: interior pixels go straight into x.grad, only the pad ring takes the detour through scratch
             scs = _round_up(x.C, self.ve)
@@ -702,7 +774,8 @@ class Graph:
         if stride == 1:
             td = [(-t[2], -t[3]) for t in taps]
             s = self._conv_launch(self.bwd, dy.gview(), pk.data_ptr(), td, 1, 0, x.gview(), x.H, x.W, accumulate=acc, stream=self._bwd_pack_tag())
-            x.buf.grad_writers[-1][2] = s          # a plain full-grid launch: can carry the BatchNorm-backward sums of x's producer
+            if not x.plane_stride():
+                x.buf.grad_writers[-1][2] = s      # a plain full-grid launch: can carry the BatchNorm-backward sums of x's producer
             return
         # stride 2: the data gradient is a transposed convolution - four output-parity phases
         phases = []
@@ -1034,6 +1107,22 @@ class Graph:
                 acc = x.grad_state()
                 tmp = Scratch('bilinear', x.B * out.H * x.W * _round_up(x.C, self.ve) * self._es()) if R >= 4 else None
                 self.bwd.add('bilinear', dtype=self.dt, x=x.gview(), y=out.gview(), R=R, backward=1, accumulate=acc, tmp=tmp, align_corners=ac)
+            self.tape.append(backward)
+        return out
+
+    def hyper_rows(self, xs, Rs, out):
+        """All up-sampled hypercolumn levels in ONE pass: out (a slice of len(xs) * C channels) <- [up(x_k, R_k)] (salt_hyper_rows); the
+        adjoints stay one salt_bilinear launch per level."""
+        ac = int(bool(getattr(getattr(self.engine, 'module', None), 'align_corners', False)))
+        assert out.C == len(xs) * xs[0].C and all(x.C == xs[0].C for x in xs)
+        self.fwd.add('hyper_rows', dtype=self.dt, nlev=len(xs), x=[x.view() for x in xs], R=list(Rs), y=out.view(), align_corners=ac)
+        if self.train:
+            def backward():
+                for k in reversed(range(len(xs))):
+                    x, R, o = xs[k], Rs[k], out.slice(k * xs[0].C, xs[0].C)
+                    acc = x.grad_state()
+                    tmp = Scratch('bilinear', x.B * o.H * x.W * _round_up(x.C, self.ve) * self._es()) if R >= 4 else None
+                    self.bwd.add('bilinear', dtype=self.dt, x=x.gview(), y=o.gview(), R=R, backward=1, accumulate=acc, tmp=tmp, align_corners=ac)
             self.tape.append(backward)
         return out
 

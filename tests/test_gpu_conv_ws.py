@@ -258,3 +258,40 @@ def test_bn_apply_in_consumer_loader_forward_is_bit_identical(shape, monkeypatch
         outs[fold] = (y.clone(), b1.running_mean.clone(), b1.running_var.clone(), b2.running_mean.clone(), b2.running_var.clone())
     for a, b in zip(outs[''], outs['1']):
         assert torch.equal(a.cpu(), b.cpu())
+
+
+@pytest.mark.parametrize('replicate', [True, False])
+def test_planar_operand_buffers_are_bit_identical_to_interleaved(replicate):
+    """salt_conv_args.x_plane (conv_ls_kernel reads its 32-channel chunks from dense 64-channel planes), y_plane (conv_ws_kernel writes
+    channel block b of the data gradient to plane b) and salt_conv_wgrad_args.q_plane (weight-gradient b-block bb reads plane bb) - the
+    planar hypercolumn's three launches (architectures/unet.py:101-109) - on a 128 -> 64 3x3 convolution whose input lives in two planes,
+    against the same program on an interleaved input: output, input gradient and weight gradient bit for bit (no BatchNorm: no atomics)."""
+    from gpu_harness import BlockRun
+    B, Cin, H, W, Cout = 2, 128, 128, 128, 64
+    conv = nn.Conv2d(Cin, Cout, 3, 1, 0 if replicate else 1, bias=False)
+    with torch.no_grad():
+        conv.weight.copy_(_rand(conv.weight.shape, 1, (2.0 / (Cin * 9)) ** 0.5))
+    x = _rand((B, Cin, H, W), 4).bfloat16().float()
+    gy = _rand((B, Cout, H, W), 9)
+    res = {}
+    for planar in (False, True):
+        def emit(g, a):
+            if planar:
+                xp = g.new_act(a.B, a.H, a.W, a.C, 'xp', planes=64)
+                for k in range(a.C // 64):
+                    g.copy(a.slice(64 * k, 64), xp.slice(64 * k, 64))
+                a = xp
+            return g.conv(a, conv, None, relu=False, replicate=replicate)
+        run = BlockRun(conv, [x], emit, train=True, dtype='bf16')
+        f = [s for n, _, s in run.g.fwd.ops if n == 'conv']
+        b = [s for n, _, s in run.g.bwd.ops if n == 'conv']
+        w = [s for n, _, s in run.g.bwd.ops if n == 'conv_wgrad']
+        assert _kernel_ids(run.g.fwd) == [10] and _kernel_ids(run.g.bwd) == [9]
+        assert (bool(f[0].x_plane), bool(b[0].y_plane), bool(w[0].q_plane)) == (planar, planar, planar)
+        y = run.forward()
+        gx, gw = run.backward(gy.to('cuda:0'))
+        res[planar] = (y, gx[0], gw['weight'])
+    yr = F.conv2d(F.pad(x, (0, 2, 2, 0), mode='replicate') if replicate else x, conv.weight.detach().cpu().bfloat16().float(), padding=0 if replicate else 1)
+    assert_close(res[True][0], yr, TOLBF, 'y vs torch')
+    for a, b_, what in zip(res[True], res[False], ('y', 'dx', 'dw')):
+        assert torch.equal(a, b_), what

@@ -340,3 +340,41 @@ def test_two_rank_rccl_fit_loop_equals_single_rank(tmp_path):
     assert outs['one']['losses'] == outs['two']['losses']
     assert torch.equal(outs['two']['grads'], outs['one']['grads'] * 2)
     assert torch.equal(outs['one']['flat'], outs['two']['flat'])
+
+
+def test_planar_hypercolumn_equals_interleaved(monkeypatch):
+    """The hypercolumn (architectures/unet.py:101-107) as five dense 64-channel planes - the final convolution reads them by plane
+    (salt_conv_args.x_plane, conv_ls_kernel), its data gradient writes them (y_plane, conv_ws_kernel), its weight gradient reads them
+    (salt_conv_wgrad_args.q_plane), the up-samplings / their adjoints / dec1's scSE each stream one dense plane - against the
+    channel-interleaved 320-channel buffer (SALT_NO_PLANAR=1).  Same arithmetic, other addresses: eval logits bit for bit; two train
+    steps to the reproducibility of the fp64 statistics shards (last bits of the BatchNorm sums, conftest.deterministic_sums)."""
+    results = {}
+    for mode in ('planar', 'interleaved'):
+        if mode == 'interleaved':
+            monkeypatch.setenv('SALT_NO_PLANAR', '1')
+        torch.manual_seed(11)
+        m = _segmentation_model('UNetResNet', 'lovasz', dtype='bf16', lr=1e-3)
+        m._to_device()
+        g = torch.Generator().manual_seed(5)
+        X = torch.randn(4, 3, 128, 128, generator=g)
+        M = (torch.rand(4, 1, 128, 128, generator=g) > 0.6).float()
+        Tt = torch.cat([1 - M, M], 1)
+        m.model.eval()
+        with torch.no_grad():
+            y_eval = m.model(X.to(DEV)).float().cpu()
+        eng = m.model.engine()
+        n_eval = sum(1 for name, _, s in eng.net((4, 3, 128, 128), False).fwd.ops if name == 'conv' and s.x_plane)
+        m.model.train()
+        ls = [float(m._fit_loop([X, Tt])['sum']) for _ in range(2)]
+        torch.cuda.synchronize()
+        net = eng.net((4, 3, 128, 128), True)
+        n = (sum(1 for name, _, s in net.fwd.ops if name == 'conv' and s.x_plane), sum(1 for name, _, s in net.bwd.ops if name == 'conv' and s.y_plane),
+             sum(1 for name, _, s in net.bwd.ops if name == 'conv_wgrad' and s.q_plane), n_eval)
+        assert n == ((1, 1, 1, 1) if mode == 'planar' else (0, 0, 0, 0)), n
+        results[mode] = (ls, eng.flat.clone(), eng.grads.clone(), y_eval)
+    a, b = results['planar'], results['interleaved']
+    assert torch.equal(a[3], b[3])
+    assert max(abs(x - y) for x, y in zip(a[0], b[0])) <= 1e-5 * max(1.0, abs(b[0][0])), (a[0], b[0])
+    gn = float(b[2].norm())
+    assert float((a[2] - b[2]).norm()) <= 2e-3 * gn, (float((a[2] - b[2]).norm()), gn)
+    assert float((a[1] - b[1]).norm()) <= 1e-4 * float(b[1].norm())

@@ -318,3 +318,54 @@ def test_hipgraph_capture_replays_the_eval_program():
     cn.fwd.release_graph()
     with pytest.raises(Exception):
         cn.fwd.replay(st)
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('ac', [False, True])
+def test_hyper_rows_equals_per_level_bilinear(dtype, ac):
+    """salt_hyper_rows (all hypercolumn levels of a pixel row in one pass, architectures/unet.py:101-107) against one salt_bilinear launch
+    per level into channel slices: bit-identical, both align_corners conventions."""
+    from torch import nn
+    from salt_amd.engine import Graph
+    from salt_amd.runtime import Engine
+    mod = nn.Linear(1, 1).to(DEV)
+    mod.align_corners = ac
+    eng = Engine(mod, torch.device(DEV), dtype)
+    g = Graph(eng, False)
+    B, H, W, C, Rs = 2, 32, 48, 16, [2, 4, 8, 16]
+    xs = [g.new_act(B, H // R, W // R, C, 'x%d' % R) for R in Rs]
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    for x in xs:
+        x.buf.t.copy_(torch.randn(x.buf.t.shape, generator=gen, device=DEV))
+    a, b = g.new_act(B, H, W, 5 * C, 'a'), g.new_act(B, H, W, 5 * C, 'b')
+    for k, (x, R) in enumerate(zip(xs, Rs)):
+        g.upsample(x, R, out=a.slice((k + 1) * C, C))
+    g.hyper_rows(xs, Rs, b.slice(C, 4 * C))
+    assert [n for n, _, _ in g.fwd.ops] == ['bilinear'] * 4 + ['hyper_rows']
+    g.finalize()
+    g.fwd.run()
+    torch.cuda.synchronize()
+    assert float(a.tensor()[..., C:].float().abs().max()) > 0.1
+    assert torch.equal(a.tensor()[..., C:], b.tensor()[..., C:])
+    assert float(b.tensor()[..., :C].float().abs().max()) == 0.0               # the first slice is not touched
+
+
+def test_eval_network_hyper_rows_is_bit_identical(monkeypatch):
+    """SALT_HYPER_ROWS=1 (default, eval mode) against the per-level launches: the same logits, bit for bit."""
+    from salt_amd import architectures as A
+    from oracle import specs as OS
+    spec = OS.SPECS['UNetResNet'](with_fc=True)
+    sd = OS.init_state(spec, seed=3)
+    x = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(1))
+    outs = {}
+    for mode in ('0', '1'):
+        monkeypatch.setenv('SALT_HYPER_ROWS', mode)
+        net = A.UNetResNet(34, 2, use_hypercolumn=True, dropout_2d=0.0, pretrained=False)
+        net.load_state_dict({k: sd[k] for k in net.state_dict() if k in sd}, strict=False)
+        net.compute_dtype = 'bf16'
+        net.to(DEV).eval()
+        with torch.no_grad():
+            outs[mode] = net(x.to(DEV)).float().cpu()
+        names = [n for n, _, _ in net.engine().net((2, 3, 64, 64), False).fwd.ops]
+        assert ('hyper_rows' in names) == (mode == '1')
+    assert torch.equal(outs['0'], outs['1'])

@@ -44,9 +44,11 @@ for fold in ('', '1'):
         rows.append((name, kid, us))
         print('%-6s %-12s kernel %-3s %7.1f us' % ('fold' if fold else 'plain', name, kid, us))
     res[fold] = rows
-# plain: [zero, conv1, affine1, conv2, affine2]; fold: [zero, conv1, conv2(in_*), affine2]
+# plain: ... conv1, affine_act1, conv2, affine_act2 ...; fold: ... conv1, conv2 (transform in the loader), affine_act2 ...
+def pick(rows, name):
+    return [r for r in rows if r[0] == name]
 p, f = res[''], res['1']
-plain = p[2][2] + p[3][2]
-folded = f[2][2]
+plain = pick(p, 'affine_act')[0][2] + pick(p, 'conv')[1][2]
+folded = pick(f, 'conv')[1][2]
 print('B%d C%d %dx%d: affine_act + conv (kernel %s) = %.1f us   |   conv with the transform in its loader (kernel %s) = %.1f us   |   fold saves %.1f us'
-      % (B, C, H, W, p[3][1], plain, f[2][1], folded, plain - folded))
+      % (B, C, H, W, pick(p, 'conv')[1][1], plain, pick(f, 'conv')[1][1], folded, plain - folded))
