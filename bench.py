@@ -26,8 +26,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # RCCL reads its NCCL_DEBUG* variables once, when librccl initialises its logger: set them before torch is imported (round 2 set them
 # next to init_process_group and the file never appeared).  %p = pid, one file per rank; rccl_summary() quotes rank 0's.
-if 'NCCL_DEBUG' not in os.environ and __name__ == '__main__':
-    os.environ['NCCL_DEBUG'] = 'INFO'
+if __name__ == '__main__' and 'NCCL_DEBUG_FILE' not in os.environ:
+    if os.environ.get('NCCL_DEBUG', '').upper() not in ('INFO', 'TRACE'):     # (the image may preset WARN: the summary needs the INFO lines)
+        os.environ['NCCL_DEBUG'] = 'INFO'
     os.environ.setdefault('NCCL_DEBUG_SUBSYS', 'INIT,GRAPH,TUNING')
     os.environ['NCCL_DEBUG_FILE'] = '/tmp/salt_rccl_%p.log'
 
@@ -432,7 +433,7 @@ def rccl_summary(limit=12):
         lines = open(RCCL_LOG, errors='replace').read().splitlines()
     except OSError:
         return None
-    pat = re.compile(r'(Ring|Tree|Channel|channels|Algo|algo|Proto|proto|via P2P|via SHM|XGMI|xgmi|nranks|comm 0x)')
+    pat = re.compile(r'(Ring|Tree|Channel|channels|Algo|algo|Proto|proto|via P2P|via SHM|XGMI|xgmi|nranks|comm 0x|RCCL version|Using network)')
     keep = [re.sub(r'^\S+:\d+:\d+ \[\d+\] ', '', ln) for ln in lines if pat.search(ln)]
     out = []
     for ln in keep:                           # one line per distinct message shape
