@@ -60,22 +60,21 @@ __global__ __launch_bounds__(256) void affine_act_kernel(salt_view y, const floa
     const int cpv = y.C / N;
     const int64_t units = (int64_t)y.B * y.H * y.W * cpv;
     const int64_t stride = gridDim.x * 256LL;
-    if constexpr (FIN) {
-        extern __shared__ float fin_sm[];
-        fin_forward_consumer(fin, y.C, fin_sm, fin_sm + y.C, blockIdx.x == 0);
-        __syncthreads();
-        scale = fin_sm; shift = fin_sm + y.C;                  // generic address space: the loads below become LDS reads
-    }
+    extern __shared__ float fin_sm[];
+    auto prologue = [&]() {                                      // every thread of the workgroup calls it exactly once
+        if constexpr (FIN) {
+            fin_forward_consumer(fin, y.C, fin_sm, fin_sm + y.C, blockIdx.x == 0);
+            __syncthreads();
+            scale = fin_sm; shift = fin_sm + y.C;              // generic address space: the loads below become LDS reads
+        }
+    };
     if (stride % cpv == 0) {
         // the thread's channel piece is the same in every iteration: per-channel parameters live in registers, U units in flight
         const int64_t u0 = blockIdx.x * 256LL + threadIdx.x;
         const int c0 = (int)(u0 % cpv) * N;
-        float sc[N], sh[N];
-#pragma unroll
-        for (int j = 0; j < N; ++j) { sc[j] = scale ? scale[c0 + j] : 1.f; sh[j] = scale ? shift[c0 + j] : 0.f; }
-        for (int64_t u = u0; u < units; u += U * stride) {
-            float f[U][N], r[U][N];
-            int64_t pix[U];
+        float f[U][N], r[U][N];
+        int64_t pix[U];
+        auto load_iter = [&](int64_t u) {
 #pragma unroll
             for (int i = 0; i < U; ++i) {
                 const int64_t ui = u + i * stride;
@@ -83,6 +82,16 @@ __global__ __launch_bounds__(256) void affine_act_kernel(salt_view y, const floa
                 Unit<T, VEC>::ld((const T*)y.p + pix[i] * y.cs + c0, f[i]);
                 if (res.p) Unit<T, VEC>::ld((const T*)res.p + pix[i] * res.cs + c0, r[i]);
             }
+        };
+        // the first iteration's loads go out BEFORE the statistics prologue (a chain of dependent shard loads + fp64 math + a barrier
+        // that every one of the <= 1024 workgroups pays): its round trip hides under theirs
+        if (u0 < units) load_iter(u0);
+        prologue();
+        float sc[N], sh[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) { sc[j] = scale ? scale[c0 + j] : 1.f; sh[j] = scale ? shift[c0 + j] : 0.f; }
+        for (int64_t u = u0; u < units; u += U * stride) {
+            if (u != u0) load_iter(u);
 #pragma unroll
             for (int i = 0; i < U; ++i) {
 #pragma unroll
@@ -97,6 +106,7 @@ __global__ __launch_bounds__(256) void affine_act_kernel(salt_view y, const floa
         }
         return;
     }
+    prologue();
     for (int64_t u = blockIdx.x * 256LL + threadIdx.x; u < units; u += stride) {
         const int64_t pix = u / cpv; const int c0 = (int)(u - pix * cpv) * N;
         float f[N], r[N];
@@ -345,12 +355,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(salt_view da, salt_vi
     constexpr int N = Unit<T, VEC>::N;
     const int C = y.C, cpv = C / N;
     const int64_t units = (int64_t)y.B * y.H * y.W * cpv;
-    if constexpr (FIN) {
-        extern __shared__ float fin_sm[];
-        fin_backward_consumer(fin, gamma, invstd, C, fin_sm, blockIdx.x == 0);
-        __syncthreads();
-        coef = fin_sm;
-    }
+    extern __shared__ float fin_sm[];
+    auto prologue = [&]() {                                      // every thread of the workgroup calls it exactly once
+        if constexpr (FIN) {
+            fin_backward_consumer(fin, gamma, invstd, C, fin_sm, blockIdx.x == 0);
+            __syncthreads();
+            coef = fin_sm;
+        }
+    };
     {
         const int64_t stride_ = gridDim.x * 256LL;
         if (stride_ % cpv == 0) {
@@ -358,6 +370,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(salt_view da, salt_vi
             const int64_t u0 = blockIdx.x * 256LL + threadIdx.x;
             const int c0 = (int)(u0 % cpv) * N;
             const bool from_y = relu && a.p == nullptr;
+            constexpr int UB = SALT_BNB_UNITS;
+            int64_t pix[UB];
+            float g[UB][N], yy[UB][N], aa[UB][N], old[UB][N];
+            auto load_iter = [&](int64_t u) {
+#pragma unroll
+                for (int i = 0; i < UB; ++i) {
+                    const int64_t ui = u + i * stride_;
+                    pix[i] = (ui < units ? ui : u) / cpv;                  // past the end: unit 0 again, never stored
+                    Unit<T, VEC>::ld((const T*)da.p + pix[i] * da.cs + c0, g[i]);
+                    Unit<T, VEC>::ld((const T*)y.p + pix[i] * y.cs + c0, yy[i]);
+                    if (relu && !from_y) Unit<T, VEC>::ld((const T*)a.p + pix[i] * a.cs + c0, aa[i]);
+                    if (dres.p && acc_dres) Unit<T, VEC>::ld((const T*)dres.p + pix[i] * dres.cs + c0, old[i]);
+                }
+            };
+            // the first iteration's loads go out BEFORE the coefficient prologue (dependent shard loads + fp64 math + a barrier in
+            // every workgroup): its round trip hides under theirs
+            if (u0 < units) load_iter(u0);
+            prologue();
             // Six per-channel vectors stay live in the loop: A, D, E with  dy = A gg + D (y - mean) + E  (= k (gg - c1 - xhat c2) with the
             // products folded), mean, and scale / shift of the forward pass for the ReLU mask (the SAME expression affine_act evaluated, so
             // the mask is the forward decision).  Round 2 kept nine (118 VGPRs, 4 waves per SIMD).
@@ -378,21 +408,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(salt_view da, salt_vi
                     A[j] = k0[j]; D[j] = -(k0[j] * k2[j]) * is[j]; E[j] = -(k0[j] * k1[j]);
                 }
             }
-            // UB units per thread in flight: all loads of an iteration are issued before the first is used (one unit per iteration was a
-            // chain of units / threads dependent round trips: 2.8 TB/s on a 67 MB tensor)
-            constexpr int UB = SALT_BNB_UNITS;
             for (int64_t u = u0; u < units; u += UB * stride_) {
-                int64_t pix[UB];
-                float g[UB][N], yy[UB][N], aa[UB][N], old[UB][N];
-#pragma unroll
-                for (int i = 0; i < UB; ++i) {
-                    const int64_t ui = u + i * stride_;
-                    pix[i] = (ui < units ? ui : u) / cpv;                  // past the end: unit 0 again, never stored
-                    Unit<T, VEC>::ld((const T*)da.p + pix[i] * da.cs + c0, g[i]);
-                    Unit<T, VEC>::ld((const T*)y.p + pix[i] * y.cs + c0, yy[i]);
-                    if (relu && !from_y) Unit<T, VEC>::ld((const T*)a.p + pix[i] * a.cs + c0, aa[i]);
-                    if (dres.p && acc_dres) Unit<T, VEC>::ld((const T*)dres.p + pix[i] * dres.cs + c0, old[i]);
-                }
+                if (u != u0) load_iter(u);
 #pragma unroll
                 for (int i = 0; i < UB; ++i) {
                     float o[N];
@@ -423,6 +440,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(salt_view da, salt_vi
             return;
         }
     }
+    prologue();
     for (int64_t u = blockIdx.x * 256LL + threadIdx.x; u < units; u += gridDim.x * 256LL) {
         const int64_t pix = u / cpv; const int c0 = (int)(u - pix * cpv) * N;
         float g[N], yy[N], o[N], msk[N];
