@@ -582,6 +582,20 @@ def main():
         out['val_iou_note'] = ('mean IoU on 128 held-out synthetic tiles after %d training steps from random init (a smoke signal that the '
                                'step learns, not an accuracy result)' % (args.warmup + args.steps))
 
+    if rank == 0 and not args.no_iou:
+        # accuracy-side parity of the headline dtype: measured by tools/convergence_parity.py (CPU oracle fp32 / HIP fp32 / HIP bf16 from
+        # identical weights and batches; the CPU leg takes minutes, so the committed result is quoted instead of re-running it here)
+        try:
+            cv = json.load(open(os.path.join(ROOT, 'profiles', 'r03_convergence.json')))
+            last = str(cv['config']['steps'])
+            out['val_iou_parity'] = {'source': 'profiles/r03_convergence.json (tools/convergence_parity.py: R34 hypercolumn, batch %d, %s steps, '
+                                               'identical init and batches, %d held-out tiles)' % (cv['config']['batch'], last, cv['config']['val_tiles']),
+                                     'val_iou_cpu_oracle_f32': cv['val_iou']['cpu_oracle_f32'][last], 'val_iou_hip_f32': cv['val_iou']['hip_f32'][last],
+                                     'val_iou_hip_bf16': cv['val_iou']['hip_bf16'][last],
+                                     'max_abs_dloss_first20_hip_f32_vs_cpu': cv['summary']['hip_f32_vs_cpu']['max_abs_dloss_first20']}
+        except (OSError, KeyError, ValueError):
+            pass
+
     if rank == 0 and 'roofline_by_class' in out:           # the fused Adam + L2 kernel (28 bytes per parameter), timed after the evaluation
         for name, _, ms in model.optimizer.prog.run_timed():
             if name == 'adam' and ms > 0:
