@@ -35,6 +35,12 @@
 #include <type_traits>
 #include "common.h"
 
+#ifndef SALT_LS_NLW
+#define SALT_LS_NLW 4            // loader waves of conv_ls_kernel (8 measured)
+#endif
+#ifndef SALT_LS_ABLATE
+#define SALT_LS_ABLATE 0         // conv_ls_kernel timing ablations (tools/ls_ablate.sh; results are wrong): 1 no fragment reads / MFMAs, 2 no DMA, 4 no epilogue
+#endif
 #ifndef SALT_WS_CLK
 #define SALT_WS_CLK 0            // 1: per-workgroup s_memtime stamps into g_ws_clk (tools/ws_clocks.py; timing build only)
 #endif
@@ -614,12 +620,13 @@ struct LsKP {
     long long x_plane;               // salt_conv_args.x_plane: chunk c is the half (c & 1) of the dense 64-channel plane x + (c >> 1) * x_plane
 };
 
-template <int NI, int MODE>
-__global__ __launch_bounds__(512) void conv_ls_kernel(LsKP p) {
+// NLW loader waves (waves 4 .. 4 + NLW - 1) + 4 MFMA waves (waves 0 .. 3)
+template <int NI, int MODE, int NLW = SALT_LS_NLW>
+__global__ __launch_bounds__(256 + 64 * NLW) void conv_ls_kernel(LsKP p) {
     typedef bf16_t T;
     constexpr int BN = 32 * NI, NT = 9, MI = 2;
     constexpr int HPC = 21, WPC = NT * BN / 16, PC = HPC + WPC;           // DMA pieces (1 KB) of one chunk: halo rows, then weights
-    constexpr int NS = (PC + 3) / 4;                                    // DMA instructions per loader wave and chunk
+    constexpr int NS = (PC + NLW - 1) / NLW;                            // DMA instructions per loader wave and chunk
     constexpr int D = NI == 1 ? 4 : 2;                                  // ring depth
     constexpr int H_BYTES = HPC * 1024, CH_BYTES = PC * 1024;
     constexpr int OFF_DUMMY = D * CH_BYTES, OFF_CONST = OFF_DUMMY + 1024;
@@ -629,7 +636,8 @@ __global__ __launch_bounds__(512) void conv_ls_kernel(LsKP p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool loader = wave >= 4;
-    const int wm = wave & 3;
+    const int wm = wave & 3;                                            // MFMA waves: pixel quarter of the tile
+    const int lw = wave - 4;                                            // loader waves: piece lane of the chunk
     const int khalf = lane >> 5, l31 = lane & 31;
 
     // ---- items of this workgroup: XCD x owns a contiguous range of pixel tiles; its workgroup j works on channel block j % n_tiles and
@@ -679,7 +687,7 @@ __global__ __launch_bounds__(512) void conv_ls_kernel(LsKP p) {
         int w_rel[NS], h_off[NS];
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
-            const int pi = wm + 4 * i;
+            const int pi = lw + NLW * i;
             w_rel[i] = 0; h_off[i] = -1;
             if (pi >= HPC && pi < PC) {
                 const int R = (pi - HPC) * 16 + (lane >> 2);               // row t * BN + n of the chunk's weight block
@@ -695,7 +703,7 @@ __global__ __launch_bounds__(512) void conv_ls_kernel(LsKP p) {
             const bool clamp = p.pad_mode != 0;
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
-                const int pi = wm + 4 * i;
+                const int pi = lw + NLW * i;
                 if (pi < HPC) {
                     const int row = pi * 16 + (lane >> 2);
                     const int hy = (int)__umulhi((unsigned)row, 238609295u);      // row / 18
@@ -717,12 +725,12 @@ __global__ __launch_bounds__(512) void conv_ls_kernel(LsKP p) {
             const T* xc = xb + (p.x_plane ? (long long)(ic >> 1) * p.x_plane + (ic & 1) * 32 : (long long)ic * 32);   // wave-uniform
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
-                const int pi = wm + 4 * i;
+                const int pi = lw + NLW * i;
                 const void* src = zp;
                 int dst = OFF_DUMMY;
                 if (live && pi < HPC) { if (h_off[i] >= 0) src = xc + h_off[i]; dst = buf + pi * 1024; }
                 else if (live && pi < PC) { src = wc + w_rel[i]; dst = buf + pi * 1024; }
-                dma(src, dst);
+                if (!(SALT_LS_ABLATE & 2)) dma(src, dst);
             }
             if (live) { ++ig; if (++ic == p.nchunk) { ic = 0; ++ik; } }
         };
@@ -778,6 +786,7 @@ __global__ __launch_bounds__(512) void conv_ls_kernel(LsKP p) {
                 asm volatile("" ::: "memory");
                 __builtin_amdgcn_s_barrier();                              // chunk g landed
                 asm volatile("" ::: "memory");
+                if (SALT_LS_ABLATE & 1) continue;
                 const unsigned char* hb = smem + (g % D) * CH_BYTES;
                 auto load_frag = [&](int s, Frag& f) {                      // s = (tap, k-step), a constant after unrolling
                     const int t = s >> 1, hx = (s & 1) << 5;
@@ -815,6 +824,17 @@ __global__ __launch_bounds__(512) void conv_ls_kernel(LsKP p) {
                 pix[i] = (unsigned)((cc.b * p.OH + cc.oy0 + (m >> 4)) * p.OW + cc.ox0 + (m & 15));
             }
             const WsLaneGeo geo = {{true, true}, false, false, false, false, 0, 0, 0, 0};
+            if (SALT_LS_ABLATE & 4) {                                      // keep the accumulators alive without the epilogue
+                float tsum = 0.f;
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) tsum += acc[i][j][r];
+                if (tsum == 123.456f) p.y[0] = f2bf(tsum);
+                continue;
+            }
             ws_epilogue_tile<NI, MODE, false>(ep, acc, pix, geo, n0, reinterpret_cast<const float*>(smem + OFF_CONST), rs0, rs1, khalf, l31);
         }
     }
@@ -837,7 +857,7 @@ int ls_launch_mode(const LsKP& k, int wgs, hipStream_t st) {
         if (e != hipSuccess) SALT_FAIL((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(512), LDS, st, k);
+    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(256 + 64 * SALT_LS_NLW), LDS, st, k);
     SALT_CHECK_LAUNCH();
     return SALT_OK;
 }
