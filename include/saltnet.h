@@ -682,6 +682,9 @@ typedef struct {
     const int* flip_ud;       /* host arrays [V] */
     const int* flip_lr;
     float* prob;              /* fp32 NCHW [B,C,H,W] */
+    const int* rot;           /* host array [V] or NULL: quarter turns k of the variant's forward np.rot90 (augmentation.py:143-153; H == W);
+                               * the inverse applied here is rot90(-k), then fliplr, then flipud (augmentation.py:156-163) */
+    int method;               /* aggregation over the variants (loaders.py:727-735): 0 mean, 1 max, 2 min, 3 gmean = exp(mean(log p)) */
 } salt_tta_mean_args;
 int salt_tta_mean(const salt_tta_mean_args*, void* stream);
 

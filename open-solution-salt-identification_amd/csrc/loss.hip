@@ -633,18 +633,29 @@ __global__ void adam_tick_kernel(float* hyper, int64_t* step) {
 }
 
 // ---------------------------------------------------------------- TTA: sigmoid -> inverse flip -> mean
-struct TtaKP { const float* logits; float* prob; int V, B, C, H, W; int ud[16], lr[16]; };
+struct TtaKP { const float* logits; float* prob; int V, B, C, H, W; int ud[16], lr[16], rq[16]; int method; };
 __global__ void tta_mean_kernel(TtaKP p) {
     const int64_t hw = (int64_t)p.H * p.W, n = (int64_t)p.B * p.C * hw;
     for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < n; i += gridDim.x * 256LL) {
         const int x = (int)(i % p.W); int64_t r = i / p.W; const int y = (int)(r % p.H); const int64_t plane = r / p.H;
-        float s = 0.f;
+        float s = p.method == 1 ? -1.f : (p.method == 2 ? 2.f : 0.f);
         for (int v = 0; v < p.V; ++v) {
-            const int yy = p.ud[v] ? p.H - 1 - y : y, xx = p.lr[v] ? p.W - 1 - x : x;
+            // out = flipud?(fliplr?(rot90(pred, -k))): undo the flips on the output coordinate, then read through the rotation
+            // (np.rot90(m, q)[i, j] for q = 1, 2, 3: m[j, n-1-i], m[n-1-i, n-1-j], m[n-1-j, i]; rq = (-k) mod 4, square maps)
+            const int yf = p.ud[v] ? p.H - 1 - y : y, xf = p.lr[v] ? p.W - 1 - x : x;
+            int yy = yf, xx = xf;
+            const int q = p.rq[v];
+            if (q == 1) { yy = xf; xx = p.W - 1 - yf; }
+            else if (q == 2) { yy = p.H - 1 - yf; xx = p.W - 1 - xf; }
+            else if (q == 3) { yy = p.H - 1 - xf; xx = yf; }
             const float zz = p.logits[((int64_t)v * p.B * p.C + plane) * hw + (int64_t)yy * p.W + xx];
-            s += 1.f / (1.f + expf(-zz));
+            const float pr = 1.f / (1.f + expf(-zz));
+            if (p.method == 0) s += pr;
+            else if (p.method == 1) s = fmaxf(s, pr);
+            else if (p.method == 2) s = fminf(s, pr);
+            else s += logf(pr);
         }
-        p.prob[i] = s / (float)p.V;
+        p.prob[i] = p.method == 0 ? s / (float)p.V : (p.method == 3 ? expf(s / (float)p.V) : s);
     }
 }
 __global__ void flip_kernel(salt_flip_args a) {
@@ -788,7 +799,14 @@ extern "C" int salt_tta_mean(const salt_tta_mean_args* a, void* stream) {
     if (!a || !a->logits || !a->prob || a->V < 1 || a->V > 16 || !a->flip_ud || !a->flip_lr) SALT_FAIL(SALT_E_BADARG, "tta_mean: bad args");
     TtaKP p;
     p.logits = a->logits; p.prob = a->prob; p.V = a->V; p.B = a->B; p.C = a->C; p.H = a->H; p.W = a->W;
-    for (int v = 0; v < a->V; ++v) { p.ud[v] = a->flip_ud[v]; p.lr[v] = a->flip_lr[v]; }
+    if (a->method < 0 || a->method > 3) SALT_FAIL(SALT_E_BADARG, "tta_mean: method %d (0 mean, 1 max, 2 min, 3 gmean)", a->method);
+    p.method = a->method;
+    for (int v = 0; v < a->V; ++v) {
+        p.ud[v] = a->flip_ud[v]; p.lr[v] = a->flip_lr[v];
+        const int k = a->rot ? ((a->rot[v] % 4) + 4) % 4 : 0;
+        if (k && a->H != a->W) SALT_FAIL(SALT_E_BADARG, "tta_mean: rotated variants need square maps");
+        p.rq[v] = (4 - k) % 4;
+    }
     const int64_t n = (int64_t)a->B * a->C * a->H * a->W;
     const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     hipLaunchKernelGGL(tta_mean_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);

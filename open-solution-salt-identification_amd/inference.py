@@ -51,37 +51,52 @@ def tta_variants(flip_ud=True, flip_lr=True):
     return out
 
 
-def flip(x, ud, lr):
-    """augmentation.py:143-153 on an NCHW batch: flipud / fliplr of every image."""
+def flip(x, ud, lr, out=None):
+    """augmentation.py:143-153 on an NCHW batch: flipud / fliplr of every image (``out``: a contiguous fp32 tensor of the same shape,
+    e.g. a slice of the batch that holds all TTA variants)."""
     x = _f32c(x)
-    y = torch.empty_like(x)
+    y = torch.empty_like(x) if out is None else out
+    if y.shape != x.shape or y.dtype != torch.float32 or not y.is_contiguous() or not y.is_cuda:
+        raise SaltError('flip: out must be a contiguous fp32 device tensor of the input shape')
     B, C, H, W = x.shape
     _run('flip', x=x.data_ptr(), B=B, C=C, H=H, W=W, flip_ud=int(ud), flip_lr=int(lr), y=y.data_ptr())
     return y
 
 
-def tta_mean(logits, variants, batch):
-    """sigmoid -> inverse flip -> mean over variants; ``logits`` is variant-major [V*B, C, H, W]."""
+TTA_METHODS = {'mean': 0, 'max': 1, 'min': 2, 'gmean': 3}
+
+
+def tta_mean(logits, variants, batch, method='mean'):
+    """sigmoid -> inverse transform -> aggregation over the variants in ONE kernel; ``logits`` is variant-major [V*B, C, H, W];
+    ``variants``: (ud, lr) or (ud, lr, k) with k the quarter turns of the variant's np.rot90 (square maps); ``method``: mean (default,
+    neptune.yaml:80) | max | min | gmean (loaders.py:727-735)."""
     logits = _f32c(logits)
     VB, C, H, W = logits.shape
     V = len(variants)
     if VB != V * batch:
         raise SaltError('tta_mean: %d logits for %d variants x batch %d' % (VB, V, batch))
+    if method not in TTA_METHODS:
+        raise SaltError('TTA aggregation %r (mean | max | min | gmean, loaders.py:727-735)' % (method,))
     ud = (ctypes.c_int * V)(*[int(v[0]) for v in variants])
     lr = (ctypes.c_int * V)(*[int(v[1]) for v in variants])
+    rot = (ctypes.c_int * V)(*[int(v[2]) if len(v) > 2 else 0 for v in variants])
     prob = torch.empty((batch, C, H, W), dtype=torch.float32, device=logits.device)
     _run('tta_mean', logits=logits.data_ptr(), V=V, B=batch, C=C, H=H, W=W, flip_ud=ctypes.cast(ud, ctypes.c_void_p).value,
-         flip_lr=ctypes.cast(lr, ctypes.c_void_p).value, prob=prob.data_ptr())
+         flip_lr=ctypes.cast(lr, ctypes.c_void_p).value, prob=prob.data_ptr(), rot=ctypes.cast(rot, ctypes.c_void_p).value,
+         method=TTA_METHODS[method])
     return prob
 
 
-def _flip_input(X, ud, lr, depth_channels):
+def _flip_input(X, ud, lr, depth_channels, out=None):
     """One TTA variant of a preprocessed batch.  The reference flips the RAW tile and only then normalises and adds the depth channels
     (loaders.py:401-423 -> 603-612, utils.py:494-500), so channel 1 (the row ramp) is NOT flipped and channel 2 is
     flipped(gray) * ramp; flipping all three channels of the network input would hand the network an inverted ramp."""
     if not (ud or lr):
-        return X
-    Y = flip(X, ud, lr)
+        if out is None:
+            return X
+        out.copy_(X)
+        return out
+    Y = flip(X, ud, lr, out=out)
     if depth_channels and ud and X.shape[1] == 3:
         Y[:, 1] = X[:, 1]
         Y[:, 2] = Y[:, 0] * X[:, 1]
@@ -118,30 +133,25 @@ def predict_tta(net, X, flip_ud=False, flip_lr=True, variants_per_pass=None, dep
                             'depth_channels=False for an ordinary 3-channel input')
         depth_channels = is_ramp
     per = len(variants) if not variants_per_pass else int(variants_per_pass)
-    outs = []
-    with torch.no_grad():
-        for i in range(0, len(variants), per):
-            xs = [_flip_input(X, ud, lr, depth_channels) for ud, lr in variants[i:i + per]]
-            outs.append(net(torch.cat(xs, 0) if len(xs) > 1 else xs[0]).float())
-    logits = torch.cat(outs, 0) if len(outs) > 1 else outs[0]
-    return _aggregate(logits, variants, B, method)
-
-
-def _aggregate(logits, variants, B, method):
-    if method == 'mean':
-        return tta_mean(logits, variants, B)
-    if method not in ('max', 'min', 'gmean'):
-        raise SaltError('TTA aggregation %r (mean | max | min | gmean, loaders.py:727-735)' % (method,))
     V = len(variants)
-    probs = []
-    for v, (ud, lr) in enumerate(variants):             # sigmoid + inverse flip of ONE variant = tta_mean over a single variant
-        probs.append(tta_mean(logits[v * B:(v + 1) * B], [(ud, lr)], B))
-    st = torch.stack(probs, 0)
-    if method == 'max':
-        return st.max(0).values
-    if method == 'min':
-        return st.min(0).values
-    return torch.exp(torch.log(st).mean(0))            # scipy.stats.gmean
+    logits = None
+    with torch.no_grad():
+        for i in range(0, V, per):
+            group = variants[i:i + per]
+            if len(group) > 1:                              # the group's variants are written side by side into ONE batch (no torch.cat)
+                xb = torch.empty((len(group) * B,) + tuple(X.shape[1:]), dtype=torch.float32, device=X.device)
+                for j, (ud, lr) in enumerate(group):
+                    _flip_input(X, ud, lr, depth_channels, out=xb[j * B:(j + 1) * B])
+            else:
+                xb = _flip_input(X, group[0][0], group[0][1], depth_channels)
+            lg = net(xb)
+            if len(group) == V:
+                logits = lg.float()
+            else:
+                if logits is None:
+                    logits = torch.empty((V * B,) + tuple(lg.shape[1:]), dtype=torch.float32, device=X.device)
+                logits[i * B:(i + len(group)) * B].copy_(lg)
+    return tta_mean(logits, variants, B, method)
 
 
 def predict_tta_tiles(net, preprocessor, images, flip_ud=False, flip_lr=True, rotation=False, method='mean'):
@@ -158,31 +168,25 @@ def predict_tta_tiles(net, preprocessor, images, flip_ud=False, flip_lr=True, ro
                                        [0, 1, 2, 3] if rotation else [0]):
         if ud or lr or k:
             specs.append((ud, lr, k))
-    probs = []
+    if method not in TTA_METHODS:
+        raise SaltError('TTA aggregation %r (mean | max | min | gmean, loaders.py:727-735)' % (method,))
+    logits = None
     with torch.no_grad():
-        for ud, lr, k in specs:
-            t = images
-            if ud:
+        for v, (ud, lr, k) in enumerate(specs):
+            t = images                                    # the RAW tiles are transformed as the reference's loader does (host-side
+            if ud:                                        # numpy there; torch index ops on the small [B,h,w] tiles here)
                 t = torch.flip(t, dims=(1,))
             if lr:
                 t = torch.flip(t, dims=(2,))
             if k:
                 t = torch.rot90(t, k, dims=(1, 2))
             x, _ = preprocessor(t.contiguous())
-            p = tta_mean(net(x).float(), [(False, False)], B)          # sigmoid of this variant
-            if k:
-                p = torch.rot90(p, -k, dims=(2, 3))
-            probs.append(flip(p, ud, lr) if (ud or lr) else p)           # inverse: rot90(-k), then fliplr, then flipud (they commute)
-    st = torch.stack(probs, 0)
-    if method == 'mean':
-        return st.mean(0)
-    if method == 'max':
-        return st.max(0).values
-    if method == 'min':
-        return st.min(0).values
-    if method == 'gmean':
-        return torch.exp(torch.log(st).mean(0))
-    raise SaltError('TTA aggregation %r (mean | max | min | gmean, loaders.py:727-735)' % (method,))
+            lg = net(x)
+            if logits is None:
+                logits = torch.empty((len(specs) * B,) + tuple(lg.shape[1:]), dtype=torch.float32, device=lg.device)
+            logits[v * B:(v + 1) * B].copy_(lg)
+    # sigmoid, inverse transform (rot90(-k), fliplr, flipud: augmentation.py:156-163) and aggregation of all variants: one kernel
+    return tta_mean(logits, specs, B, method)
 
 
 # ----------------------------------------------------------------------------- post-processing

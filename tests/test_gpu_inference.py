@@ -369,3 +369,23 @@ def test_eval_network_hyper_rows_is_bit_identical(monkeypatch):
         names = [n for n, _, _ in net.engine().net((2, 3, 64, 64), False).fwd.ops]
         assert ('hyper_rows' in names) == (mode == '1')
     assert torch.equal(outs['0'], outs['1'])
+
+
+@pytest.mark.parametrize('method', ['mean', 'max', 'min', 'gmean'])
+def test_tta_kernel_rotations_and_aggregators_vs_oracle(method):
+    """salt_tta_mean with rot / method: sigmoid, inverse transform (rot90(-k), fliplr, flipud: augmentation.py:156-163) and aggregation
+    (loaders.py:727-735) of the 16 flip x rotation variants in one launch, against the numpy restatement on random logits."""
+    from salt_amd import inference as I
+    from oracle import metrics as OM
+    g = torch.Generator().manual_seed(21)
+    B, C, n = 2, 2, 24
+    specs = OM.tta_specs(True, True, True)
+    variants = [(s['ud_flip'], s['lr_flip'], s['rotation'] // 90) for s in specs]
+    assert len(variants) == 16
+    logits = torch.randn(len(variants) * B, C, n, n, generator=g) * 3
+    prob = I.tta_mean(logits.to(DEV), variants, B, method).cpu().numpy()
+    for b in range(B):
+        preds = [OM.sigmoid(logits[v * B + b].numpy()) for v in range(len(variants))]
+        assert_close(prob[b], OM.tta_aggregate(preds, specs, method), 5e-6, 'tta %s' % method)
+    with pytest.raises(Exception):
+        I.tta_mean(torch.zeros(2 * B, C, 8, 12, device=DEV), [(False, False, 0), (False, False, 1)], B)      # rotation of a non-square map
