@@ -2713,8 +2713,14 @@ int wgrad_plan(const salt_conv_wgrad_args* a, WgradKP* k, int* nsplit_out) {
     // bf16: >= 8 pixel tiles per split (every split costs a 147 KB slab round trip).  fp32: 2 - the exact-f32 MFMA is 16x slower, so a
     // workgroup's 1024 pixels were ~200 us of matrix work on 32 workgroups (vanilla U-Net fp32: 7.47 -> 6.13 ms per step)
     static const int min_tiles_env = getenv("SALT_WGRAD_TPW") ? atoi(getenv("SALT_WGRAD_TPW")) : 0;
-    const int min_tiles = min_tiles_env > 0 ? min_tiles_env : (a->dtype == SALT_F32 ? (k->a_blocks * k->b_blocks <= 4 ? 2 : 4) : 8);
-    int ns = target_wgs / (k->a_blocks * k->b_blocks);
+    const int blocks_ = k->a_blocks * k->b_blocks;
+    // fp32 (round 3): at least 2 tiles per split and about 256 workgroups per launch - what SALT_WGRAD_TPW=4 gave the ResNet34 layers
+    // (23.5 ms per step against 24.4 with 2) and SALT_WGRAD_TPW=2 the small levels of the vanilla net (4.17 against 4.27 ms): the 8x8 /
+    // 16x16 levels run on the generic kernel, whose time is the length of a workgroup's tile chain, while more than ~256 workgroups take
+    // CUs from the data-gradient chain
+    const int min_tiles = min_tiles_env > 0 ? min_tiles_env : (a->dtype == SALT_F32 ? 2 : 8);
+    static const bool wgs_env = getenv("SALT_WGRAD_WGS") != nullptr;
+    int ns = ((a->dtype == SALT_F32 && !min_tiles_env && !wgs_env) ? 256 : target_wgs) / blocks_;
     // the stem (64 x 16 channels, launched on the MAIN stream at the very end of backward, nothing left to overlap with): finer
     // split.  NOT for the other single-block layers: their launches share the chip with the data-gradient chain, and 256 instead
     // of 128 weight-gradient workgroups cost 6.17 -> 6.24 ms per step (and halving the tiles per split wherever a launch has fewer than
