@@ -35,6 +35,9 @@
 #include <type_traits>
 #include "common.h"
 
+#ifndef SALT_LS_D1
+#define SALT_LS_D1 4             // chunk-ring depth of conv_ls_kernel<NI = 1> (3 leaves 43 KB of LDS to a neighbour: DESIGN 10)
+#endif
 #ifndef SALT_LS_NLW
 #define SALT_LS_NLW 4            // loader waves of conv_ls_kernel (8 measured)
 #endif
@@ -627,7 +630,7 @@ __global__ __launch_bounds__(256 + 64 * NLW) void conv_ls_kernel(LsKP p) {
     constexpr int BN = 32 * NI, NT = 9, MI = 2;
     constexpr int HPC = 21, WPC = NT * BN / 16, PC = HPC + WPC;           // DMA pieces (1 KB) of one chunk: halo rows, then weights
     constexpr int NS = (PC + NLW - 1) / NLW;                            // DMA instructions per loader wave and chunk
-    constexpr int D = NI == 1 ? 4 : 2;                                  // ring depth
+    constexpr int D = NI == 1 ? SALT_LS_D1 : 2;                                  // ring depth
     constexpr int H_BYTES = HPC * 1024, CH_BYTES = PC * 1024;
     constexpr int OFF_DUMMY = D * CH_BYTES, OFF_CONST = OFF_DUMMY + 1024;
     static_assert(OFF_CONST + 4 * BN * 4 <= 160 * 1024, "LDS budget");
@@ -848,7 +851,7 @@ __global__ __launch_bounds__(256 + 64 * NLW) void conv_ls_kernel(LsKP p) {
 
 template <int NI, int MODE>
 int ls_launch_mode(const LsKP& k, int wgs, hipStream_t st) {
-    constexpr int BN = 32 * NI, PC = 21 + 9 * BN / 16, D = NI == 1 ? 4 : 2;
+    constexpr int BN = 32 * NI, PC = 21 + 9 * BN / 16, D = NI == 1 ? SALT_LS_D1 : 2;
     constexpr int LDS = D * PC * 1024 + 1024 + 4 * BN * 4;
     auto kern = conv_ls_kernel<NI, MODE>;
     static bool attr_set = false;
