@@ -2903,6 +2903,33 @@ static int launch_wgrad(const WgradKP& k, hipStream_t st) {
             SALT_CHECK_LAUNCH();
             return SALT_OK;
         }
+        // round 3: the stride-2 3x3 layers (ResNet layer2-4 conv1): their halo (17 x 17 pixels for an 8 x 8 tile) only leaves room for
+        // 64-pixel K tiles, which used to send them to the generic kernel (51 us at 94 TFLOP/s); the fast kernel with 4 k-steps per tile
+        static const bool no_fast64 = getenv("SALT_WGRAD_NO_FAST64") != nullptr;
+        const bool fast64 = !generic && !no_fast64 && k.ntaps == 9 && k.bmp == 64 && k.p_cs % 8 == 0 && k.q_cs % 8 == 0 && k.Ca % 8 == 0 && k.Cb % 8 == 0 &&
+                            ((reinterpret_cast<uintptr_t>(k.P) | reinterpret_cast<uintptr_t>(k.Q) | reinterpret_cast<uintptr_t>(k.partials)) & 15) == 0 &&
+                            k.nb * k.hh * k.hw * 8 <= 10 * 256;
+        // ... and the 1x1 stride-2 projection shortcuts (one tap; 33 us at 16 TFLOP/s on the generic kernel)
+        const bool fast1 = !generic && !no_fast64 && k.ntaps == 1 && !k.pad_mode && (k.bmp == 64 || k.bmp == 128) && k.p_cs % 8 == 0 && k.q_cs % 8 == 0 &&
+                           k.Ca % 8 == 0 && k.Cb % 8 == 0 &&
+                           ((reinterpret_cast<uintptr_t>(k.P) | reinterpret_cast<uintptr_t>(k.Q) | reinterpret_cast<uintptr_t>(k.partials)) & 15) == 0 &&
+                           k.nb * k.hh * k.hw * 8 <= 10 * 256;
+        if (fast1) {
+            auto kern = k.bmp == 64 ? conv_wgrad_fast_kernel<1, 4, false, false> : conv_wgrad_fast_kernel<1, 8, false, false>;
+            if (lds > 64 * 1024) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) SALT_FAIL((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e)); }
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, k);
+            SALT_CHECK_LAUNCH();
+            return SALT_OK;
+        }
+        if (fast64) {
+            auto kern = k.pad_mode ? conv_wgrad_fast_kernel<9, 4, true, false> : conv_wgrad_fast_kernel<9, 4, false, false>;
+            if (lds > 64 * 1024) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) SALT_FAIL((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e)); }
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, k);
+            SALT_CHECK_LAUNCH();
+            return SALT_OK;
+        }
     }
     if constexpr (sizeof(T) == 4) {
         static const bool generic = getenv("SALT_WGRAD_GENERIC") != nullptr;
