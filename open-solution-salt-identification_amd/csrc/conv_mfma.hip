@@ -2880,11 +2880,13 @@ static int launch_wgrad(const WgradKP& k, hipStream_t st) {
     if constexpr (sizeof(T) == 2) {
         // fast path: whole aligned 16-byte pieces, 3x3, 128-pixel K tiles (conv_wgrad_fast_kernel)
         static const bool generic = getenv("SALT_WGRAD_GENERIC") != nullptr;
-        const bool fast = !generic && k.ntaps == 9 && k.bmp == 128 && k.p_cs % 8 == 0 && k.q_cs % 8 == 0 && k.Ca % 8 == 0 && k.Cb % 8 == 0 &&
+        // (5..8 taps - the two 8-tap halves of the 4x4 space-to-depth stem - run the 9-tap instance: the padding tap re-reads tap 0's rows
+        //  and is never stored)
+        const bool fast = !generic && k.ntaps >= 5 && k.ntaps <= 9 && k.bmp == 128 && k.p_cs % 8 == 0 && k.q_cs % 8 == 0 && k.Ca % 8 == 0 && k.Cb % 8 == 0 &&
                           ((reinterpret_cast<uintptr_t>(k.P) | reinterpret_cast<uintptr_t>(k.Q) | reinterpret_cast<uintptr_t>(k.partials)) & 15) == 0 &&
                           k.nb * k.hh * k.hw * 8 <= 10 * 256;
         if (fast) {
-            bool row16 = k.tw_log2 == 4 && k.th_log2 == 3 && k.nb == 1 && k.q_step == 1 && k.hw == 18;
+            bool row16 = k.ntaps == 9 && k.tw_log2 == 4 && k.th_log2 == 3 && k.nb == 1 && k.q_step == 1 && k.hw == 18;
             for (int t = 0; t < 9; ++t) row16 = row16 && k.tap_off[t] == (t / 3) * 18 + t % 3;       // raster tap order
             static const bool four_waves = getenv("SALT_WGRAD_W4") != nullptr;
             if (row16 && !four_waves) {
