@@ -1023,8 +1023,9 @@ extern "C" int salt_bn_fold(const salt_bn_fold_args* a, void* stream) {
 
 static int bn_bwd_nparts(const salt_bn_bwd_args* a, int64_t* ppb) {
     const int64_t npix = view_pixels(a->y);
+    static const int64_t max_parts = getenv("SALT_BNB_PARTS") ? atoi(getenv("SALT_BNB_PARTS")) : 512;
     int64_t parts = (npix + 31) / 32;                       // >= 32 pixels per block (small maps need the blocks), <= 512 blocks
-    if (parts > 512) parts = 512;
+    if (parts > max_parts) parts = max_parts;
     if (parts < 1) parts = 1;
     const int64_t per = (npix + parts - 1) / parts;
     if (ppb) *ppb = per;
