@@ -26,7 +26,7 @@ inline bool vec_ok(const salt_view& v, int ve) {
     return v.p == nullptr || ((v.C % ve) == 0 && (v.cs % ve) == 0 && (reinterpret_cast<uintptr_t>(v.p) & 15) == 0);
 }
 inline int ew_blocks(int64_t units) {
-    static const int64_t cap = getenv("SALT_EW_BLOCKS") ? atoi(getenv("SALT_EW_BLOCKS")) : 1024;
+    static const int64_t cap = getenv("SALT_EW_BLOCKS") ? atoi(getenv("SALT_EW_BLOCKS")) : 768;      // round 3: 768 (1024 before; every workgroup of the consumer-side finalize kernels pays the statistics prologue)
     int64_t b = (units + 255) / 256; return (int)(b < 1 ? 1 : (b > cap ? cap : b));
 }
 
