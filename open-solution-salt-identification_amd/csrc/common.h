@@ -74,6 +74,9 @@ int conv_ws_launch(const salt_conv_args* a, hipStream_t st);
 int conv_ls_variant(const salt_conv_args* a);
 int conv_ls_launch(const salt_conv_args* a, hipStream_t st);
 
+// conv_wgrad_ls.hip: loader-specialised row-streaming weight gradient (bf16, 3x3, unit step); 0 = not one of its shapes, else nsplit
+int conv_wgrad_ls(const salt_conv_wgrad_args* a, bool launch, hipStream_t st, int* rc);
+
 static inline int ilog2_ceil(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline bool view_ok(const salt_view& v) { return v.p && v.B > 0 && v.H > 0 && v.W > 0 && v.C > 0 && v.cs >= v.C; }

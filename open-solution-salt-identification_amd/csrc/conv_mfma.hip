@@ -2868,7 +2868,8 @@ extern "C" int salt_pack_batched(const salt_pack_batched_args* a, void* stream) 
 extern "C" int salt_conv_wgrad_nsplit(const salt_conv_wgrad_args* a) {
     WgradKP k; int ns = 0;
     if (wgrad_plan(a, &k, &ns)) return -1;
-    return ns;
+    const int ls = conv_wgrad_ls(a, false, nullptr, nullptr);       // the loader-specialised row-streaming kernel has its own split rule
+    return ls > 0 ? ls : ns;
 }
 
 template <typename T>
@@ -2971,6 +2972,7 @@ extern "C" int salt_conv_wgrad(const salt_conv_wgrad_args* a, void* stream) {
     int rc = wgrad_plan(a, &k, &ns);
     if (rc) return rc;
     if (!a->partials) SALT_FAIL(SALT_E_BADARG, "wgrad: partials workspace missing");
+    { int lrc = SALT_OK; if (conv_wgrad_ls(a, true, (hipStream_t)stream, &lrc) > 0) return lrc; }
     if (a->nsplit != ns) SALT_FAIL(SALT_E_BADARG, "wgrad: nsplit %d, expected %d", a->nsplit, ns);
     // A/B switch: the splits add into ONE slab with global_atomic_add_f32 (zeroed here, in stream order) instead of
     // writing nsplit slabs that salt_wgrad_reduce sums.  Not bit-reproducible; off by default.

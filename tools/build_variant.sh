@@ -1,14 +1,16 @@
 #!/bin/bash
-# Build an A/B variant of the library with extra compiler flags: tools/build_variant.sh <name> <flags...>
+# Build an A/B variant of the library with extra compiler flags: [SRC=<file stem>] tools/build_variant.sh <name> <flags...>
 #   -> open-solution-salt-identification_amd/csrc/_variants/libsaltnet_hip.<name>.so   (run with SALT_LIB=<that path>)
+# SRC names the one source compiled with the flags (default conv_mfma); the other objects come from csrc/_obj (build.py first).
 set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
+SRC=${SRC:-conv_mfma}
 C=open-solution-salt-identification_amd/csrc
 mkdir -p $C/_variants/obj_$name
 objs=""
-for f in runtime conv_mfma conv_ws conv_small elementwise se loss input; do
-  if [ $f = conv_mfma ]; then
+for f in runtime conv_mfma conv_ws conv_wgrad_ls conv_small elementwise se loss input; do
+  if [ $f = $SRC ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -I$C -Wno-unused-value "$@" -c $C/$f.hip -o $C/_variants/obj_$name/$f.o
     objs="$objs $C/_variants/obj_$name/$f.o"
   else

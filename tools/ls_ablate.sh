@@ -1,6 +1,6 @@
 #!/bin/bash
 # conv_ls_kernel timing ablations (compile-time, results are wrong): which part of a launch is loading, which MFMA, which epilogue.
-#   build: for a in 1 2 3 4 5 6 7; do tools/build_variant_ws.sh lsab$a -DSALT_LS_ABLATE=$a; done     then (gpurun): tools/ls_ablate.sh
+#   build: for a in 1 2 3 4 5 6 7; do SRC=conv_ws tools/build_variant.sh lsab$a -DSALT_LS_ABLATE=$a; done     then (gpurun): tools/ls_ablate.sh
 # SALT_LS_ABLATE bits: 1 = no fragment reads / MFMAs, 2 = no DMA, 4 = no epilogue  (7 = launch + prologue + barriers only)
 cd "$(dirname "$0")/.."
 V=$PWD/open-solution-salt-identification_amd/csrc/_variants
