@@ -86,7 +86,8 @@ typedef struct {
     float* stats;             /* [nparts][2][Cout] or NULL */
     float* stats_cnt;         /* [nparts] */
     int stats_part0;          /* first partial index written by this launch (ConvT phases) */
-    int cfg;                  /* 0 = auto; else tile-config id (tests / tuning) */
+    int cfg;                  /* low byte: 0 = auto, else tile-config / kernel id (tests / tuning; salt_conv_kernel_id); (cfg >> 8) & 0xff:
+                               * cap on the workgroups per XCD of conv_ws_kernel / conv_ls_kernel (0 = one per CU), whatever the low byte */
     /* Fold mode (data-gradient of a replicate-padded convolution, architectures/base.py:21-27): the launch computes the gradient on
      * the extended grid OH = y.H + fold_top + fold_bottom, OW = y.W + fold_left + fold_right; interior pixels go straight to y
      * (the UNPADDED tensor, (+)= per `accumulate`), the pad ring goes to `strip` ([B][salt_fold_strip_pixels][strip_cs], always

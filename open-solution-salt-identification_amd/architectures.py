@@ -22,6 +22,7 @@ import torch
 from torch import nn
 
 from ._abi import SaltError
+from .engine import timing_experiment
 from .runtime import Engine
 
 
@@ -401,7 +402,7 @@ class UNetResNet(HipNetwork):
         def hyper_up(x, R, k):
             # SALT_EXP_VHYPER_SKIP: TIMING experiment - the step without the four up-sampling launches and their adjoints is
             # the upper bound of what a loader that interpolates on the fly ("virtual hypercolumn") could save; the values are wrong
-            if self.use_hypercolumn and not fused_rows and not os.environ.get('SALT_EXP_VHYPER_SKIP'):
+            if self.use_hypercolumn and not fused_rows and not timing_experiment('SALT_EXP_VHYPER_SKIP'):
                 with g.side():
                     g.upsample(x, R, out=hyper.slice(k * d, d))
         d5 = self.dec5.emit(g, c, e5, cat=cat5)
@@ -412,7 +413,7 @@ class UNetResNet(HipNetwork):
         hyper_up(d3, 4, 2)
         d2 = self.dec2.emit(g, d3, e2, cat=cat2)
         hyper_up(d2, 2, 1)
-        if fused_rows and not os.environ.get('SALT_EXP_VHYPER_SKIP'):
+        if fused_rows and not timing_experiment('SALT_EXP_VHYPER_SKIP'):
             with g.side():
                 g.hyper_rows([d2, d3, d4, d5], [2, 4, 8, 16], hyper.slice(d, 4 * d))
         if self.use_hypercolumn:

@@ -1450,10 +1450,10 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
     const bool v2_ok = a->dtype == SALT_BF16 && a->in_step == 1 && (a->ntaps == 9 || a->ntaps == 4) && a->x.C % 32 == 0 &&
                        a->x.cs % 8 == 0 && (reinterpret_cast<uintptr_t>(a->x.p) & 15) == 0 && !in_tf;
     // ---- tile config heuristic (overridable for tests/tuning)
-    int id = ((a->cfg & 0xff) == 9 || (a->cfg & 0xff) == 10) ? 0 : a->cfg;   // 9 = "conv_ws_kernel where it applies" (conv_ws.hip): the heuristic decides for the rest
+    int id = ((a->cfg & 0xff) == 9 || (a->cfg & 0xff) == 10) ? 0 : (a->cfg & 0xff);   // 9 = "conv_ws_kernel where it applies" (conv_ws.hip): the heuristic decides for the rest
     if (id >= 6 && !v2_ok) id = 0;            // a forced conv_glds config applies where the kernel does (tests force one config per graph)
     if (id == 2 && vt > 1) id = 1;            // 256-pixel tiles x 4 virtual taps exceed the halo-piece budget
-    if (id == 0 && v2_ok && v2_env && (a->cfg == 0 || (a->cfg & 0xff) == 9 || (a->cfg & 0xff) == 10)) {
+    if (id == 0 && v2_ok && v2_env && ((a->cfg & 0xff) == 0 || (a->cfg & 0xff) == 9 || (a->cfg & 0xff) == 10)) {
         if (v2_env >= 6) id = v2_env;
         else {
             // measured (tools/v2_sweep.sh, tools/v2_ablate.sh): the LDS-DMA kernel wins where conv_mfma_kernel's 128x32 tiles cannot
@@ -1500,7 +1500,7 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
                 if (attempt == 0 && cfg->id != 8) { for (const auto& c : kCfgs) if (c.id == 8) cfg = &c; continue; }
                 // tiny maps (4 x 4 and below: a 128-pixel tile is 8+ images, each with its own halo ring): conv_mfma_kernel's tiles
                 // (round 3: a ResNet50 at 64 x 64 in bf16 failed here instead of falling back)
-                if (a->cfg < 6) { for (const auto& c : kCfgs) if (c.id == 4) cfg = &c; continue; }
+                if ((a->cfg & 0xff) < 6) { for (const auto& c : kCfgs) if (c.id == 4) cfg = &c; continue; }
                 SALT_FAIL(SALT_E_UNSUPPORTED, "conv: halo tile of %d pixels too large for the LDS ring", phalo);
             }
             break;

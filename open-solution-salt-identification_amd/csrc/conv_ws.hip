@@ -885,7 +885,7 @@ bool conv_ws_eligible(const salt_conv_args* a) {
     static const int env = getenv("SALT_CONV_WS") ? atoi(getenv("SALT_CONV_WS")) : 1;
     if (!a || a->dtype != SALT_BF16) return false;
     const bool asked = (a->cfg & 0xff) == 9;
-    if (a->cfg != 0 && !asked) return false;
+    if ((a->cfg & 0xff) != 0 && !asked) return false;
     if (!asked && !env) return false;
     if (a->ntaps != 9 || a->in_step != 1 || a->out_step != 1 || a->out_oy || a->out_ox || a->nphase > 1) return false;
     // plain launches, or the FUSED fold of a 3x3 replicate-padded convolution's data gradient (two pad rows on top, two columns right)
@@ -958,7 +958,7 @@ int conv_ws_launch(const salt_conv_args* a, hipStream_t st) {
     k.Cout = Cout; k.n_tiles = Cout / bn;
     int wpx = ws_cus() / 8;                              // workgroups per XCD: one per CU, fewer when the launch has fewer items
     const int cap = (a->cfg >> 8) & 0xff;
-    if ((a->cfg & 0xff) == 9 && cap && wpx > cap) wpx = cap > k.n_tiles ? cap : k.n_tiles;
+    if (cap && wpx > cap) wpx = cap > k.n_tiles ? cap : k.n_tiles;
     k.per_xcd = cdiv(k.ntiles, 8);
     k.slots = wpx / k.n_tiles;
     if (k.slots > k.per_xcd) k.slots = k.per_xcd;
@@ -1005,7 +1005,7 @@ int conv_ls_variant(const salt_conv_args* a) {
     static const int env = getenv("SALT_CONV_LS") ? atoi(getenv("SALT_CONV_LS")) : 1;
     if (!ls_common_ok(a)) return 0;
     const bool asked = (a->cfg & 0xff) == 10;
-    if (a->cfg != 0 && !asked) return 0;
+    if ((a->cfg & 0xff) != 0 && !asked) return 0;
     if (!asked && !env) return 0;
     const int Cout = a->y.C;
     int wpx = ws_cus() / 8;
@@ -1044,7 +1044,7 @@ int conv_ls_launch(const salt_conv_args* a, hipStream_t st) {
     int wpx = ws_cus() / 8;
     const int cap = (a->cfg >> 8) & 0xff;
     k.n_tiles = k.Cout / (32 * ni);
-    if ((a->cfg & 0xff) == 10 && cap && wpx > cap) wpx = cap > k.n_tiles ? cap : k.n_tiles;      // (never fewer than one workgroup per channel block)
+    if (cap && wpx > cap) wpx = cap > k.n_tiles ? cap : k.n_tiles;      // (never fewer than one workgroup per channel block)
     if (k.n_tiles > wpx) SALT_FAIL(SALT_E_UNSUPPORTED, "conv_ls: %d channel blocks for %d workgroups per XCD", k.n_tiles, wpx);
     k.per_xcd = cdiv(k.ntiles, 8);
     k.slots = wpx / k.n_tiles;

@@ -24,6 +24,18 @@ TORCH_DT = {'f32': torch.float32, 'bf16': torch.bfloat16}
 VEC = {'f32': 4, 'bf16': 8}
 
 
+def timing_experiment(name):
+    """True when the TIMING-ONLY measurement switch `name` (SALT_EXP_*: DESIGN 8 / 10) is set.  Such a switch makes the step compute
+    WRONG values (it exists to time an upper bound), so it is honoured only together with SALT_TIMING_ONLY=1 - which bench.py / tools
+    set on request and SegmentationModel.fit refuses - and fails loudly otherwise (nothing warned when one leaked into a
+    training run)."""
+    if not os.environ.get(name):
+        return False
+    if os.environ.get('SALT_TIMING_ONLY') != '1':
+        raise SaltError('%s is a timing-only experiment (results are wrong): set SALT_TIMING_ONLY=1 to acknowledge, or unset it' % name)
+    return True
+
+
 def _round_up(v, m):
     return (v + m - 1) // m * m
 
@@ -469,6 +481,10 @@ class Graph:
         stream = fold.pop('stream', None)
         kw.update(fold)
         kw.update(self._plane_args(x_view, y_view))
+        if prog is self.bwd and not (cfg >> 8) and os.environ.get('SALT_CONV_WPX_BWD'):
+            # A/B: workgroups per XCD of the whole-CU kernels (conv_ws / conv_ls) in BACKWARD, where they share the chip with the
+            # weight-gradient stream (a whole-CU workgroup waits for a CU the other stream has left completely)
+            kw['cfg'] = cfg | (int(os.environ['SALT_CONV_WPX_BWD']) << 8)
         return prog.add('conv', stream=stream, **kw)
 
     @staticmethod
@@ -535,7 +551,7 @@ class Graph:
         if F is not None:                        # the producer only adds to the shards; this operator finalizes them
             self.fwd.set_fields(sa, fin=ctypes.addressof(F))
             off = self._fin_slot('fwd', 8 * (2 * bn.num_features + 1), (producer, 'fin_acc'), (sa, 'fin_acc'))
-            if (os.environ.get('SALT_EXP_BN_FOLD') and res is None and relu and self.dtype == 'bf16' and out.c0 == 0 and out.C == out.buf.C
+            if (timing_experiment('SALT_EXP_BN_FOLD') and res is None and relu and self.dtype == 'bf16' and out.c0 == 0 and out.C == out.buf.C
                     and self.fwd.streams[-1] == 0):
                 # measurement switch: if the ONLY forward reader of `out` turns out to be one 3x3 convolution, that launch
                 # applies this BatchNorm + ReLU in its loader (salt_conv_args.in_*) and this affine_act is dropped (build_backward)
@@ -711,6 +727,8 @@ class Graph:
 
     def _wgrad(self, p_view, q_view, taps_dydx, taps_khkw, q_step, pad_mode, weight, KH, KW):
         """dW = sum_p P[p,:]^T Q[p*q_step + tap, :] -> weight.grad (reference layout [Ca][Cb][KH][KW])."""
+        if timing_experiment('SALT_EXP_NO_WGRAD'):       # TIMING ONLY: the step without its weight-gradient launches (what the side stream costs the main chain)
+            return
         gw = self._gp(weight)
         Ca, Cb = p_view.C, q_view.C
         first = True

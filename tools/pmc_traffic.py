@@ -21,8 +21,11 @@ def per_kernel(path, counter):
     rows = list(c.execute(q))
     # keep the dispatches of complete optimizer steps after the first Adam launch (skips warm-up compile / first-touch effects)
     marks = [i for i, r in enumerate(rows) if 'adam_kernel' in r[0]]
+    ntrain = int(os.environ.get('SALT_PMC_TRAIN_STEPS', '0'))          # warm-up + timed steps of the profiled run: what follows is not a training step
+    if ntrain:
+        marks = marks[:ntrain]
     lo, hi = marks[1] + 1, marks[-1] + 1
-    steps = len(marks) - 2
+    steps = len(marks) - 2                                             # the intervals between marks[1] and marks[-1]: executed steps
     agg = defaultdict(lambda: [0, 0.0])
     for name, _, v in rows[lo:hi]:
         k = name.replace('_ZN12_GLOBAL__N_1', '').replace('.kd', '')

@@ -20,4 +20,4 @@ def main(path, which=-3):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1])
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else -3)       # which Adam-delimited interval (index into the Adam launches)

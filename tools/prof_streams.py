@@ -1,9 +1,13 @@
 #!/usr/bin/env python
 """Per-queue view of a training step from a rocprofv3 rocpd database: busy time per HIP stream (hardware queue), the kernels on
-each, and the phases of the step (forward / loss / backward / optimizer) by wall time.  usage: python tools/prof_streams.py <db> [skip]"""
+each, and the phases of the step (forward / loss / backward / optimizer) by wall time.
+usage: python tools/prof_streams.py <db> [skip] [train_steps]
+train_steps = warm-up + timed steps of the profiled bench.py run: only intervals between THOSE Adam launches are steps (what follows -
+bench.py's per-operator roofline pass, the eval pass - also launches Adam-delimited work and used to inflate the per-step figures by ~12 %)."""
 import sqlite3, sys
 from collections import defaultdict
 path = sys.argv[1]; skip = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+ntrain = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 c = sqlite3.connect(path)
 t = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
 kd = [x for x in t if 'kernel_dispatch' in x][0]; ks = [x for x in t if 'kernel_symbol' in x][0]
@@ -11,6 +15,8 @@ cols = [r[1] for r in c.execute('pragma table_info(%s)' % kd)]
 qcol = 'queue_id' if 'queue_id' in cols else ('stream_id' if 'stream_id' in cols else None)
 rows = list(c.execute("select s.kernel_name, d.start, d.end, d.%s from %s d join %s s on d.kernel_id=s.id order by d.start" % (qcol, kd, ks)))
 marks = [i for i, r in enumerate(rows) if 'adam_kernel' in r[0]]
+if ntrain:
+    marks = marks[:ntrain]
 steps = [(marks[i] + 1, marks[i + 1] + 1) for i in range(skip, len(marks) - 1)]
 n = len(steps)
 perq = defaultdict(lambda: [0.0, 0, defaultdict(float)])

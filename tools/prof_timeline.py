@@ -1,19 +1,23 @@
 #!/usr/bin/env python
 """Step timeline from a rocprofv3 rocpd database: wall span per optimizer step, GPU-busy union, idle gaps,
 and per-kernel time per step (steps are delimited by the Adam kernel).
-usage: python tools/prof_timeline.py <results.db> [skip_steps]"""
+usage: python tools/prof_timeline.py <results.db> [skip_steps] [train_steps]
+train_steps = warm-up + timed steps of the profiled bench.py run: only intervals between those Adam launches count as steps (the
+roofline / eval passes behind them are not training steps)."""
 import sqlite3
 import sys
 from collections import defaultdict
 
 
-def main(path, skip=8):
+def main(path, skip=8, ntrain=0):
     c = sqlite3.connect(path)
     t = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
     kd = [x for x in t if 'kernel_dispatch' in x][0]
     ks = [x for x in t if 'kernel_symbol' in x][0]
     rows = list(c.execute("select s.kernel_name, d.start, d.end from %s d join %s s on d.kernel_id=s.id order by d.start" % (kd, ks)))
     marks = [i for i, r in enumerate(rows) if 'adam_kernel' in r[0]]
+    if ntrain:
+        marks = marks[:ntrain]
     if len(marks) < skip + 2:
         skip = 0
     steps = [(marks[i] + 1, marks[i + 1] + 1) for i in range(skip, len(marks) - 1)]
@@ -46,4 +50,4 @@ def main(path, skip=8):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 8)
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 8, int(sys.argv[3]) if len(sys.argv) > 3 else 0)
