@@ -588,7 +588,7 @@ def main():
         try:
             cv = json.load(open(os.path.join(ROOT, 'profiles', 'r03_convergence.json')))
             last = str(cv['config']['steps'])
-            out['val_iou_parity'] = {'source': 'profiles/r03_convergence.json (tools/convergence_parity.py: R34 hypercolumn, batch %d, %s steps, '
+            out['val_iou_parity_quoted'] = {'quoted': True, 'note': 'NOT measured in this run: quoted from the committed file; the measured, driver-visible check is tests/test_gpu_convergence.py (-m gpu)', 'source': 'profiles/r03_convergence.json (tools/convergence_parity.py: R34 hypercolumn, batch %d, %s steps, '
                                                'identical init and batches, %d held-out tiles)' % (cv['config']['batch'], last, cv['config']['val_tiles']),
                                      'val_iou_cpu_oracle_f32': cv['val_iou']['cpu_oracle_f32'][last], 'val_iou_hip_f32': cv['val_iou']['hip_f32'][last],
                                      'val_iou_hip_bf16': cv['val_iou']['hip_bf16'][last],

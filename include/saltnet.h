@@ -726,7 +726,11 @@ typedef struct {
     int interpolation;        /* of the resize.  1: cubic - cv2.INTER_CUBIC as imgaug 0.2.5's iaa.Scale default (augmentation.py:79-85 passes no
                                * interpolation; environment.yml:15-16): Keys kernel a = -0.75, half-pixel centres, replicated border; a uint8
                                * tile is rounded back to the uint8 grid with saturation (cv2's uint8 output) and the {0,1} mask goes through the
-                               * same resize, then round-half-up.  0: bilinear, half-pixel centres, nearest for the mask (rounds 1 - 2 default) */
+                               * same resize, then round-half-up (the FLOAT form of the filter).  2 (uint8 tiles only): the same filter as
+                               * opencv_python 3.4.0.12 evaluates it on CV_8U - per-axis coefficients rounded to 11-bit fixed point
+                               * (cvRound(c * 2048), each on its own), integer horizontal / vertical sums, saturate((v + 2^21) >> 22);
+                               * differs from 1 by one LSB on a few percent of the pixels.  0: bilinear, half-pixel centres, nearest for
+                               * the mask (rounds 1 - 2 default) */
 } salt_preprocess_args;
 int salt_preprocess(const salt_preprocess_args*, void* stream);
 

@@ -4,6 +4,8 @@
 // 247-284, utils.py:494-500, loaders.py:763-769) is one pass here:
 //   gray tile [h, w] (uint8 or float in [0,1])
 //     -> optional resize to [rh, rw]: cubic (cv2.INTER_CUBIC, imgaug's iaa.Scale default) or bilinear     train: 101 -> 102
+//        uint8 tiles: cv2's own 11-bit FIXED-POINT evaluation of the separable cubic (interpolation 2, cubic_fixed_u8 below);
+//        float tiles / interpolation 1: the float form of the same filter
 //     -> edge (replicate) pad: `top` rows / `left` columns, rest to [H, W]                                train: 13; inference 13/14
 //     -> Grayscale(3) + ToTensor + Normalize(mean, std) per channel
 //     -> AddDepthChannels: ch1 := linspace(0, 1, H)[row], ch2 := ch0 * ch1                                (3-channel mode)
@@ -33,6 +35,31 @@ __device__ __forceinline__ void cubic_w(float t, float (&w)[4]) {
     w[3] = 1.f - w[0] - w[1] - w[2];
 }
 
+// cv2.resize(..., INTER_CUBIC) on CV_8U as opencv_python 3.4.0.12 (environment.yml:16) evaluates it (modules/imgproc/src/resize.cpp:
+// resizeGeneric_<HResizeCubic<uchar, int, short>, VResizeCubic<uchar, int, short, FixedPtCast<int, uchar, 22>, ...>>), restated:
+//   per axis   fx = (float)((d + 0.5) * scale - 0.5) with scale = 1 / ((double)out / in);  s = floor(fx);  t = fx - s   (float)
+//              coefficients interpolateCubic(t) in float32 (A = -0.75f, the four expressions below, no FMA contraction), each
+//              rounded on its own to a short: cvRound(c * 2048)   (their sum is 2047 .. 2049)
+//   horizontal int sums of uchar x short over taps s - 1 .. s + 2 (indices clamped = BORDER_REPLICATE)
+//   vertical   int sum of those x short, then saturate_cast<uchar>((v + (1 << 21)) >> 22)
+// (the SSE2 build of that release runs the vertical pass of whole 8-pixel groups in float32 with round-to-nearest-even: the same
+//  value except where v / 2^22 sits within float rounding of a tie - the integer form is the documented one and is what is restated.)
+__device__ __forceinline__ void cubic_coef_fixed(int d, double scale, int& s0, int (&c)[4]) {
+    const float fx = (float)(((double)d + 0.5) * scale - 0.5);
+    const float sf = floorf(fx);
+    const float t = __fsub_rn(fx, sf);
+    s0 = (int)sf - 1;
+    const float A = -0.75f;
+    const float x1 = __fadd_rn(t, 1.f);
+    const float c0 = __fsub_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fsub_rn(__fmul_rn(A, x1), __fmul_rn(5.f, A)), x1), __fmul_rn(8.f, A)), x1), __fmul_rn(4.f, A));
+    const float c1 = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(A, 2.f), t), __fadd_rn(A, 3.f)), t), t), 1.f);
+    const float u = __fsub_rn(1.f, t);
+    const float c2 = __fadd_rn(__fmul_rn(__fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(A, 2.f), u), __fadd_rn(A, 3.f)), u), u), 1.f);
+    const float c3 = __fsub_rn(__fsub_rn(__fsub_rn(1.f, c0), c1), c2);
+    c[0] = __float2int_rn(__fmul_rn(c0, 2048.f)); c[1] = __float2int_rn(__fmul_rn(c1, 2048.f));
+    c[2] = __float2int_rn(__fmul_rn(c2, 2048.f)); c[3] = __float2int_rn(__fmul_rn(c3, 2048.f));
+}
+
 __global__ void preprocess_kernel(PreKP p) {
     const int64_t n = (int64_t)p.B * p.H * p.W;
     const float sy = (float)p.h / (float)p.rh, sx = (float)p.w / (float)p.rw;
@@ -46,6 +73,28 @@ __global__ void preprocess_kernel(PreKP p) {
         float g, mres = -1.f;                                 // mres >= 0: the mask value out of the cubic resize
         if (p.rh == p.h && p.rw == p.w) {
             g = px(ry, rx);
+        } else if (p.cubic == 2) {
+            const unsigned char* im8 = reinterpret_cast<const unsigned char*>(p.img) + (int64_t)b * p.h * p.w;
+            const unsigned char* mk8 = p.mask ? p.mask + (int64_t)b * p.h * p.w : nullptr;
+            int y0, x0, cy[4], cx[4];
+            cubic_coef_fixed(ry, 1.0 / ((double)p.rh / (double)p.h), y0, cy);
+            cubic_coef_fixed(rx, 1.0 / ((double)p.rw / (double)p.w), x0, cx);
+            int acc = 0, macc = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int yy = min(max(y0 + i, 0), p.h - 1);
+                int row = 0, mrow = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int xx = min(max(x0 + j, 0), p.w - 1);
+                    row += cx[j] * (int)im8[yy * p.w + xx];
+                    if (mk8) mrow += cx[j] * (int)mk8[yy * p.w + xx];         // the uint8 {0, 1} mask goes through the same augment_image call
+                }
+                acc += cy[i] * row; macc += cy[i] * mrow;
+            }
+            g = (float)min(max((acc + (1 << 21)) >> 22, 0), 255) * (1.f / 255.f);
+            mres = (float)min(max((macc + (1 << 21)) >> 22, 0), 255);
+            mres = mres > 0.5f ? 1.f : 0.f;
         } else if (p.cubic) {
             const float fy = ((float)ry + 0.5f) * sy - 0.5f, fx = ((float)rx + 0.5f) * sx - 0.5f;
             const float y0f = floorf(fy), x0f = floorf(fx);
@@ -107,8 +156,10 @@ extern "C" int salt_preprocess(const salt_preprocess_args* a, void* stream) {
     p.img = a->img; p.mask = a->mask; p.x = a->x; p.target = a->target;
     p.img_is_u8 = a->img_is_u8; p.B = a->B; p.h = a->h; p.w = a->w;
     p.rh = a->resize_h > 0 ? a->resize_h : a->h; p.rw = a->resize_w > 0 ? a->resize_w : a->w;
-    p.top = a->top; p.left = a->left; p.H = a->H; p.W = a->W; p.channels = a->channels; p.cubic = a->interpolation == 1;
-    if (a->interpolation != 0 && a->interpolation != 1) SALT_FAIL(SALT_E_BADARG, "preprocess: interpolation %d (0 bilinear | 1 cubic)", a->interpolation);
+    p.top = a->top; p.left = a->left; p.H = a->H; p.W = a->W; p.channels = a->channels; p.cubic = a->interpolation;
+    if (a->interpolation < 0 || a->interpolation > 2) SALT_FAIL(SALT_E_BADARG, "preprocess: interpolation %d (0 bilinear | 1 cubic, float | 2 cubic, cv2 fixed point)", a->interpolation);
+    if (a->interpolation == 2 && !a->img_is_u8) SALT_FAIL(SALT_E_BADARG, "preprocess: the fixed-point cubic resize is cv2's uint8 path: uint8 tiles only");
+    if (a->interpolation == 2 && (int64_t)a->h * a->w >= (1ll << 31)) SALT_FAIL(SALT_E_BADARG, "preprocess: tile too large");
     if (p.top + p.rh > p.H || p.left + p.rw > p.W) SALT_FAIL(SALT_E_BADARG, "preprocess: resized tile + pad offset exceeds the output");
     for (int c = 0; c < 3; ++c) {
         if (a->std[c] <= 0.f) SALT_FAIL(SALT_E_BADARG, "preprocess: std must be positive");

@@ -104,19 +104,24 @@ def _flip_input(X, ud, lr, depth_channels, out=None):
 
 
 def _looks_like_depth_channels(X):
-    """True when channel 1 of a 3-channel batch is the reference's depth ramp: constant along W and the same for every image
-    (utils.py:494-500) - an ordinary 3-channel (e.g. RGB-replicated) input is not, and must be flipped channel by channel."""
+    """True when channels 1 / 2 of a 3-channel batch are the reference's depth channels (utils.py:494-500): channel 1 the row ramp
+    linspace(0, 1, H) shared by every image and column, channel 2 = channel 0 * channel 1.  A 3-channel input that merely has a flat
+    channel 1 (blank tiles, striped data) is NOT one and must be flipped channel by channel.  One host sync; pass
+    depth_channels=True / False to predict_tta to skip the test."""
     if X.dim() != 4 or X.shape[1] != 3:
         return False
-    ramp = X[:, 1]
-    return bool(((ramp - ramp[:1, :, :1]).abs().max() <= 1e-6).item())
+    H = X.shape[2]
+    ramp = torch.linspace(0, 1, H, device=X.device, dtype=X.dtype).view(1, H, 1)
+    ok = ((X[:, 1] - ramp).abs().max() <= 1e-5) & ((X[:, 2] - X[:, 0] * X[:, 1]).abs().max() <= 1e-4 * (1 + X[:, 0].abs().max()))
+    return bool(ok.item())
 
 
 def predict_tta(net, X, flip_ud=False, flip_lr=True, variants_per_pass=None, depth_channels=None, method='mean'):
     """Probabilities [B, C, H, W] of an eval-mode HipNetwork aggregated over the flip variants (reference default main.py:282-285:
     left-right only; BASELINE C4's "4-flip" is flip_ud=True, flip_lr=True).  ``depth_channels``: the input is the reference's
     3-channel [gray, depth ramp, gray*ramp] batch, whose channels 1 / 2 an up-down flip must rebuild rather than flip (see
-    _flip_input); None (default) = decide from the data (channel 1 is a row ramp shared by the batch), True raises if it is not.
+    _flip_input); None (default) = decide from the data (channel 1 = linspace(0, 1, H) AND channel 2 = channel 0 * channel 1; one host
+    sync), True raises if it is not.
     ``method``: 'mean' (default, neptune.yaml:80; one fused kernel) or 'max' / 'min' / 'gmean' (loaders.py:727-735).
 
     The variants are forwarded ``variants_per_pass`` at a time as one larger batch (default: all of them).  For bit-faithful

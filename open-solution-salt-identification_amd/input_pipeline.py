@@ -34,9 +34,12 @@ class DevicePreprocessor:
     def __init__(self, train, channels=3, resize=102, pad=13, divisor=64, mean=MEAN, std=STD, interpolation='cubic'):
         """``interpolation`` of the train-branch resize: 'cubic' (default) is what the reference executes - augmentation.py:79-85 calls
         ``iaa.Scale({...})`` without an interpolation argument and imgaug 0.2.5 (environment.yml:15) defaults to 'cubic' =
-        cv2.INTER_CUBIC, applied to the uint8 tile AND the uint8 {0,1} mask; 'bilinear' is rounds 1-2 of this build."""
-        if interpolation not in ('cubic', 'bilinear'):
-            raise SaltError('DevicePreprocessor: interpolation %r (cubic | bilinear)' % (interpolation,))
+        cv2.INTER_CUBIC, applied to the uint8 tile AND the uint8 {0,1} mask.  uint8 tiles take cv2's own evaluation of that filter
+        (11-bit fixed-point coefficients, integer sums, saturating shift: opencv_python 3.4.0.12, environment.yml:16); float tiles -
+        and 'cubic_float' for uint8 ones - the float form of the same filter (differs by 1 LSB on a few percent of the pixels);
+        'bilinear' is rounds 1-2 of this build."""
+        if interpolation not in ('cubic', 'cubic_float', 'bilinear'):
+            raise SaltError('DevicePreprocessor: interpolation %r (cubic | cubic_float | bilinear)' % (interpolation,))
         self.interpolation = interpolation
         self.train, self.channels, self.resize, self.pad, self.divisor = bool(train), int(channels), resize, pad, divisor
         self.mean, self.std = tuple(mean), tuple(std)
@@ -68,6 +71,7 @@ class DevicePreprocessor:
         s = S()
         fill(s, img=images.data_ptr(), img_is_u8=int(images.dtype == torch.uint8), mask=mptr, B=B, h=h, w=w, resize_h=rh, resize_w=rw,
              top=top, left=left, H=H, W=W, channels=self.channels, mean=list(self.mean), std=list(self.std), x=x.data_ptr(),
-             target=target.data_ptr() if target is not None else None, interpolation=1 if self.interpolation == 'cubic' else 0)
+             target=target.data_ptr() if target is not None else None,
+             interpolation=0 if self.interpolation == 'bilinear' else (2 if self.interpolation == 'cubic' and images.dtype == torch.uint8 else 1))
         check(fn(ctypes.byref(s), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'preprocess')
         return x, target

@@ -13,78 +13,119 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
+def _synthetic_256(n, seed):
+    """n synthetic 202 x 202 salt tiles through the inference-geometry preprocessor -> (X [n,3,256,256], target [n,2,256,256]) on the device."""
+    import bench
+    from salt_amd.input_pipeline import DevicePreprocessor
+    img, msk = bench.synth_tiles(n, seed=seed, size=202)
+    u8 = torch.from_numpy((img * 255).astype(np.uint8)).to(DEV)
+    return DevicePreprocessor(False, 3)(u8, torch.from_numpy(msk.astype(np.uint8)).to(DEV))
+
+
 def test_c4_r152_tta_pipeline_bf16_full_shape():
-    """R152 + predict_tta (flip_ud x flip_lr) + crop_threshold at [16,3,256,256] bf16.
-    (1) image 0 against the fp32 oracle pipeline (numpy flips, 4 oracle forwards, sigmoid, inverse flips, mean, crop, > 0.5);
-    (2) equivariance over the whole batch: the TTA mean over the flip group commutes with a flip of the input;
-    (3) a probability is a mean of sigmoids: in [0, 1], finite."""
-    from salt_amd import architectures as A, inference as I
-    from oracle import nets as ON, specs as OS, metrics as OM
+    """R152 + predict_tta (flip_ud x flip_lr) + crop_threshold at [16,3,256,256] bf16 on a CONDITIONED network: round 3 ran this on a
+    random-init R152 whose probabilities all sat within 0.12 of the threshold, so 17 % of the mask pixels flipped under ANY bf16
+    implementation and the test could only bound the error by an emulation.  Here the network is first trained
+    for a few steps on synthetic salt tiles (the shipped fused step), which pulls the logits apart like a checkpoint's, and then:
+    (1) ALL 16 images against the fp32 oracle pipeline (numpy flips, 4 oracle forwards of the batch, sigmoid, inverse flips, mean,
+        crop, > 0.5): mask agreement >= 0.999 per image, every differing pixel within the measured probability error of the threshold;
+    (2) image 0 also against the oracle with bf16 STORAGE emulated (oracle.blocks.bf16_storage): the HIP path is no further from the
+        fp32 pipeline than 1.5x / 2x what bf16 storage costs any implementation;
+    (3) equivariance over the whole batch: the TTA mean over the flip group commutes with a flip of the input;
+    (4) a probability is a mean of sigmoids: in [0, 1], finite."""
+    from salt_amd import inference as I
+    from oracle import nets as ON, specs as OS, metrics as OM, blocks as OB
+    from test_gpu_fused_step import _segmentation_model
+    from helpers import record_parity
     torch.manual_seed(11)
-    net = A.UNetResNet(152, 2, use_hypercolumn=True, dropout_2d=0.0, pretrained=False)
+    m = _segmentation_model('UNetResNet152', 'lovasz', dtype='bf16', lr=2e-4)
     spec = OS.SPECS['UNetResNet'](with_fc=True, depth=152)
-    sd = OS.init_state(spec, seed=9)
-    net.load_state_dict({k: sd[k] for k in net.state_dict() if k in sd}, strict=False)
-    X = CF.input_for('c4', (16, 3, 256, 256))
-    Xd = X.to(DEV)
-    # a checkpoint's BatchNorm running statistics are calibrated; random init + (0, 1) statistics through 152 layers saturates every
-    # sigmoid.  Calibrate them with ONE train-mode forward at momentum 1 (fp32, on the device), then freeze: the test is about eval.
-    for mod in net.modules():
-        if isinstance(mod, torch.nn.BatchNorm2d):
-            mod.momentum = 1.0
-    net.to(DEV).train()
-    with torch.no_grad():
-        net(Xd)
+    sd0 = OS.init_state(spec, seed=9)
+    m.model.load_state_dict({k: sd0[k] for k in m.model.state_dict() if k in sd0}, strict=False)
+    m._to_device()
+    m.model.train()
+    STEPS = 24
+    Xt, Tt = _synthetic_256(16 * 8, seed=77)                              # 8 distinct batches, cycled
+    losses = []
+    for it in range(STEPS):
+        j = (it % 8) * 16
+        losses.append(float(m._fit_loop([Xt[j:j + 16], Tt[j:j + 16]])['sum']))
+    torch.cuda.synchronize()
+    assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
+    net = m.model
     net.eval()
-    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items() if k in spec}
-    net.set_compute_dtype('bf16')
-    prob = I.predict_tta(net, Xd, True, True, depth_channels=False)
+    sd = {k: v.detach().cpu().float().clone() for k, v in net.state_dict().items() if k in spec}
+    Xd, _ = _synthetic_256(16, seed=78)                                    # held-out tiles, [16,3,256,256]
+    X = Xd.cpu()
+    prob = I.predict_tta(net, Xd, True, True, depth_channels=True)
     mask = I.crop_threshold(prob, (202, 202), 0.5, cls=1)
     torch.cuda.synchronize()
     p = prob.float().cpu()
-    assert torch.isfinite(p).all() and float(p.min()) >= 0.0 and float(p.max()) <= 1.0
+    assert torch.isfinite(p).all() and float(p.min()) >= 0.0 and float(p.max()) <= 1.0                          # (4)
     assert tuple(mask.shape) == (16, 202, 202) and mask.dtype == torch.uint8
-    # (2) flip the whole input batch left-right: the aggregated probabilities flip with it (same four forwards per image, in
-    # another order: bf16 rounding is identical per variant, the fp32 mean is order dependent in its last bit only)
-    prob_f = I.predict_tta(net, torch.flip(Xd, dims=[3]).contiguous(), True, True, depth_channels=False).float().cpu()
+    # (3) flip the whole input batch left-right (channel by channel: a left-right flip leaves the depth ramp alone): the aggregated
+    # probabilities flip with it (same four forwards per image in another order; the fp32 mean is order dependent in its last bit only)
+    prob_f = I.predict_tta(net, torch.flip(Xd, dims=[3]).contiguous(), True, True, depth_channels=True).float().cpu()
     assert float((torch.flip(prob_f, dims=[3]) - p).abs().max()) <= 1e-5
-    # (1) oracle for image 0: fp32, and fp32 with bf16 STORAGE emulated at the boundaries where the HIP path stores bf16
-    # (oracle.blocks.bf16_storage) - the yardstick for what bf16 through 152 layers costs in ANY implementation
-    from oracle import blocks as OB
+    # (1) oracle pipeline for the whole batch.  A variant of the reference flips the RAW tile and then normalises / adds the depth
+    # channels (loaders.py:401-423 -> 603-612): gray flipped, ramp kept, channel 2 = flipped gray x ramp
     specs = OM.tta_specs(True, True)
 
-    def oracle_tta(emulate):
+    def variant(xb, sp):
+        ud, lr = bool(sp['ud_flip']), bool(sp['lr_flip'])
+        dims = [d for d, f in ((2, ud), (3, lr)) if f]
+        if not dims:
+            return xb
+        y = torch.flip(xb, dims=dims).contiguous()
+        if ud:
+            y[:, 1] = xb[:, 1]
+            y[:, 2] = y[:, 0] * xb[:, 1]
+        return y
+
+    def oracle_tta(xb, emulate):
         preds = []
         for sp in specs:
-            xv = OM.tta_transform(X[0].permute(1, 2, 0).numpy(), sp)
-            xv = torch.from_numpy(np.ascontiguousarray(xv)).permute(2, 0, 1)[None]
             with torch.no_grad():
                 if emulate:
                     with OB.bf16_storage():
-                        o = ON.unet_resnet(sd, xv, False, depth=152)
+                        o = ON.unet_resnet(sd, variant(xb, sp), False, depth=152)
                 else:
-                    o = ON.unet_resnet(sd, xv, False, depth=152)
-            preds.append(OM.sigmoid(o[0].float().numpy()))
-        return OM.tta_aggregate(preds, specs, 'mean')
-    ref, emu = oracle_tta(False), oracle_tta(True)
-    got = p[0].numpy()
-    err, err_emu = np.abs(got - ref), np.abs(emu - ref)
-    ref_crop = OM.crop_image(ref, (202, 202))[1]
-    ref_mask = ref_crop > 0.5
-    agree = float((mask[0].cpu().numpy().astype(bool) == ref_mask).mean())
-    agree_emu = float(((OM.crop_image(emu, (202, 202))[1] > 0.5) == ref_mask).mean())
-    print('C4 composed, image 0 vs fp32 oracle: probability error HIP bf16 mean %.3e max %.3e | emulated bf16 storage mean %.3e max %.3e | '
-          'mask agreement HIP %.5f / emulation %.5f' % (err.mean(), err.max(), err_emu.mean(), err_emu.max(), agree, agree_emu))
-    assert err.mean() <= 1.5 * err_emu.mean() + 1e-3 and err.max() <= 2.0 * err_emu.max() + 1e-2, (err.mean(), err_emu.mean(), err.max(), err_emu.max())
-    assert agree >= agree_emu - 0.01, (agree, agree_emu)
-    # every disagreeing mask pixel has a reference probability within the measured bf16 error of the threshold
-    dis = mask[0].cpu().numpy().astype(bool) != ref_mask
-    from helpers import record_parity
-    record_parity('C4_r152_tta_bf16_crop_threshold_masks', config='[16,3,256,256] bf16, 4-flip TTA mean, crop 202, > 0.5; image 0 vs fp32 oracle pipeline',
-                  decisions=int(dis.size), differ=int(dis.sum()), agreement=agree, agreement_emulated_bf16_storage=agree_emu,
-                  prob_error_mean=float(err.mean()), prob_error_max=float(err.max()),
-                  max_ref_distance_to_threshold_at_differing=float(np.abs(ref_crop - 0.5)[dis].max()) if dis.any() else 0.0)
-    assert not dis.any() or float(np.abs(ref_crop - 0.5)[dis].max()) <= float(err.max()) + 1e-6
+                    o = ON.unet_resnet(sd, variant(xb, sp), False, depth=152)
+            preds.append(OM.sigmoid(o.float().numpy()))
+        out = []
+        for b in range(xb.shape[0]):
+            out.append(OM.tta_aggregate([q[b] for q in preds], specs, 'mean'))
+        return np.stack(out)
+    ref = oracle_tta(X, False)                                             # [16, 2, 256, 256]
+    got = p.numpy()
+    err = np.abs(got - ref)
+    worst_agree, total_dis, decisions = 1.0, 0, 0
+    for b in range(16):
+        ref_crop = OM.crop_image(ref[b], (202, 202))[1]
+        ref_mask = ref_crop > 0.5
+        dis = mask[b].cpu().numpy().astype(bool) != ref_mask
+        agree = 1.0 - float(dis.mean())
+        worst_agree = min(worst_agree, agree)
+        total_dis += int(dis.sum()); decisions += int(dis.size)
+        assert agree >= 0.999, 'image %d: mask agreement %.5f' % (b, agree)
+        # every disagreeing mask pixel has a reference probability within the measured bf16 error of the threshold
+        assert not dis.any() or float(np.abs(ref_crop - 0.5)[dis].max()) <= float(err.max()) + 1e-6
+    near = float((np.abs(ref[:, 1] - 0.5) < 0.05).mean())
+    # (2) the emulation yardstick on image 0
+    emu = oracle_tta(X[:1], True)[0]
+    err0, err_emu = err[0], np.abs(emu - ref[0])
+    print('C4 composed, 16 images vs fp32 oracle: probability error HIP bf16 mean %.3e max %.3e; worst per-image mask agreement %.5f '
+          '(%d of %d decisions differ); %.2f %% of the reference probabilities within 0.05 of the threshold | image 0: HIP mean %.3e max %.3e, '
+          'emulated bf16 storage mean %.3e max %.3e | training loss %.3f -> %.3f'
+          % (err.mean(), err.max(), worst_agree, total_dis, decisions, 100 * near, err0.mean(), err0.max(), err_emu.mean(), err_emu.max(),
+             losses[0], losses[-1]))
+    # measured (round 4): HIP 8.9e-5 / 5.9e-4 (mean / max) on image 0 against 1.06e-4 / 5.7e-4 for the emulation; 3.0e-3 max over the batch
+    assert err0.mean() <= 1.5 * err_emu.mean() + 1e-4 and err0.max() <= 2.0 * err_emu.max() + 2e-3, (err0.mean(), err_emu.mean(), err0.max(), err_emu.max())
+    assert err.max() <= 2e-2 and err.mean() <= 5e-4, (err.max(), err.mean())
+    record_parity('C4_r152_tta_bf16_crop_threshold_masks',
+                  config='[16,3,256,256] bf16, 4-flip TTA mean, crop 202, > 0.5; R152 hypercolumn conditioned by %d fused training steps; all 16 images vs the fp32 oracle pipeline' % STEPS,
+                  decisions=decisions, differ=total_dis, worst_image_agreement=worst_agree, prob_error_mean=float(err.mean()), prob_error_max=float(err.max()),
+                  frac_ref_within_0p05_of_threshold=near, image0_prob_error_mean=float(err0.mean()), image0_emulated_bf16_storage_error_mean=float(err_emu.mean()))
 
 
 def test_c3_r34_batch64_train_step_fp32_vs_oracle():

@@ -208,7 +208,14 @@ def test_device_input_pipeline_vs_oracle(train, channels, as_u8, interpolation='
     Xr, Tr = OI.preprocess(img, msk, train, channels, interpolation=interpolation, uint8_grid=as_u8)
     assert tuple(X.shape) == tuple(Xr.shape) == (B, channels, 128, 128)
     if train and interpolation == 'cubic' and as_u8:
-        # both sides round the cubic value onto the uint8 grid; float summation order may move a value across a rounding boundary:
+        # uint8 tiles: cv2's fixed-point evaluation (integer sums) on both sides - the resized uint8 values are EQUAL, what remains is
+        # the float normalisation
+        g_dev = torch.round((X.cpu()[:, 0] * 0.229 + 0.485) * 255)
+        g_ref = torch.round((Xr[:, 0] * 0.229 + 0.485) * 255)
+        assert torch.equal(g_dev, g_ref), int((g_dev != g_ref).sum())
+        assert_close(X.cpu(), Xr, 2e-6, 'input batch (fixed-point cubic)')
+    elif train and interpolation == 'cubic_float' and as_u8:
+        # the float form rounds onto the uint8 grid on both sides; float summation order may move a value across a rounding boundary:
         # at most one grid step (1 / 255 / std), on a vanishing fraction of the pixels
         d = (X.cpu() - Xr)[:, 0].abs()
         assert float(d.max()) <= 1.0 / 255 / 0.229 + 1e-5, float(d.max())
@@ -218,6 +225,18 @@ def test_device_input_pipeline_vs_oracle(train, channels, as_u8, interpolation='
     assert torch.equal(Tg.cpu(), Tr)                                         # one-hot target: exact
     X2, T2 = pre(dev_img)                                                    # inference batches carry no target
     assert T2 is None and torch.equal(X2, X)
+
+
+def test_device_input_pipeline_cubic_float_mode_for_uint8_tiles():
+    """interpolation='cubic_float': round 3's float form of the cubic for uint8 tiles, kept selectable; it is NOT what cv2 computes
+    (the fixed-point default differs from it by one grey level on a few percent of the pixels of a noise tile)."""
+    test_device_input_pipeline_vs_oracle(True, 3, True, interpolation='cubic_float')
+    from salt_amd.input_pipeline import DevicePreprocessor
+    u8 = torch.from_numpy(np.random.RandomState(7).randint(0, 256, (2, 101, 101)).astype(np.uint8)).to(DEV)
+    a, _ = DevicePreprocessor(True, 1)(u8)
+    b, _ = DevicePreprocessor(True, 1, interpolation='cubic_float')(u8)
+    frac = float(((a - b).abs() > 1e-4).float().mean())
+    assert 0.005 < frac < 0.15, frac
 
 
 @pytest.mark.parametrize('as_u8', [True, False])

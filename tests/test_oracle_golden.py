@@ -267,6 +267,41 @@ def test_cubic_resize_restatement_kats():
     assert g.min() >= -1e-6 and g.max() <= 1 + 1e-6                         # saturated onto [0, 255] / 255
 
 
+def test_cv2_fixed_point_cubic_kats():
+    """cv2.INTER_CUBIC on uint8 (opencv_python 3.4.0.12, resize.cpp) evaluates the separable cubic in 11-bit fixed point; known answers
+    by hand arithmetic that tell it from the float form:
+      * t = 0.5: coefficients (-3/32, 19/32, 19/32, -3/32) x 2048 = (-192, 1216, 1216, -192), sum 2048; t = 0.25: (-216, 1800, 536, -72);
+      * 101 -> 102, output column 0: fx = 0.5 * 101 / 102 - 0.5 = -0.0049 -> first tap -2, t = 0.9951 -> (0, 8, 2048, -7): the four
+        coefficients are rounded one by one and sum to 2049, not 2048;
+      * a 1 x 4 row (0, 255, 0, 255) resized to width 4 (identity geometry, t = 0): every output equals its input exactly;
+      * the 4 x 4 image below -> 5 x 5: fixed point gives 226 / 59 where the float form rounds to 227 / 60."""
+    from oracle import inputs as OI
+    assert OI.cv_cubic_coeffs_fixed(0.5) == [-192, 1216, 1216, -192]
+    assert OI.cv_cubic_coeffs_fixed(0.25) == [-216, 1800, 536, -72]
+    first, coef = OI.cv_axis_tables(101, 102)
+    assert first[0] == -2 and coef[0] == [0, 8, 2048, -7] and sum(coef[0]) == 2049
+    assert first[101] == 99 and sum(coef[101]) in (2047, 2048, 2049)
+    row = np.array([[0, 255, 0, 255]], np.uint8)
+    assert OI.resize_cubic_u8_fixed(row, 1, 4).tolist() == row.tolist()
+    img = np.array([[19, 133, 248, 83], [57, 45, 4, 70], [176, 190, 162, 87], [191, 211, 224, 207]], np.uint8)
+    fixed = OI.resize_cubic_u8_fixed(img, 5, 5)
+    assert fixed.tolist() == [[9, 91, 229, 226, 73], [32, 48, 54, 59, 73], [119, 116, 79, 52, 67], [192, 208, 213, 174, 118], [191, 205, 223, 226, 213]]
+    flt = torch.nn.functional.interpolate(torch.from_numpy(img.astype(np.float32) / 255)[None, None], size=(5, 5), mode='bicubic', align_corners=False)
+    flt = torch.clamp(torch.floor(flt * 255 + 0.5), 0, 255)[0, 0].numpy().astype(np.uint8)
+    assert flt[0, 3] == 227 and flt[1, 3] == 60 and int((flt != fixed).sum()) == 2
+    # hand check of fixed[0][3]: output row 0 of 4 -> 5: fy = 0.5 * 0.8 - 0.5 = -0.1 -> taps rows -2 .. 1 (clamped: 0, 0, 0, 1), t = 0.9;
+    # output column 3: fx = 3.5 * 0.8 - 0.5 = 2.3 -> taps columns 1 .. 4 (4 clamped to 3), t = 0.3
+    cy, cx = OI.cv_cubic_coeffs_fixed(np.float32(np.float32(-0.1) + 1)), OI.cv_cubic_coeffs_fixed(np.float32(np.float32(2.3) - 2))
+    rows = [0, 0, 0, 1]; cols = [1, 2, 3, 3]
+    v = sum(cy[i] * sum(cx[j] * int(img[rows[i], cols[j]]) for j in range(4)) for i in range(4))
+    assert min(max((v + (1 << 21)) >> 22, 0), 255) == 226
+    # the preprocess entry point takes that path for uint8 tiles, the float form for float tiles
+    tile = np.random.RandomState(3).randint(0, 256, (1, 101, 101)).astype(np.uint8)
+    X, _ = OI.preprocess(tile.astype(np.float32) / 255, None, True, 1)
+    g = np.round((X[0, 0].numpy() * 0.229 + 0.485) * 255).astype(np.uint8)[13:115, 13:115]
+    assert (g == OI.resize_cubic_u8_fixed(tile[0], 102, 102)).all()
+
+
 def test_align_corners_restatement_kat():
     """torch 0.3.1 evaluated nn.Upsample(mode='bilinear') with src = dst (H - 1) / (R H - 1): [0, 1] x2 -> [0, 1/3, 2/3, 1]
     (the torch >= 0.4 default gives [0, 0.25, 0.75, 1])."""
