@@ -897,6 +897,10 @@ bool conv_ws_eligible(const salt_conv_args* a) {
     if (fold && !asked && (a->y.H < 64 || a->y.W < 64)) return false;
     if (!fold && (a->OH != a->y.H || a->OW != a->y.W)) return false;
     if (a->stats || a->fin_ticket || a->bnb_partials || a->bnb_ticket) return false;
+    // the kernels' MODE dispatch: MODE 1 (forward statistics) has no accumulate, MODE 2 (BatchNorm-backward sums) no bias / scale /
+    // shift / ReLU epilogue - such launches go to conv_mfma_kernel, which honours every combination
+    if (a->fin_acc && a->accumulate) return false;
+    if (a->bnb_acc && (a->bias || a->scale || a->shift || a->relu)) return false;
     const int Cin = a->x.C, Cout = a->y.C;
     if (a->x_plane) return false;
     // planar y: planes of exactly one channel block (64 channels)
@@ -973,6 +977,7 @@ int conv_ws_launch(const salt_conv_args* a, hipStream_t st) {
 // Returns NI (1 | 2) when the launch runs on conv_ls_kernel, else 0.
 static int ls_common_ok(const salt_conv_args* a) {
     if (!a || a->dtype != SALT_BF16) return 0;
+    if ((a->fin_acc && a->accumulate) || (a->bnb_acc && (a->bias || a->scale || a->shift || a->relu))) return 0;      // see conv_ws_eligible: MODE dispatch
     if (a->ntaps != 9 || a->in_step != 1 || a->out_step != 1 || a->out_oy || a->out_ox || a->nphase > 1) return 0;
     if (a->strip || a->fold_top || a->fold_bottom || a->fold_left || a->fold_right) return 0;
     if (a->stats || a->fin_ticket || a->bnb_partials || a->bnb_ticket) return 0;

@@ -67,6 +67,9 @@ class DataParallel:
         self._plans = {}
         self.measure = False            # bench.py: record an event pair around the final wait for the collectives
         self.exposed_events = []
+        self.timeline = False           # bench.py / tools/dp_overhead.py: timing events per bucket (ready / all-reduce done) and at backward end
+        self.timeline_events = []       # per step: (t0, [(ready, done)] per bucket, backward_end, wait_end)
+        self.skip_collectives = False   # tools/dp_overhead.py: the segmented backward with its events but WITHOUT the collective calls (A/B)
 
     @classmethod
     def from_env(cls):
@@ -168,6 +171,10 @@ class DataParallel:
         comm = self._comm_stream
         pos, works = 0, []
         n_ops = len(net.bwd)
+        tl = None
+        if self.timeline:
+            tl = [torch.cuda.Event(enable_timing=True), [], None, None]
+            tl[0].record(cur)
         for lo, hi, ridx in self._plans[key]:
             ridx = min(max(ridx, pos), n_ops)
             if ridx > pos:
@@ -175,15 +182,25 @@ class DataParallel:
                 # gradients come from both, so the communication stream waits for both
                 net.bwd.run(begin=pos, end=ridx, side=eng.side_stream, join=False)
                 pos = ridx
-            ev, ev_side = torch.cuda.Event(), torch.cuda.Event()
+            ev, ev_side = torch.cuda.Event(enable_timing=tl is not None), torch.cuda.Event()
             ev.record(cur)
             ev_side.record(eng.side_stream)
             with torch.cuda.stream(comm):
                 comm.wait_event(ev)
                 comm.wait_event(ev_side)
-                works.append(self._all_reduce(eng.grads[lo:hi]))
+                w = None if self.skip_collectives else self._all_reduce(eng.grads[lo:hi])
+                works.append(w)
+                if tl is not None:
+                    if w is not None:
+                        w.wait()        # orders `comm` behind the collective (ProcessGroupNCCL runs it on its own stream)
+                    done = torch.cuda.Event(enable_timing=True)
+                    done.record(comm)
+                    tl[1].append((ev, done, (hi - lo) * 4))
         if pos < n_ops:
             net.bwd.run(begin=pos, end=n_ops, side=eng.side_stream)
+        if tl is not None:
+            tl[2] = torch.cuda.Event(enable_timing=True)
+            tl[2].record(cur)
         if self.measure:        # exposed communication = what the compute stream waits for after its last backward kernel
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(cur)
@@ -194,3 +211,30 @@ class DataParallel:
         if self.measure:
             e1.record(cur)
             self.exposed_events.append((e0, e1))
+        if tl is not None:
+            tl[3] = torch.cuda.Event(enable_timing=True)
+            tl[3].record(cur)
+            self.timeline_events.append(tl)
+
+    def bucket_timeline(self):
+        """Per bucket, averaged over the recorded steps (timeline=True), all in ms RELATIVE TO THE END OF BACKWARD on the compute stream
+        (negative = before it): when its gradients were final (`ready_ms`), when its all-reduce had finished (`allreduce_done_ms`), its
+        size; plus the backward span and the wait behind it.  A collective is fully overlapped when allreduce_done_ms <= 0."""
+        if not self.timeline_events:
+            return None
+        torch.cuda.synchronize()
+        n = len(self.timeline_events)
+        nb = len(self.timeline_events[0][1])
+        out = {'steps': n, 'backward_ms': 0.0, 'wait_after_backward_ms': 0.0, 'buckets': [{'mbytes': 0.0, 'ready_ms': 0.0, 'allreduce_done_ms': 0.0} for _ in range(nb)]}
+        for t0, bs, t_end, t_wait in self.timeline_events:
+            span = t0.elapsed_time(t_end)
+            out['backward_ms'] += span / n
+            out['wait_after_backward_ms'] += t_end.elapsed_time(t_wait) / n
+            for j, (ready, done, nbytes) in enumerate(bs):
+                out['buckets'][j]['mbytes'] = round(nbytes / 1e6, 2)
+                out['buckets'][j]['ready_ms'] += (t0.elapsed_time(ready) - span) / n
+                out['buckets'][j]['allreduce_done_ms'] += (t0.elapsed_time(done) - span) / n
+        out['backward_ms'] = round(out['backward_ms'], 4); out['wait_after_backward_ms'] = round(out['wait_after_backward_ms'], 4)
+        for b in out['buckets']:
+            b['ready_ms'] = round(b['ready_ms'], 4); b['allreduce_done_ms'] = round(b['allreduce_done_ms'], 4)
+        return out

@@ -258,6 +258,9 @@ class Engine:
         bwd.finalize()
         self._pack_batched, self._pack_batched_bwd = fwd, bwd
         self._pack_batched_n = len(self._pack_ops)
+        # a captured step graph bakes the device pointers of THESE tables in: every rebuild starts a new generation, and step_graph()
+        # recaptures an executable of an older one instead of replaying it against freed tables
+        self._pack_generation = getattr(self, '_pack_generation', 0) + 1
 
     def refresh(self, train, defer_bwd=False):
         """Bring the packed weight copies (and, in eval mode, the folded BN constants) up to date.  ``defer_bwd``: leave the
@@ -297,13 +300,13 @@ class Engine:
         # net / optimizer can never alias a stale executable through a recycled id()
         cache = net.__dict__.setdefault('_step_graphs', {})
         key = (kind, float(loss_scale))
+        if getattr(self, '_pack_batched_n', -1) != len(self._pack_ops):
+            self._build_pack_batch()
         hit = cache.get(key)
-        if hit is not None and hit[0] is optimizer:
+        if hit is not None and hit[0] is optimizer and hit[2] == self._pack_generation:
             return hit[1]
         if hit is not None:
             lib.salt_graph_destroy(hit[1])
-        if getattr(self, '_pack_batched_n', -1) != len(self._pack_ops):
-            self._build_pack_batch()
         optimizer._bind()
         optimizer._sync_hyper()
         loss_prog = net.loss_program(kind, loss_scale)
@@ -326,13 +329,13 @@ class Engine:
                 rc = lib.salt_graph_end(ctypes.c_void_p(st.cuda_stream), ctypes.byref(exec_))
             _abi.check(rc, 'graph_end')
         torch.cuda.synchronize()
-        cache[key] = (optimizer, exec_)
+        cache[key] = (optimizer, exec_, self._pack_generation)
         return exec_
 
     def release_step_graphs(self):
         """Destroy the captured step executables of every compiled instance (called when the engine is dropped)."""
         for net in self.nets.values():
-            for _, ex in net.__dict__.pop('_step_graphs', {}).values():
+            for _, ex, *_gen in net.__dict__.pop('_step_graphs', {}).values():
                 lib.salt_graph_destroy(ex)
 
     def _pack_fork_entries(self):

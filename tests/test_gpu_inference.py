@@ -370,7 +370,8 @@ def test_hyper_rows_equals_per_level_bilinear(dtype, ac):
 
 
 def test_eval_network_hyper_rows_is_bit_identical(monkeypatch):
-    """SALT_HYPER_ROWS=1 (default, eval mode) against the per-level launches: the same logits, bit for bit."""
+    """SALT_HYPER_ROWS=1 (opt-in: architectures.py defaults to 0 because the fused pass measured slower) against the per-level
+    launches (the default): the same logits, bit for bit."""
     from salt_amd import architectures as A
     from oracle import specs as OS
     spec = OS.SPECS['UNetResNet'](with_fc=True)
