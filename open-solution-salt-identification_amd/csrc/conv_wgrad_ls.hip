@@ -34,6 +34,9 @@
 #ifndef SALT_WL_NS8
 #define SALT_WL_NS8 4            // ring slots, KU = 8 (34 / 36 KB each)
 #endif
+#ifndef SALT_WL_NS2S
+#define SALT_WL_NS2S 6           // ring slots of the stride-2 variant (KU = 2: 22 KB each)
+#endif
 #ifndef SALT_WL_ABLATE
 #define SALT_WL_ABLATE 0         // timing ablations (results are wrong): 1 no fragment reads / MFMAs, 2 no DMA, 4 no slab stores
 #endif
@@ -75,15 +78,23 @@ template <int N> __device__ __forceinline__ void wl_wait_vm() {
 // entry in front of unit u is still to come
 struct WlCur { int u, k, cx, img; bool pre; };
 
-template <bool PAD, int NB, int KU>
+// ST = 2: the stride-2 3x3 convolutions (ResNet layer2-4 conv1; Q = x at twice P's resolution, zero pad 1).  A Q image row is stored as
+// TWO 18-pixel halo rows - its even-column plane E (hx = 2 k) and its odd one O (hx = 2 k + 1), de-interleaved by the loader's source
+// addresses - so the fragment reads stay unit-stride and conflict-free: tap dx = 0 -> E[k], dx = 1 -> O[k], dx = 2 -> E[k + 1].  A
+// k-step (P row y) needs image rows 2 y - 1, 2 y, 2 y + 1: two new ones per k-step, the third is the previous k-step's last.  A unit
+// of KU k-steps brings 2 KU image rows = 4 KU halo rows; a pre entry the image row above the first k-step.
+template <bool PAD, int NB, int KU, int ST = 1>
 __global__ __launch_bounds__(512) void conv_wgrad_ls_kernel(WlKP p) {
-    constexpr int TW = 16 / NB, HP = NB * (TW + 2), KHS = NB == 1 ? 8 : TW + 2;
-    constexpr int P_BYTES = KU * 16 * 128, QROWS = KU * HP, Q_BYTES = QROWS * 128, SLOT = P_BYTES + Q_BYTES;
-    constexpr int NPP = P_BYTES / 1024, NQP = QROWS / 8, PCS = NPP + NQP, PPW = (PCS + 3) / 4;
-    constexpr int PRE_FIRST = ((KU - 2) * HP) / 8;                       // first Q piece a pre entry loads
-    constexpr int NS = KU == 4 ? SALT_WL_NS4 : SALT_WL_NS8;
+    constexpr int TW = 16 / NB, HP = ST == 2 ? 18 : NB * (TW + 2), KHS = NB == 1 ? 8 : (ST == 2 ? TW + 1 : TW + 2);
+    constexpr int QIR = ST == 2 ? 2 * KU : KU;                          // Q image rows a unit brings
+    constexpr int P_BYTES = KU * 16 * 128, QROWS = (ST == 2 ? 2 : 1) * QIR * HP, Q_BYTES = QROWS * 128, SLOT = P_BYTES + Q_BYTES;
+    constexpr int NPP = P_BYTES / 1024, NQP = QROWS / 8, PCS = NPP + NQP;
+    constexpr int PRE_FIRST = ((ST == 2 ? 2 * (QIR - 1) : KU - 2) * HP) / 8;  // first Q piece a pre entry loads
+    constexpr int NS = ST == 2 ? SALT_WL_NS2S : (KU == 4 ? SALT_WL_NS4 : SALT_WL_NS8);
+    static_assert(ST == 1 || !PAD, "stride 2: zero padding only");
     constexpr int OFF_DUMMY = NS * SLOT;
     constexpr int INVALID = (int)0x80000000;                             // voffset >= num_records: the lane reads zeros
+    constexpr int NPS_ = (NPP + 3) / 4, NQS_ = (NQP + 3) / 4, PPW = NPS_ + NQS_;
     static_assert(QROWS % 8 == 0 && NS >= 3 && (NS - 3) * PPW <= 63, "ring geometry");
     static_assert(OFF_DUMMY + 1024 <= 160 * 1024, "LDS budget");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -129,27 +140,37 @@ __global__ __launch_bounds__(512) void conv_wgrad_ls_kernel(WlKP p) {
         // compiler select them lane-wise and wrap every DMA in a waterfall loop.
         // kernel-invariant lane constants: row (P: k-step, Q: halo row), x | image << 8, channel element offset (-1: beyond the
         // tensor's channels)
-        constexpr int NPS = NPP / 4, NQS = (NQP + 3) / 4;
-        static_assert(NPP % 4 == 0 && NPS + NQS == PPW, "piece slots");
+        constexpr int NPS = NPS_, NQS = NQS_;
+        static_assert(NPS + NQS == PPW, "piece slots");
         int krow[PPW], kx[PPW], kch[PPW];
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
             krow[i] = 0; kx[i] = 0; kch[i] = -1;
             if (i < NPS) {
-                const int r = (lw + 4 * i) * 8 + (lane >> 3);
-                const int cs = (lane & 7) ^ (((r >> 1) & 1) << 2);
-                const int px = r & 15;
-                krow[i] = r >> 4;
-                kx[i] = NB == 1 ? px : ((px & 7) | ((px >> 3) << 8));
-                if (a0 + cs * 8 < p.Ca) kch[i] = a0 + cs * 8;
+                if (lw + 4 * i < NPP) {
+                    const int r = (lw + 4 * i) * 8 + (lane >> 3);
+                    const int cs = (lane & 7) ^ (((r >> 1) & 1) << 2);
+                    const int px = r & 15;
+                    krow[i] = r >> 4;
+                    kx[i] = NB == 1 ? px : ((px & 7) | ((px >> 3) << 8));
+                    if (a0 + cs * 8 < p.Ca) kch[i] = a0 + cs * 8;
+                }
             } else if (lw + 4 * (i - NPS) < NQP) {
                 const int r = (lw + 4 * (i - NPS)) * 8 + (lane >> 3);
                 const int cs = (lane & 7) ^ (((r >> 1) & 1) << 2);
                 const int hrl = r / HP, hx = r - hrl * HP;
-                const int im = NB == 1 ? 0 : hx / (TW + 2);
-                krow[i] = hrl;
-                kx[i] = (hx - im * (TW + 2)) | (im << 8);
-                if (c0 + cs * 8 < p.Cb) kch[i] = c0 + cs * 8;
+                if (ST == 1) {
+                    const int im = NB == 1 ? 0 : hx / (TW + 2);
+                    krow[i] = hrl;
+                    kx[i] = (hx - im * (TW + 2)) | (im << 8);
+                    if (c0 + cs * 8 < p.Cb) kch[i] = c0 + cs * 8;
+                } else {
+                    // halo row hrl = plane (hrl & 1) of image row hrl >> 1; plane pixel k of image im -> image column 2 (x0 + k) + plane + min_dx
+                    const int im = NB == 1 ? 0 : hx / (TW + 1), k = hx - im * (TW + 1);
+                    krow[i] = hrl >> 1;
+                    kx[i] = k | (im << 8) | ((hrl & 1) << 16);
+                    if (c0 + cs * 8 < p.Cb && k <= TW) kch[i] = c0 + cs * 8;
+                }
             }
         }
         // per strip (rebuilt at its pre entry): byte offset of the lane's piece from the tensor base without the entry's row term,
@@ -159,13 +180,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_ls_kernel(WlKP p) {
             const int b0 = c.img * NB, x0 = c.cx * TW;
 #pragma unroll
             for (int i = 0; i < PPW; ++i) {
-                const int x = kx[i] & 255, im = kx[i] >> 8;
+                const int x = kx[i] & 255, im = (kx[i] >> 8) & 255;
                 if (i < NPS) {
                     const bool ok = kch[i] >= 0 && x0 + x < p.PW && b0 + im < p.B;
                     voff[i] = (b0 + im) * p.PH * rowP2 + ((x0 + x) * p.p_cs + kch[i]) * 2 + krow[i] * rowP2;
                     vrow[i] = ok ? krow[i] : 255;
                 } else {
-                    int ix = x0 + p.min_dx + x;
+                    int ix = ST == 2 ? 2 * (x0 + x) + (kx[i] >> 16) + p.min_dx : x0 + p.min_dx + x;
                     bool ok = kch[i] >= 0 && b0 + im < p.B;
                     if (PAD) ix = min(max(ix, 0), p.QW - 1);
                     else ok = ok && (unsigned)ix < (unsigned)p.QW;
@@ -177,16 +198,17 @@ __global__ __launch_bounds__(512) void conv_wgrad_ls_kernel(WlKP p) {
         auto issue = [&](bool live, const WlCur& c, int slot) {
             if (live && c.pre) strip_tables(c);
             const int y0 = c.k * KU;
-            const int yq = (c.pre ? y0 - KU : y0) + 2 + p.min_dy;               // image row of the slot's halo row 0
+            // image row of the slot's Q row 0 (a pre entry is the tail of the unit that would precede the segment)
+            const int yq = ST == 2 ? 2 * (c.pre ? y0 - KU : y0) + 1 + p.min_dy : (c.pre ? y0 - KU : y0) + 2 + p.min_dy;
             const int base = slot * SLOT;
             const bool p_on = live && !c.pre;
             const int entP = y0 * rowP2, hiP = p_on ? min(KU, p.PH - y0) : 0;
             const int entQ = yq * rowQ2;
-            const int loQ = max(max(0, -yq), c.pre ? KU - 2 : 0), hiQ = max(loQ, min(KU, p.QH - yq));
+            const int loQ = max(max(0, -yq), c.pre ? (ST == 2 ? QIR - 1 : KU - 2) : 0), hiQ = max(loQ, min(QIR, p.QH - yq));
 #pragma unroll
             for (int i = 0; i < PPW; ++i) {
                 if (i < NPS) {
-                    const int dst = p_on ? base + (lw + 4 * i) * 1024 : OFF_DUMMY;
+                    const int dst = p_on && lw + 4 * i < NPP ? base + (lw + 4 * i) * 1024 : OFF_DUMMY;
                     const int vo = (unsigned)vrow[i] < (unsigned)hiP ? voff[i] + entP : INVALID;
                     if (!(SALT_WL_ABLATE & 2)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsP, (lds_ptr_t)(smem + dst), 16, vo, 0, 0, 0);
                 } else {
@@ -262,7 +284,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_ls_kernel(WlKP p) {
     int qL0[2], qL2[2];                                                  // runs from pixel 0 / pixel 2, by the parity of the halo row inside its slot
 #pragma unroll
     for (int par = 0; par < 2; ++par) {
-        const int s = NB == 1 ? (sA ^ par) : ((khalf ^ (prow >> 1)) & 1);
+        // bit 1 of the LDS row index of this lane's pixel: halo row hrl starts at row hrl HP (HP / 2 odd: its parity enters)
+        const int s = (((khalf * KHS + prow) >> 1) & 1) ^ (((HP / 2) & 1) ? par : 0);
         qL0[par] = P_BYTES + (khalf * KHS + prow) * 128 + ((csB ^ (s << 2)) << 4) + bytec;
         qL2[par] = P_BYTES + (khalf * KHS + prow + 2) * 128 + ((csB ^ ((s ^ 1) << 2)) << 4) + bytec;
     }
@@ -297,7 +320,6 @@ __global__ __launch_bounds__(512) void conv_wgrad_ls_kernel(WlKP p) {
     };
     typedef short s16x8 __attribute__((ext_vector_type(8)));
 
-    Row rb[4];
     AFr ab2[2];
 #if SALT_WL_CLK
     const unsigned long long mt0 = WL_T(); unsigned long long mt_first = 0, mt_bar = 0;
@@ -312,6 +334,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_ls_kernel(WlKP p) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     };
+    if constexpr (ST == 1) {
+    Row rb[4];
     int g = 0, u = u0;
 #pragma unroll 1
     while (g < G) {
@@ -367,6 +391,83 @@ __global__ __launch_bounds__(512) void conv_wgrad_ls_kernel(WlKP p) {
         __builtin_amdgcn_s_setprio(0);
         u += n;
     }
+    } else {
+    int g = 0, u = u0;
+    // ---- stride 2: image-row buffers {E: pixels 0-3, 4-7, (6-)8-9; O: pixels 0-3, 4-7}; A = the row above the k-step (the previous
+    // k-step's last row, copied), S[j & 1] = the k-step's two new rows, S[(j + 1) & 1] being filled for the next one
+    struct Row2 { u32x2 ea0, ea1, ec1, oa0, oa1; };
+    auto read_row2 = [&](int sb, int ir, Row2& r) {                      // ir (image row of the unit) constant after unrolling
+        const int he = 2 * ir, ho = 2 * ir + 1;                           // halo rows of its planes: even parity / odd parity
+        r.ea0 = __builtin_bit_cast(u32x2, tr(sb + qL0[0] + (he * HP) * 128));
+        r.ea1 = __builtin_bit_cast(u32x2, tr(sb + qL0[0] + (he * HP + 4) * 128));
+        r.ec1 = __builtin_bit_cast(u32x2, tr(sb + qL2[0] + (he * HP + 4) * 128));
+        r.oa0 = __builtin_bit_cast(u32x2, tr(sb + qL0[1] + (ho * HP) * 128));
+        r.oa1 = __builtin_bit_cast(u32x2, tr(sb + qL0[1] + (ho * HP + 4) * 128));
+    };
+    auto b_operand2 = [&](const Row2& r, int dx) -> bf16x8 {
+        u32x4 vv;
+        if (dx == 0) vv = u32x4{r.ea0.x, r.ea0.y, r.ea1.x, r.ea1.y};
+        else if (dx == 1) vv = u32x4{r.oa0.x, r.oa0.y, r.oa1.x, r.oa1.y};
+        else vv = u32x4{__builtin_amdgcn_alignbit(r.ea0.y, r.ea0.x, 16), __builtin_amdgcn_alignbit(r.ea1.x, r.ea0.y, 16),
+                        __builtin_amdgcn_alignbit(r.ea1.y, r.ea1.x, 16), __builtin_amdgcn_alignbit(r.ec1.y, r.ea1.y, 16)};
+        return __builtin_bit_cast(bf16x8, vv);
+    };
+    Row2 ra, rs2[2][2];                                                   // rs2[set][0 = even image row 2 y, 1 = odd image row 2 y + 1]
+#pragma unroll 1
+    while (g < G) {
+        const int k0 = u % p.U;
+        const int n = min(p.U - k0, u1 - u);
+        { WL_BAR_T0(); barrier(); WL_BAR_T1(); }                          // pre entry: image row 2 y0 - 1 = the slot's last image row
+        int sb = (g % NS) * SLOT;
+        if (!(SALT_WL_ABLATE & 1)) read_row2(sb, QIR - 1, ra);
+        ++g;
+        { WL_BAR_T0(); barrier(); WL_BAR_T1(); }
+        sb = (g % NS) * SLOT;
+        if (!(SALT_WL_ABLATE & 1)) { read_row2(sb, 0, rs2[0][0]); read_row2(sb, 1, rs2[0][1]); read_a(sb, 0, ab2[0]); }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll 1
+        for (int i = 0; i < n; ++i) {
+            const bool has_next = i + 1 < n;
+            int sbn = sb;
+#pragma unroll
+            for (int j = 0; j < KU; ++j) {
+                if (j == KU - 1) {
+                    if (has_next) {
+                        { WL_BAR_T0(); barrier(); WL_BAR_T1(); }
+                        sbn = ((g + 1) % NS) * SLOT;
+                        if (!(SALT_WL_ABLATE & 1)) {
+                            read_a(sbn, 0, ab2[(j + 1) & 1]);
+                            read_row2(sbn, 0, rs2[(j + 1) & 1][0]); read_row2(sbn, 1, rs2[(j + 1) & 1][1]);
+                        }
+                    }
+                } else if (!(SALT_WL_ABLATE & 1)) {
+                    read_a(sb, j + 1, ab2[(j + 1) & 1]);
+                    read_row2(sb, 2 * (j + 1), rs2[(j + 1) & 1][0]); read_row2(sb, 2 * (j + 1) + 1, rs2[(j + 1) & 1][1]);
+                }
+                if (!(SALT_WL_ABLATE & 1)) {
+                    const AFr& af = ab2[j & 1];
+                    const s16x8 av = {af.lo[0], af.lo[1], af.lo[2], af.lo[3], af.hi[0], af.hi[1], af.hi[2], af.hi[3]};
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) {                         // dx = 0, 1 (register quads as read) first, dx = 2 (v_alignbit) last
+                        const int dy = q < 6 ? q >> 1 : q - 6, dx = q < 6 ? (q & 1) : 2, t = dy * 3 + dx;
+                        const Row2& rr = dy == 0 ? ra : rs2[j & 1][dy - 1];
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_operand2(rr, dx), __builtin_bit_cast(bf16x8, av), acc[t], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) {                         // pin: the 12 LDS reads of the next k-step behind the first six MFMAs
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (q < 6 && j != KU - 1) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        if (q < 6) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                    }
+                    ra = rs2[j & 1][1];                                   // the next k-step's row above
+                }
+            }
+            sb = sbn; ++g;
+        }
+        __builtin_amdgcn_s_setprio(0);
+        u += n;
+    }
+    }
 #undef WL_BAR_T0
 #undef WL_BAR_T1
 
@@ -403,12 +504,12 @@ __global__ __launch_bounds__(512) void conv_wgrad_ls_kernel(WlKP p) {
 #endif
 }
 
-template <bool PAD, int NB, int KU>
+template <bool PAD, int NB, int KU, int ST = 1>
 int wl_launch_inst(const WlKP& k, hipStream_t st) {
-    constexpr int TW = 16 / NB, HP = NB * (TW + 2);
-    constexpr int SLOT = KU * 16 * 128 + KU * HP * 128, NS = KU == 4 ? SALT_WL_NS4 : SALT_WL_NS8;
+    constexpr int TW = 16 / NB, HP = ST == 2 ? 18 : NB * (TW + 2);
+    constexpr int SLOT = KU * 16 * 128 + (ST == 2 ? 4 : 1) * KU * HP * 128, NS = ST == 2 ? SALT_WL_NS2S : (KU == 4 ? SALT_WL_NS4 : SALT_WL_NS8);
     constexpr int LDS = NS * SLOT + 1024;
-    auto kern = conv_wgrad_ls_kernel<PAD, NB, KU>;
+    auto kern = conv_wgrad_ls_kernel<PAD, NB, KU, ST>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -437,7 +538,9 @@ extern "C" int salt_debug_wl_clk(unsigned long long* host_out, int n) {
 // launch status into *rc.
 int conv_wgrad_ls(const salt_conv_wgrad_args* a, bool launch, hipStream_t st, int* rc) {
     static const bool off = getenv("SALT_WGRAD_LS") && atoi(getenv("SALT_WGRAD_LS")) == 0;
-    if (off || a->dtype != SALT_BF16 || a->ntaps != 9 || a->q_step != 1) return 0;
+    if (off || a->dtype != SALT_BF16 || a->ntaps != 9 || (a->q_step != 1 && a->q_step != 2)) return 0;
+    static const bool no_s2 = getenv("SALT_WGRAD_LS_S2") && atoi(getenv("SALT_WGRAD_LS_S2")) == 0;       // A/B: stride-2 layers on the previous kernels
+    if (a->q_step == 2 && (no_s2 || a->pad_mode != 0)) return 0;
     for (int t = 0; t < 9; ++t)
         if (a->tap_dy[t] != a->tap_dy[0] + t / 3 || a->tap_dx[t] != a->tap_dx[0] + t % 3) return 0;     // raster 3 x 3 window
     if (a->p.cs % 8 || a->q.cs % 8 || a->p.C % 8 || a->q.C % 8 || a->p.B != a->q.B) return 0;
@@ -445,7 +548,7 @@ int conv_wgrad_ls(const salt_conv_wgrad_args* a, bool launch, hipStream_t st, in
     if (launch && (reinterpret_cast<uintptr_t>(a->partials) & 15)) return 0;
     if ((long long)a->q.B * a->q.H * a->q.W * (a->q_plane ? a->q.C : a->q.cs) * 2 >= (1ll << 31) || (long long)a->p.B * a->p.H * a->p.W * a->p.cs * 2 >= (1ll << 31)) return 0;
     const char* ku_env = getenv("SALT_WL_KU");                            // read per call: the tests switch it inside one process
-    const int KU = (ku_env && atoi(ku_env) == 8) ? 8 : 4;
+    const int KU = a->q_step == 2 ? 2 : ((ku_env && atoi(ku_env) == 8) ? 8 : 4);
     const int NB = a->p.W <= 8 ? 2 : 1, TW = 16 / NB;
     WlKP k;
     k.P = reinterpret_cast<const bf16_t*>(a->p.p); k.Q = reinterpret_cast<const bf16_t*>(a->q.p); k.partials = a->partials;
@@ -476,7 +579,8 @@ int conv_wgrad_ls(const salt_conv_wgrad_args* a, bool launch, hipStream_t st, in
     k.V = ns * blocks; k.per_xcd = cdiv(k.V, 8);
     const bool pad = a->pad_mode != 0;
 #define SALT_WL(NB_, KU_) (pad ? wl_launch_inst<true, NB_, KU_>(k, st) : wl_launch_inst<false, NB_, KU_>(k, st))
-    if (NB == 1) *rc = KU == 4 ? SALT_WL(1, 4) : SALT_WL(1, 8);
+    if (a->q_step == 2) *rc = NB == 1 ? wl_launch_inst<false, 1, 2, 2>(k, st) : wl_launch_inst<false, 2, 2, 2>(k, st);
+    else if (NB == 1) *rc = KU == 4 ? SALT_WL(1, 4) : SALT_WL(1, 8);
     else *rc = KU == 4 ? SALT_WL(2, 4) : SALT_WL(2, 8);
 #undef SALT_WL
     return ns;

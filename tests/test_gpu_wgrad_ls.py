@@ -12,7 +12,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-def _wgrad_hip(p_nhwc, q_nhwc, taps, pad_mode, nsplit=None, q_planar=False, Ca=None, Cb=None):
+def _wgrad_hip(p_nhwc, q_nhwc, taps, pad_mode, nsplit=None, q_planar=False, Ca=None, Cb=None, q_step=1):
     """p_nhwc [B,H,W,Csa] / q_nhwc [B,QH,QW,Csb] bf16 device tensors (views of Ca / Cb leading channels); returns dW [Ca][Cb][3][3] fp32."""
     import salt_amd  # noqa: F401
     from salt_amd._abi import STRUCTS, lib, fill, check
@@ -31,7 +31,7 @@ def _wgrad_hip(p_nhwc, q_nhwc, taps, pad_mode, nsplit=None, q_planar=False, Ca=N
         qv = shaped_view(q_nhwc.data_ptr(), B, QH, QW, Cb, csb)
         qp = 0
     S = fill(STRUCTS['salt_conv_wgrad_args'](), dtype=1, p=pv, q=qv, ntaps=9, tap_dy=[t[0] for t in taps], tap_dx=[t[1] for t in taps],
-             q_step=1, pad_mode=pad_mode, q_plane=qp)
+             q_step=q_step, pad_mode=pad_mode, q_plane=qp)
     ns = lib.salt_conv_wgrad_nsplit(ctypes.byref(S))
     assert ns >= 1, lib.salt_last_error()
     if nsplit is not None:
@@ -138,6 +138,35 @@ def test_wgrad_ls_strided_views_and_planar_q(replicate):
     got, _ = _wgrad_hip(pd, planes.view(2 * B, H, W, 64)[:B], taps, 1 if replicate else 0, q_planar=True, Cb=Cb)
     err = float((got.double() - ref.double()).norm() / ref.double().norm())
     assert err <= 2e-5, 'planar: rel-L2 %.3e' % err
+
+
+CASES_S2 = [
+    # B, QH, QW, Ca (= cout), Cb (= cin): nn.Conv2d(Cb, Ca, 3, stride 2, padding 1) - ResNet layer2-4 conv1
+    (2, 32, 32, 128, 64),
+    (2, 16, 16, 256, 128),     # P is 8 x 8: two images side by side in a k-step
+    (3, 8, 8, 512, 256),       # P is 4 x 4
+    (3, 17, 9, 72, 40),        # odd input sizes, ragged channel blocks
+    (1, 64, 64, 128, 64),
+    (5, 15, 13, 48, 32),
+]
+
+
+@pytest.mark.parametrize('case', CASES_S2)
+@pytest.mark.parametrize('nsplit', [None, 3])
+def test_wgrad_ls_stride2_vs_torch(case, nsplit):
+    """The stride-2 variant (Q de-interleaved into even / odd column planes by the loader): dW of nn.Conv2d(k3, s2, p1)."""
+    B, QH, QW, Ca, Cb = case
+    PH, PW = (QH + 2 - 3) // 2 + 1, (QW + 2 - 3) // 2 + 1
+    p, q = _mk(B, Ca, PH, PW, 11), _mk(B, Cb, QH, QW, 12)
+    w = torch.zeros(Ca, Cb, 3, 3, dtype=torch.float64, requires_grad=True)
+    (F.conv2d(q.double(), w, stride=2, padding=1) * p.double()).sum().backward()
+    ref = w.grad.float()
+    taps = [(dy - 1, dx - 1) for dy in range(3) for dx in range(3)]
+    got, ns = _wgrad_hip(p.permute(0, 2, 3, 1).contiguous().bfloat16().cuda(), q.permute(0, 2, 3, 1).contiguous().bfloat16().cuda(), taps, 0,
+                         nsplit=nsplit, q_step=2)
+    err = float((got.double() - ref.double()).norm() / ref.double().norm())
+    assert torch.isfinite(got).all()
+    assert err <= 2e-5, 'rel-L2 %.3e (nsplit %d)' % (err, ns)
 
 
 def test_wgrad_ls_is_the_kernel_that_runs_and_matches_previous_kernels():

@@ -28,6 +28,9 @@ SHAPES = [
     (32, 128, 128, 32, 64, 1),    # dec1 conv1
     (32, 128, 128, 64, 32, 1),    # dec1 conv2
     (32, 128, 128, 64, 320, 1),   # final conv over the hypercolumn
+    (32, 32, 32, 128, 64, 2),     # layer2.0.conv1, stride 2 (rep = 2: Q is twice P's size)
+    (32, 16, 16, 256, 128, 2),    # layer3.0.conv1
+    (32, 8, 8, 512, 256, 2),      # layer4.0.conv1
 ]
 
 
@@ -36,11 +39,13 @@ def main():
     st = torch.cuda.current_stream().cuda_stream
     tot = [0.0, 0.0]
     for (B, H, W, Ca, Cb, rep) in SHAPES:
+        s2 = rep == 2
         P = torch.randn(B, H, W, Ca, device='cuda:0').bfloat16()
-        Q = torch.randn(B, H, W, Cb, device='cuda:0').bfloat16()
-        taps = [(dy - 2, dx) for dy in range(3) for dx in range(3)] if rep else [(dy - 1, dx - 1) for dy in range(3) for dx in range(3)]
-        S = fill(STRUCTS['salt_conv_wgrad_args'](), dtype=1, p=shaped_view(P.data_ptr(), B, H, W, Ca), q=shaped_view(Q.data_ptr(), B, H, W, Cb),
-                 ntaps=9, tap_dy=[t[0] for t in taps], tap_dx=[t[1] for t in taps], q_step=1, pad_mode=rep, q_plane=0)
+        Q = torch.randn(B, H * (2 if s2 else 1), W * (2 if s2 else 1), Cb, device='cuda:0').bfloat16()
+        taps = [(dy - 2, dx) for dy in range(3) for dx in range(3)] if rep == 1 else [(dy - 1, dx - 1) for dy in range(3) for dx in range(3)]
+        S = fill(STRUCTS['salt_conv_wgrad_args'](), dtype=1, p=shaped_view(P.data_ptr(), B, H, W, Ca),
+                 q=shaped_view(Q.data_ptr(), B, Q.shape[1], Q.shape[2], Cb),
+                 ntaps=9, tap_dy=[t[0] for t in taps], tap_dx=[t[1] for t in taps], q_step=2 if s2 else 1, pad_mode=1 if rep == 1 else 0, q_plane=0)
         ns = lib.salt_conv_wgrad_nsplit(ctypes.byref(S))
         part = torch.empty(ns, 9, Ca, Cb, device='cuda:0')
         grad = torch.empty(Ca, Cb, 3, 3, device='cuda:0')
