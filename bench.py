@@ -165,7 +165,8 @@ def op_bytes(name, s, es):
     return 0.0
 
 
-PMC_FILE = 'profiles/r03_pmc_traffic.json'
+PMC_FILE = 'profiles/r04_pmc_traffic.json'
+INSTEP_FILE = 'profiles/r04_instep.json'        # tools/prof_instep.py: kernel time per class INSIDE the step (rocprofv3 kernel trace)
 
 
 def pmc_commit():
@@ -179,7 +180,7 @@ def pmc_commit():
 def pmc_traffic(kernel):
     """HBM bytes per launch, averaged over the kernels named in the tuple `kernel`, from the committed rocprofv3 --pmc passes (PMC_FILE;
     tools/pmc_traffic.sh regenerates it - PMC counters cannot be read from inside the timed process).  None when the file is absent."""
-    for path in (os.path.join(ROOT, PMC_FILE), os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')):
+    for path in (os.path.join(ROOT, PMC_FILE), os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')):
         try:
             ks = json.load(open(path))['kernels']
             sel = [v for k, v in ks.items() if k in kernel]
@@ -279,7 +280,7 @@ def conv_roofline(model, B, channels, dtype, loss, reps):
     dn, (dms, dfl, dcnt, dby) = max(groups.items(), key=lambda kv: kv[1][0])
     peak = MFMA_PEAK_TFLOPS[dtype]
     ach = dfl / (dms * 1e-3) / 1e12 if dms > 0 else 0.0
-    kern = {'conv': 'conv_ws_kernel + conv_ls_kernel + conv_mfma_kernel + conv_glds_kernel (fwd + dgrad launches)', 'conv_wgrad': 'conv_wgrad_kernel'}.get(dn, dn)
+    kern = {'conv': 'conv_ws_kernel + conv_ls_kernel + conv_mfma_kernel + conv_glds_kernel (fwd + dgrad launches)', 'conv_wgrad': 'conv_wgrad_ls_kernel + conv_wgrad_fast_kernel + conv_wgrad_kernel'}.get(dn, dn)
     roof = {'kernel': kern, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
             'algorithmic_bytes_per_launch': round(dby / dcnt) if dcnt else None, 'launches_per_step': dcnt // reps,
             'avg_launch_us': round(1e3 * dms / dcnt, 2), 'share_of_step': round(dms / reps / total_ms, 3),
@@ -574,6 +575,21 @@ def main():
         roof['traffic_unit'] = ('bytes per launch (rocprofv3 PMC FETCH_SIZE*2 + WRITE_SIZE, separate --pmc passes; file %s measured at commit %s - '
                                 'PMC counters cannot be read inside the timed process)' % (PMC_FILE, pmc_commit()))
         out['roofline_by_class'] = roof.pop('by_class')
+        # the same class INSIDE the step (both queues running), from the committed rocprofv3 kernel trace: quoted, not measured here
+        if headline:
+            try:
+                ins = json.load(open(os.path.join(ROOT, INSTEP_FILE)))
+                for cls in ('conv', 'conv_wgrad'):
+                    bc = out['roofline_by_class'].get(cls)
+                    us = ins['classes'].get(cls, {}).get('us_per_step')
+                    if bc and us:
+                        fl = bc['achieved'] * 1e12 * bc['ms_per_step'] * 1e-3              # algorithmic FLOPs per step of the class
+                        bc['in_step'] = {'quoted_from': INSTEP_FILE, 'commit': ins.get('commit'), 'kernel_us_per_step': us,
+                                         'achieved': round(fl / (us * 1e-6) / 1e12, 1), 'frac': round(fl / (us * 1e-6) / 1e12 / MFMA_PEAK_TFLOPS[args.dtype], 4)}
+                if dn in ('conv', 'conv_wgrad') and 'in_step' in out['roofline_by_class'].get(dn, {}):
+                    roof['in_step'] = out['roofline_by_class'][dn]['in_step']
+            except (OSError, KeyError, ValueError):
+                pass
         out['roofline'] = roof
         out['op_time_ms'] = ops
         out['op_time_serial_ms'] = round(total_ms, 3)          # every operator run back to back on ONE stream (no wgrad overlap)
