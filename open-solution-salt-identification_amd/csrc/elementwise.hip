@@ -880,7 +880,10 @@ __global__ __launch_bounds__(256) void bilinear_fwd_rows_kernel(salt_view x, sal
     const int cpv = x.C / N, ppb = 256 / cpv;                              // host: 256 % cpv == 0
     const int c0 = (int)(threadIdx.x % cpv) * N, px0 = (int)(threadIdx.x / cpv);
     const int rows = y.B * y.H;
-    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    // workgroup -> row: XCD x (= blockIdx % 8) owns a contiguous range of rows, so that neighbouring rows - which read the same
+    // source rows - meet in ONE L2 (round-robin placement sent them to 8 different ones: PMC FETCH_SIZE 3.4x the tensor for the x2 adjoint)
+    const int per_xcd = (rows + 7) >> 3, r_end = min(rows, ((int)(blockIdx.x & 7) + 1) * per_xcd);
+    for (int row = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3); row < r_end; row += (int)(gridDim.x >> 3)) {
         const int b = row / y.H, oy = row - b * y.H;
         int y0, y1; float ly;
         bil_src(oy, R, x.H, 0, y0, y1, ly);
@@ -923,7 +926,8 @@ __global__ __launch_bounds__(256) void bilinear_bwd_rows_kernel(salt_view x, sal
     const int cpv = x.C / N, ppb = 256 / cpv;
     const int c0 = (int)(threadIdx.x % cpv) * N, px0 = (int)(threadIdx.x / cpv);
     const int rows = x.B * x.H;
-    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int per_xcd = (rows + 7) >> 3, r_end = min(rows, ((int)(blockIdx.x & 7) + 1) * per_xcd);      // see bilinear_fwd_rows_kernel
+    for (int row = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3); row < r_end; row += (int)(gridDim.x >> 3)) {
         const int b = row / x.H, iy = row - b * x.H;
         const T* base = (const T*)y.p + (int64_t)b * y.H * y.W * y.cs + c0;
         T* drow = (T*)x.p + (int64_t)row * x.W * x.cs + c0;
@@ -1359,7 +1363,7 @@ extern "C" int salt_bilinear(const salt_bilinear_args* a, void* stream) {
         const int cpv = a->x.C / ve;
         const bool rows_ok = !rows_off && v && !a->align_corners && cpv >= 1 && cpv <= 256 && 256 % cpv == 0 &&
                              (int64_t)a->y.W * a->y.cs < (1ll << 30) && (int64_t)a->y.H * a->y.W * a->y.cs < (1ll << 31) && view_pixels(a->y) / a->y.W < (1ll << 31);
-        auto row_grid = [](int64_t rows) { return dim3((unsigned)(rows < 16384 ? rows : 16384)); };
+        auto row_grid = [](int64_t rows) { const int64_t g = (rows + 7) / 8 * 8; return dim3((unsigned)(g < 16384 ? g : 16384)); };      // a multiple of 8: one row range per XCD
         if (!a->backward && rows_ok) {
             hipLaunchKernelGGL((bilinear_fwd_rows_kernel<T, 4>), row_grid((int64_t)a->y.B * a->y.H), dim3(256), 0, (hipStream_t)stream, a->x, a->y, a->R);
         } else if (a->backward && rows_ok) {
