@@ -73,6 +73,9 @@ int conv_ws_launch(const salt_conv_args* a, hipStream_t st);
 // conv_ws.hip: the loader-specialised streaming kernel of the deeper 3x3 layers (conv_ls_variant: 0 = not applicable, else channel blocks of 32 NI)
 int conv_ls_variant(const salt_conv_args* a);
 int conv_ls_launch(const salt_conv_args* a, hipStream_t st);
+// conv_ws.hip: the streaming kernel of the 1x1 unit-step convolutions (eval-mode Bottleneck convs; 0 = not applicable, else channel blocks of 32 NI)
+int conv1x1_ls_variant(const salt_conv_args* a);
+int conv1x1_ls_launch(const salt_conv_args* a, hipStream_t st);
 
 // conv_wgrad_ls.hip: loader-specialised row-streaming weight gradient (bf16, 3x3, unit step); 0 = not one of its shapes, else nsplit
 int conv_wgrad_ls(const salt_conv_wgrad_args* a, bool launch, hipStream_t st, int* rc);

@@ -872,6 +872,183 @@ int ls_launch(const LsKP& k, int wgs, hipStream_t st) {
     return ls_launch_mode<NI, 0>(k, wgs, st);
 }
 
+// ------------------------------------------------------------------------------------------ conv1x1_ls_kernel (bf16, 1x1, unit steps)
+// The Bottleneck 1x1 convolutions of ResNet101 / 152 (architectures/encoders.py:13-19 through torchvision's Bottleneck) are streaming
+// operators: the 64 -> 256 expansion at 128 x 128 moves 1.2 GB (input, residual, output) for 17 GFLOP per 64 images.  On
+// conv_mfma_kernel (load -> MFMA -> stage through LDS -> store, one tile per workgroup) they ran at 2.3 - 2.5 TB/s (C4: 8.5 of 61 ms).
+// Same structure as conv_ls_kernel with the halo gone: 4 loader waves stream CHUNKS of 64 input channels - a 256-pixel tile (2 x 16 KB
+// sub-tiles of 32 channels, 64-byte rows, XOR slot swizzle on the DMA's source address) + the chunk's weights for the item's 32 NI
+// output channels - through a ring of D buffers, one raw s_barrier per chunk; 4 MFMA waves (one per SIMD) compute 64 pixels x 32 NI
+// channels each and run ws_epilogue_tile (swapped operands: whole 16-byte NHWC pieces straight to HBM, the residual read as 16-byte
+// pieces at the store addresses) while the loaders are already D - 1 chunks into the next items.  Pixels are taken 256 at a time from
+// the flattened [B H W] index (a 1x1 convolution has no geometry): the host requires B H W % 256 == 0, so no lane is ever masked.
+struct L1KP {
+    const bf16_t* x; const bf16_t* w; bf16_t* y;
+    const float* bias; const float* scale; const float* shift;
+    int x_cs, y_cs, Cout, nsc;                   // nsc: chunks of 64 input channels
+    int ntiles, per_xcd, n_tiles, slots;
+    int relu, accumulate;
+    const bf16_t* res; int res_cs;
+};
+
+template <int NI>
+__global__ __launch_bounds__(512) void conv1x1_ls_kernel(L1KP p) {
+    typedef bf16_t T;
+    constexpr int BN = 32 * NI, V = 2, MI = 2, NLW = 4;
+    constexpr int XPC = 16 * V, WPC = V * BN / 16, PC = XPC + WPC;        // DMA pieces (1 KB) of one chunk: pixel rows, then weights
+    constexpr int NS = (PC + NLW - 1) / NLW;
+    constexpr int D = NI == 1 ? 4 : 3;
+    constexpr int X_BYTES = XPC * 1024, CH_BYTES = PC * 1024;
+    constexpr int OFF_DUMMY = D * CH_BYTES, OFF_CONST = OFF_DUMMY + 1024;
+    static_assert(OFF_CONST + 4 * BN * 4 <= 160 * 1024 && (D - 2) * NS <= 63, "LDS / vmcnt budget");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = wave >= 4;
+    const int wm = wave & 3, lw = wave - 4;
+    const int khalf = lane >> 5, l31 = lane & 31;
+
+    const int xcd = blockIdx.x & 7, jwg = blockIdx.x >> 3;
+    if (jwg >= p.slots * p.n_tiles) return;
+    const int nt = jwg % p.n_tiles, slot = jwg / p.n_tiles, n0 = nt * BN;
+    const int t_lo = xcd * p.per_xcd;
+    const int t_hi = min(t_lo + p.per_xcd, p.ntiles);
+    const int n_items = (t_lo + slot < t_hi) ? (t_hi - t_lo - slot + p.slots - 1) / p.slots : 0;
+    if (n_items <= 0) return;
+    const int G = n_items * p.nsc;
+    if (tid < BN) {
+        float* sc = reinterpret_cast<float*>(smem + OFF_CONST);
+        sc[tid] = p.bias ? p.bias[n0 + tid] : 0.f; sc[BN + tid] = p.scale ? p.scale[n0 + tid] : 1.f; sc[2 * BN + tid] = p.shift ? p.shift[n0 + tid] : 0.f;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float rs0[NI][4], rs1[NI][4];
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { rs0[j][e] = 0.f; rs1[j][e] = 0.f; }
+
+    if (loader) {
+        const unsigned char* zp = reinterpret_cast<const unsigned char*>(g_ws_zero);
+        auto dma = [&](const void* src, int dst) {
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(smem + dst), 16, 0, 0);
+        };
+        // item- and chunk-invariant lane offsets (elements) of this wave's pieces
+        int off[NS];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int pi = lw + NLW * i;
+            off[i] = 0;
+            if (pi < XPC) {
+                const int sub = pi >> 4, row = (pi & 15) * 16 + (lane >> 2);
+                off[i] = row * p.x_cs + sub * 32 + ((lane ^ (row >> 2)) & 3) * 8;
+            } else if (pi < PC) {
+                const int R = (pi - XPC) * 16 + (lane >> 2);
+                const int sub = R / BN, n = R - sub * BN;
+                off[i] = (sub * p.Cout + n) * 32 + ((lane ^ (R >> 2)) & 3) * 8;
+            }
+        }
+        int ik = 0, ic = 0, ig = 0;
+        auto issue_next = [&]() {
+            const bool live = ig < G;
+            const int buf = (ig % D) * CH_BYTES;
+            const long long tile = t_lo + slot + (long long)ik * p.slots;
+            const T* xc = p.x + tile * 256 * p.x_cs + ic * (32 * V);                  // wave-uniform
+            const T* wc = p.w + ((long long)ic * V * p.Cout + n0) * 32;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const int pi = lw + NLW * i;
+                const void* src = zp;
+                int dst = OFF_DUMMY;
+                if (live && pi < XPC) { src = xc + off[i]; dst = buf + pi * 1024; }
+                else if (live && pi < PC) { src = wc + off[i]; dst = buf + pi * 1024; }
+                dma(src, dst);
+            }
+            if (live) { ++ig; if (++ic == p.nsc) { ic = 0; ++ik; } }
+        };
+#pragma unroll 1
+        for (int d = 0; d < D - 1; ++d) issue_next();
+#pragma unroll 1
+        for (int g = 0; g < G; ++g) {
+            ws_wait_vm<(D - 2) * NS>();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            issue_next();
+        }
+        ws_wait_vm<0>();
+        return;
+    }
+    // ================================================================== MFMA waves
+    const WsEpi ep = {p.y, nullptr, nullptr, p.y_cs, 0, 0, p.relu, p.accumulate, 0, p.bias || p.scale || p.shift || p.relu, false, p.res, p.res_cs};
+    int a_addr[MI], b_addr[NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) a_addr[i] = ws_swz(wm * 64 + i * 32 + l31, khalf);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) b_addr[j] = X_BYTES + ws_swz(j * 32 + l31, khalf);
+    struct Frag { u32x4 a[MI], b[NI]; };
+    int g = 0;
+#pragma unroll 1
+    for (int k = 0; k < n_items; ++k) {
+        f32x16 acc[MI][NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll 1
+        for (int c = 0; c < p.nsc; ++c, ++g) {
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const unsigned char* hb = smem + (g % D) * CH_BYTES;
+            auto load_frag = [&](int s, Frag& f) {                          // s = (sub-chunk, k-step), a constant after unrolling
+                const int t = s >> 1, hx = (s & 1) << 5;
+#pragma unroll
+                for (int i = 0; i < MI; ++i) f.a[i] = *reinterpret_cast<const u32x4*>(hb + t * 16384 + (a_addr[i] ^ hx));
+#pragma unroll
+                for (int j = 0; j < NI; ++j) f.b[j] = *reinterpret_cast<const u32x4*>(hb + t * (BN * 64) + (b_addr[j] ^ hx));
+            };
+            constexpr int NST = V * 2;
+            Frag f[NST];
+#pragma unroll
+            for (int s2 = 0; s2 < NST; ++s2) load_frag(s2, f[s2]);
+#pragma unroll
+            for (int s2 = 0; s2 < NST; ++s2)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f[s2].b[j]), __builtin_bit_cast(bf16x8, f[s2].a[i]), acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        const unsigned tile = (unsigned)(t_lo + slot + k * p.slots);
+        unsigned pix[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) pix[i] = tile * 256u + (unsigned)(wm * 64 + i * 32 + l31);
+        const WsLaneGeo geo = {{true, true}, false, false, false, false, 0, 0, 0, 0};
+        ws_epilogue_tile<NI, 0, false>(ep, acc, pix, geo, n0, reinterpret_cast<const float*>(smem + OFF_CONST), rs0, rs1, khalf, l31);
+    }
+}
+
+template <int NI>
+int l1_launch(const L1KP& k, int wgs, hipStream_t st) {
+    constexpr int BN = 32 * NI, PC = 32 + 2 * BN / 16, D = NI == 1 ? 4 : 3;
+    constexpr int LDS = D * PC * 1024 + 1024 + 4 * BN * 4;
+    auto kern = conv1x1_ls_kernel<NI>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) SALT_FAIL((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(512), LDS, st, k);
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}
+
 }  // namespace
 
 // ---- host interface (conv_mfma.hip: salt_conv / salt_conv_stats_parts try this first)
@@ -1056,6 +1233,58 @@ int conv_ls_launch(const salt_conv_args* a, hipStream_t st) {
     if (k.slots > k.per_xcd) k.slots = k.per_xcd;
     const int wgs = k.slots * k.n_tiles * 8;
     return ni == 2 ? ls_launch<2>(k, wgs, st) : ls_launch<1>(k, wgs, st);
+}
+
+
+// ---- conv1x1_ls_kernel host side.  SALT_CONV_1X1_LS = 0: off unless asked for per launch (cfg & 0xff == 11).  Returns NI (1 | 2) or 0.
+int conv1x1_ls_variant(const salt_conv_args* a) {
+    static const int env = getenv("SALT_CONV_1X1_LS") ? atoi(getenv("SALT_CONV_1X1_LS")) : 1;
+    if (!a || a->dtype != SALT_BF16 || a->ntaps != 1 || a->tap_dy[0] || a->tap_dx[0]) return 0;
+    const bool asked = (a->cfg & 0xff) == 11;
+    if ((a->cfg & 0xff) != 0 && !asked) return 0;
+    if (!asked && !env) return 0;
+    if (a->in_step != 1 || a->out_step != 1 || a->out_oy || a->out_ox || a->nphase > 1) return 0;
+    if (a->strip || a->fold_top || a->fold_bottom || a->fold_left || a->fold_right) return 0;
+    if (a->stats || a->fin || a->fin_acc || a->fin_ticket || a->bnb_acc || a->bnb_partials || a->bnb_ticket || a->in_scale || a->in_fin_acc) return 0;   // eval / plain epilogues only
+    if (a->x_plane || a->y_plane) return 0;
+    const int Cin = a->x.C, Cout = a->y.C;
+    if (Cin % 64 || Cout % 32) return 0;
+    if (a->x.B != a->y.B || a->x.H != a->y.H || a->x.W != a->y.W || a->OH != a->y.H || a->OW != a->y.W) return 0;
+    const int64_t npix = (int64_t)a->x.B * a->x.H * a->x.W;
+    if (npix % 256) return 0;
+    if (a->x.cs % 8 || a->y.cs % 8 || ((reinterpret_cast<uintptr_t>(a->x.p) | reinterpret_cast<uintptr_t>(a->y.p) | reinterpret_cast<uintptr_t>(a->w)) & 15)) return 0;
+    if (a->res.p && (a->res.cs % 8 || (reinterpret_cast<uintptr_t>(a->res.p) & 15) || a->accumulate)) return 0;
+    auto small = [&](const salt_view& v) { return !v.p || npix * v.cs < (int64_t)1 << 31; };
+    if (!small(a->x) || !small(a->y) || !small(a->res)) return 0;
+    const int wpx = ws_cus() / 8;
+    int ni = Cout % 64 == 0 ? 2 : 1;
+    const int force_ni = asked ? (a->cfg >> 16) & 3 : 0;
+    if (force_ni == 1 || (force_ni == 2 && Cout % 64 == 0)) ni = force_ni;
+    if (Cout / (32 * ni) > wpx) return 0;
+    if (!asked && (npix / 256) * (Cout / (32 * ni)) < ws_cus() / 2) return 0;        // too few items to fill the chip
+    return ni;
+}
+
+int conv1x1_ls_launch(const salt_conv_args* a, hipStream_t st) {
+    const int ni = conv1x1_ls_variant(a);
+    if (!ni) SALT_FAIL(SALT_E_UNSUPPORTED, "conv1x1_ls: not applicable");
+    L1KP k;
+    k.x = reinterpret_cast<const bf16_t*>(a->x.p); k.w = reinterpret_cast<const bf16_t*>(a->w); k.y = reinterpret_cast<bf16_t*>(a->y.p);
+    k.bias = a->bias; k.scale = a->scale; k.shift = a->shift;
+    k.x_cs = a->x.cs; k.y_cs = a->y.cs; k.Cout = a->y.C; k.nsc = a->x.C / 64;
+    k.ntiles = (int)((int64_t)a->x.B * a->x.H * a->x.W / 256);
+    k.relu = a->relu; k.accumulate = a->accumulate;
+    k.res = reinterpret_cast<const bf16_t*>(a->res.p); k.res_cs = a->res.cs;
+    int wpx = ws_cus() / 8;
+    const int cap = (a->cfg >> 8) & 0xff;
+    k.n_tiles = k.Cout / (32 * ni);
+    if (cap && wpx > cap) wpx = cap > k.n_tiles ? cap : k.n_tiles;
+    k.per_xcd = cdiv(k.ntiles, 8);
+    k.slots = wpx / k.n_tiles;
+    if (k.slots > k.per_xcd) k.slots = k.per_xcd;
+    if (k.slots < 1) k.slots = 1;
+    const int wgs = k.slots * k.n_tiles * 8;
+    return ni == 2 ? l1_launch<2>(k, wgs, st) : l1_launch<1>(k, wgs, st);
 }
 
 extern "C" int salt_debug_ws_clk(unsigned long long* host_out, int n) {

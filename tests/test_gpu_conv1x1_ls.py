@@ -1,0 +1,91 @@
+"""conv1x1_ls_kernel (round 4): the streaming kernel of the eval-mode Bottleneck 1x1 convolutions (architectures/encoders.py:13-19 through
+torchvision's Bottleneck: conv1 / conv3 with folded BatchNorm, ReLU, residual) through the C-ABI, asked for per launch (cfg = 11)
+on tensors small enough for the CPU: against torch in fp32 on the same bf16-rounded operands, and against conv_mfma_kernel (cfg = 1)."""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # B, H, W, Cin, Cout, residual, affine + relu, accumulate, view slack (pixel stride > channels), cap (workgroups per XCD; 0 = auto)
+    (2, 16, 16, 64, 256, True, True, False, 0, 0),        # 64 -> 256 expansion + residual (layer1 conv3)
+    (2, 16, 16, 256, 64, False, True, False, 0, 0),       # 256 -> 64 reduction (conv1)
+    (1, 16, 32, 128, 96, False, False, False, 0, 0),      # Cout % 64 != 0: 32-channel items
+    (4, 8, 8, 512, 128, False, True, True, 0, 0),         # accumulate, 8 chunks of 64 channels (ring wraps several times)
+    (2, 16, 16, 128, 512, True, True, False, 64, 0),      # strided views
+    (8, 16, 16, 256, 128, True, True, False, 0, 2),       # 2 workgroups per XCD: several items per workgroup
+    (8, 16, 16, 64, 64, False, False, False, 0, 1),
+]
+
+
+def _conv1x1(case, cfg):
+    import salt_amd  # noqa: F401
+    from salt_amd._abi import STRUCTS, lib, fill, check
+    from salt_amd.engine import shaped_view
+    B, H, W, Cin, Cout, res, aff, acc, slack, cap = case
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, H, W, Cin + slack, generator=g).bfloat16().cuda()
+    w = (torch.randn(Cout, Cin, 1, 1, generator=g) * (2.0 / Cin) ** 0.5).cuda()
+    r = torch.randn(B, H, W, Cout + slack, generator=g).bfloat16().cuda()
+    y = (torch.randn(B, H, W, Cout + slack, generator=g).bfloat16() if acc else torch.zeros(B, H, W, Cout + slack).bfloat16()).cuda()
+    y0 = y.clone()
+    bias = torch.randn(Cout, generator=g).cuda(); scale = (1 + 0.1 * torch.randn(Cout, generator=g)).cuda(); shift = (0.1 * torch.randn(Cout, generator=g)).cuda()
+    n = lib.salt_packed_weight_elems(1, 1, Cout, Cin)
+    wp = torch.zeros(n, dtype=torch.bfloat16, device='cuda:0')
+    st = torch.cuda.current_stream().cuda_stream
+    check(lib.salt_pack_conv_weight(ctypes.byref(fill(STRUCTS['salt_pack_conv_weight_args'](), dtype=1, w=w.data_ptr(), D0=Cout, D1=Cin, KH=1, KW=1, ntaps=1,
+                                                      tap_kh=[0], tap_kw=[0], transpose=0, wp=wp.data_ptr())), st))
+    S = fill(STRUCTS['salt_conv_args'](), dtype=1, x=shaped_view(x.data_ptr(), B, H, W, Cin, Cin + slack), w=wp.data_ptr(), ntaps=1, tap_dy=[0], tap_dx=[0],
+             in_step=1, pad_mode=0, y=shaped_view(y.data_ptr(), B, H, W, Cout, Cout + slack), OH=H, OW=W, out_step=1,
+             bias=bias.data_ptr() if aff else None, scale=scale.data_ptr() if aff else None, shift=shift.data_ptr() if aff else None,
+             relu=int(aff), accumulate=int(acc), cfg=cfg | (cap << 8))
+    if res:
+        S.res = shaped_view(r.data_ptr(), B, H, W, Cout, Cout + slack)
+    kid = lib.salt_conv_kernel_id(ctypes.byref(S))
+    check(lib.salt_conv(ctypes.byref(S), st), 'salt_conv')
+    torch.cuda.synchronize()
+    # fp32 reference on the bf16-rounded operands, with the kernel's rounding points (bf16 before the residual add)
+    xf, wf = x[..., :Cin].float().cpu(), w.bfloat16().float().cpu().view(Cout, Cin)
+    v = xf.reshape(-1, Cin) @ wf.t()
+    if aff:
+        v = (v + bias.cpu()) * scale.cpu() + shift.cpu()
+        if not res:
+            v = v.clamp_min(0)
+    v = v.view(B, H, W, Cout)
+    if res:
+        v = v.bfloat16().float() + r[..., :Cout].float().cpu()
+        if aff:
+            v = v.clamp_min(0)
+    if acc:
+        v = v.bfloat16().float() + y0[..., :Cout].float().cpu()
+    return y.float().cpu(), v, kid, (y0.float().cpu() if slack else None)
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_conv1x1_ls_vs_torch_and_conv_mfma(case):
+    y, ref, kid, y0 = _conv1x1(case, 11)
+    assert kid == 11, kid
+    Cout, slack = case[4], case[8]
+    got = y[..., :Cout]
+    assert torch.isfinite(got).all()
+    err = float((got - ref).abs().max() / ref.abs().max())
+    assert err <= 1e-2, err                                                 # one bf16 rounding of the stored value
+    if slack:
+        assert torch.equal(y[..., Cout:], y0[..., Cout:])                   # the channels beside the view are untouched
+    y1, _, kid1, _ = _conv1x1(case, 1)
+    assert kid1 == 1
+    d = float((y1[..., :Cout] - got).abs().max() / ref.abs().max())
+    assert d <= 8e-3, d                                                     # same products, same bf16 rounding points: at most one ulp apart
+
+
+def test_conv1x1_ls_is_picked_for_the_bottleneck_shapes():
+    """Without a request the plan hands the big eval-mode 1x1 launches (enough items for the chip) to the streaming kernel and keeps
+    the rest on conv_mfma_kernel."""
+    big = (16, 64, 64, 64, 256, True, True, False, 0, 0)
+    _, _, kid, _ = _conv1x1(big, 0)
+    assert kid == 11
+    small = (1, 16, 16, 64, 256, True, True, False, 0, 0)
+    _, _, kid, _ = _conv1x1(small, 0)
+    assert kid != 11
