@@ -889,6 +889,7 @@ struct L1KP {
     int ntiles, per_xcd, n_tiles, slots;
     int relu, accumulate;
     const bf16_t* res; int res_cs;
+    int step, IH, IW, OH, OW, tiles_x, tiles_y;   // step 2 (projection shortcuts): 16 x 16 OUTPUT-pixel tiles, input pixel = 2 x output pixel
 };
 
 template <int NI>
@@ -941,7 +942,9 @@ __global__ __launch_bounds__(512) void conv1x1_ls_kernel(L1KP p) {
             off[i] = 0;
             if (pi < XPC) {
                 const int sub = pi >> 4, row = (pi & 15) * 16 + (lane >> 2);
-                off[i] = row * p.x_cs + sub * 32 + ((lane ^ (row >> 2)) & 3) * 8;
+                // step 1: row = flattened pixel of the tile; step 2: row = (ty, tx) of a 16 x 16 output tile -> input pixel (2 ty, 2 tx)
+                const int prow = p.step == 2 ? ((row >> 4) * 2 * p.IW + (row & 15) * 2) : row;
+                off[i] = prow * p.x_cs + sub * 32 + ((lane ^ (row >> 2)) & 3) * 8;
             } else if (pi < PC) {
                 const int R = (pi - XPC) * 16 + (lane >> 2);
                 const int sub = R / BN, n = R - sub * BN;
@@ -953,7 +956,13 @@ __global__ __launch_bounds__(512) void conv1x1_ls_kernel(L1KP p) {
             const bool live = ig < G;
             const int buf = (ig % D) * CH_BYTES;
             const long long tile = t_lo + slot + (long long)ik * p.slots;
-            const T* xc = p.x + tile * 256 * p.x_cs + ic * (32 * V);                  // wave-uniform
+            long long pix0 = tile * 256;                                              // first input pixel of the tile (wave-uniform)
+            if (p.step == 2) {
+                const int tx = (int)(tile % p.tiles_x); const long long r = tile / p.tiles_x;
+                const int ty = (int)(r % p.tiles_y); const long long b = r / p.tiles_y;
+                pix0 = (b * p.IH + ty * 32) * p.IW + tx * 32;
+            }
+            const T* xc = p.x + pix0 * p.x_cs + ic * (32 * V);
             const T* wc = p.w + ((long long)ic * V * p.Cout + n0) * 32;
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
@@ -1026,8 +1035,17 @@ __global__ __launch_bounds__(512) void conv1x1_ls_kernel(L1KP p) {
         __builtin_amdgcn_s_setprio(0);
         const unsigned tile = (unsigned)(t_lo + slot + k * p.slots);
         unsigned pix[MI];
+        if (p.step == 2) {
+            const unsigned tx = tile % (unsigned)p.tiles_x, r = tile / (unsigned)p.tiles_x, ty = r % (unsigned)p.tiles_y, b = r / (unsigned)p.tiles_y;
 #pragma unroll
-        for (int i = 0; i < MI; ++i) pix[i] = tile * 256u + (unsigned)(wm * 64 + i * 32 + l31);
+            for (int i = 0; i < MI; ++i) {
+                const unsigned m = (unsigned)(wm * 64 + i * 32 + l31);
+                pix[i] = (b * (unsigned)p.OH + ty * 16u + (m >> 4)) * (unsigned)p.OW + tx * 16u + (m & 15u);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) pix[i] = tile * 256u + (unsigned)(wm * 64 + i * 32 + l31);
+        }
         const WsLaneGeo geo = {{true, true}, false, false, false, false, 0, 0, 0, 0};
         ws_epilogue_tile<NI, 0, false>(ep, acc, pix, geo, n0, reinterpret_cast<const float*>(smem + OFF_CONST), rs0, rs1, khalf, l31);
     }
@@ -1243,18 +1261,21 @@ int conv1x1_ls_variant(const salt_conv_args* a) {
     const bool asked = (a->cfg & 0xff) == 11;
     if ((a->cfg & 0xff) != 0 && !asked) return 0;
     if (!asked && !env) return 0;
-    if (a->in_step != 1 || a->out_step != 1 || a->out_oy || a->out_ox || a->nphase > 1) return 0;
+    if ((a->in_step != 1 && a->in_step != 2) || a->out_step != 1 || a->out_oy || a->out_ox || a->nphase > 1) return 0;
     if (a->strip || a->fold_top || a->fold_bottom || a->fold_left || a->fold_right) return 0;
     if (a->stats || a->fin || a->fin_acc || a->fin_ticket || a->bnb_acc || a->bnb_partials || a->bnb_ticket || a->in_scale || a->in_fin_acc) return 0;   // eval / plain epilogues only
     if (a->x_plane || a->y_plane) return 0;
     const int Cin = a->x.C, Cout = a->y.C;
     if (Cin % 64 || Cout % 32) return 0;
-    if (a->x.B != a->y.B || a->x.H != a->y.H || a->x.W != a->y.W || a->OH != a->y.H || a->OW != a->y.W) return 0;
-    const int64_t npix = (int64_t)a->x.B * a->x.H * a->x.W;
+    if (a->x.B != a->y.B || a->OH != a->y.H || a->OW != a->y.W) return 0;
+    if (a->in_step == 1 && (a->x.H != a->y.H || a->x.W != a->y.W)) return 0;
+    // stride 2 (ResNet projection shortcuts): 16 x 16 output tiles, every tap inside the input
+    if (a->in_step == 2 && (a->y.H % 16 || a->y.W % 16 || 2 * a->y.H > a->x.H + 1 || 2 * a->y.W > a->x.W + 1)) return 0;
+    const int64_t npix = (int64_t)a->y.B * a->y.H * a->y.W;
     if (npix % 256) return 0;
     if (a->x.cs % 8 || a->y.cs % 8 || ((reinterpret_cast<uintptr_t>(a->x.p) | reinterpret_cast<uintptr_t>(a->y.p) | reinterpret_cast<uintptr_t>(a->w)) & 15)) return 0;
     if (a->res.p && (a->res.cs % 8 || (reinterpret_cast<uintptr_t>(a->res.p) & 15) || a->accumulate)) return 0;
-    auto small = [&](const salt_view& v) { return !v.p || npix * v.cs < (int64_t)1 << 31; };
+    auto small = [&](const salt_view& v) { return !v.p || (int64_t)v.B * v.H * v.W * v.cs < (int64_t)1 << 31; };
     if (!small(a->x) || !small(a->y) || !small(a->res)) return 0;
     const int wpx = ws_cus() / 8;
     int ni = Cout % 64 == 0 ? 2 : 1;
@@ -1272,7 +1293,9 @@ int conv1x1_ls_launch(const salt_conv_args* a, hipStream_t st) {
     k.x = reinterpret_cast<const bf16_t*>(a->x.p); k.w = reinterpret_cast<const bf16_t*>(a->w); k.y = reinterpret_cast<bf16_t*>(a->y.p);
     k.bias = a->bias; k.scale = a->scale; k.shift = a->shift;
     k.x_cs = a->x.cs; k.y_cs = a->y.cs; k.Cout = a->y.C; k.nsc = a->x.C / 64;
-    k.ntiles = (int)((int64_t)a->x.B * a->x.H * a->x.W / 256);
+    k.ntiles = (int)((int64_t)a->y.B * a->y.H * a->y.W / 256);
+    k.step = a->in_step; k.IH = a->x.H; k.IW = a->x.W; k.OH = a->y.H; k.OW = a->y.W; k.tiles_x = a->y.W / 16; k.tiles_y = a->y.H / 16;
+    if (k.step == 2 && (k.tiles_x < 1 || k.tiles_y < 1)) SALT_FAIL(SALT_E_UNSUPPORTED, "conv1x1_ls: stride 2 needs 16 x 16 output tiles");
     k.relu = a->relu; k.accumulate = a->accumulate;
     k.res = reinterpret_cast<const bf16_t*>(a->res.p); k.res_cs = a->res.cs;
     int wpx = ws_cus() / 8;

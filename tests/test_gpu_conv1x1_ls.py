@@ -18,6 +18,12 @@ CASES = [
     (8, 16, 16, 256, 128, True, True, False, 0, 2),       # 2 workgroups per XCD: several items per workgroup
     (8, 16, 16, 64, 64, False, False, False, 0, 1),
 ]
+CASES_S2 = [
+    # B, OH, OW, Cin, Cout, affine, view slack, cap: nn.Conv2d(Cin, Cout, 1, stride 2) of the ResNet projection shortcuts (input 2 OH x 2 OW)
+    (2, 16, 16, 256, 512, True, 0, 0),
+    (4, 16, 32, 64, 96, False, 0, 0),
+    (3, 32, 16, 128, 256, True, 128, 2),
+]
 
 
 def _conv1x1(case, cfg):
@@ -89,3 +95,34 @@ def test_conv1x1_ls_is_picked_for_the_bottleneck_shapes():
     small = (1, 16, 16, 64, 256, True, True, False, 0, 0)
     _, _, kid, _ = _conv1x1(small, 0)
     assert kid != 11
+
+
+@pytest.mark.parametrize('case', CASES_S2)
+def test_conv1x1_ls_stride2_vs_torch(case):
+    import salt_amd  # noqa: F401
+    from salt_amd._abi import STRUCTS, lib, fill, check
+    from salt_amd.engine import shaped_view
+    B, OH, OW, Cin, Cout, aff, slack, cap = case
+    H, W = 2 * OH, 2 * OW
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, H, W, Cin + slack, generator=g).bfloat16().cuda()
+    w = (torch.randn(Cout, Cin, 1, 1, generator=g) * (2.0 / Cin) ** 0.5).cuda()
+    y = torch.zeros(B, OH, OW, Cout).bfloat16().cuda()
+    scale = (1 + 0.1 * torch.randn(Cout, generator=g)).cuda(); shift = (0.1 * torch.randn(Cout, generator=g)).cuda()
+    wp = torch.zeros(lib.salt_packed_weight_elems(1, 1, Cout, Cin), dtype=torch.bfloat16, device='cuda:0')
+    st = torch.cuda.current_stream().cuda_stream
+    check(lib.salt_pack_conv_weight(ctypes.byref(fill(STRUCTS['salt_pack_conv_weight_args'](), dtype=1, w=w.data_ptr(), D0=Cout, D1=Cin, KH=1, KW=1, ntaps=1,
+                                                      tap_kh=[0], tap_kw=[0], transpose=0, wp=wp.data_ptr())), st))
+    S = fill(STRUCTS['salt_conv_args'](), dtype=1, x=shaped_view(x.data_ptr(), B, H, W, Cin, Cin + slack), w=wp.data_ptr(), ntaps=1, tap_dy=[0], tap_dx=[0],
+             in_step=2, pad_mode=0, y=shaped_view(y.data_ptr(), B, OH, OW, Cout), OH=OH, OW=OW, out_step=1,
+             scale=scale.data_ptr() if aff else None, shift=shift.data_ptr() if aff else None, relu=0, accumulate=0, cfg=11 | (cap << 8))
+    assert lib.salt_conv_kernel_id(ctypes.byref(S)) == 11
+    check(lib.salt_conv(ctypes.byref(S), st), 'salt_conv')
+    torch.cuda.synchronize()
+    xs = x[:, ::2, ::2, :Cin].float().cpu()
+    v = xs.reshape(-1, Cin) @ w.bfloat16().float().cpu().view(Cout, Cin).t()
+    if aff:
+        v = v * scale.cpu() + shift.cpu()
+    v = v.view(B, OH, OW, Cout)
+    err = float((y.float().cpu() - v).abs().max() / v.abs().max())
+    assert err <= 1e-2, err
