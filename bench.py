@@ -254,6 +254,72 @@ def cpu_baseline_subprocess(loss, arch_name, threads=0, batch=0):
     return {'value': None, 'unit': 'images/s', 'cores': threads, 'host_logical_cpus': os.cpu_count(), 'kind': 'port', 'sample': note}
 
 
+DP_LEG_TIMEOUT_S = 300
+
+
+def dp_leg(workload, dtype, B, loss):
+    """Child mode (--dp-leg): the headline step through parallel.DataParallel.backward with a 1-rank RCCL communicator against the plain
+    step, alternated inside this one fresh process (2 x 20 steps each), plus the exposed all-reduce time and the per-bucket timeline."""
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(0)
+    os.environ['SALT_FORCE_DP_PATH'] = '1'
+    init_rccl(0)
+    import salt_amd  # noqa: F401
+    m2, b2, _, _ = train_config(workload, dtype, B, loss, 4, 6, dev)
+
+    def timed(dp_on, n=20):
+        if dp_on:
+            os.environ['SALT_FORCE_DP_PATH'] = '1'
+        else:
+            os.environ.pop('SALT_FORCE_DP_PATH', None)
+        m2.dp.measure = False
+        for i in range(3):
+            m2._fit_loop(list(b2[i % len(b2)]))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            m2._fit_loop(list(b2[i % len(b2)]))
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / n
+    ms_plain, ms_dp = [], []
+    for _ in range(2):
+        ms_plain.append(timed(False)); ms_dp.append(timed(True))
+    os.environ['SALT_FORCE_DP_PATH'] = '1'
+    m2.dp.measure = True
+    for i in range(4):
+        m2._fit_loop(list(b2[i % len(b2)]))
+    ex = m2.dp.exposed_allreduce_ms()
+    m2.dp.measure = False
+    m2.dp.timeline = True
+    for i in range(6):
+        m2._fit_loop(list(b2[i % len(b2)]))
+    res = {'config': 'the headline step through the bucketed all-reduce path (parallel.DataParallel.backward) with a 1-rank RCCL communicator, '
+                     'alternated with the plain step in one fresh process (2 x 20 steps each)',
+           'ms_per_step': round(min(ms_dp), 3), 'ms_per_step_plain_same_process': round(min(ms_plain), 3),
+           'ms_per_step_all': [round(v, 3) for v in ms_dp], 'ms_per_step_plain_all': [round(v, 3) for v in ms_plain],
+           'overhead_frac': round(min(ms_dp) / min(ms_plain) - 1.0, 4), 'images_per_s': round(B / min(ms_dp) * 1e3, 1),
+           'buckets': len(list(m2.dp._plans.values())[0]) if m2.dp._plans else 0, 'rccl_info': rccl_summary(6),
+           'exposed_allreduce_ms_per_step': round(ex, 4) if ex is not None else None, 'bucket_timeline': m2.dp.bucket_timeline()}
+    print(json.dumps(res))
+    dist.destroy_process_group()
+
+
+def dp_leg_subprocess(workload, dtype, B, loss):
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--dp-leg', '--workload', workload, '--dtype', dtype, '--batch', str(B), '--loss', loss]
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'SALT_FORCE_DP_PATH'):
+        env.pop(k, None)
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=DP_LEG_TIMEOUT_S)
+        line = [x for x in r.stdout.splitlines() if x.startswith('{')]
+        if r.returncode == 0 and line:
+            return json.loads(line[-1])
+        return {'error': 'dp leg failed: ' + (r.stderr.strip().splitlines() or ['?'])[-1][:200]}
+    except subprocess.TimeoutExpired:
+        return {'error': 'dp leg exceeded %d s' % DP_LEG_TIMEOUT_S}
+
+
 WORKLOADS = {'r34_hyper': ('UNetResNet', 3, 'architectures.unet.UNetResNet(34, hypercolumn)'),
              'ternaus34': ('TernausUNetResNet', 3, 'unet_models.UNetResNet(34, deconv)'),
              'vanilla': ('VanillaUNet', 1, 'vanilla 4-level U-Net (16 filters, 1 channel)')}
@@ -502,10 +568,14 @@ def main():
     ap.add_argument('--no-iou', action='store_true')
     ap.add_argument('--no-configs', action='store_true', help='skip the other BASELINE configurations (C1, fp32, C3 shape, C4)')
     ap.add_argument('--cpu-leg', default=None, help=argparse.SUPPRESS)       # child mode of the cpu_baseline leg
+    ap.add_argument('--dp-leg', action='store_true', help=argparse.SUPPRESS)     # child mode of configs.dp_path_1rank
     ap.add_argument('--cpu-threads', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--cpu-batch', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--selftest-launch', action='store_true', help=argparse.SUPPRESS)   # launcher self-test under gloo (no GPU)
     args = ap.parse_args()
+    if args.dp_leg:
+        dp_leg(args.workload, args.dtype, args.batch, args.loss)
+        return
     if args.cpu_leg:
         cpu_baseline_leg(args.cpu_leg, args.loss, 1 if args.cpu_leg == 'VanillaUNet' else 3, args.cpu_threads, args.cpu_batch)
         return
@@ -638,53 +708,11 @@ def main():
         torch.cuda.empty_cache()
         out['configs'] = extra_configs(dev)
         if not dist.is_initialized():
-            # the bucketed data-parallel step against a 1-rank RCCL communicator: what the N > 1 code path costs before any wire time
-            os.environ['SALT_FORCE_DP_PATH'] = '1'
-            try:
-                init_rccl(0)
-                m2, b2, _, _ = train_config(args.workload, args.dtype, B, args.loss, 4, 6, dev)
-                # alternated inside ONE process (a 12-step run of its own read 6.6 % slower than the 40-step headline in round 3 - mostly
-                # the shorter run): plain backward / bucketed backward, 2 x 20 steps each, same model, same batches
-                def timed(dp_on, n=20):
-                    if dp_on:
-                        os.environ['SALT_FORCE_DP_PATH'] = '1'
-                    else:
-                        os.environ.pop('SALT_FORCE_DP_PATH', None)
-                    m2.dp.measure = False
-                    for i in range(3):
-                        m2._fit_loop(list(b2[i % len(b2)]))
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    for i in range(n):
-                        m2._fit_loop(list(b2[i % len(b2)]))
-                    torch.cuda.synchronize()
-                    return 1e3 * (time.perf_counter() - t0) / n
-                ms_plain, ms_dp = [], []
-                for _ in range(2):
-                    ms_plain.append(timed(False)); ms_dp.append(timed(True))
-                os.environ['SALT_FORCE_DP_PATH'] = '1'
-                m2.dp.measure = True
-                for i in range(4):
-                    m2._fit_loop(list(b2[i % len(b2)]))
-                ex = m2.dp.exposed_allreduce_ms()
-                m2.dp.measure = False
-                m2.dp.timeline = True
-                for i in range(6):
-                    m2._fit_loop(list(b2[i % len(b2)]))
-                out['configs']['dp_path_1rank'] = {
-                    'config': 'the headline step through the bucketed all-reduce path (parallel.DataParallel.backward) with a 1-rank RCCL communicator, '
-                              'alternated with the plain step in one process (2 x 20 steps each)',
-                    'ms_per_step': round(min(ms_dp), 3), 'ms_per_step_plain_same_process': round(min(ms_plain), 3),
-                    'overhead_frac': round(min(ms_dp) / min(ms_plain) - 1.0, 4), 'images_per_s': round(B / min(ms_dp) * 1e3, 1),
-                    'buckets': len(list(m2.dp._plans.values())[0]) if m2.dp._plans else 0, 'rccl_info': rccl_summary(6),
-                    'exposed_allreduce_ms_per_step': round(ex, 4) if ex is not None else None,
-                    'bucket_timeline': m2.dp.bucket_timeline()}
-                del m2
-            except Exception as e:            # a missing RCCL transport on a 1-GPU box must not cost the headline line
-                out['configs']['dp_path_1rank'] = {'error': repr(e)[:200]}
-            finally:
-                os.environ.pop('SALT_FORCE_DP_PATH', None)
-            torch.cuda.empty_cache()
+            # the bucketed data-parallel step against a 1-rank RCCL communicator, alternated with the plain step - in a FRESH child
+            # process, which is what a rank of a real run looks like: inside this process (a dozen HIP streams created and destroyed by
+            # the configurations above) the communication stream aliases a hardware queue of the compute streams and the same A/B
+            # reads +6.5 % instead of +3 %
+            out['configs']['dp_path_1rank'] = dp_leg_subprocess(args.workload, args.dtype, B, args.loss)
 
     # ------------------------------------------------------------------ CPU baseline: the oracle on the host cores (bounded sample)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

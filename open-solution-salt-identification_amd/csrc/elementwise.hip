@@ -913,6 +913,59 @@ __global__ __launch_bounds__(256) void bilinear_fwd_rows_kernel(salt_view x, sal
     }
 }
 
+// xR (R = 2, 4, 8, 16): a thread owns an R x R block of OUTPUT pixels for one channel piece - rows [gy R, (gy + 1) R) x columns [gx R, (gx + 1) R).
+// Its source pixels are the 3 x 3 neighbourhood of (gy, gx) (the first half of the rows interpolates between source rows gy - 1 and gy,
+// the second between gy and gy + 1; columns likewise): 9 gathers, then R^2 outputs from registers - the horizontal interpolation of a
+// column serves the R / 2 rows of its quadrant.  Same bil_src / bil_mix operations as the kernels above: bit-identical.  The stores are
+// what is left: lanes = channel pieces of one pixel, so a wave writes whole pixel rows (C4: 2.1 GB per level).
+template <typename T, int R>
+__global__ __launch_bounds__(256) void bilinear_fwd_cells_kernel(salt_view x, salt_view y) {
+    constexpr int N = Elem<T>::VE, H2 = R / 2;
+    const int cpv = x.C / N;
+    const int64_t units = (int64_t)x.B * x.H * x.W * cpv;
+    for (int64_t u = blockIdx.x * 256LL + threadIdx.x; u < units; u += gridDim.x * 256LL) {
+        const unsigned q = (unsigned)(u / cpv); const int c0 = (int)(u - (int64_t)q * cpv) * N;       // (host: B H W < 2^31)
+        const unsigned r = q / (unsigned)x.W; const int gx = (int)(q - r * (unsigned)x.W);
+        const int b = (int)(r / (unsigned)x.H), gy = (int)(r - (unsigned)b * (unsigned)x.H);
+        const T* base = (const T*)x.p + (int64_t)b * x.H * x.W * x.cs + c0;
+        int ry[3], rx[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { ry[k] = min(max(gy - 1 + k, 0), x.H - 1); rx[k] = min(max(gx - 1 + k, 0), x.W - 1); }
+        u32x4 cr[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) cr[i][j] = *reinterpret_cast<const u32x4*>(base + ((int64_t)ry[i] * x.W + rx[j]) * x.cs);
+        T* obase = (T*)y.p + (((int64_t)b * y.H + (int64_t)gy * R) * y.W + (int64_t)gx * R) * y.cs + c0;
+#pragma unroll
+        for (int qx = 0; qx < 2; ++qx) {
+#pragma unroll
+            for (int qy = 0; qy < 2; ++qy) {
+                float fa[N], fb[N], fc[N], fd[N];
+                unpack16<T>(cr[qy][qx], fa); unpack16<T>(cr[qy][qx + 1], fb); unpack16<T>(cr[qy + 1][qx], fc); unpack16<T>(cr[qy + 1][qx + 1], fd);
+                for (int ox = 0; ox < H2; ++ox) {
+                    const int oxl = qx * H2 + ox;
+                    int x0, x1; float lx;
+                    bil_src(gx * R + oxl, R, x.W, 0, x0, x1, lx);
+                    float top[N], bot[N];
+#pragma unroll
+                    for (int j = 0; j < N; ++j) { top[j] = __fmaf_rn(lx, fb[j], __fmul_rn(1.f - lx, fa[j])); bot[j] = __fmaf_rn(lx, fd[j], __fmul_rn(1.f - lx, fc[j])); }
+#pragma unroll
+                    for (int oy = 0; oy < H2; ++oy) {
+                        const int oyl = qy * H2 + oy;
+                        int y0, y1; float ly;
+                        bil_src(gy * R + oyl, R, x.H, 0, y0, y1, ly);
+                        float o[N];
+#pragma unroll
+                        for (int j = 0; j < N; ++j) o[j] = __fmaf_rn(ly, bot[j], __fmul_rn(1.f - ly, top[j]));
+                        *reinterpret_cast<u32x4*>(obase + ((int64_t)oyl * y.W + oxl) * y.cs) = pack16<T>(o);
+                    }
+                }
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ float bil_wgt(int o_, int R, int n, int i_) {      // weight of output o on input i along one axis (0: not referenced)
     int i0, i1; float l;
     bil_src(o_, R, n, 0, i0, i1, l);
@@ -1364,7 +1417,16 @@ extern "C" int salt_bilinear(const salt_bilinear_args* a, void* stream) {
         const bool rows_ok = !rows_off && v && !a->align_corners && cpv >= 1 && cpv <= 256 && 256 % cpv == 0 &&
                              (int64_t)a->y.W * a->y.cs < (1ll << 30) && (int64_t)a->y.H * a->y.W * a->y.cs < (1ll << 31) && view_pixels(a->y) / a->y.W < (1ll << 31);
         auto row_grid = [](int64_t rows) { const int64_t g = (rows + 7) / 8 * 8; return dim3((unsigned)(g < 16384 ? g : 16384)); };      // a multiple of 8: one row range per XCD
-        if (!a->backward && rows_ok) {
+        static const bool cells_off = getenv("SALT_BILINEAR_CELLS") && atoi(getenv("SALT_BILINEAR_CELLS")) == 0;
+        const bool cells_ok = rows_ok && !cells_off && !a->backward && view_pixels(a->x) < (1ll << 31) && (a->R == 2 || a->R == 4 || a->R == 8 || a->R == 16);
+        if (cells_ok) {
+            const int64_t units = view_pixels(a->x) * cpv;
+            const dim3 grid((unsigned)((units + 255) / 256 < 65536 ? (units + 255) / 256 : 65536));
+            if (a->R == 2) hipLaunchKernelGGL((bilinear_fwd_cells_kernel<T, 2>), grid, dim3(256), 0, (hipStream_t)stream, a->x, a->y);
+            else if (a->R == 4) hipLaunchKernelGGL((bilinear_fwd_cells_kernel<T, 4>), grid, dim3(256), 0, (hipStream_t)stream, a->x, a->y);
+            else if (a->R == 8) hipLaunchKernelGGL((bilinear_fwd_cells_kernel<T, 8>), grid, dim3(256), 0, (hipStream_t)stream, a->x, a->y);
+            else hipLaunchKernelGGL((bilinear_fwd_cells_kernel<T, 16>), grid, dim3(256), 0, (hipStream_t)stream, a->x, a->y);
+        } else if (!a->backward && rows_ok) {
             hipLaunchKernelGGL((bilinear_fwd_rows_kernel<T, 4>), row_grid((int64_t)a->y.B * a->y.H), dim3(256), 0, (hipStream_t)stream, a->x, a->y, a->R);
         } else if (a->backward && rows_ok) {
             if (a->R >= 4 && a->tmp) {
