@@ -868,6 +868,9 @@ __global__ void bilinear_bwd_kernel(salt_view x, salt_view y, int R, int accumul
     }
 }
 
+#ifndef SALT_BIL_G
+#define SALT_BIL_G 8
+#endif
 // ---------------------------------------------------------------- bilinear, row-structured (round 4; vectorised views, align_corners = False)
 // The unit-per-thread kernels above decode every unit with three 64-bit divisions and evaluate the interpolation weights per gather; the
 // x2 adjoint issues its 4 x 4 window as four dependent batches.  Measured in the C2 step: 27 us to WRITE a 16.8 MB level, 35 us to
@@ -1033,7 +1036,7 @@ __global__ __launch_bounds__(256) void bilinear_bwd_rows_kernel(salt_view x, sal
                 *reinterpret_cast<u32x4*>(dst) = pack16<T>(o);
             }
         } else {
-            constexpr int G = 4;
+            constexpr int G = SALT_BIL_G;                                       // gathers in flight per batch (raw 16-byte pieces: 4 registers each)
             for (int ix = px0; ix < x.W; ix += ppb) {
                 int ox_lo = max(0, R * ix - R / 2), ox_hi = min(y.W - 1, R * ix + (3 * R) / 2 - 1);
                 if (MODE == 2) { ox_lo = ix; ox_hi = ix; }
