@@ -327,3 +327,18 @@ def test_bench_refuses_more_gpus_than_visible_with_a_message():
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '64'], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 3 and 'needs 64 visible GPUs' in r.stderr
+
+
+def test_wgrad_ls_index_model_is_consistent():
+    """conv_wgrad_ls_kernel's LDS layout on the CPU (tools/wgrad_ls_model.py): the loader's (piece, lane) -> (row, 16-byte slot) -> (pixel,
+    channel slot) map, every transposed-read address of the MFMA waves (unit-step and stride-2 geometry, one or two images per k-step)
+    and the bank sets of every 32-lane group - the checks that let the kernel pass its parity tests on its first GPU run."""
+    import importlib.util
+    path = os.path.join(ROOT, 'tools', 'wgrad_ls_model.py')
+    spec = importlib.util.spec_from_file_location('wgrad_ls_model', path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for NB in (1, 2):
+        assert mod.check(NB, 4)['pieces'] == (17 if NB == 1 else 18)
+        assert mod.check(NB, 8)['pre_pieces'] == 5
+        assert mod.check_stride2(NB, 2) == {'pieces': 22, 'pre_first_q_piece': 13, 'pre_pieces': 5}
