@@ -241,6 +241,7 @@ def test_bn_apply_in_consumer_loader_forward_is_bit_identical(shape, monkeypatch
     for fold in ('', '1'):
         if fold:
             monkeypatch.setenv('SALT_EXP_BN_FOLD', '1')
+            monkeypatch.setenv('SALT_TIMING_ONLY', '1')       # the switch is a timing experiment: honoured only with this acknowledgement (engine.timing_experiment)
         else:
             monkeypatch.delenv('SALT_EXP_BN_FOLD', raising=False)
         for m in (b1, b2):

@@ -342,3 +342,17 @@ def test_wgrad_ls_index_model_is_consistent():
         assert mod.check(NB, 4)['pieces'] == (17 if NB == 1 else 18)
         assert mod.check(NB, 8)['pre_pieces'] == 5
         assert mod.check_stride2(NB, 2) == {'pieces': 22, 'pre_first_q_piece': 13, 'pre_pieces': 5}
+
+
+def test_timing_only_switches_fail_loudly_without_the_acknowledgement(monkeypatch):
+    """SALT_EXP_* measurement switches compute wrong gradients; they raise unless SALT_TIMING_ONLY=1 is set too."""
+    from salt_amd import engine
+    from salt_amd._abi import SaltError
+    monkeypatch.delenv('SALT_TIMING_ONLY', raising=False)
+    monkeypatch.delenv('SALT_EXP_NO_WGRAD', raising=False)
+    assert engine.timing_experiment('SALT_EXP_NO_WGRAD') is False
+    monkeypatch.setenv('SALT_EXP_NO_WGRAD', '1')
+    with pytest.raises(SaltError):
+        engine.timing_experiment('SALT_EXP_NO_WGRAD')
+    monkeypatch.setenv('SALT_TIMING_ONLY', '1')
+    assert engine.timing_experiment('SALT_EXP_NO_WGRAD') is True

@@ -21,6 +21,7 @@ res = {}
 for fold in ('', '1'):
     if fold:
         os.environ['SALT_EXP_BN_FOLD'] = '1'
+        os.environ['SALT_TIMING_ONLY'] = '1'
     else:
         os.environ.pop('SALT_EXP_BN_FOLD', None)
     mod.train()
