@@ -1804,6 +1804,8 @@ struct WgradKP {
     int bmp;                        // pixels per K tile (64 | 128)
     long long q_plane;              // salt_conv_wgrad_args.q_plane: b-block bb reads the dense plane Q + bb * q_plane (0: channel-interleaved rows)
     int atomic;                     // SALT_WGRAD_ATOMIC=1 (A/B): every split ADDS into slab 0 with global_atomic_add_f32 instead of writing its own slab
+    int ksplit;                     // conv_wgrad_kernel<float>: 0 off; 4: Ca, Cb <= 32 - the four waves share block (0, 0) and a quarter of the k-steps each;
+                                    // 2: Ca <= 32 - waves (wa, wb) work on block (0, wb), k-step pairs of parity wa; 3: Cb <= 32 - block (wa, 0), parity wb
 };
 
 template <typename T> struct WRow { static constexpr int BYTES = 64 * (int)sizeof(T); };
@@ -1903,8 +1905,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradKP p) {
         if constexpr (sizeof(T) == 4) {
             // f32: v_mfma_f32_32x32x2_f32, A[i=a][k=pixel], B[k=pixel][j=b]; one dword per lane per operand.
             const int khalf = lane >> 5, l31 = lane & 31;
-            const int aoff = (wa * 32 + l31) * 4, boff = (wb * 32 + l31) * 4;
+            // K-split (round 4): a layer with <= 32 output or input channels fills a quarter / half of the 64 x 64 block and the exact-f32
+            // MFMA takes 64 cycles per 2 pixels - the waves of the empty quadrants take a share of the k-steps of the real one instead
+            const int ks = p.ksplit;
+            const int wa_e = (ks == 4 || ks == 2) ? 0 : wa, wb_e = (ks == 4 || ks == 3) ? 0 : wb;
+            const int kmod = ks == 4 ? 3 : (ks ? 1 : 0), kidx = ks == 4 ? wave : (ks == 2 ? wa : (ks == 3 ? wb : 0));
+            const int aoff = (wa_e * 32 + l31) * 4, boff = (wb_e * 32 + l31) * 4;
             for (int k0 = 0; k0 < BMP; k0 += 2) {
+                if (((k0 >> 1) & kmod) != kidx) continue;
                 const int m = k0 + khalf;
                 const int tx = m & ((1 << p.tw_log2) - 1);
                 const int ty = (m >> p.tw_log2) & ((1 << p.th_log2) - 1);
@@ -2027,15 +2035,42 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradKP p) {
             advance(cur);
         }
     }
+    // K-split (fp32): the waves that shared a channel block meet in LDS tap by tap, fixed order (leader + partner 1 [+ 2 + 3])
+    int wa_o = wa, wb_o = wb;
+    bool leader = true;
+    if (sizeof(T) == 4 && p.ksplit) {
+        const int ks = p.ksplit;
+        const int step = ks == 4 ? 1 : (ks == 2 ? 2 : 1), cnt = ks == 4 ? 4 : 2;          // partners of leader w: w + step, w + 2 step, ...
+        leader = ks == 4 ? wave == 0 : (ks == 2 ? wa == 0 : wb == 0);
+        wa_o = (ks == 4 || ks == 2) ? 0 : wa; wb_o = (ks == 4 || ks == 3) ? 0 : wb;
+        float* red = reinterpret_cast<float*>(smem);                                       // [wave][16][64] floats: 4 KB per wave
+        __syncthreads();                                                                   // every wave is done with the tile buffers
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (!leader) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[t][r];
+            }
+            __syncthreads();
+            if (leader) {
+                for (int q = 1; q < cnt; ++q) {
+                    const int w2 = wave + q * step;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][r] += red[(w2 * 16 + r) * 64 + lane];
+                }
+            }
+            __syncthreads();
+        }
+    }
     // write the partial slab: partials[split][t][a][b]
     const int khalf = lane >> 5, l31 = lane & 31;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        if (t < p.ntaps) {
+        if (t < p.ntaps && leader) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int a = a0 + wa * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                const int b = c0 + wb * 32 + l31;
+                const int a = a0 + wa_o * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                const int b = c0 + wb_o * 32 + l31;
                 if (a < p.Ca && b < p.Cb) {
                     float* d = p.partials + (((int64_t)(p.atomic ? 0 : split) * p.ntaps + t) * p.Ca + a) * p.Cb + b;
                     if (p.atomic) unsafeAtomicAdd(d, acc[t][r]); else *d = acc[t][r];
@@ -2698,7 +2733,7 @@ int wgrad_plan(const salt_conv_wgrad_args* a, WgradKP* k, int* nsplit_out) {
         if ((size_t)(bmp + k->nb * k->hh * k->hw) * rowb <= 80 * 1024) break;     // keep >= 2 workgroups per CU
     }
     k->P = a->p.p; k->Q = a->q.p; k->partials = a->partials;
-    k->q_plane = a->q_plane;
+    k->q_plane = a->q_plane; k->ksplit = 0; k->atomic = 0;
     k->B = a->p.B; k->PH = a->p.H; k->PW = a->p.W; k->Ca = a->p.C; k->p_cs = a->p.cs;
     k->QH = a->q.H; k->QW = a->q.W; k->Cb = a->q.C; k->q_cs = a->q.cs;
     k->ntaps = a->ntaps; k->q_step = a->q_step; k->pad_mode = a->pad_mode; k->min_dy = min_dy; k->min_dx = min_dx;
@@ -2955,10 +2990,18 @@ static int launch_wgrad(const WgradKP& k, hipStream_t st) {
             return SALT_OK;
         }
     }
+    WgradKP kg = k;
+    if constexpr (sizeof(T) == 4) {
+        static const bool no_ks = getenv("SALT_WGRAD32_NOSPLIT") != nullptr;
+        if (!no_ks && !k.atomic && lds >= 4 * 16 * 64 * sizeof(float)) {
+            const bool a32 = k.Ca <= 32, b32 = k.Cb <= 32;
+            kg.ksplit = (a32 && b32) ? 4 : (a32 ? 2 : (b32 ? 3 : 0));
+        }
+    }
 #define SALT_WG(NT) { auto kern = conv_wgrad_kernel<T, NT>; \
         if (lds > 64 * 1024) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
             if (e != hipSuccess) SALT_FAIL((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e)); } \
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, k); }
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, kg); }
     if (k.ntaps == 1) SALT_WG(1)
     else if (k.ntaps <= 3) SALT_WG(3)
     else if (k.ntaps == 4) SALT_WG(4)
