@@ -296,7 +296,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_ls_kernel(WlKP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    struct Row { u32x2 a0, a1, c0, c1; };                                 // pixels 0-3, 4-7, 2-5, 6-9 of the wave's run (x 2 k-halves)
+    struct Row { u32x2 a0, a1, c0, c1; u32x4 sh; };                       // pixels 0-3, 4-7, 2-5, 6-9 of the wave's run (x 2 k-halves); sh: the dx = 1 operand
     struct AFr { s16x4 lo, hi; };
     auto tr = [&](int addr) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(smem + addr)); };
     auto read_row = [&](int sb, int hrl, Row& r) {                        // hrl constant after unrolling
@@ -310,12 +310,17 @@ __global__ __launch_bounds__(512) void conv_wgrad_ls_kernel(WlKP p) {
         a.lo = tr(sb + paL + (j * 16) * 128);
         a.hi = tr(sb + paL + (j * 16 + 4) * 128);
     };
+    // the dx = 1 operand (pixels 1 .. 8) of a row: four v_alignbit, made ONCE per row at the head of the k-step that uses the row first -
+    // one k-step after its reads were issued (left to itself the compiler makes them right behind the reads and waits for those)
+    auto make_sh = [&](Row& r) {
+        r.sh = u32x4{__builtin_amdgcn_alignbit(r.a0.y, r.a0.x, 16), __builtin_amdgcn_alignbit(r.a1.x, r.a0.y, 16),
+                     __builtin_amdgcn_alignbit(r.a1.y, r.a1.x, 16), __builtin_amdgcn_alignbit(r.c1.y, r.a1.y, 16)};
+    };
     auto b_operand = [&](const Row& r, int dx) -> bf16x8 {                // dx constant after unrolling
         u32x4 vv;
         if (dx == 0) vv = u32x4{r.a0.x, r.a0.y, r.a1.x, r.a1.y};
         else if (dx == 2) vv = u32x4{r.c0.x, r.c0.y, r.c1.x, r.c1.y};
-        else vv = u32x4{__builtin_amdgcn_alignbit(r.a0.y, r.a0.x, 16), __builtin_amdgcn_alignbit(r.a1.x, r.a0.y, 16),
-                        __builtin_amdgcn_alignbit(r.a1.y, r.a1.x, 16), __builtin_amdgcn_alignbit(r.c1.y, r.a1.y, 16)};
+        else vv = r.sh;
         return __builtin_bit_cast(bf16x8, vv);
     };
     typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -344,7 +349,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_ls_kernel(WlKP p) {
         const int n = min(p.U - k0, u1 - u);                              // units of this segment (>= 1)
         { WL_BAR_T0(); barrier(); WL_BAR_T1(); }
         int sb = (g % NS) * SLOT;
-        if (!(SALT_WL_ABLATE & 1)) { read_row(sb, KU - 2, rb[0]); read_row(sb, KU - 1, rb[1]); }
+        if (!(SALT_WL_ABLATE & 1)) { read_row(sb, KU - 2, rb[0]); read_row(sb, KU - 1, rb[1]); make_sh(rb[0]); make_sh(rb[1]); }
         ++g;
         { WL_BAR_T0(); barrier(); WL_BAR_T1(); }                          // its first unit
         sb = (g % NS) * SLOT;
@@ -361,29 +366,34 @@ __global__ __launch_bounds__(512) void conv_wgrad_ls_kernel(WlKP p) {
                     if (has_next) {
                         { WL_BAR_T0(); barrier(); WL_BAR_T1(); }          // entry g + 1 landed
                         sbn = ((g + 1) % NS) * SLOT;
-                        if (!(SALT_WL_ABLATE & 1)) { read_a(sbn, 0, ab2[(j + 1) & 1]); read_row(sbn, 0, rb[(j + 3) & 3]); }
                     }
+                    // (always issued - after the last unit of a segment from this slot again, unused - so that both paths carry the
+                    //  same number of LDS reads: the compiler's s_waitcnt insertion is conservative at the join otherwise)
+                    if (!(SALT_WL_ABLATE & 1)) { read_a(sbn, 0, ab2[(j + 1) & 1]); read_row(sbn, 0, rb[(j + 3) & 3]); }
                 } else if (!(SALT_WL_ABLATE & 1)) {
                     read_a(sb, j + 1, ab2[(j + 1) & 1]);
                     read_row(sb, j + 1, rb[(j + 3) & 3]);
                 }
                 if (!(SALT_WL_ABLATE & 1)) {
+                    make_sh(rb[(j + 2) & 3]);                             // the row whose reads were issued one k-step ago
                     const AFr& af = ab2[j & 1];
                     const s16x8 av = {af.lo[0], af.lo[1], af.lo[2], af.lo[3], af.hi[0], af.hi[1], af.hi[2], af.hi[3]};
-                    // the six taps whose operands are register quads as they were read first, the three dx = 1 taps (4 v_alignbit each) last
+                    // the six taps whose operands are register quads as they were read first, the three dx = 1 taps (v_alignbit) last
 #pragma unroll
                     for (int q = 0; q < 9; ++q) {
                         const int dy = q < 6 ? q >> 1 : q - 6, dx = q < 6 ? (q & 1) * 2 : 1, t = dy * 3 + dx;
                         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b_operand(rb[(j + dy) & 3], dx), __builtin_bit_cast(bf16x8, av), acc[t], 0, 0, 0);
                     }
-                    // pin: the six LDS reads of the NEXT k-step behind the first three MFMAs (most slack before their first use), two
-                    // v_alignbit of this k-step behind each of the first six
+                    // pin: the six LDS reads of the NEXT k-step behind the first three MFMAs, this k-step's four v_alignbit behind the
+                    // next two; nothing moves across the k-step boundary (the scheduler otherwise pulls the next row's v_alignbit up to
+                    // its reads and waits for them: 1 510 instead of 1 152 cycles per 36-MFMA unit)
 #pragma unroll
                     for (int q = 0; q < 9; ++q) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        if (q < 3 && j != KU - 1) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                        if (q < 6) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                        if (q < 3) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                        if (q >= 3 && q < 5) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
                     }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             sb = sbn; ++g;
