@@ -41,6 +41,9 @@
 #ifndef SALT_LS_NLW
 #define SALT_LS_NLW 4            // loader waves of conv_ls_kernel (8 measured)
 #endif
+#ifndef SALT_LS_PREFETCH
+#define SALT_LS_PREFETCH 1       // conv_ls_kernel MODE 2: the (+)= / BatchNorm-backward operand tiles of an item are requested BEFORE its chunk loop (0: in the epilogue)
+#endif
 #ifndef SALT_LS_ABLATE
 #define SALT_LS_ABLATE 0         // conv_ls_kernel timing ablations (tools/ls_ablate.sh; results are wrong): 1 no fragment reads / MFMAs, 2 no DMA, 4 no epilogue
 #endif
@@ -114,6 +117,27 @@ struct WsEpi {
     bool has_affine, sums;
     const bf16_t* res; int res_cs;        // MODE 0 residual epilogue (salt_conv_args.res): y = relu?(bf16(affine) + res)
 };
+// The operand tiles of the (+)= / BatchNorm-backward epilogue (MODE 2) of a whole wave tile: 16-byte pieces at the lane's store addresses.
+// conv_ls_kernel requests them before the item's chunk loop (its MFMA waves run loop and epilogue back to back: requested in the
+// epilogue, the matrix pipe waits for 3 x 32 KB of HBM reads per item; the whole-CU workgroup leaves each wave 256 VGPRs to hold them).
+template <int NI> struct WsOps { u32x4 oldv[2][NI][2], yv[2][NI][2], av[2][NI][2]; };
+template <int NI, bool OLD>
+__device__ __forceinline__ void ws_prefetch_operands(const WsEpi& p, const unsigned (&pix)[2], int n0, int khalf, WsOps<NI>& o) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                const unsigned c = n0 + 8 * khalf + 32 * j + 16 * gp;
+                if (OLD && p.accumulate) o.oldv[i][j][gp] = *reinterpret_cast<const u32x4*>(p.y + (pix[i] * (unsigned)p.y_cs + c));
+                if (p.sums) {
+                    o.yv[i][j][gp] = *reinterpret_cast<const u32x4*>(p.bnb_y + (pix[i] * (unsigned)p.bnb_cs + c));
+                    if (p.bnb_a) o.av[i][j][gp] = *reinterpret_cast<const u32x4*>(p.bnb_a + (pix[i] * (unsigned)p.bnb_acs + c));
+                }
+            }
+}
+
 // Per-lane geometry of the wave tile: which of the lane's two pixels are stored (ragged grids, pad-ring pixels of a fused fold), and
 // - FOLD, the data gradient of a replicate-padded convolution on the extended grid (salt_conv_args.fold_top / fold_right = 2, tile
 // columns right-aligned) - where the pad-ring values it must add come from.  The ring pixels a pixel folds share its WAVE: the two
@@ -130,7 +154,8 @@ struct WsLaneGeo {
 
 template <int NI, int MODE, bool FOLD>
 __device__ __forceinline__ void ws_epilogue_tile(const WsEpi& p, f32x16 (&acc)[2][NI], const unsigned (&pix)[2], const WsLaneGeo& geo, int n0,
-                                                 const float* cst, float (&rs0)[NI][4], float (&rs1)[NI][4], int khalf, int l31) {
+                                                 const float* cst, float (&rs0)[NI][4], float (&rs1)[NI][4], int khalf, int l31,
+                                                 const WsOps<NI>* pre = nullptr, bool pre_old = true) {
     typedef bf16_t T;
     constexpr int MI = 2, BN = 32 * NI;
 #pragma unroll
@@ -139,6 +164,15 @@ __device__ __forceinline__ void ws_epilogue_tile(const WsEpi& p, f32x16 (&acc)[2
         u32x4 oldv[MI][2], yv[MI][2], av[MI][2];
         auto load_operands = [&](int i) {                                       // i is a constant after unrolling
             if (!geo.valid[i]) return;
+            if (pre) {                                                          // (MODE 2, conv_ls_kernel: requested before the chunk loop)
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    if (pre_old) oldv[i][gp] = pre->oldv[i][j][gp];
+                    else if (p.accumulate) oldv[i][gp] = *reinterpret_cast<const u32x4*>(p.y + (pix[i] * (unsigned)p.y_cs + n0 + 8 * khalf + 32 * j + 16 * gp));
+                    yv[i][gp] = pre->yv[i][j][gp]; av[i][gp] = pre->av[i][j][gp];
+                }
+                return;
+            }
             if (MODE != 1 && p.accumulate) {
 #pragma unroll
                 for (int gp = 0; gp < 2; ++gp)
@@ -783,6 +817,17 @@ __global__ __launch_bounds__(256 + 64 * NLW) void conv_ls_kernel(LsKP p) {
 #pragma unroll
                 for (int j = 0; j < NI; ++j) b_addr[j] = H_BYTES + ws_swz(j * 32 + lb, khalf);
             }
+            const TC cc = coords(k);
+            unsigned pix[MI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int m = wm * 64 + i * 32 + ws_perm(l31);
+                pix[i] = (unsigned)((cc.b * p.OH + cc.oy0 + (m >> 4)) * p.OW + cc.ox0 + (m & 15));
+            }
+            constexpr bool PRE = MODE == 2 && SALT_LS_PREFETCH != 0;
+            WsOps<PRE ? NI : 1> ops;
+            constexpr bool PRE_OLD = NI == 1;                              // (NI = 2: 96 more registers do not fit beside the accumulators)
+            if constexpr (PRE) ws_prefetch_operands<NI, PRE_OLD>(ep, pix, n0, khalf, ops);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll 1
             for (int c = 0; c < p.nchunk; ++c, ++g) {
@@ -819,13 +864,6 @@ __global__ __launch_bounds__(256 + 64 * NLW) void conv_ls_kernel(LsKP p) {
                 }
             }
             __builtin_amdgcn_s_setprio(0);
-            const TC cc = coords(k);
-            unsigned pix[MI];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int m = wm * 64 + i * 32 + ws_perm(l31);
-                pix[i] = (unsigned)((cc.b * p.OH + cc.oy0 + (m >> 4)) * p.OW + cc.ox0 + (m & 15));
-            }
             const WsLaneGeo geo = {{true, true}, false, false, false, false, 0, 0, 0, 0};
             if (SALT_LS_ABLATE & 4) {                                      // keep the accumulators alive without the epilogue
                 float tsum = 0.f;
@@ -838,7 +876,8 @@ __global__ __launch_bounds__(256 + 64 * NLW) void conv_ls_kernel(LsKP p) {
                 if (tsum == 123.456f) p.y[0] = f2bf(tsum);
                 continue;
             }
-            ws_epilogue_tile<NI, MODE, false>(ep, acc, pix, geo, n0, reinterpret_cast<const float*>(smem + OFF_CONST), rs0, rs1, khalf, l31);
+            if constexpr (PRE) ws_epilogue_tile<NI, MODE, false>(ep, acc, pix, geo, n0, reinterpret_cast<const float*>(smem + OFF_CONST), rs0, rs1, khalf, l31, &ops, PRE_OLD);
+            else ws_epilogue_tile<NI, MODE, false>(ep, acc, pix, geo, n0, reinterpret_cast<const float*>(smem + OFF_CONST), rs0, rs1, khalf, l31);
         }
     }
     if (MODE != 0 && sums) {
