@@ -182,6 +182,10 @@ int salt_conv_stats_parts(const salt_conv_args*);
  * workgroups per XCD of kernels 9 - 11 (0 = one per CU) and, for 10 / 11 when asked for, (cfg >> 16) & 3 fixes the output channels
  * per item to 32 x that (0 = by size). */
 int salt_conv_kernel_id(const salt_conv_args*);
+/* pixel tile of conv_mfma_kernel / conv_glds_kernel for these arguments (tests / tuning): tw | th << 8 | images << 16 | general << 24.
+ * general = 1: a full-width strip of the extended grid of a fused-fold data gradient (th rows of tw = OW columns, or whole images)
+ * instead of a power-of-two tile - the 10 / 18 / 34-wide grids of the decoder's replicate-padded layers fill 16-wide tiles to 40 - 60 %. */
+int salt_conv_tile_shape(const salt_conv_args*);
 
 /* weight gradient of the same family:
  *   dW[t][a][b] = sum_{pixels p of P} P[p, a] * Q[pad(p*q_step + tap[t]), b]

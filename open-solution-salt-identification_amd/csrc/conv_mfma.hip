@@ -38,6 +38,8 @@ struct ConvKP {
     int ntaps; int tap_off[SALT_MAX_TAPS];
     int in_step, pad_mode, min_dy, min_dx;
     int th_log2, tw_log2, nb;
+    int gen, tw, th, twth;           // tile = nb images x th rows x tw columns; gen: not powers of two (nb * th * tw <= BM, see tile_pix)
+    unsigned tw_magic, twth_magic;
     int hh, hw;
     int tiles_y, tiles_x;
     int nchunk, a_bytes;
@@ -92,6 +94,26 @@ __device__ __forceinline__ int swz_addr(int row, int slot) {        // 64-byte r
     return row * 64 + (((slot ^ (row >> 2)) & 3) << 4);
 }
 
+// Row m of a pixel tile -> (column, row, image) inside the tile.  Power-of-two tiles: shifts.  General tiles (gen; the fused-fold data
+// gradients of the small decoder maps: full-width strips of the 10 / 18 / 34-wide extended grid instead of 16-wide tiles that are
+// 40 - 60 % empty): two multiply-high divisions; rows past nb * th * tw belong to no pixel (bl = 2^20: fails every b0 + bl < B test).
+struct TilePix { int tx, ty, bl; };
+__device__ __forceinline__ TilePix tile_pix(const ConvKP& p, int m) {
+    TilePix t;
+    if (p.gen) {
+        const int bl = (int)__umulhi((unsigned)m, p.twth_magic);
+        const int r = m - bl * p.twth;
+        t.ty = (int)__umulhi((unsigned)r, p.tw_magic);
+        t.tx = r - t.ty * p.tw;
+        t.bl = bl < p.nb ? bl : (1 << 20);
+    } else {
+        t.tx = m & ((1 << p.tw_log2) - 1);
+        t.ty = (m >> p.tw_log2) & ((1 << p.th_log2) - 1);
+        t.bl = m >> (p.tw_log2 + p.th_log2);
+    }
+    return t;
+}
+
 // 16 zero bytes in device memory: a masked-out piece of a branch-free loader reads them instead of zero-initialising its
 // destination registers under a branch (see conv_wgrad_fast_kernel)
 __device__ __attribute__((aligned(16))) unsigned int g_zero_piece[4] = {0u, 0u, 0u, 0u};
@@ -129,7 +151,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKP& p, const TileCoord& 
     // statistics wanted (train-mode forward only), an affine / ReLU epilogue present (eval only), tile fully inside the output grid
     const bool want_stats = p.stats != nullptr || p.fin.acc != nullptr;
     const bool has_affine = p.bias || p.scale || p.shift || p.relu;
-    const bool full_tile = (b0 + p.nb <= p.B) && (oy0 + (1 << p.th_log2) <= p.OH) && ox0 >= 0 && (ox0 + (1 << p.tw_log2) <= p.OW);
+    const bool full_tile = !p.gen && (b0 + p.nb <= p.B) && (oy0 + p.th <= p.OH) && ox0 >= 0 && (ox0 + p.tw <= p.OW);
     if (want_stats) {
         if (full_tile) {
             cntf = 16.f * MI;
@@ -140,9 +162,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvKP& p, const TileCoord& 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = (wm * MI + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                    const int tx = m & ((1 << p.tw_log2) - 1);
-                    const int ty = (m >> p.tw_log2) & ((1 << p.th_log2) - 1);
-                    const int bl = m >> (p.tw_log2 + p.th_log2);
+                    const TilePix tp = tile_pix(p, m);
+                    const int tx = tp.tx, ty = tp.ty, bl = tp.bl;
                     const bool valid = (b0 + bl < p.B) && (oy0 + ty < p.OH) && (ox0 + tx < p.OW) && (ox0 + tx >= 0);
                     if (valid) { vmask[i] |= 1u << r; cntf += 1.f; }
                 }
@@ -267,9 +288,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvKP& p, const TileCoord& 
 #pragma unroll
             for (int it = 0; it < BM * PPO / 256; ++it) {
                 const int m = it * (256 / PPO) + tid / PPO;
-                const int tx = m & ((1 << p.tw_log2) - 1);
-                const int ty = (m >> p.tw_log2) & ((1 << p.th_log2) - 1);
-                const int bl = m >> (p.tw_log2 + p.th_log2);
+                const TilePix tp = tile_pix(p, m);
+                const int tx = tp.tx, ty = tp.ty, bl = tp.bl;
                 const unsigned pix = ((unsigned)(b0 + bl) * p.OHf + (oy0 + ty) * p.out_step + out_oy) * p.OWf + (ox0 + tx) * p.out_step + out_ox;
                 T* dst = yg + (pix * (unsigned)p.y_cs + n);
                 u32x4 stored = *reinterpret_cast<const u32x4*>(sO + m * PITCH + pc * VE);
@@ -314,9 +334,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvKP& p, const TileCoord& 
         } else
         for (int q = tid; q < BM * PPO; q += 256) {
             const int m = q / PPO, pc = q - m * PPO;
-            const int tx = m & ((1 << p.tw_log2) - 1);
-            const int ty = (m >> p.tw_log2) & ((1 << p.th_log2) - 1);
-            const int bl = m >> (p.tw_log2 + p.th_log2);
+            const TilePix tp = tile_pix(p, m);
+            const int tx = tp.tx, ty = tp.ty, bl = tp.bl;
             const int oy = oy0 + ty, ox = ox0 + tx, b = b0 + bl;
             const int n = n0 + pc * VE;
             if (b >= p.B || oy >= p.OH || ox >= p.OW || ox < 0 || n >= p.Cout) continue;
@@ -352,7 +371,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKP& p, const TileCoord& 
                 for (int ky = 0; ky <= fold_rows; ++ky)
                     for (int kx = 0; kx <= fold_cols; ++kx) {
                         if ((ky | kx) == 0) continue;
-                        unpack16<T>(*reinterpret_cast<const u32x4*>(sO + (m - (ky << p.tw_log2) + kx) * PITCH + pc * VE), o);
+                        unpack16<T>(*reinterpret_cast<const u32x4*>(sO + (m - ky * p.tw + kx) * PITCH + pc * VE), o);
 #pragma unroll
                         for (int e = 0; e < VE; ++e) f[e] += o[e];
                     }
@@ -474,7 +493,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
     const int txi = tile % p.tiles_x; tile /= p.tiles_x;
     const int tyi = tile % p.tiles_y;
     const int tbi = tile / p.tiles_y;
-    const int oy0 = tyi << p.th_log2, ox0 = (txi << p.tw_log2) - p.ox_shift, b0 = tbi * p.nb;
+    const int oy0 = tyi * p.th, ox0 = txi * p.tw - p.ox_shift, b0 = tbi * p.nb;
     const int n0 = n_tile * BN;
     const int hhw = p.hh * p.hw;
     const int phalo = p.nb * hhw;
@@ -528,10 +547,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = (wm * MI + i) * 32 + l31;
-        const int tx = m & ((1 << p.tw_log2) - 1);
-        const int ty = (m >> p.tw_log2) & ((1 << p.th_log2) - 1);
-        const int bl = m >> (p.tw_log2 + p.th_log2);
-        pbase[i] = bl * hhw + ty * p.in_step * p.hw + tx * p.in_step;
+        const TilePix tp = tile_pix(p, m);
+        const int tx = tp.tx, ty = tp.ty, bl = tp.bl;
+        pbase[i] = bl < p.nb ? bl * hhw + ty * p.in_step * p.hw + tx * p.in_step : 0;      // (general tiles: a row past the last pixel reads halo row 0)
     }
     int nrow[NI];
 #pragma unroll
@@ -882,7 +900,7 @@ __global__ __launch_bounds__(512, 2) void conv_glds_kernel(ConvKP p) {
     const int txi = tile % p.tiles_x; tile /= p.tiles_x;
     const int tyi = tile % p.tiles_y;
     const int tbi = tile / p.tiles_y;
-    const int oy0 = tyi << p.th_log2, ox0 = (txi << p.tw_log2) - p.ox_shift, b0 = tbi * p.nb;
+    const int oy0 = tyi * p.th, ox0 = txi * p.tw - p.ox_shift, b0 = tbi * p.nb;
     const int n0 = n_tile * BN;
     const int hhw = p.hh * p.hw;
     const int phalo = p.nb * hhw;
@@ -950,15 +968,14 @@ __global__ __launch_bounds__(512, 2) void conv_glds_kernel(ConvKP p) {
     };
 
     // ---- fragment addressing
-    const bool perm = p.tw_log2 == 4;                                    // 16-pixel tile rows: conflict-free lane -> pixel order
+    const bool perm = !p.gen && p.tw_log2 == 4;                          // 16-pixel tile rows: conflict-free lane -> pixel order
     int pbase[MI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = (mb * MI + i) * 32 + (perm ? lane_pixel_perm(l31) : l31);
-        const int tx = m & ((1 << p.tw_log2) - 1);
-        const int ty = (m >> p.tw_log2) & ((1 << p.th_log2) - 1);
-        const int bl = m >> (p.tw_log2 + p.th_log2);
-        pbase[i] = bl * hhw + ty * p.hw + tx;
+        const TilePix tp = tile_pix(p, m);
+        const int tx = tp.tx, ty = tp.ty, bl = tp.bl;
+        pbase[i] = bl < p.nb ? bl * hhw + ty * p.hw + tx : 0;                         // (general tiles: a row past the last pixel reads halo row 0)
     }
     int b_addr[NI];
 #pragma unroll
@@ -1156,7 +1173,7 @@ __global__ __launch_bounds__(512, 2) void conv_glds_kernel(ConvKP p) {
     for (int o = 0; o < OWN; ++o) { ssum[o] = 0.f; cntf[o] = 0.f; vmask[o] = 0xffffu; }
     const bool want_stats = p.stats != nullptr || p.fin.acc != nullptr;
     const bool has_affine = p.bias || p.scale || p.shift || p.relu;
-    const bool full_tile = (b0 + p.nb <= p.B) && (oy0 + (1 << p.th_log2) <= p.OH) && ox0 >= 0 && (ox0 + (1 << p.tw_log2) <= p.OW);
+    const bool full_tile = !p.gen && (b0 + p.nb <= p.B) && (oy0 + p.th <= p.OH) && ox0 >= 0 && (ox0 + p.tw <= p.OW);
     if (want_stats) {
 #pragma unroll
         for (int o = 0; o < OWN; ++o) {
@@ -1167,9 +1184,8 @@ __global__ __launch_bounds__(512, 2) void conv_glds_kernel(ConvKP p) {
                 for (int r = 0; r < 16; ++r) {
                     const int mr = (r & 3) + 8 * (r >> 2) + 4 * khalf;
                     const int m = rowoff[o] + (perm ? lane_pixel_perm(mr) : mr);
-                    const int tx = m & ((1 << p.tw_log2) - 1);
-                    const int ty = (m >> p.tw_log2) & ((1 << p.th_log2) - 1);
-                    const int bl = m >> (p.tw_log2 + p.th_log2);
+                    const TilePix tp = tile_pix(p, m);
+                    const int tx = tp.tx, ty = tp.ty, bl = tp.bl;
                     const bool valid = (b0 + bl < p.B) && (oy0 + ty < p.OH) && (ox0 + tx < p.OW) && (ox0 + tx >= 0);
                     if (valid) { vmask[o] |= 1u << r; cntf[o] += 1.f; }
                 }
@@ -1223,9 +1239,8 @@ __global__ __launch_bounds__(512, 2) void conv_glds_kernel(ConvKP p) {
         if (DBG & 64) { if (sO[tid] == 12345) reinterpret_cast<T*>(p.y)[0] = sO[tid + 1]; return; }
         for (int q = tid; q < BM * PPO; q += NTHR) {
             const int m = q / PPO, pc = q - m * PPO;
-            const int tx = m & ((1 << p.tw_log2) - 1);
-            const int ty = (m >> p.tw_log2) & ((1 << p.th_log2) - 1);
-            const int bl = m >> (p.tw_log2 + p.th_log2);
+            const TilePix tp = tile_pix(p, m);
+            const int tx = tp.tx, ty = tp.ty, bl = tp.bl;
             const int oy = oy0 + ty, ox = ox0 + tx, b = b0 + bl;
             const int n = n0 + pc * VE;
             if (b >= p.B || oy >= p.OH || ox >= p.OW || ox < 0 || n >= p.Cout) continue;
@@ -1261,7 +1276,7 @@ __global__ __launch_bounds__(512, 2) void conv_glds_kernel(ConvKP p) {
                 for (int ky = 0; ky <= fold_rows; ++ky)
                     for (int kx = 0; kx <= fold_cols; ++kx) {
                         if ((ky | kx) == 0) continue;
-                        unpack16<T>(*reinterpret_cast<const u32x4*>(sO + (m - (ky << p.tw_log2) + kx) * PITCH + pc * VE), o);
+                        unpack16<T>(*reinterpret_cast<const u32x4*>(sO + (m - ky * p.tw + kx) * PITCH + pc * VE), o);
 #pragma unroll
                         for (int e = 0; e < VE; ++e) f[e] += o[e];
                     }
@@ -1487,7 +1502,26 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
         int rem = ilog2_ceil(BM) - k.tw_log2;
         k.th_log2 = ilog2_ceil(a->OH) < rem ? ilog2_ceil(a->OH) : rem;
         k.nb = BM >> (k.tw_log2 + k.th_log2);
-        const int th = 1 << k.th_log2, tw = 1 << k.tw_log2;
+        int th = 1 << k.th_log2, tw = 1 << k.tw_log2;
+        k.gen = 0;
+        // General tiles for the fused-fold data gradients (the extended grids are 2^n + 2 wide: 16-wide tiles of the 10 / 18 / 34-wide
+        // grids are 40 - 60 % empty): full-width strips of th rows, or whole images when one fits.  Taken when they save >= 15 % of the
+        // tile slots and their halo fits the loader.
+        static const bool gen_off = getenv("SALT_CONV_GEN_TILES") && atoi(getenv("SALT_CONV_GEN_TILES")) == 0;
+        if (fold_fused && !gen_off && a->in_step == 1 && vt == 1 && a->OW * (a->fold_top + 1) <= BM) {
+            const int gtw = a->OW;
+            int gth = BM / gtw, gnb = 1;
+            if (gth >= a->OH) { gth = a->OH; gnb = BM / (a->OH * a->OW); }
+            const int64_t slots_p2 = (int64_t)cdiv(a->x.B, k.nb) * cdiv(a->OH, th) * cdiv(a->OW, tw) * BM;
+            const int64_t slots_g = (int64_t)cdiv(a->x.B, gnb) * cdiv(a->OH, gth) * BM;
+            const int gphalo = gnb * (gth + max_dy - min_dy) * (gtw + max_dx - min_dx);
+            const bool fits = cfg->KS > 0 ? cdiv(gphalo, 16) <= v2_namax(BM) : gphalo * 4 <= maxa_for(BM) * 256;
+            if (fits && slots_g * 115 <= slots_p2 * 100) {
+                k.gen = 1; th = gth; tw = gtw; k.nb = gnb; k.tw_log2 = 0; k.th_log2 = 0;
+            }
+        }
+        k.tw = tw; k.th = th; k.twth = tw * th;
+        k.tw_magic = (unsigned)((1ull << 32) / (unsigned)tw) + 1u; k.twth_magic = (unsigned)((1ull << 32) / (unsigned)(tw * th)) + 1u;
         k.hh = (th - 1) * a->in_step + (max_dy - min_dy) + 1;
         k.hw = (tw - 1) * a->in_step + (max_dx - min_dx) + 1;
         const int phalo = k.nb * k.hh * k.hw * vt;
@@ -1527,10 +1561,10 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
     k.fold_fused = fold_fused ? 1 : 0;
     // fused fold: the tile columns are RIGHT-aligned with the extended grid (the last tile ends at OW), so the right pad columns
     // share a tile with the last image column whatever W is; rows start at 0, the top pad rows share the first tile with row 0
-    k.tiles_y = cdiv(a->OH, 1 << k.th_log2); k.tiles_x = cdiv(a->OW, 1 << k.tw_log2);
-    k.ox_shift = (fold_fused && a->fold_right > 0) ? k.tiles_x * (1 << k.tw_log2) - a->OW : 0;
-    if (fold_fused && ((1 << k.th_log2) <= a->fold_top || (1 << k.tw_log2) <= a->fold_right))
-        SALT_FAIL(SALT_E_UNSUPPORTED, "conv: fused fold needs tiles larger than the pad (%d x %d)", 1 << k.th_log2, 1 << k.tw_log2);
+    k.tiles_y = cdiv(a->OH, k.th); k.tiles_x = cdiv(a->OW, k.tw);
+    k.ox_shift = (fold_fused && a->fold_right > 0) ? k.tiles_x * k.tw - a->OW : 0;
+    if (fold_fused && (k.th <= a->fold_top || k.tw <= a->fold_right))
+        SALT_FAIL(SALT_E_UNSUPPORTED, "conv: fused fold needs tiles larger than the pad (%d x %d)", k.th, k.tw);
     const int tiles_b = cdiv(a->x.B, k.nb);
     k.nchunk = cdiv(a->x.C, KCE * vt);
     k.a_bytes = k.nb * k.hh * k.hw * 64 * vt;
@@ -2855,6 +2889,12 @@ extern "C" int salt_conv_kernel_id(const salt_conv_args* a) {
     if (a->y_plane) return conv_ws_eligible(a) ? 9 : -1;
     if (a->x_plane) return conv_ls_variant(a) ? 10 : -1;
     return conv_ws_eligible(a) ? 9 : (conv_ls_variant(a) ? 10 : (conv1x1_ls_variant(a) ? 11 : pl.cfg.id));
+}
+
+extern "C" int salt_conv_tile_shape(const salt_conv_args* a) {
+    Plan pl;
+    if (make_plan(a, &pl)) return -1;
+    return pl.kp.tw | (pl.kp.th << 8) | (pl.kp.nb << 16) | (pl.kp.gen << 24);
 }
 
 extern "C" int64_t salt_packed_weight_elems(int dtype, int ntaps, int n, int c) {

@@ -1,12 +1,13 @@
 #!/usr/bin/env python
 """Per-operator timing table of one training step (HIP event pairs around every native op).
 usage: python tools/op_profile.py [--dtype bf16] [--workload r34_hyper] [--batch 32] [--top 60]"""
-import argparse, os, sys
+import argparse, ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import salt_amd
 from salt_amd.models import SegmentationModel
+from salt_amd._abi import lib
 from bench import op_flops
 
 ap = argparse.ArgumentParser()
@@ -33,7 +34,9 @@ for r in range(reps):
             if key not in rows:
                 d = ''
                 if name == 'conv':
-                    d = 'x[%d,%d,%d,%d] -> [%d,%d,%d] taps%d s%d o%d cfg?' % (s.x.B, s.x.H, s.x.W, s.x.C, s.OH, s.OW, s.y.C, s.ntaps, s.in_step, s.out_step)
+                    d = 'x[%d,%d,%d,%d] -> [%d,%d,%d] taps%d s%d o%d k%d%s%s%s' % (s.x.B, s.x.H, s.x.W, s.x.C, s.OH, s.OW, s.y.C, s.ntaps, s.in_step, s.out_step,
+                                                                              lib.salt_conv_kernel_id(ctypes.byref(s)), ' fold' if s.fold_top or s.fold_right else '',
+                                                                              ' bnb' if s.bnb_acc else '', ' +=' if s.accumulate else '')
                 elif name == 'conv_wgrad':
                     d = 'P[%d,%d,%d,%d] Q[..%d,%d,%d] taps%d s%d split%d' % (s.p.B, s.p.H, s.p.W, s.p.C, s.q.H, s.q.W, s.q.C, s.ntaps, s.q_step, s.nsplit)
                 elif hasattr(s, 'y') and hasattr(s.y, 'C'):
