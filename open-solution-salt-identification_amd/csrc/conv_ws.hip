@@ -929,9 +929,11 @@ struct L1KP {
     int relu, accumulate;
     const bf16_t* res; int res_cs;
     int step, IH, IW, OH, OW, tiles_x, tiles_y;   // step 2 (projection shortcuts): 16 x 16 OUTPUT-pixel tiles, input pixel = 2 x output pixel
+    double* fin_acc;                              // MODE 1: train-mode BatchNorm statistics of the result (fp64 shards, salt_conv_args.fin_acc)
 };
 
-template <int NI>
+// MODE 0: eval / plain epilogue; 1: + train-mode BatchNorm statistics (the projection shortcuts of a ResNet in training)
+template <int NI, int MODE>
 __global__ __launch_bounds__(512) void conv1x1_ls_kernel(L1KP p) {
     typedef bf16_t T;
     constexpr int BN = 32 * NI, V = 2, MI = 2, NLW = 4;
@@ -1025,10 +1027,9 @@ __global__ __launch_bounds__(512) void conv1x1_ls_kernel(L1KP p) {
             issue_next();
         }
         ws_wait_vm<0>();
-        return;
-    }
+    } else {
     // ================================================================== MFMA waves
-    const WsEpi ep = {p.y, nullptr, nullptr, p.y_cs, 0, 0, p.relu, p.accumulate, 0, p.bias || p.scale || p.shift || p.relu, false, p.res, p.res_cs};
+    const WsEpi ep = {p.y, nullptr, nullptr, p.y_cs, 0, 0, p.relu, p.accumulate, 0, p.bias || p.scale || p.shift || p.relu, MODE == 1, p.res, p.res_cs};
     int a_addr[MI], b_addr[NI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) a_addr[i] = ws_swz(wm * 64 + i * 32 + l31, khalf);
@@ -1086,15 +1087,22 @@ __global__ __launch_bounds__(512) void conv1x1_ls_kernel(L1KP p) {
             for (int i = 0; i < MI; ++i) pix[i] = tile * 256u + (unsigned)(wm * 64 + i * 32 + l31);
         }
         const WsLaneGeo geo = {{true, true}, false, false, false, false, 0, 0, 0, 0};
-        ws_epilogue_tile<NI, 0, false>(ep, acc, pix, geo, n0, reinterpret_cast<const float*>(smem + OFF_CONST), rs0, rs1, khalf, l31);
+        ws_epilogue_tile<NI, MODE, false>(ep, acc, pix, geo, n0, reinterpret_cast<const float*>(smem + OFF_CONST), rs0, rs1, khalf, l31);
+    }
+    }
+    if (MODE == 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        ws_sums_flush<NI, 1, 4>(rs0, rs1, !loader, wm, reinterpret_cast<float*>(smem), n0, p.Cout, p.fin_acc, nullptr,
+                                nt == 0 ? (double)n_items * 256.0 : 0.0, khalf, l31);
     }
 }
 
-template <int NI>
-int l1_launch(const L1KP& k, int wgs, hipStream_t st) {
+template <int NI, int MODE>
+int l1_launch_mode(const L1KP& k, int wgs, hipStream_t st) {
     constexpr int BN = 32 * NI, PC = 32 + 2 * BN / 16, D = NI == 1 ? 4 : 3;
     constexpr int LDS = D * PC * 1024 + 1024 + 4 * BN * 4;
-    auto kern = conv1x1_ls_kernel<NI>;
+    auto kern = conv1x1_ls_kernel<NI, MODE>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1104,6 +1112,11 @@ int l1_launch(const L1KP& k, int wgs, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(512), LDS, st, k);
     SALT_CHECK_LAUNCH();
     return SALT_OK;
+}
+
+template <int NI>
+int l1_launch(const L1KP& k, int wgs, hipStream_t st) {
+    return k.fin_acc ? l1_launch_mode<NI, 1>(k, wgs, st) : l1_launch_mode<NI, 0>(k, wgs, st);
 }
 
 }  // namespace
@@ -1302,7 +1315,9 @@ int conv1x1_ls_variant(const salt_conv_args* a) {
     if (!asked && !env) return 0;
     if ((a->in_step != 1 && a->in_step != 2) || a->out_step != 1 || a->out_oy || a->out_ox || a->nphase > 1) return 0;
     if (a->strip || a->fold_top || a->fold_bottom || a->fold_left || a->fold_right) return 0;
-    if (a->stats || a->fin || a->fin_acc || a->fin_ticket || a->bnb_acc || a->bnb_partials || a->bnb_ticket || a->in_scale || a->in_fin_acc) return 0;   // eval / plain epilogues only
+    // eval / plain epilogues, or the train-mode statistics through the fp64 shards finalized by the consumer (as conv_ls_kernel's MODE 1)
+    if (a->stats || a->fin_ticket || a->bnb_acc || a->bnb_partials || a->bnb_ticket || a->in_scale || a->in_fin_acc) return 0;
+    if (a->fin_acc && (a->accumulate || a->res.p || a->bias || a->scale || a->shift || a->relu)) return 0;
     if (a->x_plane || a->y_plane) return 0;
     const int Cin = a->x.C, Cout = a->y.C;
     if (Cin % 64 || Cout % 32) return 0;
@@ -1337,6 +1352,7 @@ int conv1x1_ls_launch(const salt_conv_args* a, hipStream_t st) {
     if (k.step == 2 && (k.tiles_x < 1 || k.tiles_y < 1)) SALT_FAIL(SALT_E_UNSUPPORTED, "conv1x1_ls: stride 2 needs 16 x 16 output tiles");
     k.relu = a->relu; k.accumulate = a->accumulate;
     k.res = reinterpret_cast<const bf16_t*>(a->res.p); k.res_cs = a->res.cs;
+    k.fin_acc = a->fin_acc;
     int wpx = ws_cus() / 8;
     const int cap = (a->cfg >> 8) & 0xff;
     k.n_tiles = k.Cout / (32 * ni);

@@ -126,3 +126,52 @@ def test_conv1x1_ls_stride2_vs_torch(case):
     v = v.view(B, OH, OW, Cout)
     err = float((y.float().cpu() - v).abs().max() / v.abs().max())
     assert err <= 1e-2, err
+
+
+@pytest.mark.parametrize('case', [(4, 64, 32, 32, 128, 2), (2, 128, 32, 32, 256, 2), (4, 64, 16, 16, 96, 1), (8, 256, 32, 32, 512, 2)])
+def test_conv1x1_ls_train_statistics_vs_torch(case):
+    """Train mode: the ResNet projection shortcut nn.Conv2d(Cin, Cout, 1, stride) + BatchNorm (torchvision's `downsample`, via
+    architectures/encoders.py:6-45): conv1x1_ls_kernel's MODE 1 adds the per-channel sums of the stored values to the fp64 shards that the
+    consumer finalizes.  Forward, running statistics, data / weight / BatchNorm gradients against torch CPU fp32."""
+    import ctypes as C
+    from torch import nn
+    import torch.nn.functional as F
+    from gpu_harness import BlockRun
+    from helpers import assert_close
+    from salt_amd._abi import lib
+    B, Cin, H, W, Cout, stride = case
+    conv, bn = nn.Conv2d(Cin, Cout, 1, stride, 0, bias=False), nn.BatchNorm2d(Cout)
+    mod = nn.Sequential(conv, bn)
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (2.0 / Cin) ** 0.5)
+        bn.weight.copy_(1 + 0.1 * torch.randn(Cout, generator=g)); bn.bias.copy_(0.1 * torch.randn(Cout, generator=g))
+    x = torch.randn(B, Cin, H, W, generator=g).bfloat16().float()
+    mod.train()
+    from test_gpu_conv_ws import _force_cfg
+
+    def emit(gr, a):
+        _force_cfg(gr, 11)                                        # (small tensors: the kernel is not picked by itself below half a tile per CU)
+        return gr.conv(a, conv, bn, relu=False)
+    run = BlockRun(mod, [x], emit, train=True, dtype='bf16')
+    ids = [lib.salt_conv_kernel_id(C.byref(s)) for name, _, s in run.g.fwd.ops if name == 'conv']
+    assert ids == [11], ids
+    y = run.forward()
+    rc, rb = nn.Conv2d(Cin, Cout, 1, stride, 0, bias=False), nn.BatchNorm2d(Cout)
+    with torch.no_grad():
+        rc.weight.copy_(conv.weight.detach().cpu().bfloat16().float()); rb.weight.copy_(bn.weight.detach().cpu()); rb.bias.copy_(bn.bias.detach().cpu())
+    xr = x.clone().requires_grad_(True)
+    yr = rb(rc(xr))
+    assert_close(y, yr, 4e-2, 'y')
+    assert_close(bn.running_mean.cpu(), rb.running_mean, 4e-2, 'running_mean')
+    assert_close(bn.running_var.cpu(), rb.running_var, 4e-2, 'running_var')
+    gy = torch.randn(tuple(yr.shape), generator=g)
+    yr.backward(gy)
+    gx, grads = run.backward(gy.to('cuda:0'))
+    for name, got, want in [('dgrad', gx[0], xr.grad), ('wgrad', grads['0.weight'], rc.weight.grad)]:
+        l2 = float((got.double() - want.double()).norm() / want.double().norm())
+        assert l2 <= 4e-2, '%s: rel-L2 %.3e' % (name, l2)
+    assert_close(grads['1.weight'], rb.weight.grad, 0.12, 'dgamma')
+    assert_close(grads['1.bias'], rb.bias.grad, 0.12, 'dbeta')
+    y2 = run.forward()
+    assert float((y2.float() - y.float()).abs().max()) <= 1e-6 * float(y.float().abs().max())
