@@ -1778,6 +1778,40 @@ __global__ void pack_weight_kernel(PackKP p) {
 }
 
 constexpr int PACK_EPB = 2048;          // packed elements per block in the batched pack kernel
+
+// Vector path of the forward packs (bf16, KH * KW = 9 | 1 taps in raster order, D1 a multiple of 32, 16-byte aligned pointers - the 3x3
+// and 1x1 layers of a ResNet, 97 % of its parameters): a thread owns 8 input channels of one output channel for ALL taps - 2 KK float4
+// loads of 32 KK contiguous bytes, KK 16-byte stores; consecutive threads are consecutive (chunk, n, channel group) in the packed order,
+// so a wave's stores of one tap are 1 KB contiguous.  The forward pack opens every training step on the main stream (the scalar path:
+// 94 us for ResNet34's 21 M parameters, 2-byte stores).  Same values: the same fp32 -> bf16 conversion of the same elements.
+__host__ __device__ inline bool pack_vec_ok(const salt_pack_conv_weight_args& a, int dtype) {
+    const int kk = a.KH * a.KW;
+    if (dtype != SALT_BF16 || a.transpose || (kk != 9 && kk != 1) || a.ntaps != kk || a.D1 % 32) return false;
+    if ((reinterpret_cast<uintptr_t>(a.w) | reinterpret_cast<uintptr_t>(a.wp)) & 15) return false;
+    for (int t = 0; t < kk; ++t) if (a.tap_kh[t] * a.KW + a.tap_kw[t] != t) return false;
+    return true;
+}
+template <int KK>
+__device__ __forceinline__ void pack_vec(const salt_pack_conv_weight_args& a, int64_t gi) {
+    const int N = a.D0, C = a.D1;
+    const int q = (int)(gi & 3);
+    const int64_t r = gi >> 2;
+    const int chunk = (int)(r / N), n = (int)(r - (int64_t)chunk * N);
+    if (chunk >= C / 32) return;
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.w + ((int64_t)n * C + chunk * 32 + q * 8) * KK);
+    float v[8 * KK];
+#pragma unroll
+    for (int i = 0; i < 2 * KK; ++i) { const f32x4 x = src[i]; v[4 * i] = x.x; v[4 * i + 1] = x.y; v[4 * i + 2] = x.z; v[4 * i + 3] = x.w; }
+    bf16_t* out = reinterpret_cast<bf16_t*>(a.wp);
+#pragma unroll
+    for (int t = 0; t < KK; ++t) {
+        u32x4 o;
+        o.x = f2bf_pk(v[0 * KK + t], v[1 * KK + t]); o.y = f2bf_pk(v[2 * KK + t], v[3 * KK + t]);
+        o.z = f2bf_pk(v[4 * KK + t], v[5 * KK + t]); o.w = f2bf_pk(v[6 * KK + t], v[7 * KK + t]);
+        *reinterpret_cast<u32x4*>(out + (((int64_t)chunk * KK + t) * N + n) * 32 + q * 8) = o;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void pack_batched_kernel(const salt_pack_conv_weight_args* jobs, const int* job_block0, int njobs) {
     constexpr int KCE = 64 / (int)sizeof(T);
@@ -1790,6 +1824,13 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const salt_pack_conv_
     const int64_t total = (int64_t)nchunk * a.ntaps * N * KCE;
     const int64_t base = (int64_t)(blockIdx.x - job_block0[lo]) * PACK_EPB;
     T* out = reinterpret_cast<T*>(a.wp);
+    if constexpr (sizeof(T) == 2) {
+        if (pack_vec_ok(a, a.dtype)) {
+            const int64_t gi = (int64_t)(blockIdx.x - job_block0[lo]) * 256 + threadIdx.x;
+            if (a.KH * a.KW == 9) pack_vec<9>(a, gi); else pack_vec<1>(a, gi);
+            return;
+        }
+    }
     if (!a.transpose) {
         // forward packs: thread = one (output channel n, input channel ch) pair, lanes along ch.  The KH*KW weights of a pair are
         // contiguous (neighbouring lanes read neighbouring 36-byte blocks: coalesced), and for every tap the lanes of a chunk write
@@ -2926,6 +2967,7 @@ extern "C" int salt_pack_job_blocks(const salt_pack_conv_weight_args* a) {
     if (!a) return -1;
     const int KCE = a->dtype == SALT_F32 ? 16 : 32;
     const int N = a->transpose ? a->D1 : a->D0, C = a->transpose ? a->D0 : a->D1;
+    if (pack_vec_ok(*a, a->dtype)) return (int)(((int64_t)N * (C / 32) * 4 + 255) / 256);      // one thread per (chunk, n, 8 channels)
     if (!a->transpose) return (int)(((int64_t)N * cdiv(C, KCE) * KCE + 255) / 256);      // one thread per (n, padded channel) pair
     const int64_t total = (int64_t)cdiv(C, KCE) * a->ntaps * N * KCE;
     return (int)((total + PACK_EPB - 1) / PACK_EPB);
