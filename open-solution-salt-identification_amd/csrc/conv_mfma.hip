@@ -1784,10 +1784,13 @@ constexpr int PACK_EPB = 2048;          // packed elements per block in the batc
 // loads of 32 KK contiguous bytes, KK 16-byte stores; consecutive threads are consecutive (chunk, n, channel group) in the packed order,
 // so a wave's stores of one tap are 1 KB contiguous.  The forward pack opens every training step on the main stream (the scalar path:
 // 94 us for ResNet34's 21 M parameters, 2-byte stores).  Same values: the same fp32 -> bf16 conversion of the same elements.
+// The transposed (data-gradient) packs take the same thread mapping with gathered scalar loads (8 rows of KK contiguous floats, lanes
+// along the packed order): the scalar path's launch (16 062 workgroups, 2-byte stores, 141 us on the side stream) kept the stem
+// convolution of the forward pass waiting for wave slots - 164 us in the step against 45 us alone.
 __host__ __device__ inline bool pack_vec_ok(const salt_pack_conv_weight_args& a, int dtype) {
     const int kk = a.KH * a.KW;
-    if (dtype != SALT_BF16 || a.transpose || (kk != 9 && kk != 1) || a.ntaps != kk || a.D1 % 32) return false;
-    if ((reinterpret_cast<uintptr_t>(a.w) | reinterpret_cast<uintptr_t>(a.wp)) & 15) return false;
+    if (dtype != SALT_BF16 || (kk != 9 && kk != 1) || a.ntaps != kk || (a.transpose ? a.D0 : a.D1) % 32) return false;
+    if ((reinterpret_cast<uintptr_t>(a.wp) & 15) || (!a.transpose && (reinterpret_cast<uintptr_t>(a.w) & 15))) return false;
     for (int t = 0; t < kk; ++t) if (a.tap_kh[t] * a.KW + a.tap_kw[t] != t) return false;
     return true;
 }
@@ -1802,6 +1805,29 @@ __device__ __forceinline__ void pack_vec(const salt_pack_conv_weight_args& a, in
     float v[8 * KK];
 #pragma unroll
     for (int i = 0; i < 2 * KK; ++i) { const f32x4 x = src[i]; v[4 * i] = x.x; v[4 * i + 1] = x.y; v[4 * i + 2] = x.z; v[4 * i + 3] = x.w; }
+    bf16_t* out = reinterpret_cast<bf16_t*>(a.wp);
+#pragma unroll
+    for (int t = 0; t < KK; ++t) {
+        u32x4 o;
+        o.x = f2bf_pk(v[0 * KK + t], v[1 * KK + t]); o.y = f2bf_pk(v[2 * KK + t], v[3 * KK + t]);
+        o.z = f2bf_pk(v[4 * KK + t], v[5 * KK + t]); o.w = f2bf_pk(v[6 * KK + t], v[7 * KK + t]);
+        *reinterpret_cast<u32x4*>(out + (((int64_t)chunk * KK + t) * N + n) * 32 + q * 8) = o;
+    }
+}
+
+template <int KK>
+__device__ __forceinline__ void pack_vec_t(const salt_pack_conv_weight_args& a, int64_t gi) {
+    const int N = a.D1, C = a.D0;                                       // transposed: packed rows = input channels, chunks over output channels
+    const int q = (int)(gi & 3);
+    const int64_t r = gi >> 2;
+    const int chunk = (int)(r / N), n = (int)(r - (int64_t)chunk * N);
+    if (chunk >= C / 32) return;
+    const float* src = a.w + ((int64_t)(chunk * 32 + q * 8) * N + n) * KK;
+    float v[8 * KK];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int t = 0; t < KK; ++t) v[j * KK + t] = src[(int64_t)j * N * KK + t];
     bf16_t* out = reinterpret_cast<bf16_t*>(a.wp);
 #pragma unroll
     for (int t = 0; t < KK; ++t) {
@@ -1827,7 +1853,8 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const salt_pack_conv_
     if constexpr (sizeof(T) == 2) {
         if (pack_vec_ok(a, a.dtype)) {
             const int64_t gi = (int64_t)(blockIdx.x - job_block0[lo]) * 256 + threadIdx.x;
-            if (a.KH * a.KW == 9) pack_vec<9>(a, gi); else pack_vec<1>(a, gi);
+            if (a.transpose) { if (a.KH * a.KW == 9) pack_vec_t<9>(a, gi); else pack_vec_t<1>(a, gi); }
+            else if (a.KH * a.KW == 9) pack_vec<9>(a, gi); else pack_vec<1>(a, gi);
             return;
         }
     }

@@ -17,7 +17,7 @@ def test_pack_batched_equals_single_packs_bitwise():
     st = torch.cuda.current_stream().cuda_stream
     # D0 (out), D1 (in), KH, KW, transpose
     shapes = [(96, 64, 3, 3, 0), (64, 128, 1, 1, 0), (64, 16, 3, 3, 0), (40, 96, 3, 3, 0), (128, 320, 3, 3, 0), (64, 32, 3, 3, 1), (24, 64, 2, 2, 0),
-              (512, 768, 3, 3, 0), (256, 64, 1, 1, 1)]
+              (512, 768, 3, 3, 0), (256, 64, 1, 1, 1), (64, 96, 3, 3, 1), (320, 64, 3, 3, 1), (48, 64, 3, 3, 1), (512, 512, 3, 3, 1)]
     jobs, singles, outs = [], [], []
     keep = []
     for (D0, D1, KH, KW, tr) in shapes:
