@@ -1,0 +1,102 @@
+"""conv_thin_kernel (csrc/conv_thin.hip): the persistent weight-stationary fp32 kernel of the 3x3 layers with 16 / 32 channels on both
+sides (the outer levels of the vanilla U-Net, unet_models.py:21-30) through the C-ABI, asked for per launch (cfg = 12) on tensors
+small enough for the CPU: two stacked conv + BN + ReLU layers against torch CPU fp32 - train mode (statistics through the fp64
+shards, both data gradients, the second one carrying the first layer's BatchNorm-backward sums, weight / BN gradients) and eval mode
+(folded BatchNorm + ReLU in the epilogue) - and against conv_mfma_kernel on the same launches."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from helpers import assert_close
+from test_gpu_conv_ws import _force_cfg, _kernel_ids, _rand
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-4
+
+# B, Cin, H, W, Cmid, Cout
+CASES = [(2, 16, 32, 32, 16, 16), (1, 32, 48, 32, 32, 32), (2, 16, 16, 64, 32, 16), (3, 32, 32, 16, 16, 32), (5, 16, 16, 16, 16, 32)]
+
+
+def _build(case):
+    B, Cin, H, W, Cmid, Cout = case
+    c1, b1, c2, b2 = nn.Conv2d(Cin, Cmid, 3, 1, 1, bias=False), nn.BatchNorm2d(Cmid), nn.Conv2d(Cmid, Cout, 3, 1, 1, bias=True), nn.BatchNorm2d(Cout)
+    mod = nn.Sequential(c1, b1, c2, b2)
+    with torch.no_grad():
+        c1.weight.copy_(_rand(c1.weight.shape, 11, (2.0 / (Cin * 9)) ** 0.5)); c2.weight.copy_(_rand(c2.weight.shape, 12, (2.0 / (Cmid * 9)) ** 0.5))
+        c2.bias.copy_(0.1 * _rand((Cout,), 19))
+        for i, b in enumerate((b1, b2)):
+            b.weight.copy_(1 + 0.1 * _rand(b.weight.shape, 13 + i)); b.bias.copy_(0.1 * _rand(b.bias.shape, 15 + i))
+            b.running_mean.copy_(0.1 * _rand(b.bias.shape, 23 + i)); b.running_var.copy_(1 + 0.1 * _rand(b.bias.shape, 25 + i).abs())
+    x = _rand((B, Cin, H, W), 17)
+    ref = nn.Sequential(nn.Conv2d(Cin, Cmid, 3, 1, 1, bias=False), nn.BatchNorm2d(Cmid), nn.Conv2d(Cmid, Cout, 3, 1, 1, bias=True), nn.BatchNorm2d(Cout))
+    ref.load_state_dict({k: v.clone() for k, v in mod.state_dict().items()})
+    return mod, ref, x
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_thin_conv_bn_relu_train_vs_torch_and_conv_mfma(case):
+    from gpu_harness import BlockRun
+    outs = {}
+    for cfg in (12, 4):
+        mod, ref, x = _build(case)
+        c1, b1, c2, b2 = mod
+
+        def emit(g, a):
+            _force_cfg(g, cfg)
+            h = g.conv(a, c1, b1, relu=True)
+            return g.conv(h, c2, b2, relu=True)
+
+        mod.train()
+        run = BlockRun(mod, [x], emit, train=True, dtype='f32')
+        ids_f, ids_b = _kernel_ids(run.g.fwd), _kernel_ids(run.g.bwd)
+        if cfg == 12:
+            assert ids_f == [12, 12] and ids_b == [12, 12], (ids_f, ids_b)
+            ready = [int(st.partials_ready) for name, _, st in run.g.bwd.ops if name == 'bn_bwd']
+            assert ready == [0, 3], ready                  # layer 1's BatchNorm-backward sums came from layer 2's data-gradient launch
+        else:
+            assert 12 not in ids_f + ids_b
+        y = run.forward()
+        gy = _rand(tuple(y.shape), 18)
+        gx, grads = run.backward(gy.to('cuda:0'))
+        outs[cfg] = (y, gx[0], grads, {k: v.detach().cpu().clone() for k, v in mod.state_dict().items()})
+    mod, ref, x = _build(case)
+    ref.train()
+    xr = x.clone().requires_grad_(True)
+    yr = F.relu(ref[3](ref[2](F.relu(ref[1](ref[0](xr))))))
+    yr.backward(_rand(tuple(yr.shape), 18))
+    y, gx, grads, sd = outs[12]
+    assert_close(y, yr, TOL, 'y')
+    assert_close(gx, xr.grad, 4 * TOL, 'dgrad')
+    for k in grads:
+        if k == '2.bias':                                  # a bias in front of a train-mode BatchNorm has no gradient (rounding noise only)
+            assert float(grads[k].abs().max()) < 1e-4
+            continue
+        assert_close(grads[k], dict(ref.named_parameters())[k].grad, 4 * TOL, k)
+    for k in ('1.running_mean', '1.running_var', '3.running_mean', '3.running_var'):
+        assert_close(sd[k], ref.state_dict()[k], TOL, k)
+    # the two kernels on the same launches: fp32 sums in different orders
+    assert_close(outs[12][0], outs[4][0], TOL, 'forward thin vs mfma')
+    assert_close(outs[12][1], outs[4][1], 4 * TOL, 'dgrad thin vs mfma')
+
+
+@pytest.mark.parametrize('case', CASES[:3])
+def test_thin_conv_eval_folded_bn_relu_vs_torch(case):
+    from gpu_harness import BlockRun
+    mod, ref, x = _build(case)
+    c1, b1, c2, b2 = mod
+
+    def emit(g, a):
+        _force_cfg(g, 12)
+        h = g.conv(a, c1, b1, relu=True)
+        return g.conv(h, c2, b2, relu=False)
+
+    mod.eval(); ref.eval()
+    run = BlockRun(mod, [x], emit, train=False, dtype='f32')
+    assert _kernel_ids(run.g.fwd) == [12, 12]
+    y = run.forward()
+    with torch.no_grad():
+        yr = ref[3](ref[2](F.relu(ref[1](ref[0](x)))))
+    assert_close(y, yr, TOL, 'eval y')
