@@ -80,6 +80,8 @@ int conv1x1_ls_launch(const salt_conv_args* a, hipStream_t st);
 // conv_thin.hip: the persistent weight-stationary kernel of the fp32 3x3 layers with 16 / 32 channels on both sides (0 = not applicable)
 int conv_thin_variant(const salt_conv_args* a);
 int conv_thin_launch(const salt_conv_args* a, hipStream_t st);
+// conv_thin.hip: weight gradient of the same layers; 0 = not one of its shapes, else the number of slabs
+int conv_wgrad_thin(const salt_conv_wgrad_args* a, bool launch, hipStream_t st, int* rc);
 
 // conv_wgrad_ls.hip: loader-specialised row-streaming weight gradient (bf16, 3x3, unit step); 0 = not one of its shapes, else nsplit
 int conv_wgrad_ls(const salt_conv_wgrad_args* a, bool launch, hipStream_t st, int* rc);

@@ -3014,6 +3014,8 @@ extern "C" int salt_pack_batched(const salt_pack_batched_args* a, void* stream) 
 extern "C" int salt_conv_wgrad_nsplit(const salt_conv_wgrad_args* a) {
     WgradKP k; int ns = 0;
     if (wgrad_plan(a, &k, &ns)) return -1;
+    const int th = conv_wgrad_thin(a, false, nullptr, nullptr);     // fp32, 16 / 32 channels on both sides: one slab per persistent workgroup
+    if (th > 0) return th;
     const int ls = conv_wgrad_ls(a, false, nullptr, nullptr);       // the loader-specialised row-streaming kernel has its own split rule
     return ls > 0 ? ls : ns;
 }
@@ -3126,6 +3128,7 @@ extern "C" int salt_conv_wgrad(const salt_conv_wgrad_args* a, void* stream) {
     int rc = wgrad_plan(a, &k, &ns);
     if (rc) return rc;
     if (!a->partials) SALT_FAIL(SALT_E_BADARG, "wgrad: partials workspace missing");
+    { int lrc = SALT_OK; if (conv_wgrad_thin(a, true, (hipStream_t)stream, &lrc) > 0) return lrc; }
     { int lrc = SALT_OK; if (conv_wgrad_ls(a, true, (hipStream_t)stream, &lrc) > 0) return lrc; }
     if (a->nsplit != ns) SALT_FAIL(SALT_E_BADARG, "wgrad: nsplit %d, expected %d", a->nsplit, ns);
     // A/B switch: the splits add into ONE slab with global_atomic_add_f32 (zeroed here, in stream order) instead of

@@ -120,9 +120,9 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ThKP p) {
 
 #pragma unroll 1
     for (int k = 0; k < n_my; ++k) {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");         // this wave's pieces of tile k (and the weights) landed; its stores are out
-        __builtin_amdgcn_s_barrier();                                        // ... everybody's; every wave is done reading the other buffer
-        asm volatile("" ::: "memory");
+        if (k == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the weights, this wave's pieces of tile 0, the constants
+        __builtin_amdgcn_s_barrier();                                        // tile k landed for everybody (each wave waited for its own pieces
+        asm volatile("" ::: "memory");                                       // before its last epilogue); everybody is done reading the other buffer
         const TC cur = coords(k);
         if (k + 1 < n_my) issue_halo(coords(k + 1), (k + 1) & 1);
         const unsigned char* hb = smem + OFF_H + (k & 1) * H_BYTES;
@@ -159,6 +159,8 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ThKP p) {
             if (s + 1 < NST) load_frag(s + 1, f[(s + 1) & 1]);
             mma_frag(f[s & 1]);
         }
+        // the next tile's pieces of this wave had the whole MFMA phase to land; waiting HERE keeps this tile's stores out of the wait
+        if (k + 1 < n_my) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // ---- epilogue: lane = pixel l15 of tile row 4 wave + pb, channels 16 cb + 4 kg .. + 3: one 16-byte piece
 #pragma unroll
         for (int cb = 0; cb < CO; ++cb) {
@@ -243,6 +245,126 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ThKP p) {
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------ conv_wgrad_thin_kernel
+// Weight gradient of the same layers: dW[t][a][b] = sum_pixels P[pixel, a] Q[pixel + tap_t, b] with 16 / 32 channels on both sides -
+// a 9 x 16 x 16 result (9 KB) contracted over B H W = 524 288 pixels.  The 64 x 64 (a x b) blocks of the general kernels compute
+// 16 x the MACs there (105 us per launch).  Here the contraction dimension of v_mfma_f32_16x16x4_f32 is FOUR CONSECUTIVE PIXELS of a
+// tile row: lane (channel l15, pixel kg) reads one float of P and, per tap, one float of Q's halo tile (ds_read_b32: 64 lanes = 256
+// contiguous bytes, conflict free without a swizzle), 9 AB BB MFMAs per pixel quad.  A persistent workgroup streams 16 x 16-pixel
+// tiles (P tile + 18 x 18 Q halo, double buffered by LDS-DMA), its four waves take a quarter of each tile's pixels, their accumulators
+// meet in LDS at the end, and the workgroup writes ONE slab [taps][Ca][Cb] (salt_wgrad_reduce sums the slabs as for every other kernel).
+struct TwKP {
+    const float* P; const float* Q; float* partials;
+    int B, PH, PW, p_cs, QH, QW, q_cs;
+    int tiles_x, tiles_y, ntiles;
+    int min_dy, min_dx, pad_mode;
+    int tap_off[9];
+};
+
+template <int AB, int BB>
+__global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(TwKP p) {
+    constexpr int Ca = 16 * AB, Cb = 16 * BB;
+    constexpr int PP = AB * 16, QP = BB * 21, NP = PP + QP;              // DMA pieces (1 KB) per tile: P rows, then Q halo rows
+    constexpr int NS = (NP + 3) / 4;
+    constexpr int T_BYTES = NP * 1024, OFF_DUMMY = 2 * T_BYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kg = lane >> 4;
+    const int n_my = ((int)blockIdx.x < p.ntiles) ? (p.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    struct TC { int b, oy0, ox0; };
+    auto coords = [&](int k) {
+        const int t = (int)blockIdx.x + k * (int)gridDim.x;
+        TC c; const int tx = t % p.tiles_x; const int r = t / p.tiles_x;
+        c.ox0 = tx << 4; c.oy0 = (r % p.tiles_y) << 4; c.b = r / p.tiles_y; return c;
+    };
+    const unsigned char* zp = reinterpret_cast<const unsigned char*>(g_thin_zero);
+    auto dma = [&](const void* src, int dst) {
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(smem + dst), 16, 0, 0);
+    };
+    auto issue_tile = [&](const TC& c, int buf) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const float* pb = p.P + (int64_t)c.b * p.PH * p.PW * p.p_cs;
+        const float* qb = p.Q + (int64_t)c.b * p.QH * p.QW * p.q_cs;
+        const int iy0 = c.oy0 + p.min_dy, ix0 = c.ox0 + p.min_dx;
+        const bool clamp = p.pad_mode != 0;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int pidx = wave + 4 * i;
+            const unsigned char* src = zp;
+            int dst = OFF_DUMMY;
+            if (pidx < PP) {
+                const int ch = pidx >> 4, row = (pidx & 15) * 16 + (ln >> 2);            // row = pixel (ty, tx) of the tile
+                src = reinterpret_cast<const unsigned char*>(pb + (((c.oy0 + (row >> 4)) * p.PW + c.ox0 + (row & 15)) * p.p_cs + ch * 16 + (ln & 3) * 4));
+                dst = buf * T_BYTES + pidx * 1024;
+            } else if (pidx < NP) {
+                const int q = pidx - PP;
+                const int ch = q / 21, row = (q - ch * 21) * 16 + (ln >> 2);
+                const int hy = (int)__umulhi((unsigned)row, 238609295u);                  // row / 18
+                const int hx = row - hy * 18;
+                const int iy = iy0 + hy, ix = ix0 + hx;
+                const int iyc = min(max(iy, 0), p.QH - 1), ixc = min(max(ix, 0), p.QW - 1);
+                const bool inside = ((unsigned)iy < (unsigned)p.QH) & ((unsigned)ix < (unsigned)p.QW);
+                if ((row < 324) & (clamp | inside))
+                    src = reinterpret_cast<const unsigned char*>(qb + ((iyc * p.QW + ixc) * p.q_cs + ch * 16 + (ln & 3) * 4));
+                dst = buf * T_BYTES + pidx * 1024;
+            }
+            dma(src, dst);
+        }
+    };
+    f32x4 acc[AB][BB][9];
+#pragma unroll
+    for (int a = 0; a < AB; ++a)
+#pragma unroll
+        for (int b = 0; b < BB; ++b)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[a][b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (n_my > 0) issue_tile(coords(0), 0);
+#pragma unroll 1
+    for (int k = 0; k < n_my; ++k) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // this wave's pieces of tile k landed
+        __builtin_amdgcn_s_barrier();                                        // ... everybody's; everybody is done reading the other buffer
+        asm volatile("" ::: "memory");
+        if (k + 1 < n_my) issue_tile(coords(k + 1), (k + 1) & 1);
+        const unsigned char* tb = smem + (k & 1) * T_BYTES;
+        const unsigned char* qh = tb + PP * 1024;
+#pragma unroll 2
+        for (int qd = 0; qd < 16; ++qd) {                                    // pixel quads of this wave's 4 tile rows
+            const int r = wave * 4 + (qd >> 2), x0 = (qd & 3) * 4 + kg;
+            float av[AB], bv[BB][9];
+#pragma unroll
+            for (int a = 0; a < AB; ++a) av[a] = *reinterpret_cast<const float*>(tb + a * 16384 + (r * 16 + x0) * 64 + l15 * 4);
+#pragma unroll
+            for (int b = 0; b < BB; ++b)
+#pragma unroll
+                for (int t = 0; t < 9; ++t) bv[b][t] = *reinterpret_cast<const float*>(qh + b * 21504 + (r * 18 + x0 + p.tap_off[t]) * 64 + l15 * 4);
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int a = 0; a < AB; ++a)
+#pragma unroll
+                    for (int b = 0; b < BB; ++b) acc[a][b][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a], bv[b][t], acc[a][b][t], 0, 0, 0);
+        }
+    }
+    // ---- the four waves' accumulators meet in LDS (the tile buffers are free), fixed order; one slab per workgroup
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);                             // [4][9][Ca][Cb]
+#pragma unroll
+    for (int a = 0; a < AB; ++a)
+#pragma unroll
+        for (int b = 0; b < BB; ++b)
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    red[((wave * 9 + t) * Ca + a * 16 + 4 * kg + e) * Cb + b * 16 + l15] = acc[a][b][t][e];
+    __syncthreads();
+    float* slab = p.partials + (int64_t)blockIdx.x * 9 * Ca * Cb;
+    for (int i = tid; i < 9 * Ca * Cb; i += 256)
+        slab[i] = ((red[i] + red[9 * Ca * Cb + i]) + red[2 * 9 * Ca * Cb + i]) + red[3 * 9 * Ca * Cb + i];
 }
 
 int thin_cus() {
@@ -346,4 +468,58 @@ int conv_thin_launch(const salt_conv_args* a, hipStream_t st) {
         case 10: return thin_launch<2, 2>(k, st);
     }
     SALT_FAIL(SALT_E_UNSUPPORTED, "conv_thin: variant %d", v);
+}
+
+// ---- weight gradient of the same layers (conv_mfma.hip: salt_conv_wgrad_nsplit / salt_conv_wgrad).  Returns 0 (not one of its shapes)
+// or the number of slabs it writes; launch: also enqueues it (*rc = status).  SALT_WGRAD_THIN = 0: off.
+namespace {
+template <int AB, int BB>
+int tw_launch(const TwKP& k, int wgs, hipStream_t st) {
+    constexpr int LDS = 2 * (AB * 16 + BB * 21) * 1024 + 1024;
+    static_assert(LDS <= 160 * 1024 && 4 * 9 * 16 * AB * 16 * BB * 4 <= LDS, "LDS budget");
+    auto kern = conv_wgrad_thin_kernel<AB, BB>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) SALT_FAIL((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(256), LDS, st, k);
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}
+}  // namespace
+
+int conv_wgrad_thin(const salt_conv_wgrad_args* a, bool launch, hipStream_t st, int* rc) {
+    static const int env = getenv("SALT_WGRAD_THIN") ? atoi(getenv("SALT_WGRAD_THIN")) : 1;
+    if (!a || !env || a->dtype != SALT_F32 || a->ntaps != 9 || a->q_step != 1 || a->q_plane) return 0;
+    if (!view_ok(a->p) || !view_ok(a->q) || a->p.B != a->q.B) return 0;
+    const int Ca = a->p.C, Cb = a->q.C;
+    if ((Ca != 16 && Ca != 32) || (Cb != 16 && Cb != 32) || a->p.H % 16 || a->p.W % 16) return 0;
+    int min_dy = 1 << 30, max_dy = -(1 << 30), min_dx = 1 << 30, max_dx = -(1 << 30);
+    for (int t = 0; t < 9; ++t) {
+        min_dy = a->tap_dy[t] < min_dy ? a->tap_dy[t] : min_dy; max_dy = a->tap_dy[t] > max_dy ? a->tap_dy[t] : max_dy;
+        min_dx = a->tap_dx[t] < min_dx ? a->tap_dx[t] : min_dx; max_dx = a->tap_dx[t] > max_dx ? a->tap_dx[t] : max_dx;
+    }
+    if (max_dy - min_dy > 2 || max_dx - min_dx > 2) return 0;
+    if (a->p.cs % 4 || a->q.cs % 4 || ((reinterpret_cast<uintptr_t>(a->p.p) | reinterpret_cast<uintptr_t>(a->q.p)) & 15)) return 0;
+    if ((int64_t)a->p.B * a->p.H * a->p.W * a->p.cs >= (int64_t)1 << 31 || (int64_t)a->q.B * a->q.H * a->q.W * a->q.cs >= (int64_t)1 << 31) return 0;
+    const int ntiles = a->p.B * (a->p.H / 16) * (a->p.W / 16);
+    if (ntiles < thin_cus() / 2) return 0;
+    const int lds = 2 * ((Ca / 16) * 16 + (Cb / 16) * 21) * 1024 + 1024;
+    int per_cu = (160 * 1024) / lds;
+    if (per_cu > 2) per_cu = 2;
+    int wgs = thin_cus() * per_cu;
+    if (wgs > ntiles) wgs = ntiles;
+    if (!launch) return wgs;
+    if (!a->partials || a->nsplit != wgs) { salt_set_error("wgrad_thin: nsplit %d, expected %d", a->nsplit, wgs); *rc = SALT_E_BADARG; return wgs; }
+    TwKP k;
+    k.P = reinterpret_cast<const float*>(a->p.p); k.Q = reinterpret_cast<const float*>(a->q.p); k.partials = a->partials;
+    k.B = a->p.B; k.PH = a->p.H; k.PW = a->p.W; k.p_cs = a->p.cs; k.QH = a->q.H; k.QW = a->q.W; k.q_cs = a->q.cs;
+    k.tiles_x = a->p.W / 16; k.tiles_y = a->p.H / 16; k.ntiles = ntiles;
+    k.min_dy = min_dy; k.min_dx = min_dx; k.pad_mode = a->pad_mode;
+    for (int t = 0; t < 9; ++t) k.tap_off[t] = (a->tap_dy[t] - min_dy) * 18 + (a->tap_dx[t] - min_dx);
+    const int v = 4 * (Ca / 16) + Cb / 16;
+    *rc = v == 5 ? tw_launch<1, 1>(k, wgs, st) : v == 6 ? tw_launch<1, 2>(k, wgs, st) : v == 9 ? tw_launch<2, 1>(k, wgs, st) : tw_launch<2, 2>(k, wgs, st);
+    return wgs;
 }

@@ -100,3 +100,38 @@ def test_thin_conv_eval_folded_bn_relu_vs_torch(case):
     with torch.no_grad():
         yr = ref[3](ref[2](F.relu(ref[1](ref[0](x)))))
     assert_close(y, yr, TOL, 'eval y')
+
+
+@pytest.mark.parametrize('case', [(16, 16, 0), (32, 16, 0), (16, 32, 1), (32, 32, 0), (32, 32, 1)])
+def test_thin_wgrad_vs_torch(case):
+    """conv_wgrad_thin_kernel through salt_conv_wgrad + salt_wgrad_reduce (one slab per persistent workgroup) against
+    torch.nn.grad.conv2d_weight on the CPU: zero padding (taps -1 .. 1) and the reference's replicate top / right padding (rows -2 .. 0,
+    columns 0 .. 2, clamped), enough tiles (8 x 64 x 64) for the launch plan to pick the kernel by itself."""
+    import salt_amd  # noqa: F401
+    from salt_amd._abi import STRUCTS, lib, fill, check
+    from salt_amd.engine import shaped_view
+    Ca, Cb, rep = case
+    B, H, W = 8, 64, 64
+    g = torch.Generator().manual_seed(7)
+    P = torch.randn(B, H, W, Ca, generator=g)
+    Q = torch.randn(B, H, W, Cb, generator=g)
+    taps = [(dy - 2, dx) for dy in range(3) for dx in range(3)] if rep else [(dy - 1, dx - 1) for dy in range(3) for dx in range(3)]
+    Pd, Qd = P.cuda(), Q.cuda()
+    S = fill(STRUCTS['salt_conv_wgrad_args'](), dtype=0, p=shaped_view(Pd.data_ptr(), B, H, W, Ca), q=shaped_view(Qd.data_ptr(), B, H, W, Cb),
+             ntaps=9, tap_dy=[t[0] for t in taps], tap_dx=[t[1] for t in taps], q_step=1, pad_mode=rep, q_plane=0)
+    ns = lib.salt_conv_wgrad_nsplit(ctypes.byref(S))
+    assert ns == 128, ns                                   # 8 x 4 x 4 tiles, one per workgroup: the thin kernel's plan (the general kernels split differently)
+    part = torch.full((ns, 9, Ca, Cb), float('nan'), device='cuda:0')
+    grad = torch.empty(Ca, Cb, 3, 3, device='cuda:0')
+    S.partials = part.data_ptr(); S.nsplit = ns
+    R = fill(STRUCTS['salt_wgrad_reduce_args'](), partials=part.data_ptr(), nsplit=ns, ntaps=9, Ca=Ca, Cb=Cb, KH=3, KW=3,
+             tap_kh=[t // 3 for t in range(9)], tap_kw=[t % 3 for t in range(9)], grad=grad.data_ptr(), accumulate=0)
+    st = torch.cuda.current_stream().cuda_stream
+    check(lib.salt_conv_wgrad(ctypes.byref(S), st)); check(lib.salt_wgrad_reduce(ctypes.byref(R), st))
+    torch.cuda.synchronize()
+    X, dY = Q.permute(0, 3, 1, 2).contiguous(), P.permute(0, 3, 1, 2).contiguous()
+    if rep:
+        ref = torch.nn.grad.conv2d_weight(F.pad(X, (0, 2, 2, 0), mode='replicate'), (Ca, Cb, 3, 3), dY, padding=0)
+    else:
+        ref = torch.nn.grad.conv2d_weight(X, (Ca, Cb, 3, 3), dY, padding=1)
+    assert_close(grad.cpu(), ref, 1e-4, 'dW')
