@@ -176,9 +176,12 @@ int salt_conv_stats_parts(const salt_conv_args*);
 /* which kernel salt_conv runs these arguments on: 1..5 conv_mfma_kernel tile configs, 6..8 conv_glds_kernel, 9 conv_ws_kernel (the
  * weight-stationary multi-tile kernel of the 3x3 layers with <= 64 channels: bf16, Cin in {32, 64}, Cout in {32, 64}, output grid a
  * multiple of 16 x 16), 10 conv_ls_kernel (the loader-specialised streaming kernel of the deeper 3x3 layers: bf16, Cin >= 64 and Cout
- * multiples of 32, same grid rule), 11 conv1x1_ls_kernel (the streaming kernel of the 1x1 convolutions with eval / plain epilogues:
- * bf16, Cin a multiple of 64, Cout of 32, B OH OW a multiple of 256; stride 1, or stride 2 on 16 x 16 output tiles).  `cfg` & 0xff:
- * 0 = heuristic, 1..8 = that config, 9 / 10 / 11 = that kernel wherever it applies (else heuristic); (cfg >> 8) & 0xff caps the
+ * multiples of 32, same grid rule), 11 conv1x1_ls_kernel (the streaming kernel of the 1x1 convolutions with eval / plain epilogues
+ * or train-mode statistics through fin_acc: bf16, Cin a multiple of 64, Cout of 32, B OH OW a multiple of 256; stride 1, or stride 2
+ * on 16 x 16 output tiles), 12 conv_thin_kernel (the persistent weight-stationary kernel of the fp32 3x3 layers with 16 or 32
+ * channels on BOTH sides, unit steps, output grid a multiple of 16 x 16; statistics / BatchNorm-backward sums through the fp64 shards
+ * only).  `cfg` & 0xff:
+ * 0 = heuristic, 1..8 = that config, 9 / 10 / 11 / 12 = that kernel wherever it applies (else heuristic); (cfg >> 8) & 0xff caps the
  * workgroups per XCD of kernels 9 - 11 (0 = one per CU) and, for 10 / 11 when asked for, (cfg >> 16) & 3 fixes the output channels
  * per item to 32 x that (0 = by size). */
 int salt_conv_kernel_id(const salt_conv_args*);
