@@ -29,7 +29,7 @@ def timing_experiment(name):
     WRONG values (it exists to time an upper bound), so it is honoured only together with SALT_TIMING_ONLY=1 - which bench.py / tools
     set on request and SegmentationModel.fit refuses - and fails loudly otherwise (nothing warned when one leaked into a
     training run)."""
-    if not os.environ.get(name):
+    if os.environ.get(name, '0') in ('', '0'):
         return False
     if os.environ.get('SALT_TIMING_ONLY') != '1':
         raise SaltError('%s is a timing-only experiment (results are wrong): set SALT_TIMING_ONLY=1 to acknowledge, or unset it' % name)
