@@ -346,7 +346,7 @@ def conv_roofline(model, B, channels, dtype, loss, reps):
     dn, (dms, dfl, dcnt, dby) = max(groups.items(), key=lambda kv: kv[1][0])
     peak = MFMA_PEAK_TFLOPS[dtype]
     ach = dfl / (dms * 1e-3) / 1e12 if dms > 0 else 0.0
-    kern = {'conv': 'conv_ws_kernel + conv_ls_kernel + conv_mfma_kernel + conv_glds_kernel (fwd + dgrad launches)', 'conv_wgrad': 'conv_wgrad_ls_kernel + conv_wgrad_fast_kernel + conv_wgrad_kernel'}.get(dn, dn)
+    kern = {'conv': 'conv_ws_kernel + conv_ls_kernel + conv1x1_ls_kernel + conv_mfma_kernel + conv_glds_kernel (fwd + dgrad launches)', 'conv_wgrad': 'conv_wgrad_ls_kernel + conv_wgrad_fast_kernel + conv_wgrad_kernel'}.get(dn, dn)
     roof = {'kernel': kern, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
             'algorithmic_bytes_per_launch': round(dby / dcnt) if dcnt else None, 'launches_per_step': dcnt // reps,
             'avg_launch_us': round(1e3 * dms / dcnt, 2), 'share_of_step': round(dms / reps / total_ms, 3),
@@ -641,7 +641,7 @@ def main():
         net.x.copy_(batches[0][0]); net.target.copy_(batches[0][1])
         roof, ops, total_ms, side_ms, all_fl, dn = conv_roofline(model, B, channels, args.dtype, args.loss, 3)
         headline = args.dtype == 'bf16' and args.workload == 'r34_hyper' and B == 32
-        roof['traffic'] = pmc_traffic({'conv': ('conv_ws_kernel', 'conv_ls_kernel', 'conv_mfma_kernel', 'conv_glds_kernel'), 'conv_wgrad': ('conv_wgrad_kernel',)}.get(dn, (dn,))) if headline else None
+        roof['traffic'] = pmc_traffic({'conv': ('conv_ws_kernel', 'conv_ls_kernel', 'conv1x1_ls_kernel', 'conv_thin_kernel', 'conv_mfma_kernel', 'conv_glds_kernel'), 'conv_wgrad': ('conv_wgrad_kernel',)}.get(dn, (dn,))) if headline else None
         roof['traffic_unit'] = ('bytes per launch (rocprofv3 PMC FETCH_SIZE*2 + WRITE_SIZE, separate --pmc passes; file %s measured at commit %s - '
                                 'PMC counters cannot be read inside the timed process)' % (PMC_FILE, pmc_commit()))
         out['roofline_by_class'] = roof.pop('by_class')
