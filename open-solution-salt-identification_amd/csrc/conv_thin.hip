@@ -22,6 +22,7 @@ struct ThKP {
     const float* x; const float* w; float* y;
     const float* bias; const float* scale; const float* shift;
     int B, H, W, x_cs, y_cs, OH, OW;
+    int yH, yW, out_step;                // y is [B,yH,yW,*]; grid pixel (oy, ox) of phase (py, px) -> y pixel (oy out_step + py, ox out_step + px)
     int tiles_x, tiles_y, ntiles;
     int min_dy, min_dx, pad_mode;
     int tap_off[9];
@@ -38,11 +39,13 @@ typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
 __device__ __forceinline__ int th_swz(int row, int slot) { return row * 64 + (((slot ^ (row >> 2)) & 3) << 4); }
 
-// CI / CO: 16-channel chunks of the input / blocks of the output
-template <int CI, int CO, int MODE>
+// CI / CO: 16-channel chunks of the input / blocks of the output; NT taps; PH = 4: the phase-fused launch of a stride-2 transposed
+// convolution (salt_conv_args.nphase: four output-parity phases with a packed weight block each, out_step 2) - a tile's halo is staged
+// once and serves its four phases
+template <int CI, int CO, int MODE, int NT = 9, int PH = 1>
 __global__ __launch_bounds__(256) void conv_thin_kernel(ThKP p) {
     constexpr int BN = 16 * CO;
-    constexpr int WP = CI * 9 * CO;                      // weight DMA pieces (1 KB = 16 rows of 64 bytes): rows (chunk, tap, n)
+    constexpr int WP = PH * CI * NT * CO;                // weight DMA pieces (1 KB = 16 rows of 64 bytes): rows (phase, chunk, tap, n)
     constexpr int HPC = 21;                              // halo pieces per chunk: 18 x 18 = 324 rows, padded to 336
     constexpr int HP = CI * HPC;
     constexpr int NSW = (WP + 3) / 4, NSH = (HP + 3) / 4;
@@ -126,6 +129,8 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ThKP p) {
         const TC cur = coords(k);
         if (k + 1 < n_my) issue_halo(coords(k + 1), (k + 1) & 1);
         const unsigned char* hb = smem + OFF_H + (k & 1) * H_BYTES;
+#pragma unroll 1
+        for (int ph = 0; ph < PH; ++ph) {
         // ---- MFMA phase: this wave's 4 tile rows (one 16-pixel block each) x CO channel blocks
         f32x4 acc[CO][4];
 #pragma unroll
@@ -136,10 +141,11 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ThKP p) {
 #pragma unroll
         for (int pb = 0; pb < 4; ++pb) brow[pb] = (wave * 4 + pb) * 18 + l15;
         struct Frag { f32x4 a[CO], b[4]; };
+        const int wrow0 = ph * (CI * NT * BN);                               // this phase's weight rows
         auto load_frag = [&](int s, Frag& f) {                               // s = (chunk, tap), a constant after unrolling
-            const int c = s / 9, t = s - c * 9;
+            const int c = s / NT, t = s - c * NT;
 #pragma unroll
-            for (int cb = 0; cb < CO; ++cb) f.a[cb] = *reinterpret_cast<const f32x4*>(smem + th_swz(s * BN + cb * 16 + l15, kg));
+            for (int cb = 0; cb < CO; ++cb) f.a[cb] = *reinterpret_cast<const f32x4*>(smem + th_swz(wrow0 + s * BN + cb * 16 + l15, kg));
 #pragma unroll
             for (int pb = 0; pb < 4; ++pb) f.b[pb] = *reinterpret_cast<const f32x4*>(hb + c * HC_BYTES + th_swz(brow[pb] + p.tap_off[t], kg));
         };
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ThKP p) {
 #pragma unroll
                     for (int pb = 0; pb < 4; ++pb) acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[cb][e], f.b[pb][e], acc[cb][pb], 0, 0, 0);
         };
-        constexpr int NST = CI * 9;
+        constexpr int NST = CI * NT;
         Frag f[2];
         load_frag(0, f[0]);
 #pragma unroll
@@ -160,7 +166,8 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ThKP p) {
             mma_frag(f[s & 1]);
         }
         // the next tile's pieces of this wave had the whole MFMA phase to land; waiting HERE keeps this tile's stores out of the wait
-        if (k + 1 < n_my) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (ph == 0 && k + 1 < n_my) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int py = PH > 1 ? ph >> 1 : 0, px = PH > 1 ? ph & 1 : 0;
         // ---- epilogue: lane = pixel l15 of tile row 4 wave + pb, channels 16 cb + 4 kg .. + 3: one 16-byte piece
 #pragma unroll
         for (int cb = 0; cb < CO; ++cb) {
@@ -170,7 +177,7 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ThKP p) {
             f32x4 oldv[4], yv[4], av[4];
 #pragma unroll
             for (int pb = 0; pb < 4; ++pb) {
-                const unsigned pix = (unsigned)((cur.b * p.OH + cur.oy0 + wave * 4 + pb) * p.OW + cur.ox0 + l15);
+                const unsigned pix = (unsigned)((cur.b * p.yH + (cur.oy0 + wave * 4 + pb) * p.out_step + py) * p.yW + (cur.ox0 + l15) * p.out_step + px);
                 if (MODE != 1 && p.accumulate) oldv[pb] = *reinterpret_cast<const f32x4*>(p.y + (pix * (unsigned)p.y_cs + ch0));
                 if (MODE == 2 && sums) {
                     yv[pb] = *reinterpret_cast<const f32x4*>(p.bnb_y + (pix * (unsigned)p.bnb_cs + ch0));
@@ -179,7 +186,7 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ThKP p) {
             }
 #pragma unroll
             for (int pb = 0; pb < 4; ++pb) {
-                const unsigned pix = (unsigned)((cur.b * p.OH + cur.oy0 + wave * 4 + pb) * p.OW + cur.ox0 + l15);
+                const unsigned pix = (unsigned)((cur.b * p.yH + (cur.oy0 + wave * 4 + pb) * p.out_step + py) * p.yW + (cur.ox0 + l15) * p.out_step + px);
                 f32x4 v = acc[cb][pb];
                 if (MODE != 2 && has_affine) {
 #pragma unroll
@@ -208,6 +215,7 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ThKP p) {
                 }
             }
         }
+        }                                                                     // phases
     }
     // ---- per-workgroup sums -> fp64 shard atomics: the 16 lanes of a channel group, then the 4 waves through LDS (fixed order)
     if (MODE != 0 && sums) {
@@ -239,7 +247,7 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ThKP p) {
             if (MODE == 1) {
                 double* a = p.fin_acc + (blockIdx.x & 7) * (2 * BN + 1);
                 fin_add(a + st * BN + n, t);
-                if (tid == 0) fin_add(a + 2 * BN, (double)n_my * 256.0);
+                if (tid == 0) fin_add(a + 2 * BN, (double)n_my * 256.0 * PH);
             } else {
                 fin_add(p.bnb_acc + ((blockIdx.x & 7) * 2 + st) * BN + n, t);
             }
@@ -377,11 +385,11 @@ int thin_cus() {
     return cus;
 }
 
-template <int CI, int CO, int MODE>
+template <int CI, int CO, int MODE, int NT = 9, int PH = 1>
 int thin_launch_mode(const ThKP& k, hipStream_t st) {
-    constexpr int LDS = CI * 9 * CO * 1024 + 2 * CI * 21 * 1024 + 1024 + 4 * 16 * CO * 4;
-    static_assert(LDS <= 160 * 1024 && 4 * 2 * 16 * CO * 4 <= CI * 9 * CO * 1024, "LDS budget");
-    auto kern = conv_thin_kernel<CI, CO, MODE>;
+    constexpr int LDS = PH * CI * NT * CO * 1024 + 2 * CI * 21 * 1024 + 1024 + 4 * 16 * CO * 4;
+    static_assert(LDS <= 160 * 1024 && 4 * 2 * 16 * CO * 4 <= PH * CI * NT * CO * 1024, "LDS budget");
+    auto kern = conv_thin_kernel<CI, CO, MODE, NT, PH>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -401,6 +409,10 @@ int thin_launch_mode(const ThKP& k, hipStream_t st) {
 
 template <int CI, int CO>
 int thin_launch(const ThKP& k, hipStream_t st) {
+    if (k.out_step == 2) {                                                  // phase-fused transposed convolution: 4 taps x 4 phases
+        if (k.fin_acc) return thin_launch_mode<CI, CO, 1, 4, 4>(k, st);
+        return thin_launch_mode<CI, CO, 0, 4, 4>(k, st);
+    }
     if (k.fin_acc) return thin_launch_mode<CI, CO, 1>(k, st);
     if (k.bnb_acc) return thin_launch_mode<CI, CO, 2>(k, st);
     return thin_launch_mode<CI, CO, 0>(k, st);
@@ -412,19 +424,24 @@ int thin_launch(const ThKP& k, hipStream_t st) {
 // (cfg & 0xff == 12).  Returns 0 (not applicable) or 4 CI + CO.
 int conv_thin_variant(const salt_conv_args* a) {
     static const int env = getenv("SALT_CONV_THIN") ? atoi(getenv("SALT_CONV_THIN")) : 1;
-    if (!a || a->dtype != SALT_F32 || a->ntaps != 9) return 0;
+    if (!a || a->dtype != SALT_F32) return 0;
+    const bool phased = a->nphase > 1;           // the phase-fused launch of a stride-2 transposed convolution (4 taps, 4 phases, out_step 2)
+    if (a->ntaps != (phased ? 4 : 9)) return 0;
     const bool asked = (a->cfg & 0xff) == 12;
     if ((a->cfg & 0xff) != 0 && !asked) return 0;
     if (!asked && !env) return 0;
-    if (a->in_step != 1 || a->out_step != 1 || a->out_oy || a->out_ox || a->nphase > 1) return 0;
+    if (a->in_step != 1 || a->out_oy || a->out_ox) return 0;
+    if (phased ? (a->nphase != 4 || a->out_step != 2 || a->bnb_acc || a->accumulate ||
+                  a->w_phase_elems != (int64_t)(a->x.C / 16) * 4 * a->y.C * 16 || a->y.H != 2 * a->OH || a->y.W != 2 * a->OW)
+               : (a->out_step != 1 || a->OH != a->y.H || a->OW != a->y.W)) return 0;
     if (a->strip || a->fold_top || a->fold_bottom || a->fold_left || a->fold_right || a->x_plane || a->y_plane || a->res.p) return 0;
     if (a->stats || a->fin_ticket || a->bnb_partials || a->bnb_ticket || a->in_scale || a->in_fin_acc) return 0;
     if ((a->fin_acc && (a->accumulate || a->bnb_acc)) || (a->bnb_acc && (a->bias || a->scale || a->shift || a->relu))) return 0;     // MODE dispatch
     const int Cin = a->x.C, Cout = a->y.C;
     if ((Cin != 16 && Cin != 32) || (Cout != 16 && Cout != 32)) return 0;
-    if (a->x.B != a->y.B || a->OH != a->y.H || a->OW != a->y.W || a->OH % 16 || a->OW % 16) return 0;
+    if (a->x.B != a->y.B || a->OH % 16 || a->OW % 16) return 0;
     int min_dy = 1 << 30, max_dy = -(1 << 30), min_dx = 1 << 30, max_dx = -(1 << 30);
-    for (int t = 0; t < 9; ++t) {
+    for (int t = 0; t < a->ntaps; ++t) {
         min_dy = a->tap_dy[t] < min_dy ? a->tap_dy[t] : min_dy; max_dy = a->tap_dy[t] > max_dy ? a->tap_dy[t] : max_dy;
         min_dx = a->tap_dx[t] < min_dx ? a->tap_dx[t] : min_dx; max_dx = a->tap_dx[t] > max_dx ? a->tap_dx[t] : max_dx;
     }
@@ -450,11 +467,12 @@ int conv_thin_launch(const salt_conv_args* a, hipStream_t st) {
     k.x = reinterpret_cast<const float*>(a->x.p); k.w = reinterpret_cast<const float*>(a->w); k.y = reinterpret_cast<float*>(a->y.p);
     k.bias = a->bias; k.scale = a->scale; k.shift = a->shift;
     k.B = a->x.B; k.H = a->x.H; k.W = a->x.W; k.x_cs = a->x.cs; k.y_cs = a->y.cs; k.OH = a->OH; k.OW = a->OW;
+    k.yH = a->y.H; k.yW = a->y.W; k.out_step = a->out_step;
     k.tiles_x = a->OW / 16; k.tiles_y = a->OH / 16; k.ntiles = a->y.B * k.tiles_x * k.tiles_y;
     int min_dy = 1 << 30, min_dx = 1 << 30;
-    for (int t = 0; t < 9; ++t) { min_dy = a->tap_dy[t] < min_dy ? a->tap_dy[t] : min_dy; min_dx = a->tap_dx[t] < min_dx ? a->tap_dx[t] : min_dx; }
+    for (int t = 0; t < a->ntaps; ++t) { min_dy = a->tap_dy[t] < min_dy ? a->tap_dy[t] : min_dy; min_dx = a->tap_dx[t] < min_dx ? a->tap_dx[t] : min_dx; }
     k.min_dy = min_dy; k.min_dx = min_dx; k.pad_mode = a->pad_mode;
-    for (int t = 0; t < 9; ++t) k.tap_off[t] = (a->tap_dy[t] - min_dy) * 18 + (a->tap_dx[t] - min_dx);
+    for (int t = 0; t < 9; ++t) k.tap_off[t] = t < a->ntaps ? (a->tap_dy[t] - min_dy) * 18 + (a->tap_dx[t] - min_dx) : 0;
     k.relu = a->relu; k.accumulate = a->accumulate;
     k.bnb_y = reinterpret_cast<const float*>(a->bnb_y.p); k.bnb_a = reinterpret_cast<const float*>(a->bnb_a.p);
     k.bnb_cs = a->bnb_y.cs; k.bnb_acs = a->bnb_a.cs; k.bnb_relu = a->bnb_relu;

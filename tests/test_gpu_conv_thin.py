@@ -135,3 +135,44 @@ def test_thin_wgrad_vs_torch(case):
     else:
         ref = torch.nn.grad.conv2d_weight(X, (Ca, Cb, 3, 3), dY, padding=1)
     assert_close(grad.cpu(), ref, 1e-4, 'dW')
+
+
+@pytest.mark.parametrize('case', [(2, 32, 16, 16, 16), (3, 16, 32, 16, 32), (2, 32, 16, 32, 32)])
+@pytest.mark.parametrize('train', [True, False])
+def test_thin_transposed_conv_phases_vs_torch(case, train):
+    """nn.ConvTranspose2d(Cin, Cout, 3, stride 2, padding 1, output_padding 1) + BatchNorm + ReLU (unet_models.py:38-50,
+    base.py:40-57: the up-sampling step of the vanilla / Ternaus decoders) as ONE phase-fused launch on conv_thin_kernel<..., 4, 4>
+    (a tile's halo serves its four output-parity phases): forward (train statistics / folded eval), data and weight gradients vs torch."""
+    from gpu_harness import BlockRun
+    B, Cin, H, W, Cout = case
+    dc, bn = nn.ConvTranspose2d(Cin, Cout, 3, 2, 1, 1, bias=True), nn.BatchNorm2d(Cout)
+    mod = nn.Sequential(dc, bn)
+    with torch.no_grad():
+        dc.weight.copy_(_rand(dc.weight.shape, 31, (2.0 / (Cin * 9)) ** 0.5)); dc.bias.copy_(0.1 * _rand((Cout,), 32))
+        bn.weight.copy_(1 + 0.1 * _rand((Cout,), 33)); bn.bias.copy_(0.1 * _rand((Cout,), 34))
+        bn.running_mean.copy_(0.1 * _rand((Cout,), 35)); bn.running_var.copy_(1 + 0.1 * _rand((Cout,), 36).abs())
+    ref_dc, ref_bn = nn.ConvTranspose2d(Cin, Cout, 3, 2, 1, 1, bias=True), nn.BatchNorm2d(Cout)
+    ref_dc.load_state_dict(dc.state_dict()); ref_bn.load_state_dict(bn.state_dict())
+    x = _rand((B, Cin, H, W), 37)
+
+    def emit(g, a):
+        _force_cfg(g, 12)
+        return g.conv_transpose(a, dc, bn, relu=True)
+
+    mod.train(train); ref_dc.train(train); ref_bn.train(train)
+    run = BlockRun(mod, [x], emit, train=train, dtype='f32')
+    assert _kernel_ids(run.g.fwd) == [12], _kernel_ids(run.g.fwd)
+    y = run.forward()
+    xr = x.clone().requires_grad_(True)
+    yr = F.relu(ref_bn(ref_dc(xr)))
+    assert_close(y, yr.detach(), TOL, 'y')
+    if train:
+        assert_close(bn.running_mean.cpu(), ref_bn.running_mean, TOL, 'running_mean')
+        assert_close(bn.running_var.cpu(), ref_bn.running_var, TOL, 'running_var')
+        gy = _rand(tuple(yr.shape), 38)
+        yr.backward(gy)
+        gx, grads = run.backward(gy.to('cuda:0'))
+        assert_close(gx[0], xr.grad, 4 * TOL, 'dgrad')
+        assert_close(grads['0.weight'], ref_dc.weight.grad, 4 * TOL, 'wgrad')
+        assert_close(grads['1.weight'], ref_bn.weight.grad, 4 * TOL, 'dgamma')
+        assert_close(grads['1.bias'], ref_bn.bias.grad, 4 * TOL, 'dbeta')
