@@ -271,10 +271,15 @@ struct TwKP {
     int tap_off[9];
 };
 
-template <int AB, int BB>
+// QS = 2: the stride-2 operand of a transposed convolution's weight gradient (Q pixel = 2 p + tap): 8 x 16-pixel P tiles, 17 x 33 Q halo
+template <int AB, int BB, int QS = 1>
 __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(TwKP p) {
     constexpr int Ca = 16 * AB, Cb = 16 * BB;
-    constexpr int PP = AB * 16, QP = BB * 21, NP = PP + QP;              // DMA pieces (1 KB) per tile: P rows, then Q halo rows
+    constexpr int TR = QS == 1 ? 16 : 8;                                  // tile rows
+    constexpr int HH = QS * (TR - 1) + 3, HW = QS * 15 + 3;               // Q halo: 18 x 18 | 17 x 33
+    constexpr int QPC = (HH * HW + 15) / 16, PPC = TR;                    // DMA pieces (1 KB) per 16-channel chunk
+    constexpr unsigned HW_MAGIC = (unsigned)((1ull << 32) / HW) + 1u;
+    constexpr int PP = AB * PPC, QP = BB * QPC, NP = PP + QP;             // DMA pieces per tile: P rows, then Q halo rows
     constexpr int NS = (NP + 3) / 4;
     constexpr int T_BYTES = NP * 1024, OFF_DUMMY = 2 * T_BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -286,7 +291,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(TwKP p) {
     auto coords = [&](int k) {
         const int t = (int)blockIdx.x + k * (int)gridDim.x;
         TC c; const int tx = t % p.tiles_x; const int r = t / p.tiles_x;
-        c.ox0 = tx << 4; c.oy0 = (r % p.tiles_y) << 4; c.b = r / p.tiles_y; return c;
+        c.ox0 = tx << 4; c.oy0 = (r % p.tiles_y) * TR; c.b = r / p.tiles_y; return c;
     };
     const unsigned char* zp = reinterpret_cast<const unsigned char*>(g_thin_zero);
     auto dma = [&](const void* src, int dst) {
@@ -297,7 +302,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(TwKP p) {
         asm volatile("" : "+v"(ln));
         const float* pb = p.P + (int64_t)c.b * p.PH * p.PW * p.p_cs;
         const float* qb = p.Q + (int64_t)c.b * p.QH * p.QW * p.q_cs;
-        const int iy0 = c.oy0 + p.min_dy, ix0 = c.ox0 + p.min_dx;
+        const int iy0 = c.oy0 * QS + p.min_dy, ix0 = c.ox0 * QS + p.min_dx;
         const bool clamp = p.pad_mode != 0;
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
@@ -305,18 +310,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(TwKP p) {
             const unsigned char* src = zp;
             int dst = OFF_DUMMY;
             if (pidx < PP) {
-                const int ch = pidx >> 4, row = (pidx & 15) * 16 + (ln >> 2);            // row = pixel (ty, tx) of the tile
+                const int ch = pidx / PPC, row = (pidx - ch * PPC) * 16 + (ln >> 2);      // row = pixel (ty, tx) of the tile
                 src = reinterpret_cast<const unsigned char*>(pb + (((c.oy0 + (row >> 4)) * p.PW + c.ox0 + (row & 15)) * p.p_cs + ch * 16 + (ln & 3) * 4));
                 dst = buf * T_BYTES + pidx * 1024;
             } else if (pidx < NP) {
                 const int q = pidx - PP;
-                const int ch = q / 21, row = (q - ch * 21) * 16 + (ln >> 2);
-                const int hy = (int)__umulhi((unsigned)row, 238609295u);                  // row / 18
-                const int hx = row - hy * 18;
+                const int ch = q / QPC, row = (q - ch * QPC) * 16 + (ln >> 2);
+                const int hy = (int)__umulhi((unsigned)row, HW_MAGIC);                    // row / HW
+                const int hx = row - hy * HW;
                 const int iy = iy0 + hy, ix = ix0 + hx;
                 const int iyc = min(max(iy, 0), p.QH - 1), ixc = min(max(ix, 0), p.QW - 1);
                 const bool inside = ((unsigned)iy < (unsigned)p.QH) & ((unsigned)ix < (unsigned)p.QW);
-                if ((row < 324) & (clamp | inside))
+                if ((row < HH * HW) & (clamp | inside))
                     src = reinterpret_cast<const unsigned char*>(qb + ((iyc * p.QW + ixc) * p.q_cs + ch * 16 + (ln & 3) * 4));
                 dst = buf * T_BYTES + pidx * 1024;
             }
@@ -340,15 +345,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(TwKP p) {
         const unsigned char* tb = smem + (k & 1) * T_BYTES;
         const unsigned char* qh = tb + PP * 1024;
 #pragma unroll 2
-        for (int qd = 0; qd < 16; ++qd) {                                    // pixel quads of this wave's 4 tile rows
-            const int r = wave * 4 + (qd >> 2), x0 = (qd & 3) * 4 + kg;
+        for (int qd = 0; qd < TR; ++qd) {                                    // pixel quads of this wave's TR / 4 tile rows
+            const int r = wave * (TR / 4) + (qd >> 2), x0 = (qd & 3) * 4 + kg;
             float av[AB], bv[BB][9];
 #pragma unroll
-            for (int a = 0; a < AB; ++a) av[a] = *reinterpret_cast<const float*>(tb + a * 16384 + (r * 16 + x0) * 64 + l15 * 4);
+            for (int a = 0; a < AB; ++a) av[a] = *reinterpret_cast<const float*>(tb + a * (PPC * 1024) + (r * 16 + x0) * 64 + l15 * 4);
 #pragma unroll
             for (int b = 0; b < BB; ++b)
 #pragma unroll
-                for (int t = 0; t < 9; ++t) bv[b][t] = *reinterpret_cast<const float*>(qh + b * 21504 + (r * 18 + x0 + p.tap_off[t]) * 64 + l15 * 4);
+                for (int t = 0; t < 9; ++t) bv[b][t] = *reinterpret_cast<const float*>(qh + b * (QPC * 1024) + (QS * (r * HW + x0) + p.tap_off[t]) * 64 + l15 * 4);
 #pragma unroll
             for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -491,11 +496,11 @@ int conv_thin_launch(const salt_conv_args* a, hipStream_t st) {
 // ---- weight gradient of the same layers (conv_mfma.hip: salt_conv_wgrad_nsplit / salt_conv_wgrad).  Returns 0 (not one of its shapes)
 // or the number of slabs it writes; launch: also enqueues it (*rc = status).  SALT_WGRAD_THIN = 0: off.
 namespace {
-template <int AB, int BB>
+template <int AB, int BB, int QS>
 int tw_launch(const TwKP& k, int wgs, hipStream_t st) {
-    constexpr int LDS = 2 * (AB * 16 + BB * 21) * 1024 + 1024;
+    constexpr int LDS = 2 * (AB * (QS == 1 ? 16 : 8) + BB * (QS == 1 ? 21 : 36)) * 1024 + 1024;
     static_assert(LDS <= 160 * 1024 && 4 * 9 * 16 * AB * 16 * BB * 4 <= LDS, "LDS budget");
-    auto kern = conv_wgrad_thin_kernel<AB, BB>;
+    auto kern = conv_wgrad_thin_kernel<AB, BB, QS>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -510,10 +515,10 @@ int tw_launch(const TwKP& k, int wgs, hipStream_t st) {
 
 int conv_wgrad_thin(const salt_conv_wgrad_args* a, bool launch, hipStream_t st, int* rc) {
     static const int env = getenv("SALT_WGRAD_THIN") ? atoi(getenv("SALT_WGRAD_THIN")) : 1;
-    if (!a || !env || a->dtype != SALT_F32 || a->ntaps != 9 || a->q_step != 1 || a->q_plane) return 0;
+    if (!a || !env || a->dtype != SALT_F32 || a->ntaps != 9 || (a->q_step != 1 && a->q_step != 2) || a->q_plane) return 0;
     if (!view_ok(a->p) || !view_ok(a->q) || a->p.B != a->q.B) return 0;
-    const int Ca = a->p.C, Cb = a->q.C;
-    if ((Ca != 16 && Ca != 32) || (Cb != 16 && Cb != 32) || a->p.H % 16 || a->p.W % 16) return 0;
+    const int Ca = a->p.C, Cb = a->q.C, qs = a->q_step, tr = qs == 1 ? 16 : 8;
+    if ((Ca != 16 && Ca != 32) || (Cb != 16 && Cb != 32) || a->p.H % tr || a->p.W % 16 || (qs == 2 && Cb != 16)) return 0;
     int min_dy = 1 << 30, max_dy = -(1 << 30), min_dx = 1 << 30, max_dx = -(1 << 30);
     for (int t = 0; t < 9; ++t) {
         min_dy = a->tap_dy[t] < min_dy ? a->tap_dy[t] : min_dy; max_dy = a->tap_dy[t] > max_dy ? a->tap_dy[t] : max_dy;
@@ -522,9 +527,9 @@ int conv_wgrad_thin(const salt_conv_wgrad_args* a, bool launch, hipStream_t st, 
     if (max_dy - min_dy > 2 || max_dx - min_dx > 2) return 0;
     if (a->p.cs % 4 || a->q.cs % 4 || ((reinterpret_cast<uintptr_t>(a->p.p) | reinterpret_cast<uintptr_t>(a->q.p)) & 15)) return 0;
     if ((int64_t)a->p.B * a->p.H * a->p.W * a->p.cs >= (int64_t)1 << 31 || (int64_t)a->q.B * a->q.H * a->q.W * a->q.cs >= (int64_t)1 << 31) return 0;
-    const int ntiles = a->p.B * (a->p.H / 16) * (a->p.W / 16);
+    const int ntiles = a->p.B * (a->p.H / tr) * (a->p.W / 16);
     if (ntiles < thin_cus() / 2) return 0;
-    const int lds = 2 * ((Ca / 16) * 16 + (Cb / 16) * 21) * 1024 + 1024;
+    const int lds = 2 * ((Ca / 16) * tr + (Cb / 16) * (qs == 1 ? 21 : 36)) * 1024 + 1024;
     int per_cu = (160 * 1024) / lds;
     if (per_cu > 2) per_cu = 2;
     int wgs = thin_cus() * per_cu;
@@ -534,10 +539,11 @@ int conv_wgrad_thin(const salt_conv_wgrad_args* a, bool launch, hipStream_t st, 
     TwKP k;
     k.P = reinterpret_cast<const float*>(a->p.p); k.Q = reinterpret_cast<const float*>(a->q.p); k.partials = a->partials;
     k.B = a->p.B; k.PH = a->p.H; k.PW = a->p.W; k.p_cs = a->p.cs; k.QH = a->q.H; k.QW = a->q.W; k.q_cs = a->q.cs;
-    k.tiles_x = a->p.W / 16; k.tiles_y = a->p.H / 16; k.ntiles = ntiles;
+    k.tiles_x = a->p.W / 16; k.tiles_y = a->p.H / tr; k.ntiles = ntiles;
     k.min_dy = min_dy; k.min_dx = min_dx; k.pad_mode = a->pad_mode;
-    for (int t = 0; t < 9; ++t) k.tap_off[t] = (a->tap_dy[t] - min_dy) * 18 + (a->tap_dx[t] - min_dx);
+    for (int t = 0; t < 9; ++t) k.tap_off[t] = (a->tap_dy[t] - min_dy) * (qs == 1 ? 18 : 33) + (a->tap_dx[t] - min_dx);
     const int v = 4 * (Ca / 16) + Cb / 16;
-    *rc = v == 5 ? tw_launch<1, 1>(k, wgs, st) : v == 6 ? tw_launch<1, 2>(k, wgs, st) : v == 9 ? tw_launch<2, 1>(k, wgs, st) : tw_launch<2, 2>(k, wgs, st);
+    if (qs == 1) *rc = v == 5 ? tw_launch<1, 1, 1>(k, wgs, st) : v == 6 ? tw_launch<1, 2, 1>(k, wgs, st) : v == 9 ? tw_launch<2, 1, 1>(k, wgs, st) : tw_launch<2, 2, 1>(k, wgs, st);
+    else *rc = v == 5 ? tw_launch<1, 1, 2>(k, wgs, st) : tw_launch<2, 1, 2>(k, wgs, st);      // (Cb == 16: the 17 x 33 halo of 32 channels would not fit twice)
     return wgs;
 }

@@ -176,3 +176,34 @@ def test_thin_transposed_conv_phases_vs_torch(case, train):
         assert_close(grads['0.weight'], ref_dc.weight.grad, 4 * TOL, 'wgrad')
         assert_close(grads['1.weight'], ref_bn.weight.grad, 4 * TOL, 'dgamma')
         assert_close(grads['1.bias'], ref_bn.bias.grad, 4 * TOL, 'dbeta')
+
+
+@pytest.mark.parametrize('case', [(32, 16), (16, 16)])
+def test_thin_wgrad_stride2_operand_vs_torch(case):
+    """The weight gradient of nn.ConvTranspose2d(Ca, Cb, 3, 2, 1, 1) (P = x, Q = dY read at 2 p + tap: salt_conv_wgrad_args.q_step 2) on
+    conv_wgrad_thin_kernel<.., .., 2> (8 x 16-pixel tiles, 17 x 33 halo) against torch autograd on the CPU."""
+    import salt_amd  # noqa: F401
+    from salt_amd._abi import STRUCTS, lib, fill, check
+    from salt_amd.engine import shaped_view
+    Ca, Cb = case
+    B, H, W = 8, 32, 64                                    # 8 x 4 x 4 tiles of 8 x 16
+    g = torch.Generator().manual_seed(9)
+    X = torch.randn(B, Ca, H, W, generator=g)
+    dY = torch.randn(B, Cb, 2 * H, 2 * W, generator=g)
+    taps = [(u - 1, v - 1) for u in range(3) for v in range(3)]
+    Pd, Qd = X.permute(0, 2, 3, 1).contiguous().cuda(), dY.permute(0, 2, 3, 1).contiguous().cuda()
+    S = fill(STRUCTS['salt_conv_wgrad_args'](), dtype=0, p=shaped_view(Pd.data_ptr(), B, H, W, Ca), q=shaped_view(Qd.data_ptr(), B, 2 * H, 2 * W, Cb),
+             ntaps=9, tap_dy=[t[0] for t in taps], tap_dx=[t[1] for t in taps], q_step=2, pad_mode=0, q_plane=0)
+    ns = lib.salt_conv_wgrad_nsplit(ctypes.byref(S))
+    assert ns == 128, ns
+    part = torch.full((ns, 9, Ca, Cb), float('nan'), device='cuda:0')
+    grad = torch.empty(Ca, Cb, 3, 3, device='cuda:0')
+    S.partials = part.data_ptr(); S.nsplit = ns
+    R = fill(STRUCTS['salt_wgrad_reduce_args'](), partials=part.data_ptr(), nsplit=ns, ntaps=9, Ca=Ca, Cb=Cb, KH=3, KW=3,
+             tap_kh=[t // 3 for t in range(9)], tap_kw=[t % 3 for t in range(9)], grad=grad.data_ptr(), accumulate=0)
+    st = torch.cuda.current_stream().cuda_stream
+    check(lib.salt_conv_wgrad(ctypes.byref(S), st)); check(lib.salt_wgrad_reduce(ctypes.byref(R), st))
+    torch.cuda.synchronize()
+    dc = nn.ConvTranspose2d(Ca, Cb, 3, 2, 1, 1, bias=False)
+    dc(X).backward(dY)
+    assert_close(grad.cpu(), dc.weight.grad, 1e-4, 'dW')
