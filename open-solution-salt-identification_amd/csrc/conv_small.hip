@@ -131,6 +131,7 @@ constexpr int MAXKK = 40;
 struct FirstWgKP {
     const float* x; const void* dy; float* partials;
     int B, Cin, H, W, K, stride, pad, OH, OW, Cout, dy_cs, tiles_y, tiles_x, halo, groups, per;
+    int mfma;                        // 1: the MFMA path of conv_first_wgrad_kernel (Cout % 16 == 0, K K Cin <= 16)
 };
 
 // PER: compile-time bound of the taps a thread accumulates (p.per <= PER): with the runtime bound alone the pixel loop carried
@@ -158,6 +159,36 @@ __global__ __launch_bounds__(256) void conv_first_wgrad_kernel(FirstWgKP p) {
         s_dy[i] = (oy < p.OH && ox < p.OW) ? Elem<T>::ld((const T*)p.dy + (((int64_t)b * p.OH + oy) * p.OW + ox) * p.dy_cs + co) : 0.f;
     }
     __syncthreads();
+    if (p.mfma) {
+        // Cout a multiple of 16, <= 16 taps (host): dW[co][tap] = sum_px dy[px][co] x[px + tap] on v_mfma_f32_16x16x4_f32 - rows = 16
+        // output channels, columns = taps (padded to 16), contraction = 4 pixels per instruction; a wave takes 64 of the tile's 256
+        // pixels, the four partial results meet in LDS.  (The scalar loop below walks the 256 pixels in ONE thread per (co, tap).)
+        const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, kg = lane >> 4;
+        float* s_red = s_dy + 256 * p.Cout;                                   // [4][16][16]
+        int koff = 0;
+        const bool tap_on = l15 < KKC;
+        if (tap_on) { const int kw = l15 % p.K; int r = l15 / p.K; const int kh = r % p.K; const int ci = r / p.K; koff = (ci * p.halo + kh) * p.halo + kw; }
+        for (int cb = 0; cb < p.Cout; cb += 16) {
+            f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+            for (int q = 0; q < 16; ++q) {
+                const int px = wave * 64 + q * 4 + kg;
+                const float a = s_dy[px * p.Cout + cb + l15];
+                const float bq = tap_on ? s_in[((px >> 4) * p.stride) * p.halo + (px & 15) * p.stride + koff] : 0.f;
+                acc4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq, acc4, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_red[(wave * 16 + 4 * kg + r) * 16 + l15] = acc4[r];      // D[co = 4 kg + r][tap = l15]
+            __syncthreads();
+            {
+                const int c16 = tid >> 4, t16 = tid & 15;
+                const float v = ((s_red[c16 * 16 + t16] + s_red[(16 + c16) * 16 + t16]) + s_red[(32 + c16) * 16 + t16]) + s_red[(48 + c16) * 16 + t16];
+                if (t16 < KKC) p.partials[(int64_t)blockIdx.x * p.Cout * KKC + (int64_t)(cb + c16) * KKC + t16] = v;
+            }
+            __syncthreads();
+        }
+        return;
+    }
     const int co = tid % p.Cout, grp = tid / p.Cout;
     if (grp >= p.groups) return;
     float acc[PER];
@@ -623,7 +654,9 @@ extern "C" int salt_conv_first_wgrad(const salt_conv_first_wgrad_args* a, void* 
     if (p.per > MAXKK) SALT_FAIL(SALT_E_UNSUPPORTED, "conv_first_wgrad: %d taps per thread > %d", p.per, MAXKK);
     const int nparts = a->B * p.tiles_y * p.tiles_x;
     if (a->nparts != nparts) SALT_FAIL(SALT_E_BADARG, "conv_first_wgrad: nparts %d, expected %d", a->nparts, nparts);
-    const size_t lds = sizeof(float) * ((size_t)p.Cin * p.halo * p.halo + (size_t)256 * Cout);
+    static const bool mfma_off = getenv("SALT_FIRST_WGRAD_MFMA") && atoi(getenv("SALT_FIRST_WGRAD_MFMA")) == 0;
+    p.mfma = (!mfma_off && Cout % 16 == 0 && KKC <= 16) ? 1 : 0;
+    const size_t lds = sizeof(float) * ((size_t)p.Cin * p.halo * p.halo + (size_t)256 * Cout + (p.mfma ? 1024 : 0));
     if (lds > 160 * 1024) SALT_FAIL(SALT_E_LDS, "conv_first_wgrad: needs %zu bytes of LDS", lds);
     SALT_DISPATCH_DTYPE(a->dtype, T, {
         auto kern = p.per <= 1 ? conv_first_wgrad_kernel<T, 1> : p.per <= 4 ? conv_first_wgrad_kernel<T, 4> : p.per <= 12 ? conv_first_wgrad_kernel<T, 12>
