@@ -131,6 +131,7 @@ __device__ __forceinline__ void ws_prefetch_operands(const WsEpi& p, const unsig
             for (int gp = 0; gp < 2; ++gp) {
                 const unsigned c = n0 + 8 * khalf + 32 * j + 16 * gp;
                 if (OLD && p.accumulate) o.oldv[i][j][gp] = *reinterpret_cast<const u32x4*>(p.y + (pix[i] * (unsigned)p.y_cs + c));
+                if (OLD && p.res) o.oldv[i][j][gp] = *reinterpret_cast<const u32x4*>(p.res + (pix[i] * (unsigned)p.res_cs + c));      // (host: never with accumulate)
                 if (p.sums) {
                     o.yv[i][j][gp] = *reinterpret_cast<const u32x4*>(p.bnb_y + (pix[i] * (unsigned)p.bnb_cs + c));
                     if (p.bnb_a) o.av[i][j][gp] = *reinterpret_cast<const u32x4*>(p.bnb_a + (pix[i] * (unsigned)p.bnb_acs + c));
@@ -1046,6 +1047,25 @@ __global__ __launch_bounds__(512) void conv1x1_ls_kernel(L1KP p) {
             for (int j = 0; j < NI; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const unsigned tile = (unsigned)(t_lo + slot + k * p.slots);
+        unsigned pix[MI];
+        if (p.step == 2) {
+            const unsigned tx = tile % (unsigned)p.tiles_x, r = tile / (unsigned)p.tiles_x, ty = r % (unsigned)p.tiles_y, b = r / (unsigned)p.tiles_y;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const unsigned m = (unsigned)(wm * 64 + i * 32 + l31);
+                pix[i] = (b * (unsigned)p.OH + ty * 16u + (m >> 4)) * (unsigned)p.OW + tx * 16u + (m & 15u);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) pix[i] = tile * 256u + (unsigned)(wm * 64 + i * 32 + l31);
+        }
+        // the residual / (+)= operand tile of the item is requested before its chunks are waited for: a 64 -> 256 expansion is ONE chunk,
+        // so an item was DMA wait -> 8 MFMAs -> residual loads -> wait -> stores, with the HBM latency of the residual exposed per item
+        constexpr bool PRE = MODE == 0 && SALT_LS_PREFETCH != 0;
+        WsOps<PRE ? NI : 1> ops;
+        const bool pre_on = PRE && (p.res != nullptr || p.accumulate);
+        if constexpr (PRE) { if (pre_on) ws_prefetch_operands<NI, true>(ep, pix, n0, khalf, ops); }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll 1
         for (int c = 0; c < p.nsc; ++c, ++g) {
@@ -1073,21 +1093,11 @@ __global__ __launch_bounds__(512) void conv1x1_ls_kernel(L1KP p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f[s2].b[j]), __builtin_bit_cast(bf16x8, f[s2].a[i]), acc[i][j], 0, 0, 0);
         }
         __builtin_amdgcn_s_setprio(0);
-        const unsigned tile = (unsigned)(t_lo + slot + k * p.slots);
-        unsigned pix[MI];
-        if (p.step == 2) {
-            const unsigned tx = tile % (unsigned)p.tiles_x, r = tile / (unsigned)p.tiles_x, ty = r % (unsigned)p.tiles_y, b = r / (unsigned)p.tiles_y;
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const unsigned m = (unsigned)(wm * 64 + i * 32 + l31);
-                pix[i] = (b * (unsigned)p.OH + ty * 16u + (m >> 4)) * (unsigned)p.OW + tx * 16u + (m & 15u);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < MI; ++i) pix[i] = tile * 256u + (unsigned)(wm * 64 + i * 32 + l31);
-        }
         const WsLaneGeo geo = {{true, true}, false, false, false, false, 0, 0, 0, 0};
-        ws_epilogue_tile<NI, MODE, false>(ep, acc, pix, geo, n0, reinterpret_cast<const float*>(smem + OFF_CONST), rs0, rs1, khalf, l31);
+        if constexpr (PRE) {
+            if (pre_on) ws_epilogue_tile<NI, MODE, false>(ep, acc, pix, geo, n0, reinterpret_cast<const float*>(smem + OFF_CONST), rs0, rs1, khalf, l31, &ops, true);
+            else ws_epilogue_tile<NI, MODE, false>(ep, acc, pix, geo, n0, reinterpret_cast<const float*>(smem + OFF_CONST), rs0, rs1, khalf, l31);
+        } else ws_epilogue_tile<NI, MODE, false>(ep, acc, pix, geo, n0, reinterpret_cast<const float*>(smem + OFF_CONST), rs0, rs1, khalf, l31);
     }
     }
     if (MODE == 1) {
