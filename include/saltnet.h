@@ -180,8 +180,9 @@ int salt_conv_stats_parts(const salt_conv_args*);
  * or train-mode statistics through fin_acc: bf16, Cin a multiple of 64, Cout of 32, B OH OW a multiple of 256; stride 1, or stride 2
  * on 16 x 16 output tiles), 12 conv_thin_kernel (the persistent weight-stationary kernel of the fp32 3x3 layers with 16 or 32
  * channels on BOTH sides, unit steps, output grid a multiple of 16 x 16; statistics / BatchNorm-backward sums through the fp64 shards
- * only).  `cfg` & 0xff:
- * 0 = heuristic, 1..8 = that config, 9 / 10 / 11 / 12 = that kernel wherever it applies (else heuristic); (cfg >> 8) & 0xff caps the
+ * only), 13 conv_stem16_kernel (the ResNet stem after the 2 x 2 space-to-depth: bf16, 16 taps over 16 input channels -> 64, zero
+ * padding, eval epilogue or train-mode statistics through fin_acc).  `cfg` & 0xff:
+ * 0 = heuristic, 1..8 = that config, 9 .. 13 = that kernel wherever it applies (else heuristic); (cfg >> 8) & 0xff caps the
  * workgroups per XCD of kernels 9 - 11 (0 = one per CU) and, for 10 / 11 when asked for, (cfg >> 16) & 3 fixes the output channels
  * per item to 32 x that (0 = by size). */
 int salt_conv_kernel_id(const salt_conv_args*);

@@ -77,6 +77,9 @@ int conv_ls_launch(const salt_conv_args* a, hipStream_t st);
 int conv1x1_ls_variant(const salt_conv_args* a);
 int conv1x1_ls_launch(const salt_conv_args* a, hipStream_t st);
 
+// conv_ws.hip: the ResNet stem after space-to-depth (bf16, 16 taps over 16 channels -> 64); 0 = not applicable
+int conv_stem16_variant(const salt_conv_args* a);
+int conv_stem16_launch(const salt_conv_args* a, hipStream_t st);
 // conv_thin.hip: the persistent weight-stationary kernel of the fp32 3x3 layers with 16 / 32 channels on both sides (0 = not applicable)
 int conv_thin_variant(const salt_conv_args* a);
 int conv_thin_launch(const salt_conv_args* a, hipStream_t st);

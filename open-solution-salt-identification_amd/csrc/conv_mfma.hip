@@ -1465,10 +1465,10 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
     const bool v2_ok = a->dtype == SALT_BF16 && a->in_step == 1 && (a->ntaps == 9 || a->ntaps == 4) && a->x.C % 32 == 0 &&
                        a->x.cs % 8 == 0 && (reinterpret_cast<uintptr_t>(a->x.p) & 15) == 0 && !in_tf;
     // ---- tile config heuristic (overridable for tests/tuning)
-    int id = ((a->cfg & 0xff) >= 9 && (a->cfg & 0xff) <= 12) ? 0 : (a->cfg & 0xff);   // 9 = "conv_ws_kernel where it applies" (conv_ws.hip): the heuristic decides for the rest
+    int id = ((a->cfg & 0xff) >= 9 && (a->cfg & 0xff) <= 13) ? 0 : (a->cfg & 0xff);   // 9 = "conv_ws_kernel where it applies" (conv_ws.hip): the heuristic decides for the rest
     if (id >= 6 && !v2_ok) id = 0;            // a forced conv_glds config applies where the kernel does (tests force one config per graph)
     if (id == 2 && vt > 1) id = 1;            // 256-pixel tiles x 4 virtual taps exceed the halo-piece budget
-    if (id == 0 && v2_ok && v2_env && ((a->cfg & 0xff) == 0 || ((a->cfg & 0xff) >= 9 && (a->cfg & 0xff) <= 12))) {
+    if (id == 0 && v2_ok && v2_env && ((a->cfg & 0xff) == 0 || ((a->cfg & 0xff) >= 9 && (a->cfg & 0xff) <= 13))) {
         if (v2_env >= 6) id = v2_env;
         else {
             // measured (tools/v2_sweep.sh, tools/v2_ablate.sh): the LDS-DMA kernel wins where conv_mfma_kernel's 128x32 tiles cannot
@@ -2938,6 +2938,7 @@ extern "C" int salt_conv(const salt_conv_args* a, void* stream) {
     if (a->x_plane) SALT_FAIL(SALT_E_UNSUPPORTED, "conv: planar x (x_plane) is read by conv_ls_kernel only and this launch is not eligible for it");
     if (!in_tf && conv1x1_ls_variant(a)) return conv1x1_ls_launch(a, (hipStream_t)stream);
     if (!in_tf && conv_thin_variant(a)) return conv_thin_launch(a, (hipStream_t)stream);
+    if (!in_tf && conv_stem16_variant(a)) return conv_stem16_launch(a, (hipStream_t)stream);
     if (a->dtype == SALT_F32) return launch_T<float>(pl, (hipStream_t)stream);
     if (a->dtype == SALT_BF16) return launch_T<bf16_t>(pl, (hipStream_t)stream);
     SALT_FAIL(SALT_E_BADARG, "conv: dtype %d", a->dtype);
@@ -2957,7 +2958,7 @@ extern "C" int salt_conv_kernel_id(const salt_conv_args* a) {
     if (a->in_scale || a->in_fin_acc) return pl.cfg.id;
     if (a->y_plane) return conv_ws_eligible(a) ? 9 : -1;
     if (a->x_plane) return conv_ls_variant(a) ? 10 : -1;
-    return conv_ws_eligible(a) ? 9 : (conv_ls_variant(a) ? 10 : (conv1x1_ls_variant(a) ? 11 : (conv_thin_variant(a) ? 12 : pl.cfg.id)));
+    return conv_ws_eligible(a) ? 9 : (conv_ls_variant(a) ? 10 : (conv1x1_ls_variant(a) ? 11 : (conv_thin_variant(a) ? 12 : (conv_stem16_variant(a) ? 13 : pl.cfg.id))));
 }
 
 extern "C" int salt_conv_tile_shape(const salt_conv_args* a) {

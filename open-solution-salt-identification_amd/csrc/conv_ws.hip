@@ -1129,6 +1129,150 @@ int l1_launch(const L1KP& k, int wgs, hipStream_t st) {
     return k.fin_acc ? l1_launch_mode<NI, 1>(k, wgs, st) : l1_launch_mode<NI, 0>(k, wgs, st);
 }
 
+
+// ------------------------------------------------------------------------------------------ conv_stem16_kernel (bf16, 16 input channels)
+// The ResNet stem after the 2 x 2 space-to-depth (engine.py _stem_s2d: 16 taps over 16 channels -> 64, torchvision's conv1 via
+// architectures/encoders.py:20-27): K = 16 per tap is exactly ONE v_mfma_f32_32x32x16_bf16 step, but the general kernels stage 32-channel
+// chunks (half of them zero padding) and one tile per workgroup: 45 us for 4.3 GFLOP (of which 2.1 padding) / 21 MB at B = 32.  Here a
+// persistent 4-wave workgroup keeps the weights of all 16 taps in LDS as 32-byte rows (32 KB), streams 16 x 16-pixel tiles through a
+// double-buffered 19 x 19 halo of 32-byte pixel rows (LDS-DMA, one tile ahead; 1-KB wave reads of 32 consecutive rows are conflict free
+// without a swizzle) and runs conv_ws_kernel's swapped-operand epilogue (ws_epilogue_tile: 16-byte stores, statistics in registers).
+struct S16KP {
+    const bf16_t* x; const bf16_t* w; bf16_t* y;
+    const float* bias; const float* scale; const float* shift;
+    int B, H, W, x_cs, y_cs, OH, OW;
+    int tiles_x, tiles_y, ntiles;
+    int min_dy, min_dx;
+    int tap_off[16];
+    int relu;
+    double* fin_acc;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void conv_stem16_kernel(S16KP p) {
+    constexpr int NI = 2, MI = 2, BN = 64, NT = 16;
+    constexpr int WPIECES = NT * BN / 32;                // 32 pieces of 1 KB = 32 rows of 32 bytes
+    constexpr int HPIECES = 12;                          // 19 x 19 = 361 rows, padded to 384
+    constexpr int W_BYTES = WPIECES * 1024, H_BYTES = HPIECES * 1024;
+    constexpr int OFF_H = W_BYTES, OFF_DUMMY = OFF_H + 2 * H_BYTES, OFF_CONST = OFF_DUMMY + 1024;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int khalf = lane >> 5, l31 = lane & 31;
+    const int n_my = ((int)blockIdx.x < p.ntiles) ? (p.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    if (n_my <= 0) return;
+    struct TC { int b, oy0, ox0; };
+    auto coords = [&](int k) {
+        const int t = (int)blockIdx.x + k * (int)gridDim.x;
+        TC c; const int tx = t % p.tiles_x; const int r = t / p.tiles_x;
+        c.ox0 = tx << 4; c.oy0 = (r % p.tiles_y) << 4; c.b = r / p.tiles_y; return c;
+    };
+    const unsigned char* zp = reinterpret_cast<const unsigned char*>(g_ws_zero);
+    auto dma = [&](const void* src, int dst) {
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)(smem + dst), 16, 0, 0);
+    };
+    // weights: LDS row (tap, n) = the first 32 bytes (16 channels) of the packed 64-byte row [tap][Cout][32]
+#pragma unroll
+    for (int i = 0; i < WPIECES / 4; ++i) {
+        const int q = wave + 4 * i;
+        const int R = q * 32 + (lane >> 1);
+        dma(reinterpret_cast<const unsigned char*>(p.w + (R * 32 + (lane & 1) * 8)), q * 1024);
+    }
+    auto issue_halo = [&](const TC& c, int buf) {
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const bf16_t* xb = p.x + (int64_t)c.b * p.H * p.W * p.x_cs;
+        const int iy0 = c.oy0 + p.min_dy, ix0 = c.ox0 + p.min_dx;
+#pragma unroll
+        for (int i = 0; i < HPIECES / 4; ++i) {
+            const int pidx = wave + 4 * i;
+            const int row = pidx * 32 + (ln >> 1);
+            const int hy = (int)__umulhi((unsigned)row, 226050911u);         // row / 19
+            const int hx = row - hy * 19;
+            const int iy = iy0 + hy, ix = ix0 + hx;
+            const bool valid = (row < 361) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+            const unsigned char* src = reinterpret_cast<const unsigned char*>(xb + ((iy * p.W + ix) * p.x_cs + (ln & 1) * 8));
+            dma(valid ? src : zp, OFF_H + buf * H_BYTES + pidx * 1024);
+        }
+    };
+    issue_halo(coords(0), 0);
+    if (tid < BN) {
+        float* sc = reinterpret_cast<float*>(smem + OFF_CONST);
+        sc[tid] = p.bias ? p.bias[tid] : 0.f; sc[BN + tid] = p.scale ? p.scale[tid] : 1.f; sc[2 * BN + tid] = p.shift ? p.shift[tid] : 0.f;
+    }
+    float rs0[NI][4], rs1[NI][4];
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { rs0[j][e] = 0.f; rs1[j][e] = 0.f; }
+    const bool sums = MODE == 1 && p.fin_acc;
+    const WsEpi ep = {p.y, nullptr, nullptr, p.y_cs, 0, 0, p.relu, 0, 0, p.bias || p.scale || p.shift || p.relu, sums, nullptr, 0};
+    int pbase[MI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = wave * 64 + i * 32 + ws_perm(l31);
+        pbase[i] = (m >> 4) * 19 + (m & 15);
+    }
+#pragma unroll 1
+    for (int k = 0; k < n_my; ++k) {
+        if (k == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const TC cur = coords(k);
+        if (k + 1 < n_my) issue_halo(coords(k + 1), (k + 1) & 1);
+        const unsigned char* hb = smem + OFF_H + (k & 1) * H_BYTES;
+        f32x16 acc[MI][NI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        struct Frag { u32x4 a[MI], b[NI]; };
+        auto load_frag = [&](int t, Frag& f) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) f.a[i] = *reinterpret_cast<const u32x4*>(hb + (pbase[i] + p.tap_off[t]) * 32 + khalf * 16);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) f.b[j] = *reinterpret_cast<const u32x4*>(smem + (t * BN + j * 32 + l31) * 32 + khalf * 16);
+        };
+        Frag f[2];
+        load_frag(0, f[0]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (t + 1 < NT) load_frag(t + 1, f[(t + 1) & 1]);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f[t & 1].b[j]), __builtin_bit_cast(bf16x8, f[t & 1].a[i]), acc[i][j], 0, 0, 0);
+        }
+        if (k + 1 < n_my) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the next tile's pieces landed; this tile's stores stay out of the wait
+        unsigned pix[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = wave * 64 + i * 32 + ws_perm(l31);
+            pix[i] = (unsigned)((cur.b * p.OH + cur.oy0 + (m >> 4)) * p.OW + cur.ox0 + (m & 15));
+        }
+        const WsLaneGeo geo = {{true, true}, false, false, false, false, 0, 0, 0, 0};
+        ws_epilogue_tile<NI, MODE, false>(ep, acc, pix, geo, 0, reinterpret_cast<const float*>(smem + OFF_CONST), rs0, rs1, khalf, l31);
+    }
+    if (MODE == 1 && sums) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        ws_sums_flush<NI, 1, 4>(rs0, rs1, true, wave, reinterpret_cast<float*>(smem), 0, BN, p.fin_acc, nullptr, (double)n_my * 256.0, khalf, l31);
+    }
+}
+
+template <int MODE>
+int stem16_launch_mode(const S16KP& k, hipStream_t st) {
+    constexpr int LDS = 32 * 1024 + 2 * 12 * 1024 + 1024 + 4 * 64 * 4;
+    int wgs = ws_cus() * 2;
+    if (wgs > k.ntiles) wgs = k.ntiles;
+    hipLaunchKernelGGL(conv_stem16_kernel<MODE>, dim3((unsigned)wgs), dim3(256), LDS, st, k);
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}
+
 }  // namespace
 
 // ---- host interface (conv_mfma.hip: salt_conv / salt_conv_stats_parts try this first)
@@ -1373,6 +1517,46 @@ int conv1x1_ls_launch(const salt_conv_args* a, hipStream_t st) {
     if (k.slots < 1) k.slots = 1;
     const int wgs = k.slots * k.n_tiles * 8;
     return ni == 2 ? l1_launch<2>(k, wgs, st) : l1_launch<1>(k, wgs, st);
+}
+
+
+// ---- conv_stem16_kernel host side.  SALT_CONV_STEM16 = 0: off unless asked for per launch (cfg & 0xff == 13).
+int conv_stem16_variant(const salt_conv_args* a) {
+    static const int env = getenv("SALT_CONV_STEM16") ? atoi(getenv("SALT_CONV_STEM16")) : 1;
+    if (!a || a->dtype != SALT_BF16 || a->ntaps != 16) return 0;
+    const bool asked = (a->cfg & 0xff) == 13;
+    if ((a->cfg & 0xff) != 0 && !asked) return 0;
+    if (!asked && !env) return 0;
+    if (a->in_step != 1 || a->out_step != 1 || a->out_oy || a->out_ox || a->nphase > 1 || a->pad_mode != 0) return 0;
+    if (a->strip || a->fold_top || a->fold_bottom || a->fold_left || a->fold_right || a->x_plane || a->y_plane || a->res.p || a->accumulate) return 0;
+    if (a->stats || a->fin_ticket || a->bnb_acc || a->bnb_partials || a->bnb_ticket || a->in_scale || a->in_fin_acc) return 0;
+    if (a->fin_acc && (a->bias || a->scale || a->shift || a->relu)) { /* MODE 1 applies the affine part before the sums, as conv_ws_kernel */ }
+    if (a->x.C != 16 || a->y.C != 64 || a->x.B != a->y.B || a->OH != a->y.H || a->OW != a->y.W || a->OH % 16 || a->OW % 16) return 0;
+    int min_dy = 1 << 30, max_dy = -(1 << 30), min_dx = 1 << 30, max_dx = -(1 << 30);
+    for (int t = 0; t < 16; ++t) {
+        min_dy = a->tap_dy[t] < min_dy ? a->tap_dy[t] : min_dy; max_dy = a->tap_dy[t] > max_dy ? a->tap_dy[t] : max_dy;
+        min_dx = a->tap_dx[t] < min_dx ? a->tap_dx[t] : min_dx; max_dx = a->tap_dx[t] > max_dx ? a->tap_dx[t] : max_dx;
+    }
+    if (max_dy - min_dy > 3 || max_dx - min_dx > 3) return 0;
+    if (a->x.cs % 8 || a->y.cs % 8 || ((reinterpret_cast<uintptr_t>(a->x.p) | reinterpret_cast<uintptr_t>(a->y.p) | reinterpret_cast<uintptr_t>(a->w)) & 15)) return 0;
+    if ((int64_t)a->x.B * a->x.H * a->x.W * a->x.cs >= (int64_t)1 << 31 || (int64_t)a->y.B * a->y.H * a->y.W * a->y.cs >= (int64_t)1 << 31) return 0;
+    if (!asked && (int64_t)a->y.B * (a->OH / 16) * (a->OW / 16) < ws_cus() / 2) return 0;
+    return 1;
+}
+
+int conv_stem16_launch(const salt_conv_args* a, hipStream_t st) {
+    if (!conv_stem16_variant(a)) SALT_FAIL(SALT_E_UNSUPPORTED, "conv_stem16: not applicable");
+    S16KP k;
+    k.x = reinterpret_cast<const bf16_t*>(a->x.p); k.w = reinterpret_cast<const bf16_t*>(a->w); k.y = reinterpret_cast<bf16_t*>(a->y.p);
+    k.bias = a->bias; k.scale = a->scale; k.shift = a->shift;
+    k.B = a->x.B; k.H = a->x.H; k.W = a->x.W; k.x_cs = a->x.cs; k.y_cs = a->y.cs; k.OH = a->OH; k.OW = a->OW;
+    k.tiles_x = a->OW / 16; k.tiles_y = a->OH / 16; k.ntiles = a->y.B * k.tiles_x * k.tiles_y;
+    int min_dy = 1 << 30, min_dx = 1 << 30;
+    for (int t = 0; t < 16; ++t) { min_dy = a->tap_dy[t] < min_dy ? a->tap_dy[t] : min_dy; min_dx = a->tap_dx[t] < min_dx ? a->tap_dx[t] : min_dx; }
+    k.min_dy = min_dy; k.min_dx = min_dx;
+    for (int t = 0; t < 16; ++t) k.tap_off[t] = (a->tap_dy[t] - min_dy) * 19 + (a->tap_dx[t] - min_dx);
+    k.relu = a->relu; k.fin_acc = a->fin_acc;
+    return a->fin_acc ? stem16_launch_mode<1>(k, st) : stem16_launch_mode<0>(k, st);
 }
 
 extern "C" int salt_debug_ws_clk(unsigned long long* host_out, int n) {

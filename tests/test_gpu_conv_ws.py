@@ -296,3 +296,63 @@ def test_planar_operand_buffers_are_bit_identical_to_interleaved(replicate):
     assert_close(res[True][0], yr, TOLBF, 'y vs torch')
     for a, b_, what in zip(res[True], res[False], ('y', 'dx', 'dw')):
         assert torch.equal(a, b_), what
+
+
+@pytest.mark.parametrize('case', [(4, 64, 64), (2, 96, 64), (3, 32, 128)])
+@pytest.mark.parametrize('train', [True, False])
+def test_stem16_kernel_vs_torch_and_conv_mfma(case, train):
+    """conv_stem16_kernel (the ResNet stem nn.Conv2d(3, 64, 7, 2, 3) after the 2 x 2 space-to-depth: 16 taps over 16 channels, bf16,
+    persistent workgroups with the weights of all taps in LDS) asked for per launch (cfg 13): forward with train-mode statistics /
+    folded eval BatchNorm + ReLU against torch on the bf16-rounded operands and against conv_mfma_kernel (cfg 2) on the same launch;
+    in train mode also the running statistics and the weight / BatchNorm gradients behind it."""
+    from gpu_harness import DEV
+    from salt_amd.engine import Graph
+    from salt_amd.runtime import Engine
+    B, H, W = case
+    outs = {}
+    for cfg in (13, 2):
+        conv, bn = nn.Conv2d(3, 64, 7, 2, 3, bias=False), nn.BatchNorm2d(64)
+        with torch.no_grad():
+            conv.weight.copy_(_rand(conv.weight.shape, 41, (2.0 / 147) ** 0.5))
+            bn.weight.copy_(1 + 0.1 * _rand((64,), 42)); bn.bias.copy_(0.1 * _rand((64,), 43))
+            bn.running_mean.copy_(0.1 * _rand((64,), 44)); bn.running_var.copy_(1 + 0.1 * _rand((64,), 45).abs())
+        mod = nn.Sequential(conv, bn).to(DEV)
+        mod.train(train)
+        eng = Engine(mod, torch.device(DEV), 'bf16')
+        g = Graph(eng, train)
+        _force_cfg(g, cfg)
+        x = _rand((B, 3, H, W), 46)
+        xd = g.alloc(tuple(x.shape), torch.float32); xd.copy_(x)
+        a = g.conv_first(xd, conv, bn, relu=True)
+        out = g.alloc((a.B, a.C, a.H, a.W), torch.float32)
+        g.to_nchw(a, out)
+        if train:
+            g.build_backward()
+        g.finalize()
+        ids = _kernel_ids(g.fwd)
+        assert ids == [cfg], ids
+        eng.refresh(train); g.fwd.run()
+        res = [out.cpu().clone()]
+        if train:
+            gy = _rand(tuple(out.shape), 47)
+            g.dlogits.copy_(gy); g.bwd.run(); torch.cuda.synchronize()
+            off, n = eng.grad_range(conv.weight)
+            res += [eng.grads[off:off + n].view(conv.weight.shape).cpu().clone(), bn.running_mean.cpu().clone(), bn.running_var.cpu().clone()]
+        outs[cfg] = res
+    rc, rb = nn.Conv2d(3, 64, 7, 2, 3, bias=False), nn.BatchNorm2d(64)
+    with torch.no_grad():
+        rc.weight.copy_(_rand(rc.weight.shape, 41, (2.0 / 147) ** 0.5).bfloat16().float())
+        rb.weight.copy_(1 + 0.1 * _rand((64,), 42)); rb.bias.copy_(0.1 * _rand((64,), 43))
+        rb.running_mean.copy_(0.1 * _rand((64,), 44)); rb.running_var.copy_(1 + 0.1 * _rand((64,), 45).abs())
+    rc.train(train); rb.train(train)
+    x = _rand((B, 3, H, W), 46).bfloat16().float()
+    yr = F.relu(rb(rc(x)))
+    assert_close(outs[13][0], yr.detach(), TOLBF, 'y vs torch')
+    assert_close(outs[13][0], outs[2][0], 2e-2, 'y: stem16 vs conv_mfma')
+    if train:
+        yr.backward(_rand(tuple(yr.shape), 47))
+        l2 = float((outs[13][1].double() - rc.weight.grad.double()).norm() / rc.weight.grad.double().norm())
+        assert l2 <= TOLBF, 'wgrad rel-L2 %.3e' % l2
+        assert_close(outs[13][2], rb.running_mean, TOLBF, 'running_mean')
+        assert_close(outs[13][3], rb.running_var, TOLBF, 'running_var')
+        assert_close(outs[13][2], outs[2][2], 1e-3, 'running_mean: stem16 vs conv_mfma')
