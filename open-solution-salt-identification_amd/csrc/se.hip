@@ -252,7 +252,9 @@ __global__ __launch_bounds__(1024) void se_fc_bwd_kernel(const float* partials, 
     // everything the loops touch repeatedly is staged in LDS first (one coalesced sweep); the batch loops then run out of LDS
     extern __shared__ float sm[];       // du [B][C], dh [B][R], gp [B][C], hd [B][R], ps [B][C+1] (spatial-SE sums)
     float* du = sm; float* dh = du + B * C; float* gp = dh + B * R; float* hd = gp + B * C; float* ps = hd + B * R;
+    float* sw1 = ps + B * (C + 1); float* sw2 = sw1 + R * C;            // the FC weights: the batch loops below read them C / R times per output
     const int tid = threadIdx.x, nt = blockDim.x;
+    for (int i = tid; i < R * C; i += nt) { sw1[i] = w1[i]; sw2[i] = w2[i]; }
     for (int i = tid; i < B * C; i += nt) {
         const int b = i / C, c = i - b * C;
         const float* row = partials + ((int64_t)b * nparts) * (2 * C + 1);
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(1024) void se_fc_bwd_kernel(const float* partials, 
     for (int i = tid; i < B * R; i += nt) {
         const int b = i / R, r = i - b * R;
         float t = 0.f;
-        for (int c = 0; c < C; ++c) t += du[b * C + c] * w2[c * R + r];
+        for (int c = 0; c < C; ++c) t += du[b * C + c] * sw2[c * R + r];
         dh[i] = hd[i] > 0.f ? t : 0.f;
     }
     for (int i = tid; i < C * R; i += nt) {
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(1024) void se_fc_bwd_kernel(const float* partials, 
     for (int i = tid; i < B * C; i += nt) {
         const int b = i / C, c = i - b * C;
         float t = 0.f;
-        for (int r = 0; r < R; ++r) t += dh[b * R + r] * w1[r * C + c];
+        for (int r = 0; r < R; ++r) t += dh[b * R + r] * sw1[r * C + c];
         dgap[i] = t * inv_hw;
     }
 }
@@ -381,7 +383,7 @@ extern "C" int salt_scse_bwd(const salt_scse_bwd_args* a, void* stream) {
     if (a->nparts != nparts) SALT_FAIL(SALT_E_BADARG, "scse_bwd: nparts %d, expected %d", a->nparts, nparts);
     hipStream_t st = (hipStream_t)stream;
     const int C = a->x.C, B = a->x.B;
-    const size_t fc_lds = (size_t)B * (3 * C + 2 * a->R + 1) * sizeof(float);
+    const size_t fc_lds = ((size_t)B * (3 * C + 2 * a->R + 1) + (size_t)2 * a->R * C) * sizeof(float);
     if (fc_lds > 160 * 1024) SALT_FAIL(SALT_E_LDS, "scse_bwd: batch*channels too large for the FC backward (%zu B)", fc_lds);
     if (fc_lds > 64 * 1024) {
         static bool attr_set = false;
