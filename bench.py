@@ -144,6 +144,8 @@ def op_bytes(name, s, es):
         return (1 if s.partials_ready else 2) * rd + _vb(s.dy, es) + _vb(s.dres, es) * (2 if s.accumulate_dres else 1)
     if name == 'bilinear':
         return _vb(s.x, es) * (2 if (s.backward and s.accumulate) else 1) + _vb(s.y, es)
+    if name == 'hyper_stencil':   # forward: partial sum + every level's z read, y written; adjoint: y read, every level's dz written
+        return sum(_vb(s.z[k], es) for k in range(s.nlev)) + _vb(s.y, es) + (_vb(s.y_in, es) if not s.backward else 0.0)
     if name in ('maxpool2', 'maxpool3s2', 'avgpool2'):
         return _vb(s.x, es) + _vb(s.y, es)
     if name in ('maxpool2_bwd', 'maxpool3s2_bwd'):
@@ -350,7 +352,10 @@ def conv_roofline(model, B, channels, dtype, loss, reps):
     roof = {'kernel': kern, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
             'algorithmic_bytes_per_launch': round(dby / dcnt) if dcnt else None, 'launches_per_step': dcnt // reps,
             'avg_launch_us': round(1e3 * dms / dcnt, 2), 'share_of_step': round(dms / reps / total_ms, 3),
-            'algorithmic_gflop_per_step': round(dfl / reps / 1e9, 2)}
+            # FLOPs the launches of this class EXECUTE (2 MAC per tap of every launch, from the argument structs).  Since round 5 the
+            # x4 / x8 / x16 hypercolumn levels are contracted at their own resolution (salt_hyper_stencil), so this is LESS than the
+            # reference network's algorithmic count for the same step (`flops` in the line has both); `frac` is priced on what ran
+            'executed_gflop_per_step': round(dfl / reps / 1e9, 2)}
     ops = {k: round(v[0] / reps, 3) for k, v in sorted(groups.items(), key=lambda kv: -kv[1][0])[:8]}
     side = sum(v[0] for k, v in groups.items() if k in ('conv_wgrad', 'wgrad_reduce', 'conv_first_wgrad', 'stem_grad_unfold')) / reps
     # per kernel class: matrix kernels against the dense MFMA peak of the compute dtype, streaming kernels as
@@ -407,6 +412,102 @@ def train_config(workload, dtype, B, loss, steps, warmup, dev, rank=0, world=1, 
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te[0])
     return model, batches, elapsed, float(loss_v['sum'])
+
+
+def fit_e2e_leg(dev, workload, dtype, B, loss, n_train=3200, n_val=800, epochs=2):
+    """The product the way a user runs it (reference models.py:78-103 driven by main.py): SegmentationModel.fit() over HOST uint8
+    101x101 tiles + masks (3 200 train / 800 validation, seed 1234) -> one pinned H2D copy per batch -> DevicePreprocessor
+    (resize 101 -> 102, edge pad, normalise, depth channels, one-hot target: loaders.py:603-624 on the device) -> fused step, with the
+    reference's callback stack: TrainingMonitor, ValidationMonitor (GPU threshold sweep, callbacks.py:499-527), ReduceLROnPlateau,
+    ModelCheckpoint, EarlyStopping.  Reports training images/s of the epoch loops (host generator + H2D + preprocessing + step + batch
+    callbacks inside the timed region; the validation pass of each epoch is timed separately) and the validation metrics."""
+    from salt_amd.models import SegmentationModel
+    from salt_amd.input_pipeline import DevicePreprocessor
+    from salt_amd.callbacks import Callback
+    arch_name, channels, _ = WORKLOADS[workload]
+    img, msk = synth_tiles(n_train + n_val, seed=1234)
+    img8, msk8 = np.clip(img * 255 + 0.5, 0, 255).astype(np.uint8), msk.astype(np.uint8)
+    host = {'train': (torch.from_numpy(img8[:n_train]), torch.from_numpy(msk8[:n_train])),
+            'valid': (torch.from_numpy(img8[n_train:]), torch.from_numpy(msk8[n_train:]))}
+    pre = {'train': DevicePreprocessor(True, channels), 'valid': DevicePreprocessor(False, channels)}
+    host_s = {'train': 0.0, 'valid': 0.0}
+
+    class Batches:
+        """re-iterable host generator: shuffled index -> gather on the host into a pinned staging buffer -> async H2D -> device preprocessing"""
+        def __init__(self, split, shuffle):
+            self.split, self.shuffle, self.epoch = split, shuffle, 0
+            X8, M8 = host[split]
+            self.n = X8.shape[0] // B
+            self.stage = [(torch.empty((B,) + tuple(X8.shape[1:]), dtype=torch.uint8).pin_memory(),
+                           torch.empty((B,) + tuple(M8.shape[1:]), dtype=torch.uint8).pin_memory(), torch.cuda.Event()) for _ in range(4)]
+
+        def __iter__(self):
+            X8, M8 = host[self.split]
+            g = torch.Generator().manual_seed(1234 + self.epoch)
+            order = torch.randperm(X8.shape[0], generator=g) if self.shuffle else torch.arange(X8.shape[0])
+            self.epoch += 1
+            for i in range(self.n):
+                t0 = time.perf_counter()
+                idx = order[i * B:(i + 1) * B]
+                sx, sm, ev = self.stage[i % len(self.stage)]
+                ev.synchronize()                               # the copy that last used this staging slot has left it
+                torch.index_select(X8, 0, idx, out=sx); torch.index_select(M8, 0, idx, out=sm)
+                xb, mb = sx.to(dev, non_blocking=True), sm.to(dev, non_blocking=True)
+                ev.record()
+                out = list(pre[self.split](xb, mb))
+                host_s[self.split] += time.perf_counter() - t0
+                yield out
+
+    class EpochTimer(Callback):
+        """first in the callback list: its on_epoch_end runs BEFORE the validation pass of the monitors behind it"""
+        def __init__(self):
+            super().__init__()
+            self.train_s, self.t0 = [], None
+
+        def on_epoch_begin(self, *a, **k):
+            torch.cuda.synchronize(); self.t0 = time.perf_counter()
+
+        def on_epoch_end(self, *a, **k):
+            torch.cuda.synchronize(); self.train_s.append(time.perf_counter() - self.t0)
+            self.epoch_id += 1
+
+    timer = EpochTimer()
+    ckpt = '/tmp/salt_bench_ckpt_%d/best.torch' % os.getpid()
+    cbs = {'callbacks': [timer], 'training_monitor': {'batch_every': 0, 'epoch_every': 1}, 'validation_monitor': {'epoch_every': 1},
+           'model_checkpoint': {'filepath': ckpt, 'metric_name': 'iout', 'epoch_every': 1, 'minimize': False},
+           'reduce_lr_on_plateau_scheduler': {'metric_name': 'iout', 'minimize': False, 'reduce_factor': 0.5, 'reduce_patience': 10, 'min_lr': 1e-6},
+           'early_stopping': {'metric_name': 'iout', 'patience': 100, 'minimize': False}}
+    arch = {'model_params': {'architecture': arch_name, 'out_channels': 2, 'activation': 'sigmoid', 'loss': loss, 'compute_dtype': dtype},
+            'optimizer_params': {'lr': 1e-4}, 'regularizer_params': {'regularize': True, 'weight_decay_conv2d': 1e-4}}
+    torch.manual_seed(1234)
+    model = SegmentationModel(arch, {'epochs': epochs}, cbs)
+    tr, va = Batches('train', True), Batches('valid', False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    model.fit((tr, tr.n - 1), (va, va.n - 1))
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    last = max(model.validation_loss)
+    val = model.validation_loss[last]
+    steps = tr.n * epochs
+    # the first epoch builds the programs (one-time: graph construction, kernel attributes): the steady-state figure is the LAST epoch's
+    out = {'what': 'SegmentationModel.fit(): host uint8 tiles -> pinned H2D -> DevicePreprocessor -> fused step, callbacks: training / validation '
+                   'monitor (GPU threshold sweep), ReduceLROnPlateau, ModelCheckpoint, EarlyStopping',
+           'n_train': n_train, 'n_val': n_val, 'batch': B, 'epochs': epochs, 'steps': steps, 'dtype': dtype,
+           'images_per_s': round(tr.n * B / timer.train_s[-1], 1), 'ms_per_step': round(1e3 * timer.train_s[-1] / tr.n, 3),
+           'images_per_s_first_epoch_incl_program_build': round(tr.n * B / timer.train_s[0], 1),
+           'host_ms_per_step': round(1e3 * host_s['train'] / steps, 3),
+           'validation_s_per_epoch': round((wall - sum(timer.train_s)) / epochs, 3),
+           'val_iou': round(float(val['iou']), 4), 'val_iout': round(float(val['iout']), 4), 'val_loss': round(float(val['sum']), 5),
+           'best_threshold': round(float(model.best_threshold), 4), 'lr_after': model.optimizer.param_groups[0]['lr'],
+           'checkpoint_written': os.path.exists(ckpt), 'wall_s': round(wall, 2)}
+    try:
+        os.remove(ckpt); os.rmdir(os.path.dirname(ckpt))
+    except OSError:
+        pass
+    del model
+    torch.cuda.empty_cache()
+    return out
 
 
 def extra_configs(dev, steps=12, warmup=4):
@@ -565,7 +666,7 @@ def main():
     ap.add_argument('--batch', type=int, default=32, help='images per GPU per step')
     ap.add_argument('--loss', default='lovasz', choices=['lovasz', 'bce_dice'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-iou', action='store_true')
+    ap.add_argument('--no-iou', action='store_true', help='skip the fit_e2e leg (SegmentationModel.fit over host tiles with the callback stack + validation IoU)')
     ap.add_argument('--no-configs', action='store_true', help='skip the other BASELINE configurations (C1, fp32, C3 shape, C4)')
     ap.add_argument('--cpu-leg', default=None, help=argparse.SUPPRESS)       # child mode of the cpu_baseline leg
     ap.add_argument('--dp-leg', action='store_true', help=argparse.SUPPRESS)     # child mode of configs.dp_path_1rank
@@ -665,35 +766,17 @@ def main():
         out['op_time_serial_ms'] = round(total_ms, 3)          # every operator run back to back on ONE stream (no wgrad overlap)
         out['op_time_side_stream_ms'] = round(side_ms, 3)
         out['step_tflops'] = round(all_fl / (elapsed / args.steps) / 1e12, 2)
+        # reference-algorithmic work of the same step: 2 MAC over every Conv / ConvT of the network as the reference defines it (SURVEY 3.4 / 8d:
+        # 9.75 GMAC per 128 x 128 image forward for the ResNet34 hypercolumn U-Net), x3 for forward + data gradient + weight gradient
+        ref_gf = 6 * 9.75 * B if args.workload == 'r34_hyper' else None
+        out['flops'] = {'executed_matrix_gflop_per_step': round(all_fl / 1e9, 1), 'reference_algorithmic_gflop_per_step': ref_gf,
+                        'step_tflops_executed': out['step_tflops'],
+                        'step_tflops_reference_algorithmic': round(ref_gf * 1e9 / (elapsed / args.steps) / 1e12, 2) if ref_gf else None,
+                        'note': 'executed < reference: the factored hypercolumn replaces 3/5 of the final 3x3 convolution (fwd + both gradients) by 1x1 '
+                                'contractions at 1/16 .. 1/256 of the pixels + a vector-ALU stencil; roofline fractions are priced on EXECUTED matrix FLOPs'}
 
-    # ------------------------------------------------------------------ val IoU on held-out synthetic tiles (after the K steps)
-    if not args.no_iou and rank == 0:
-        vi, vm = synth_tiles(128, seed=999)
-        Xv, _ = preprocess(vi, vm, False, channels)
-        model.model.eval()
-        preds = []
-        with torch.no_grad():
-            for i in range(0, 128, B):
-                lg = model.model(Xv[i:i + B].to(dev))
-                preds.append((lg[:, 1, 13:114, 14:115] > 0).cpu().numpy())      # crop 128->101 (postprocessing.py:24-38), sigmoid>0.5
-        model.model.train()
-        out['val_iou'] = round(iou_metric(np.concatenate(preds), vm > 0.5), 4)
-        out['val_iou_note'] = ('mean IoU on 128 held-out synthetic tiles after %d training steps from random init (a smoke signal that the '
-                               'step learns, not an accuracy result)' % (args.warmup + args.steps))
-
-    if rank == 0 and not args.no_iou:
-        # accuracy-side parity of the headline dtype: measured by tools/convergence_parity.py (CPU oracle fp32 / HIP fp32 / HIP bf16 from
-        # identical weights and batches; the CPU leg takes minutes, so the committed result is quoted instead of re-running it here)
-        try:
-            cv = json.load(open(os.path.join(ROOT, 'profiles', 'r03_convergence.json')))
-            last = str(cv['config']['steps'])
-            out['val_iou_parity_quoted'] = {'quoted': True, 'note': 'NOT measured in this run: quoted from the committed file; the measured, driver-visible check is tests/test_gpu_convergence.py (-m gpu)', 'source': 'profiles/r03_convergence.json (tools/convergence_parity.py: R34 hypercolumn, batch %d, %s steps, '
-                                               'identical init and batches, %d held-out tiles)' % (cv['config']['batch'], last, cv['config']['val_tiles']),
-                                     'val_iou_cpu_oracle_f32': cv['val_iou']['cpu_oracle_f32'][last], 'val_iou_hip_f32': cv['val_iou']['hip_f32'][last],
-                                     'val_iou_hip_bf16': cv['val_iou']['hip_bf16'][last],
-                                     'max_abs_dloss_first20_hip_f32_vs_cpu': cv['summary']['hip_f32_vs_cpu']['max_abs_dloss_first20']}
-        except (OSError, KeyError, ValueError):
-            pass
+    # ------------------------------------------------------------------ end to end: SegmentationModel.fit() over host tiles (N = 1 only)
+    fit_pending = not args.no_iou and rank == 0 and world == 1
 
     if rank == 0 and 'roofline_by_class' in out:           # the fused Adam + L2 kernel (28 bytes per parameter), timed after the evaluation
         for name, _, ms in model.optimizer.prog.run_timed():
@@ -703,9 +786,21 @@ def main():
                                                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
     # ------------------------------------------------------------------ the other BASELINE configurations, same run (N = 1 only)
-    if rank == 0 and world == 1 and not args.no_configs:
+    if fit_pending:
         del model, batches
         torch.cuda.empty_cache()
+        model = batches = None
+        fe = fit_e2e_leg(dev, args.workload, args.dtype, B, args.loss)
+        out['fit_e2e'] = fe
+        out['fit_e2e']['vs_fit_loop_headline'] = round(fe['images_per_s'] / (B * args.steps / elapsed), 4)
+        out['val_iou'] = fe['val_iou']
+        out['val_iou_note'] = ('validation IoU (reference metric, threshold from the sweep) on %d held-out synthetic tiles after fit(): %d epochs x %d '
+                               'steps from random init - a signal that the shipped trainer learns, not an accuracy result; convergence PARITY is '
+                               'tests/test_gpu_convergence.py' % (fe['n_val'], fe['epochs'], fe['steps'] // fe['epochs']))
+    if rank == 0 and world == 1 and not args.no_configs:
+        if model is not None:
+            del model, batches
+            torch.cuda.empty_cache()
         out['configs'] = extra_configs(dev)
         if not dist.is_initialized():
             # the bucketed data-parallel step against a 1-rank RCCL communicator, alternated with the plain step - in a FRESH child

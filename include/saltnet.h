@@ -224,6 +224,9 @@ typedef struct {
     int tap_kw[SALT_MAX_TAPS];
     float* grad;              /* fp32, reference layout */
     int accumulate;
+    int ldb;                  /* > 0: `grad` points at channel b = 0 of a SLICE of a wider [Ca][ldb][KH][KW] tensor (row stride of the Cb axis); 0: Cb */
+    int a_mod;                /* > 0: "tap GEMM" slab (ntaps must be 1): slab row a = t * a_mod + a' is tap (tap_kh[t], tap_kw[t]) of reference row a';
+                               * Ca / a_mod <= SALT_MAX_TAPS.  The factored hypercolumn (salt_hyper_stencil) computes the 3x3 weights of a level this way */
 } salt_wgrad_reduce_args;
 int salt_wgrad_reduce(const salt_wgrad_reduce_args*, void* stream);
 
@@ -242,6 +245,15 @@ typedef struct {
     int tap_kw[SALT_MAX_TAPS];
     int transpose;
     void* wp;
+    /* Sub-blocks (all 0: the whole tensor, as before).  d1_cnt > 0: only d1 in [0, d1_cnt) is packed - `w` points at the first channel of
+     * a slice of the D1 axis, D1 stays the row stride.  n_off / n_total / chunk_off place the job inside a WIDER packed tensor: packed row
+     * n + n_off of n_total rows (0: the job's own count), channel chunk + chunk_off.  The "tap GEMM" of the factored hypercolumn packs
+     * the nine [Cout][Cin] tap matrices of a level as ONE 1x1 weight with 9 Cout output channels (forward: n_off = t Cout) and its
+     * transpose with 9 Cout input channels (chunk_off = t Cout / KC). */
+    int d1_cnt;
+    int n_off;
+    int n_total;
+    int chunk_off;
 } salt_pack_conv_weight_args;
 int salt_pack_conv_weight(const salt_pack_conv_weight_args*, void* stream);
 int64_t salt_packed_weight_elems(int dtype, int ntaps, int n, int c);
@@ -515,6 +527,32 @@ typedef struct {
     int align_corners;
 } salt_hyper_rows_args;
 int salt_hyper_rows(const salt_hyper_rows_args*, void* stream);
+
+/* Factored hypercolumn (architectures/unet.py:101-109 + architectures/base.py:21-37).  The reference builds
+ *   hyper = cat([dec1, up2(dec2), up4(dec3), up8(dec4), up16(dec5)])  and runs  Conv2dBnRelu(5 C, C): replicate pad (top 2, right 2), 3x3.
+ * A 1x1 contraction over channels commutes with bilinear up-sampling and with the tap shift, so for an up-sampled level k
+ *   conv3x3(pad(up_R(x_k)))[o, Y, X] = sum_{t = (kh, kw)} up_R(z_k[t])[o, max(Y + kh - 2, 0), min(X + kw, W - 1)],   z_k[t] = W[:, level k, kh, kw] x_k
+ * with z_k computed at LOW resolution by one 1x1 convolution (Cin -> 9 Cout; salt_conv + the tap-GEMM pack above).  This operator is the
+ * remaining stencil: forward   y = y_in + sum_k sum_t shift_t(up_R[k](z[k][t]))   (+ train-mode BatchNorm statistics of y through
+ * fin_acc, or the eval epilogue relu?(y scale + shift)); backward (backward = 1): z[k] (gradients, overwritten) = adjoint of that sum
+ * applied to y (the gradient of the convolution output).  The up-sampled level, its 9-tap convolution (R^2 times the MACs of the 1x1
+ * at low resolution) and its weight-gradient slab never exist.  z[k] is [B, H / R[k], W / R[k], 9 C], channel t C + o = tap t = 3 kh + kw.
+ * Views 16-byte aligned, C and every pixel stride multiples of 8; backward: W <= 256. */
+typedef struct {
+    int dtype;
+    int nlev;                 /* 1..4 */
+    salt_view z[4];
+    int R[4];                 /* H / z[k].H, powers of two in 4 .. 32 (a x2 level gains nothing: its z is 9/4 of the up-sampled plane) */
+    salt_view y_in;           /* forward: [B,H,W,C] partial sum (the convolution over the full-resolution operands); p == NULL: zero */
+    salt_view y;              /* forward: out [B,H,W,C] (may alias y_in);  backward: the gradient read */
+    int backward;
+    int align_corners;        /* as salt_bilinear_args.align_corners */
+    const float* scale;       /* forward, eval: y = relu?(y scale[c] + shift[c]); NULL: none */
+    const float* shift;
+    int relu;
+    double* fin_acc;          /* forward, train: [8][2 C + 1] fp64 shards (sum, sum of squares, count) of y, as salt_conv_args.fin_acc without a ticket */
+} salt_hyper_stencil_args;
+int salt_hyper_stencil(const salt_hyper_stencil_args*, void* stream);
 
 typedef struct {              /* adjoint of replicate padding: fold an extended grad back (base.py:21-27) */
     int dtype;

@@ -22,7 +22,6 @@ import torch
 from torch import nn
 
 from ._abi import SaltError
-from .engine import timing_experiment
 from .runtime import Engine
 
 
@@ -390,19 +389,34 @@ class UNetResNet(HipNetwork):
         # instead of four launches into channel slices - measured SLOWER on both streams, kept selectable
         rows_mode = int(os.environ.get('SALT_HYPER_ROWS', '0'))
         fused_rows = self.use_hypercolumn and (rows_mode == 2 or (rows_mode == 1 and not g.train))
+        # FACTORED hypercolumn (round 5; DESIGN 4, saltnet.h salt_hyper_stencil): the levels up-sampled by R >= SALT_HYPER_FACTOR (default 4;
+        # 0 = off) are never up-sampled, stored or convolved at full resolution.  A 1x1 contraction commutes with the bilinear
+        # interpolation and the tap shift, so each such level enters the final convolution as z_k = [W_tap] dec_k - ONE 1x1 launch at the
+        # level's own resolution - plus a separable stencil that adds sum_tap shift_tap(up(z_k[tap])) to the convolution over the
+        # remaining full-resolution channels [dec1 | up2(dec2)]
+        fmin = int(os.environ.get('SALT_HYPER_FACTOR', '4'))
+        levels = [(16, 4), (8, 3), (4, 2), (2, 1)]          # (R, channel block of the hypercolumn)
+        fact = [(R, k) for R, k in levels if fmin and R >= fmin] if (self.use_hypercolumn and not fused_rows) else []
+        if fact and not g.hyper_factor_ok(B, H, W, d, [R for R, _ in fact]):
+            fact = []
+        nfull = 5 - len(fact)                               # channel blocks that stay at full resolution (contiguous from block 0)
+        if fact and sorted(k for _, k in fact) != list(range(nfull, 5)):
+            raise SaltError('factored hypercolumn levels must be the deepest ones')
+        zs = {}
         if self.use_hypercolumn:
             # PLANAR hypercolumn where the kernels allow it (bf16, conv_ls / conv_ws eligible): five dense [B,H,W,64] planes instead of
             # 320-channel rows.  Every producer (dec1's scSE, the four up-samplings) and every gradient consumer then streams ONE dense
             # tensor instead of 128-byte pieces at a 640-byte pitch (0.6 TB/s at the C4 size); the final convolution, its data gradient
             # and its weight gradient address the planes themselves (salt_conv_args.x_plane / y_plane, salt_conv_wgrad_args.q_plane)
-            planes = d if (not fused_rows and g.planar_ok(B, H, W, 5 * d, d, self.final[0].conv)) else 0
-            hyper = g.new_act(B, H, W, 5 * d, 'hypercolumn', planes=planes)
+            planes = d if (not fused_rows and nfull > 1 and g.planar_ok(B, H, W, nfull * d, d, self.final[0].conv)) else 0
+            hyper = g.new_act(B, H, W, nfull * d, 'hypercolumn', planes=planes)
         # the hypercolumn up-samplings only feed the final convolution: each one goes to the side stream as soon as its decoder
         # level exists and overlaps the remaining decoder levels; the final convolution joins
         def hyper_up(x, R, k):
-            # SALT_EXP_VHYPER_SKIP: TIMING experiment - the step without the four up-sampling launches and their adjoints is
-            # the upper bound of what a loader that interpolates on the fly ("virtual hypercolumn") could save; the values are wrong
-            if self.use_hypercolumn and not fused_rows and not timing_experiment('SALT_EXP_VHYPER_SKIP'):
+            if (R, k) in fact:
+                with g.side():
+                    zs[k] = g.hyper_level(x, self.final[0].conv, k * d, name='hyper.z%d' % k)
+            elif self.use_hypercolumn and not fused_rows:
                 with g.side():
                     g.upsample(x, R, out=hyper.slice(k * d, d))
         d5 = self.dec5.emit(g, c, e5, cat=cat5)
@@ -413,13 +427,18 @@ class UNetResNet(HipNetwork):
         hyper_up(d3, 4, 2)
         d2 = self.dec2.emit(g, d3, e2, cat=cat2)
         hyper_up(d2, 2, 1)
-        if fused_rows and not timing_experiment('SALT_EXP_VHYPER_SKIP'):
+        if fused_rows:
             with g.side():
                 g.hyper_rows([d2, d3, d4, d5], [2, 4, 8, 16], hyper.slice(d, 4 * d))
         if self.use_hypercolumn:
             d1 = self.dec1.emit(g, d2, None, out=hyper.slice(0, d))
             g.join()
-            f = self.final[0].emit(g, hyper)
+            if fact:
+                ks = sorted(zs)
+                f = g.conv_hyper(hyper, [zs[k] for k in ks], [dict((k_, R_) for R_, k_ in fact)[k] for k in ks], self.final[0].conv,
+                                 self.final[0].batch_norm, relu=self.final[0].use_relu)
+            else:
+                f = self.final[0].emit(g, hyper)
         else:
             d1 = self.dec1.emit(g, d2, None)
             f = self.final[0].emit(g, d1)

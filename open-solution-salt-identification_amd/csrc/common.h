@@ -56,6 +56,18 @@ template <> __device__ __forceinline__ u32x4 pack16<bf16_t>(const float* f) {
     return v;
 }
 
+// bilinear xR source coordinates of destination index d along an axis of n source elements (ac = 0: align_corners=False, 1: True;
+// saltnet.h salt_bilinear_args): elementwise.hip's up-sampling kernels and hyper.hip's stencil must agree
+__device__ __forceinline__ void bil_src(int d, int R, int n, int ac, int& i0, int& i1, float& lam) {
+    float s;
+    if (ac) s = n > 1 ? (float)d * ((float)(n - 1) / (float)(R * n - 1)) : 0.f;      // torch area_pixel_compute_scale, align_corners=True
+    else { s = ((float)d + 0.5f) * (1.0f / (float)R) - 0.5f; s = s < 0.f ? 0.f : s; }
+    i0 = (int)s;
+    i0 = i0 < n - 1 ? i0 : n - 1;
+    i1 = i0 + 1 < n ? i0 + 1 : n - 1;
+    lam = s - (float)i0;
+}
+
 // ---- host-side helpers
 void salt_set_error(const char* fmt, ...);
 // Fork hand-off (runtime.hip): when the two-stream executor is about to fork the side stream right after a main-stream

@@ -1755,6 +1755,7 @@ int launch_T(const Plan& pl, hipStream_t st) {
 // ------------------------------------------------------------------------------------------ weight packing
 struct PackKP {
     const float* w; void* wp; int D0, D1, KH, KW, ntaps, transpose, N, C, nchunk;
+    int n_off, n_total, chunk_off;                 // placement inside a wider packed tensor (salt_pack_conv_weight_args)
     int tap_kh[SALT_MAX_TAPS], tap_kw[SALT_MAX_TAPS];
 };
 template <typename T>
@@ -1773,7 +1774,7 @@ __global__ void pack_weight_kernel(PackKP p) {
             const int d0 = p.transpose ? ch : n, d1 = p.transpose ? n : ch;
             v = p.w[(((int64_t)d0 * p.D1 + d1) * p.KH + p.tap_kh[t]) * p.KW + p.tap_kw[t]];
         }
-        Elem<T>::st(out + i, v);
+        Elem<T>::st(out + ((((int64_t)(r / p.ntaps) + p.chunk_off) * p.ntaps + t) * p.n_total + n + p.n_off) * KCE + kc, v);
     }
 }
 
@@ -1789,6 +1790,7 @@ constexpr int PACK_EPB = 2048;          // packed elements per block in the batc
 // convolution of the forward pass waiting for wave slots - 164 us in the step against 45 us alone.
 __host__ __device__ inline bool pack_vec_ok(const salt_pack_conv_weight_args& a, int dtype) {
     const int kk = a.KH * a.KW;
+    if (a.d1_cnt || a.n_off || a.n_total || a.chunk_off) return false;          // sub-block jobs: scalar paths
     if (dtype != SALT_BF16 || (kk != 9 && kk != 1) || a.ntaps != kk || (a.transpose ? a.D0 : a.D1) % 32) return false;
     if ((reinterpret_cast<uintptr_t>(a.wp) & 15) || (!a.transpose && (reinterpret_cast<uintptr_t>(a.w) & 15))) return false;
     for (int t = 0; t < kk; ++t) if (a.tap_kh[t] * a.KW + a.tap_kw[t] != t) return false;
@@ -1845,7 +1847,9 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const salt_pack_conv_
     int lo = 0, hi = njobs - 1;
     while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (job_block0[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
     const salt_pack_conv_weight_args& a = jobs[lo];
-    const int N = a.transpose ? a.D1 : a.D0, C = a.transpose ? a.D0 : a.D1;
+    const int S1 = a.d1_cnt > 0 ? a.d1_cnt : a.D1;                      // channels of the D1 axis this job packs (D1 stays the row stride)
+    const int N = a.transpose ? S1 : a.D0, C = a.transpose ? a.D0 : S1;
+    const int NT_ = a.n_total > 0 ? a.n_total : N;                      // rows of the packed tensor the job writes into
     const int nchunk = (C + KCE - 1) / KCE;
     const int64_t total = (int64_t)nchunk * a.ntaps * N * KCE;
     const int64_t base = (int64_t)(blockIdx.x - job_block0[lo]) * PACK_EPB;
@@ -1870,7 +1874,7 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const salt_pack_conv_
         const float* src = a.w + ((int64_t)n * a.D1 + ch) * a.KH * a.KW;
         for (int t = 0; t < a.ntaps; ++t) {
             const float v = (ch < C && a.tap_kh[t] >= 0) ? src[a.tap_kh[t] * a.KW + a.tap_kw[t]] : 0.f;      // tap_kh < 0: a zero tap
-            Elem<T>::st(out + (((int64_t)chunk * a.ntaps + t) * N + n) * KCE + kc, v);
+            Elem<T>::st(out + (((int64_t)(chunk + a.chunk_off) * a.ntaps + t) * NT_ + n + a.n_off) * KCE + kc, v);
         }
         return;
     }
@@ -1887,7 +1891,7 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const salt_pack_conv_
             const int d0 = a.transpose ? ch : n, d1 = a.transpose ? n : ch;
             v = a.w[(((int64_t)d0 * a.D1 + d1) * a.KH + a.tap_kh[t]) * a.KW + a.tap_kw[t]];
         }
-        Elem<T>::st(out + i, v);
+        Elem<T>::st(out + ((((int64_t)(r / a.ntaps) + a.chunk_off) * a.ntaps + t) * NT_ + n + a.n_off) * KCE + kc, v);
     }
 }
 
@@ -2873,6 +2877,7 @@ int wgrad_plan(const salt_conv_wgrad_args* a, WgradKP* k, int* nsplit_out) {
 
 struct ReduceKP {
     const float* partials; float* grad; int nsplit, ntaps, Ca, Cb, KH, KW, accumulate;
+    int ldb, a_mod;                                // slice of a wider tensor / tap-GEMM slab (salt_wgrad_reduce_args)
     int tap_kh[SALT_MAX_TAPS], tap_kw[SALT_MAX_TAPS];
 };
 // 256 threads = 4 split-rows x 64 consecutive slab elements: coalesced 256-B reads, 4x the parallelism of one thread
@@ -2894,9 +2899,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(ReduceKP p) {
     const float s = sm[0][e] + sm[1][e] + sm[2][e] + sm[3][e];
     const int b = (int)(i % p.Cb);
     int64_t r = i / p.Cb;
-    const int a = (int)(r % p.Ca);
-    const int t = (int)(r / p.Ca);
-    float* dst = p.grad + (((int64_t)a * p.Cb + b) * p.KH + p.tap_kh[t]) * p.KW + p.tap_kw[t];
+    int a = (int)(r % p.Ca);
+    int t = (int)(r / p.Ca);
+    if (p.a_mod) { t = a / p.a_mod; a -= t * p.a_mod; }               // tap-GEMM slab: row = (tap, reference row)
+    float* dst = p.grad + (((int64_t)a * p.ldb + b) * p.KH + p.tap_kh[t]) * p.KW + p.tap_kw[t];
     *dst = p.accumulate ? (*dst + s) : s;
 }
 
@@ -2912,9 +2918,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce8_kernel(ReduceKP p) {
     const float s = (((v[0] + v[4]) + (v[1] + v[5])) + (v[2] + v[6])) + (v[3] + v[7]);
     const int b = (int)(i % p.Cb);
     int64_t r = i / p.Cb;
-    const int a = (int)(r % p.Ca);
-    const int t = (int)(r / p.Ca);
-    float* dst = p.grad + (((int64_t)a * p.Cb + b) * p.KH + p.tap_kh[t]) * p.KW + p.tap_kw[t];
+    int a = (int)(r % p.Ca);
+    int t = (int)(r / p.Ca);
+    if (p.a_mod) { t = a / p.a_mod; a -= t * p.a_mod; }               // tap-GEMM slab: row = (tap, reference row)
+    float* dst = p.grad + (((int64_t)a * p.ldb + b) * p.KH + p.tap_kh[t]) * p.KW + p.tap_kw[t];
     *dst = p.accumulate ? (*dst + s) : s;
 }
 
@@ -2976,7 +2983,11 @@ extern "C" int salt_pack_conv_weight(const salt_pack_conv_weight_args* a, void* 
     if (!a || !a->w || !a->wp || a->ntaps < 1 || a->ntaps > SALT_MAX_TAPS) SALT_FAIL(SALT_E_BADARG, "pack: bad args");
     PackKP p;
     p.w = a->w; p.wp = a->wp; p.D0 = a->D0; p.D1 = a->D1; p.KH = a->KH; p.KW = a->KW; p.ntaps = a->ntaps; p.transpose = a->transpose;
-    p.N = a->transpose ? a->D1 : a->D0; p.C = a->transpose ? a->D0 : a->D1;
+    const int S1 = a->d1_cnt > 0 ? a->d1_cnt : a->D1;
+    if (a->d1_cnt < 0 || a->d1_cnt > a->D1 || a->n_off < 0 || a->n_total < 0 || a->chunk_off < 0) SALT_FAIL(SALT_E_BADARG, "pack: sub-block");
+    p.N = a->transpose ? S1 : a->D0; p.C = a->transpose ? a->D0 : S1;
+    p.n_off = a->n_off; p.n_total = a->n_total > 0 ? a->n_total : p.N; p.chunk_off = a->chunk_off;
+    if (p.n_off + p.N > p.n_total) SALT_FAIL(SALT_E_BADARG, "pack: n_off + rows > n_total");
     const int KCE = a->dtype == SALT_F32 ? 16 : 32;
     p.nchunk = cdiv(p.C, KCE);
     for (int t = 0; t < a->ntaps; ++t) {
@@ -2995,7 +3006,8 @@ extern "C" int salt_pack_conv_weight(const salt_pack_conv_weight_args* a, void* 
 extern "C" int salt_pack_job_blocks(const salt_pack_conv_weight_args* a) {
     if (!a) return -1;
     const int KCE = a->dtype == SALT_F32 ? 16 : 32;
-    const int N = a->transpose ? a->D1 : a->D0, C = a->transpose ? a->D0 : a->D1;
+    const int S1 = a->d1_cnt > 0 ? a->d1_cnt : a->D1;
+    const int N = a->transpose ? S1 : a->D0, C = a->transpose ? a->D0 : S1;
     if (pack_vec_ok(*a, a->dtype)) return (int)(((int64_t)N * (C / 32) * 4 + 255) / 256);      // one thread per (chunk, n, 8 channels)
     if (!a->transpose) return (int)(((int64_t)N * cdiv(C, KCE) * KCE + 255) / 256);      // one thread per (n, padded channel) pair
     const int64_t total = (int64_t)cdiv(C, KCE) * a->ntaps * N * KCE;
@@ -3150,7 +3162,17 @@ extern "C" int salt_wgrad_reduce(const salt_wgrad_reduce_args* a, void* stream) 
     ReduceKP p;
     p.partials = a->partials; p.grad = a->grad; p.nsplit = a->nsplit; p.ntaps = a->ntaps; p.Ca = a->Ca; p.Cb = a->Cb;
     p.KH = a->KH; p.KW = a->KW; p.accumulate = a->accumulate;
-    for (int t = 0; t < a->ntaps; ++t) { p.tap_kh[t] = a->tap_kh[t]; p.tap_kw[t] = a->tap_kw[t]; }
+    p.ldb = a->ldb > 0 ? a->ldb : a->Cb; p.a_mod = a->a_mod;
+    int nt_tab = a->ntaps;
+    if (a->a_mod) {
+        if (a->a_mod < 0 || a->ntaps != 1 || a->Ca % a->a_mod || a->Ca / a->a_mod > SALT_MAX_TAPS) SALT_FAIL(SALT_E_BADARG, "wgrad_reduce: tap-GEMM slab");
+        nt_tab = a->Ca / a->a_mod;
+    }
+    if (a->ldb && a->ldb < a->Cb) SALT_FAIL(SALT_E_BADARG, "wgrad_reduce: ldb < Cb");
+    for (int t = 0; t < nt_tab; ++t) {
+        if (a->tap_kh[t] < 0 || a->tap_kh[t] >= a->KH || a->tap_kw[t] < 0 || a->tap_kw[t] >= a->KW) SALT_FAIL(SALT_E_BADARG, "wgrad_reduce: tap");
+        p.tap_kh[t] = a->tap_kh[t]; p.tap_kw[t] = a->tap_kw[t];
+    }
     const int64_t slab = (int64_t)a->ntaps * a->Ca * a->Cb;
     static const bool atomic = getenv("SALT_WGRAD_ATOMIC") != nullptr;
     if (atomic && p.nsplit > 1) p.nsplit = 1;                      // salt_conv_wgrad added every split into slab 0

@@ -533,15 +533,12 @@ int wl_launch_inst(const WlKP& k, hipStream_t st) {
 
 }  // namespace
 
+#if SALT_WL_CLK      // clock-instrumented variant builds only (tools/build_variant.sh -DSALT_WL_CLK=1): not part of the C-ABI of the shipped library
 extern "C" int salt_debug_wl_clk(unsigned long long* host_out, int n) {
-#if SALT_WL_CLK
     if (n > 1024 * 16) n = 1024 * 16;
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_wl_clk), (size_t)n * sizeof(unsigned long long));
-#else
-    (void)host_out; (void)n;
-    return -1;
-#endif
 }
+#endif
 
 // salt_conv_wgrad / salt_conv_wgrad_nsplit try this first (conv_mfma.hip).  Returns 0 when the launch is not one of this kernel's
 // shapes, else nsplit (>= 1); with `launch` it also enqueues the kernel (a->partials, a->nsplit as returned here) and puts the
@@ -555,8 +552,14 @@ int conv_wgrad_ls(const salt_conv_wgrad_args* a, bool launch, hipStream_t st, in
         if (a->tap_dy[t] != a->tap_dy[0] + t / 3 || a->tap_dx[t] != a->tap_dx[0] + t % 3) return 0;     // raster 3 x 3 window
     if (a->p.cs % 8 || a->q.cs % 8 || a->p.C % 8 || a->q.C % 8 || a->p.B != a->q.B) return 0;
     if ((reinterpret_cast<uintptr_t>(a->p.p) | reinterpret_cast<uintptr_t>(a->q.p)) & 15) return 0;
-    if (launch && (reinterpret_cast<uintptr_t>(a->partials) & 15)) return 0;
     if ((long long)a->q.B * a->q.H * a->q.W * (a->q_plane ? a->q.C : a->q.cs) * 2 >= (1ll << 31) || (long long)a->p.B * a->p.H * a->p.W * a->p.cs * 2 >= (1ll << 31)) return 0;
+    // (salt_conv_wgrad_nsplit reported THIS kernel's split count for the shape: a misaligned slab pointer must not silently fall through
+    //  to the generic kernel, whose split count differs - ADVICE r4)
+    if (launch && (reinterpret_cast<uintptr_t>(a->partials) & 15)) {
+        salt_set_error("conv_wgrad: the partials workspace must be 16-byte aligned for this shape (conv_wgrad_ls_kernel)");
+        if (rc) *rc = SALT_E_BADARG;
+        return 1;
+    }
     const char* ku_env = getenv("SALT_WL_KU");                            // read per call: the tests switch it inside one process
     const int KU = a->q_step == 2 ? 2 : ((ku_env && atoi(ku_env) == 8) ? 8 : 4);
     const int NB = a->p.W <= 8 ? 2 : 1, TW = 16 / NB;

@@ -1559,12 +1559,9 @@ int conv_stem16_launch(const salt_conv_args* a, hipStream_t st) {
     return a->fin_acc ? stem16_launch_mode<1>(k, st) : stem16_launch_mode<0>(k, st);
 }
 
+#if SALT_WS_CLK      // clock-instrumented variant builds only (tools/build_variant.sh -DSALT_WS_CLK=1): not part of the C-ABI of the shipped library
 extern "C" int salt_debug_ws_clk(unsigned long long* host_out, int n) {
-#if SALT_WS_CLK
     if (n > 256 * 48) n = 256 * 48;
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_ws_clk), (size_t)n * sizeof(unsigned long long));
-#else
-    (void)host_out; (void)n;
-    return SALT_E_UNSUPPORTED;
-#endif
 }
+#endif

@@ -691,15 +691,7 @@ __global__ void avgpool2_kernel(salt_view x, salt_view y, int backward, int accu
 }
 
 // ---------------------------------------------------------------- bilinear xR (AC = 0: align_corners=False, AC = 1: True; saltnet.h)
-__device__ __forceinline__ void bil_src(int d, int R, int n, int ac, int& i0, int& i1, float& lam) {
-    float s;
-    if (ac) s = n > 1 ? (float)d * ((float)(n - 1) / (float)(R * n - 1)) : 0.f;      // torch area_pixel_compute_scale, align_corners=True
-    else { s = ((float)d + 0.5f) * (1.0f / (float)R) - 0.5f; s = s < 0.f ? 0.f : s; }
-    i0 = (int)s;
-    i0 = i0 < n - 1 ? i0 : n - 1;
-    i1 = i0 + 1 < n ? i0 + 1 : n - 1;
-    lam = s - (float)i0;
-}
+// (bil_src: common.h - shared with hyper.hip)
 
 // U output units per thread in flight: the 4 U gathers of an iteration are issued before any of them is used.  (One unit per
 // iteration was a chain of ~16 dependent memory round trips per thread: 33 us for a 67 MB level, whatever the write pitch - round 3.)

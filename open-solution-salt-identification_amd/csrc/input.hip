@@ -88,7 +88,7 @@ __global__ void preprocess_kernel(PreKP p) {
                 for (int j = 0; j < 4; ++j) {
                     const int xx = min(max(x0 + j, 0), p.w - 1);
                     row += cx[j] * (int)im8[yy * p.w + xx];
-                    if (mk8) mrow += cx[j] * (int)mk8[yy * p.w + xx];         // the uint8 {0, 1} mask goes through the same augment_image call
+                    if (mk8) mrow += cx[j] * (int)(mk8[yy * p.w + xx] != 0);  // the uint8 mask goes through the same augment_image call, binarised first like the float path / oracle.inputs (a 0 / 255 mask must not dilate)
                 }
                 acc += cy[i] * row; macc += cy[i] * mrow;
             }

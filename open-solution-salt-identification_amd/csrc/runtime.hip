@@ -20,7 +20,7 @@ void salt_set_error(const char* fmt, ...) {
 
 extern "C" const char* salt_last_error(void) { return g_err; }
 
-extern "C" int salt_abi_version(void) { return 20; }
+extern "C" int salt_abi_version(void) { return 21; }
 
 extern "C" int salt_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name_len) {
     int dev = 0;
@@ -285,6 +285,7 @@ extern "C" int salt_abi_struct_sizes(int* out, int n) {
     (int)sizeof(salt_avgpool2_args),
     (int)sizeof(salt_bilinear_args),
     (int)sizeof(salt_hyper_rows_args),
+    (int)sizeof(salt_hyper_stencil_args),
     (int)sizeof(salt_pad_fold_args),
     (int)sizeof(salt_pad_fold_strip_args),
     (int)sizeof(salt_add_args),

@@ -248,13 +248,16 @@ __global__ void se_parts_reduce_kernel(float* partials, int nparts, int width) {
 __global__ __launch_bounds__(1024) void se_fc_bwd_kernel(const float* partials, int nparts, int B, int C, int R, const float* w1, const float* w2,
                                  const float* gap, const float* hidden, const float* gate_c,
                                  float* g_w1, float* g_b1, float* g_w2, float* g_b2, float* g_ws, float* g_bs, float* dgap, float inv_hw,
-                                 const double* acc) {
+                                 const double* acc, int stage_w) {
     // everything the loops touch repeatedly is staged in LDS first (one coalesced sweep); the batch loops then run out of LDS
     extern __shared__ float sm[];       // du [B][C], dh [B][R], gp [B][C], hd [B][R], ps [B][C+1] (spatial-SE sums)
     float* du = sm; float* dh = du + B * C; float* gp = dh + B * R; float* hd = gp + B * C; float* ps = hd + B * R;
-    float* sw1 = ps + B * (C + 1); float* sw2 = sw1 + R * C;            // the FC weights: the batch loops below read them C / R times per output
+    // the FC weights: the batch loops below read them C / R times per output - staged too when the batch leaves room (stage_w), else read
+    // from global as before round 4 (R101 / R152 decoders, C = 256, R = 16: batches 41 - 51 fit only without them)
+    float* lw1 = ps + B * (C + 1); float* lw2 = lw1 + R * C;
+    const float* sw1 = stage_w ? lw1 : w1; const float* sw2 = stage_w ? lw2 : w2;
     const int tid = threadIdx.x, nt = blockDim.x;
-    for (int i = tid; i < R * C; i += nt) { sw1[i] = w1[i]; sw2[i] = w2[i]; }
+    if (stage_w) for (int i = tid; i < R * C; i += nt) { lw1[i] = w1[i]; lw2[i] = w2[i]; }
     for (int i = tid; i < B * C; i += nt) {
         const int b = i / C, c = i - b * C;
         const float* row = partials + ((int64_t)b * nparts) * (2 * C + 1);
@@ -383,7 +386,9 @@ extern "C" int salt_scse_bwd(const salt_scse_bwd_args* a, void* stream) {
     if (a->nparts != nparts) SALT_FAIL(SALT_E_BADARG, "scse_bwd: nparts %d, expected %d", a->nparts, nparts);
     hipStream_t st = (hipStream_t)stream;
     const int C = a->x.C, B = a->x.B;
-    const size_t fc_lds = ((size_t)B * (3 * C + 2 * a->R + 1) + (size_t)2 * a->R * C) * sizeof(float);
+    const size_t fc_base = (size_t)B * (3 * C + 2 * a->R + 1) * sizeof(float), fc_w = (size_t)2 * a->R * C * sizeof(float);
+    const int stage_w = fc_base + fc_w <= 160 * 1024;             // the FC weights ride along only when they fit beside the per-image vectors
+    const size_t fc_lds = fc_base + (stage_w ? fc_w : 0);
     if (fc_lds > 160 * 1024) SALT_FAIL(SALT_E_LDS, "scse_bwd: batch*channels too large for the FC backward (%zu B)", fc_lds);
     if (fc_lds > 64 * 1024) {
         static bool attr_set = false;
@@ -405,7 +410,7 @@ extern "C" int salt_scse_bwd(const salt_scse_bwd_args* a, void* stream) {
             SALT_CHECK_LAUNCH();
         }
         hipLaunchKernelGGL(se_fc_bwd_kernel, dim3(1), dim3(1024), fc_lds, st, a->partials, nparts, B, C, a->R, a->w1, a->w2, a->gap, a->hidden,
-                           a->gate_c, a->g_w1, a->g_b1, a->g_w2, a->g_b2, a->g_ws, a->g_bs, a->dgap, 1.0f / (float)(a->x.H * a->x.W), a->acc);
+                           a->gate_c, a->g_w1, a->g_b1, a->g_w2, a->g_b2, a->g_ws, a->g_bs, a->dgap, 1.0f / (float)(a->x.H * a->x.W), a->acc, stage_w);
         SALT_CHECK_LAUNCH();
         if (!a->skip_bcast) {                      // else: the consumer adds dgap[b][c] on the fly (salt_bn_bwd_args.da_bias)
             const int64_t units = view_pixels(a->dx) * (C / VE);

@@ -24,16 +24,12 @@ TORCH_DT = {'f32': torch.float32, 'bf16': torch.bfloat16}
 VEC = {'f32': 4, 'bf16': 8}
 
 
-def timing_experiment(name):
-    """True when the TIMING-ONLY measurement switch `name` (SALT_EXP_*: DESIGN 8 / 10) is set.  Such a switch makes the step compute
-    WRONG values (it exists to time an upper bound), so it is honoured only together with SALT_TIMING_ONLY=1 - which bench.py / tools
-    set on request and SegmentationModel.fit refuses - and fails loudly otherwise (nothing warned when one leaked into a
-    training run)."""
-    if os.environ.get(name, '0') in ('', '0'):
-        return False
-    if os.environ.get('SALT_TIMING_ONLY') != '1':
-        raise SaltError('%s is a timing-only experiment (results are wrong): set SALT_TIMING_ONLY=1 to acknowledge, or unset it' % name)
-    return True
+def fwd_bn_fold():
+    """SALT_FWD_BN_FOLD=1 (measurement / verification switch, DESIGN history round 3): the BatchNorm apply + ReLU of a conv -> BN -> ReLU output whose
+    only reader is ONE 3x3 convolution runs in that convolution's loader (salt_conv_args.in_*; forward values bit-identical, tested).
+    The weight-gradient kernels cannot re-derive the activation, so such a graph is FORWARD-ONLY: its backward closure raises instead
+    of computing a wrong gradient."""
+    return os.environ.get('SALT_FWD_BN_FOLD', '0') not in ('', '0')
 
 
 def _round_up(v, m):
@@ -198,7 +194,7 @@ class Buffer:
         self.grad_t = None
         self.grad_init = np.zeros(self.Ct, dtype=bool)
         self.grad_writers = []         # one entry per gradient writer in backward-program order: [c0, C, conv-args struct | None]
-        self.reads = 0                 # views handed out (SALT_EXP_BN_FOLD: an activation nobody else reads need not be materialised)
+        self.reads = 0                 # views handed out (SALT_FWD_BN_FOLD: an activation nobody else reads need not be materialised)
 
     def _shape(self):
         return (self.C // self.planes, self.B, self.H, self.W, self.planes) if self.planes else (self.B, self.H, self.W, self.Ct)
@@ -368,13 +364,22 @@ class Graph:
                     obj = getattr(obj, a)
                 setattr(obj, path[-1], self.scratch[sc.name].data_ptr())
             prog.finalize()
-        for which, z in self._fin_zero.items():
-            nb = self._fin_bytes[which]
-            arena = self.alloc((max(nb // 8, 1),), torch.float64)
-            fill(z, p=arena.data_ptr(), bytes=nb)
+        # ONE arena for the fp64 statistics shards of both programs, cleared by ONE salt_zero at the head of the FORWARD program (a
+        # training step runs forward -> loss -> backward exactly once each; the backward program's own clear - a 6 us launch at the
+        # head of the critical queue - is dropped: its salt_zero entry stays in the program with 0 bytes, which launches nothing).
+        # SALT_SPLIT_ZERO=1: each program clears its own half (for callers that replay a backward program on its own).
+        split = bool(os.environ.get('SALT_SPLIT_ZERO')) or 'fwd' not in self._fin_zero
+        nbf, nbb = self._fin_bytes['fwd'], self._fin_bytes['bwd']
+        if self._fin_zero:
+            arena = self.alloc((max((nbf + nbb) // 8, 1),), torch.float64)
+            base = {'fwd': arena.data_ptr(), 'bwd': arena.data_ptr() + nbf}
+            for which, z in self._fin_zero.items():
+                if split:
+                    fill(z, p=base[which], bytes=self._fin_bytes[which])
+                else:
+                    fill(z, p=base[which], bytes=(nbf + nbb) if which == 'fwd' else 0)
             for st, field, w, off in self._fin_patches:
-                if w == which:
-                    setattr(st, field, arena.data_ptr() + off)
+                setattr(st, field, base[w] + off)
         return self
 
     def _fin_slot(self, which, ndoubles, *targets):
@@ -448,7 +453,7 @@ class Graph:
         return lib.salt_conv_wgrad_nsplit(ctypes.byref(Wg)) >= 1
 
     def _resolve_lazies(self):
-        """SALT_EXP_BN_FOLD: drop the affine_act of every conv -> BN -> ReLU output whose only forward reader is ONE convolution that
+        """SALT_FWD_BN_FOLD: drop the affine_act of every conv -> BN -> ReLU output whose only forward reader is ONE convolution that
         applies the transform in its loader; every other candidate goes back to reading the materialised activation."""
         drop = []
         for buf in getattr(self, '_lazies', []):
@@ -551,7 +556,7 @@ class Graph:
         if F is not None:                        # the producer only adds to the shards; this operator finalizes them
             self.fwd.set_fields(sa, fin=ctypes.addressof(F))
             off = self._fin_slot('fwd', 8 * (2 * bn.num_features + 1), (producer, 'fin_acc'), (sa, 'fin_acc'))
-            if (timing_experiment('SALT_EXP_BN_FOLD') and res is None and relu and self.dtype == 'bf16' and out.c0 == 0 and out.C == out.buf.C
+            if (fwd_bn_fold() and res is None and relu and self.dtype == 'bf16' and out.c0 == 0 and out.C == out.buf.C
                     and self.fwd.streams[-1] == 0):
                 # measurement switch: if the ONLY forward reader of `out` turns out to be one 3x3 convolution, that launch
                 # applies this BatchNorm + ReLU in its loader (salt_conv_args.in_*) and this affine_act is dropped (build_backward)
@@ -713,11 +718,11 @@ class Graph:
                     if relu:
                         self.bwd.add('relu_bwd', dtype=self.dt, da=out.gview(), a=out.view(), dy=out.gview(), accumulate=0)
                 # weight gradient: P = dY (a = cout), Q = X (b = cin)
-                xq = x
                 if lz is not None and lz['dropped']:
-                    # SALT_EXP_BN_FOLD is a TIMING experiment: the activation was never materialised and the weight-gradient kernels
-                    # (LDS-DMA loaders) cannot transform their operand, so they read the producer's RAW output - wrong weight gradients
-                    xq = lz['y']
+                    # the activation was never materialised and the weight-gradient kernels (LDS-DMA loaders) cannot transform their
+                    # operand: a graph built under SALT_FWD_BN_FOLD has no backward pass (fail loudly, never a wrong gradient)
+                    raise SaltError('SALT_FWD_BN_FOLD graphs are forward-only (the folded activation of %s does not exist for the weight gradient)' % name)
+                xq = x
                 self._wgrad(dy.gview(), xq.view(), td, tk, stride, pad_mode, conv.weight, KH, KW)
                 # data gradient
                 if x.buf.name != '__input__':
@@ -725,12 +730,98 @@ class Graph:
             self.tape.append(backward)
         return out
 
-    def _wgrad(self, p_view, q_view, taps_dydx, taps_khkw, q_step, pad_mode, weight, KH, KW):
-        """dW = sum_p P[p,:]^T Q[p*q_step + tap, :] -> weight.grad (reference layout [Ca][Cb][KH][KW])."""
-        if timing_experiment('SALT_EXP_NO_WGRAD'):       # TIMING ONLY: the step without its weight-gradient launches (what the side stream costs the main chain)
-            return
+    # ------------------------------------------------------------------ factored hypercolumn (saltnet.h: salt_hyper_stencil)
+    def hyper_factor_ok(self, B, H, W, C, Rs):
+        """Can the levels up-sampled by ``Rs`` leave the hypercolumn (architectures/unet.py:101-109) and enter the final Conv2dBnRelu
+        through the low-resolution tap GEMM + stencil instead?  (the stencil's shape rules, saltnet.h; consumer-side BatchNorm shards)"""
+        if not Rs or C % 8 or (self.train and self._fin_mode() != 2) or (self.train and W > 256):
+            return False
+        if C % (16 if self.dtype == 'f32' else 32):
+            return False                                # the transposed tap-GEMM pack places whole chunks
+        return all(R >= 4 and R & (R - 1) == 0 and R <= 32 and H % R == 0 and W % R == 0 for R in Rs)
+
+    def hyper_level(self, x, conv, c0, name='hyper.z'):
+        """z = [W[:, c0 : c0 + x.C, kh, kw]]_taps x  at x's (LOW) resolution: one 1x1 convolution x.C -> 9 Cout whose output channel
+        t Cout + o is tap t of output channel o of the 3x3 convolution ``conv`` restricted to the input channels of this level.
+        Backward (from dz, which conv_hyper's stencil adjoint writes): the 1x1 weight gradient scattered into conv.weight.grad and
+        the 1x1 data gradient into dL/dx."""
+        eng = self.engine
+        Cout, _, KH, KW = conv.weight.shape
+        taps = [(kh, kw) for kh in range(KH) for kw in range(KW)]
+        pk = eng.packed_tapgemm(conv, c0, x.C, transposed=False)
+        z = self.new_act(x.B, x.H, x.W, len(taps) * Cout, name)
+        # cfg 11 | 1 << 16: ask for conv1x1_ls_kernel with 32-channel items wherever it applies - the heuristic sends these few-pixel
+        # launches to conv_mfma_kernel's 128 x 32 tiles (a serial chain of K / 32 staged chunks per workgroup: 30 us for 0.15 GFLOP)
+        ask = 11 | (1 << 16)
+        self._conv_launch(self.fwd, x.view(), pk.data_ptr(), [(0, 0)], 1, 0, z.view(), x.H, x.W, cfg=ask)
+        z.on_side = self.fwd.default_stream == 1
+        if self.train:
+            D1 = conv.weight.shape[1]
+
+            def backward():
+                if not z.grad_ready():
+                    raise SaltError('hyper_level: dL/dz was never written (conv_hyper must consume %s)' % name)
+                self._wgrad(z.gview(), x.view(), [(0, 0)], None, 1, 0, conv.weight, KH, KW, b_slice=(c0, D1), tapgemm=(Cout, taps))
+                pkt = eng.packed_tapgemm(conv, c0, x.C, transposed=True, bwd=True)
+                acc = x.grad_state()
+                self._conv_launch(self.bwd, z.gview(), pkt.data_ptr(), [(0, 0)], 1, 0, x.gview(), x.H, x.W, accumulate=acc, stream=self._bwd_pack_tag(), cfg=ask)
+            self.tape.append(backward)
+        return z
+
+    def conv_hyper(self, x, zs, Rs, conv, bn, relu=True, out=None, name='final'):
+        """Conv2dBnRelu over the hypercolumn (architectures/unet.py:84-87,101-109; base.py:21-37) with the levels of ``zs`` factored out:
+        y = conv3x3_replicate(x; W[:, :x.C]) + bias, then salt_hyper_stencil adds sum_k stencil_k(z_k) (and takes the BatchNorm
+        statistics of the sum in training / applies the folded BatchNorm + ReLU in eval); x holds the full-resolution channels only."""
+        eng = self.engine
+        Cout, Cin, KH, KW = conv.weight.shape
+        assert (KH, KW) == (3, 3) and bn is not None and x.C <= Cin and all(z.C == 9 * Cout for z in zs)
+        taps = [(kh, kw, kh - (KH - 1), kw) for kh in range(KH) for kw in range(KW)]
+        tk = [(t[0], t[1]) for t in taps]
+        td = [(t[2], t[3]) for t in taps]
+        d1 = (0, x.C)
+        pk = eng.packed(conv, tk, transposed=False, d1=d1)
+        bias = conv.bias.data_ptr() if conv.bias is not None else None
+        if out is None:
+            out = self.new_act(x.B, x.H, x.W, Cout, name)
+        ac = int(bool(getattr(getattr(self.engine, 'module', None), 'align_corners', False)))
+        y = self.new_act(x.B, x.H, x.W, Cout, name + '.y')
+        self._conv_launch(self.fwd, x.view(), pk.data_ptr(), td, 1, 1, y.view(), x.H, x.W, bias=bias)
+        if any(getattr(z, 'on_side', False) for z in zs):
+            self.join()
+        st = dict(dtype=self.dt, nlev=len(zs), z=[z.view() for z in zs], R=list(Rs), y_in=y.view(), backward=0, align_corners=ac)
+        if self.train:
+            prod = self.fwd.add('hyper_stencil', y=y.view(), **st)
+            w = self._bn_train_fwd(y, bn, relu, None, out, 0, None, None, producer=prod)
+        else:
+            w = eng.bn_work(bn)
+            self.fwd.add('hyper_stencil', y=out.view(), scale=w['scale'].data_ptr(), shift=w['shift'].data_ptr(), relu=int(relu), **st)
+        out.on_side = False
+        if self.train:
+            def backward():
+                self._bn_train_bwd(y, bn, relu, None, out, w)
+                for z in zs:
+                    assert z.grad_state() == 0
+                self.bwd.add('hyper_stencil', dtype=self.dt, nlev=len(zs), z=[z.gview() for z in zs], R=list(Rs), y_in=null_view(), y=y.gview(),
+                             backward=1, align_corners=ac)
+                self._wgrad(y.gview(), x.view(), td, tk, 1, 1, conv.weight, KH, KW, b_slice=(0, Cin))
+                self._dgrad(conv, x, y, taps, 1, True, KH, KW, d1=d1)
+            self.tape.append(backward)
+        return out
+
+    def _wgrad(self, p_view, q_view, taps_dydx, taps_khkw, q_step, pad_mode, weight, KH, KW, b_slice=None, tapgemm=None):
+        """dW = sum_p P[p,:]^T Q[p*q_step + tap, :] -> weight.grad (reference layout [Ca][Cb][KH][KW]).
+        ``b_slice`` = (first, row stride): Q covers only channels [first, first + Cb) of the weight's second axis (salt_wgrad_reduce_args.ldb).
+        ``tapgemm`` = (rows, [(kh, kw)]): a 1x1 launch whose P channels are t * rows + a (salt_wgrad_reduce_args.a_mod) - Graph.hyper_level."""
         gw = self._gp(weight)
         Ca, Cb = p_view.C, q_view.C
+        extra = {}
+        if b_slice is not None:
+            gw += 4 * b_slice[0] * KH * KW
+            extra['ldb'] = b_slice[1]
+        if tapgemm is not None:
+            assert len(taps_dydx) == 1 and Ca == tapgemm[0] * len(tapgemm[1])
+            extra['a_mod'] = tapgemm[0]
+            taps_khkw = list(tapgemm[1])
         first = True
         for i in range(0, len(taps_dydx), 9 if len(taps_dydx) != 16 else 4):
             chunk = list(range(i, min(i + (9 if len(taps_dydx) != 16 else 4), len(taps_dydx))))
@@ -744,8 +835,9 @@ class Graph:
             nbytes = ns * len(chunk) * Ca * Cb * 4
             self.bwd.add('conv_wgrad', stream=1, dtype=self.dt, p=p_view, q=q_view, ntaps=len(chunk), tap_dy=[taps_dydx[j][0] for j in chunk],
                          tap_dx=[taps_dydx[j][1] for j in chunk], q_step=q_step, pad_mode=pad_mode, partials=Scratch('wgrad', nbytes), nsplit=ns, q_plane=qp)
+            rt = range(len(taps_khkw)) if tapgemm is not None else chunk
             self.bwd.add('wgrad_reduce', stream=1, partials=Scratch('wgrad', nbytes), nsplit=ns, ntaps=len(chunk), Ca=Ca, Cb=Cb, KH=KH, KW=KW,
-                         tap_kh=[taps_khkw[j][0] for j in chunk], tap_kw=[taps_khkw[j][1] for j in chunk], grad=gw, accumulate=0)
+                         tap_kh=[taps_khkw[j][0] for j in rt], tap_kw=[taps_khkw[j][1] for j in rt], grad=gw, accumulate=0, **extra)
             first = False
 
     def _bwd_pack_tag(self):
@@ -754,10 +846,10 @@ class Graph:
         self._uses_bwd_packs = True
         return None
 
-    def _dgrad(self, conv, x, dy, taps, stride, replicate, KH, KW):
+    def _dgrad(self, conv, x, dy, taps, stride, replicate, KH, KW, d1=None):
         eng = self.engine
         tk = [(t[0], t[1]) for t in taps]
-        pk = eng.packed(conv, tk, transposed=True, bwd=True)       # n = cin, c = cout
+        pk = eng.packed(conv, tk, transposed=True, bwd=True, d1=d1)       # n = cin, c = cout
         if replicate:
             # gradient w.r.t. the replicate-padded input on the extended domain, then fold the pad back
             top, right = KH - 1, KW - 1

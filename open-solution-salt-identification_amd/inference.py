@@ -111,8 +111,12 @@ def _looks_like_depth_channels(X):
     if X.dim() != 4 or X.shape[1] != 3:
         return False
     H = X.shape[2]
-    ramp = torch.linspace(0, 1, H, device=X.device, dtype=X.dtype).view(1, H, 1)
-    ok = ((X[:, 1] - ramp).abs().max() <= 1e-5) & ((X[:, 2] - X[:, 0] * X[:, 1]).abs().max() <= 1e-4 * (1 + X[:, 0].abs().max()))
+    # compared in float32 with tolerances scaled by the input's own precision (a bf16 / fp16 ramp is ~4e-3 / 5e-4 off the fp32 one)
+    eps = torch.finfo(X.dtype).eps if X.dtype.is_floating_point else 0.0
+    Xf = X.float()
+    ramp = torch.linspace(0, 1, H, device=X.device, dtype=torch.float32).view(1, H, 1)
+    ok = ((Xf[:, 1] - ramp).abs().max() <= max(1e-5, 2 * eps)) & \
+         ((Xf[:, 2] - Xf[:, 0] * Xf[:, 1]).abs().max() <= max(1e-4, 4 * eps) * (1 + Xf[:, 0].abs().max()))
     return bool(ok.item())
 
 

