@@ -2925,6 +2925,29 @@ __global__ __launch_bounds__(256) void wgrad_reduce8_kernel(ReduceKP p) {
     *dst = p.accumulate ? (*dst + s) : s;
 }
 
+// (VERDICT r4 #3a, built and measured in round 5: no gain - kept opt-in behind SALT_WGRAD_REDUCE9=1.)
+// nsplit <= 8 AND the nine taps of a 3x3 weight in raster order: one thread per (a, b) pair sums its nine taps (9 x nsplit coalesced
+// loads in flight) and stores them as the 36 contiguous bytes they are in the reference layout - a wave writes 2304 contiguous bytes.
+// wgrad_reduce8_kernel's thread-per-element form stores 4 bytes at a 36-byte stride (every 128-byte line of a 512 x 512 layer's
+// 9.4 MB gradient is written nine times, a ninth each).  Same summation order per element: bit-identical results.
+__global__ __launch_bounds__(256) void wgrad_reduce9_kernel(ReduceKP p) {
+    const int64_t ab = (int64_t)blockIdx.x * 256 + threadIdx.x, nab = (int64_t)p.Ca * p.Cb;
+    if (ab >= nab) return;
+    const int a = (int)(ab / p.Cb), b = (int)(ab - (int64_t)a * p.Cb);
+    const int64_t slab = 9 * nab;
+    float s[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = k < p.nsplit ? p.partials[k * slab + t * nab + ab] : 0.f;
+        s[t] = (((v[0] + v[4]) + (v[1] + v[5])) + (v[2] + v[6])) + (v[3] + v[7]);
+    }
+    float* dst = p.grad + ((int64_t)a * p.ldb + b) * 9;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) dst[t] = p.accumulate ? dst[t] + s[t] : s[t];
+}
+
 }  // namespace
 
 extern "C" int salt_conv(const salt_conv_args* a, void* stream) {
@@ -3177,7 +3200,15 @@ extern "C" int salt_wgrad_reduce(const salt_wgrad_reduce_args* a, void* stream) 
     static const bool atomic = getenv("SALT_WGRAD_ATOMIC") != nullptr;
     if (atomic && p.nsplit > 1) p.nsplit = 1;                      // salt_conv_wgrad added every split into slab 0
     static const bool rows_reduce = getenv("SALT_WGRAD_REDUCE_ROWS") != nullptr;
-    if (!rows_reduce && a->nsplit <= 8) hipLaunchKernelGGL(wgrad_reduce8_kernel, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+    bool raster9 = a->ntaps == 9 && a->KH == 3 && a->KW == 3 && !a->a_mod && a->nsplit <= 8;
+    for (int t = 0; t < 9 && raster9; ++t) raster9 = a->tap_kh[t] * 3 + a->tap_kw[t] == t;
+    // opt-in (SALT_WGRAD_REDUCE9=1; per call, the parity test switches it): measured NOT faster than the thread-per-element kernel (the
+    // 512 x 512 layers 14.0 against 12.8 us, the class 0.56 against 0.55 ms per step - the 36-byte-stride stores are merged in L2)
+    const char* r9_env = getenv("SALT_WGRAD_REDUCE9");
+    const bool use_r9 = r9_env && atoi(r9_env) == 1;
+    if (!rows_reduce && raster9 && use_r9)
+        hipLaunchKernelGGL(wgrad_reduce9_kernel, dim3((unsigned)(((int64_t)a->Ca * a->Cb + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+    else if (!rows_reduce && a->nsplit <= 8) hipLaunchKernelGGL(wgrad_reduce8_kernel, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((slab + 63) / 64)), dim3(256), 0, (hipStream_t)stream, p);
     SALT_CHECK_LAUNCH();
     return SALT_OK;

@@ -21,11 +21,13 @@
 namespace {
 
 constexpr int HS_TH = 32, HS_TW = 16, HS_CB = 64, HS_NT = 1024;     // forward: pixel tile, channel block and threads of a workgroup
+constexpr int HS_TWL = 4;                                           // log2(HS_TW).  (32 x 8 tiles on 512-thread workgroups, two per CU, measured 3 % SLOWER:
+                                                                    //  the rounds are VALU / LDS bound, not latency bound - DESIGN 7)
 constexpr int HS_VR = HS_TH * HS_TW * (HS_CB / 8) / HS_NT;          // rows of a column a thread accumulates in stage V (4)
 
 struct HsCoef { int i0, i1; float lam; int pad_; };    // bil_src of one full-resolution coordinate
 
-struct HsLevel { void* z; int h, w, cs, R; unsigned blk0; int blk_lg, xlen; };   // adjoint: first workgroup of the level, log2 of the X-range split of its gather items, columns per gather range
+struct HsLevel { void* z; int h, w, cs, R; unsigned blk0, nblk; int blk_lg, xlen; };   // adjoint: first workgroup id (a multiple of 8) / workgroups of the level, log2 of the X-range split of its gather items, columns per gather range
 struct HsKP {
     HsLevel lev[4]; int nlev;
     const void* yin; int yin_cs;
@@ -113,9 +115,9 @@ __global__ __launch_bounds__(HS_NT) void hyper_stencil_fwd_kernel(HsKP p) {
     constexpr int TABN = HS_TH + 2 + HS_TW + 2;
 
     // stage V / epilogue role: HS_VR rows (HS_VR vq ..) of column vx, channels 8 cp8 .. 8 cp8 + 7
-    const int cp8 = tid & 7, vx = (tid >> 3) & 15, vq = tid >> 7;
-    // stage H role: column hx, channel quad cq, patch rows hi, hi + HS_NT / 256, ..
-    const int hx = (tid >> 4) & 15, cq = tid & 15, hi = tid >> 8;
+    const int cp8 = tid & 7, vx = (tid >> 3) & (HS_TW - 1), vq = tid >> (3 + HS_TWL);
+    // stage H role: column hx, channel quad cq, patch rows hi, hi + HS_NT / (16 HS_TW), ..
+    const int hx = (tid >> 4) & (HS_TW - 1), cq = tid & 15, hi = tid >> (4 + HS_TWL);
     const bool cok = cp8 * 8 < cbn;
     const int X = X0 + vx;
 
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(HS_NT) void hyper_stencil_fwd_kernel(HsKP p) {
                 o0[dx] = (c.i0 * 3 + dx) * HS_CB + cq * 4; o1[dx] = (c.i1 * 3 + dx) * HS_CB + cq * 4;
                 w1[dx].x = c.lam; w1[dx].y = c.lam; w0[dx].x = 1.f - c.lam; w0[dx].y = w0[dx].x;
             }
-            for (int i = hi; i < nr; i += HS_NT / 256) {
+            for (int i = hi; i < nr; i += HS_NT / (16 * HS_TW)) {
                 const float* row = zp + i * nc * 3 * HS_CB;
                 f32x2_t vlo = {0.f, 0.f}, vhi = {0.f, 0.f};
 #pragma unroll
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(HS_NT) void hyper_stencil_fwd_kernel(HsKP p) {
 #pragma unroll
             for (int o = 8; o < 64; o <<= 1) { s8[e] += __shfl_xor(s8[e], o); q8[e] += __shfl_xor(q8[e], o); }
         }
-        // (the loop's last barrier: everybody is done with hbuf) reuse it as [16 waves][2][64]
+        // (the loop's last barrier: everybody is done with hbuf) reuse it as [waves][2][64]
         const int lane = tid & 63, wv = tid >> 6;
         if (lane < 8) {
 #pragma unroll
@@ -337,17 +339,20 @@ __global__ __launch_bounds__(HB_NT) void hyper_stencil_bwd_kernel(HsbKP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char hs_smem[];
     constexpr int NK = TI * 3, UY = (sizeof(T) == 2 ? 8 : 4) / NSLOT;      // full-resolution rows in flight per thread
     const int tid = threadIdx.x;
-    const unsigned lid = (blockIdx.x & 7u) * p.per_xcd + (blockIdx.x >> 3);
-    if (lid >= p.nblocks) return;
+    // Every level owns a range of workgroup ids that is a multiple of 8, and inside it the ids go round-robin over the XCDs: an XCD
+    // takes a contiguous eighth of EVERY level (neighbouring row blocks share their full-resolution rows in its L2, and the long
+    // workgroups of the coarse levels - listed first by the host - are spread over all XCDs instead of filling the last ones)
     int l = 0;
-    if (p.nlev > 1 && lid >= p.lev[1].blk0) l = 1;
-    if (p.nlev > 2 && lid >= p.lev[2].blk0) l = 2;
-    if (p.nlev > 3 && lid >= p.lev[3].blk0) l = 3;
+    if (p.nlev > 1 && blockIdx.x >= p.lev[1].blk0) l = 1;
+    if (p.nlev > 2 && blockIdx.x >= p.lev[2].blk0) l = 2;
+    if (p.nlev > 3 && blockIdx.x >= p.lev[3].blk0) l = 3;
     HsLevel L = p.lev[0];
     if (l == 1) L = p.lev[1];
     if (l == 2) L = p.lev[2];
     if (l == 3) L = p.lev[3];
-    unsigned r = lid - L.blk0;
+    const unsigned bl = blockIdx.x - L.blk0, per = (L.nblk + 7u) >> 3;
+    unsigned r = (bl & 7u) * per + (bl >> 3);
+    if (r >= L.nblk) return;
     const int cb = (int)(r % (unsigned)p.cblocks); r /= (unsigned)p.cblocks;
     const int nib = (L.h + TI - 1) / TI;
     const int i0 = (int)(r % (unsigned)nib) * TI;
@@ -443,7 +448,7 @@ __global__ __launch_bounds__(HB_NT) void hyper_stencil_bwd_kernel(HsbKP p) {
     // ---- stage H^T: NDY rows of G (all kernel rows dy of one low-resolution row ti, or one at a time for wide images) go through LDS
     const int lg = (int)L.blk_lg, nsp = 1 << lg;
     const int q16 = tid & 15, part = (tid >> 4) & (nsp - 1), pair0 = tid >> (4 + lg), ipp = HB_NT >> (4 + lg);
-    const int npairs = NDY * 3 * L.w;                          // (j, dy, dx), taps fastest: consecutive lane groups store consecutive 128 bytes of dz
+    const int npairs = 3 * L.w;                                // items (j, dx) x channel quad, each for all NDY kernel rows: one weight read feeds NDY G reads
     const int plen = (L.xlen + nsp - 1) >> lg, n0 = part * plen, n1 = min(n0 + plen, L.xlen);
 #pragma unroll
     for (int kc = 0; kc < NK / NDY; ++kc) {
@@ -467,28 +472,39 @@ __global__ __launch_bounds__(HB_NT) void hyper_stencil_bwd_kernel(HsbKP p) {
             for (int pr = pair0; pr - pair0 < npairs; pr += ipp) {     // (every lane runs the same number of passes: the shuffles below need all of them)
                 const bool valid = pr < npairs;
                 const int prv = valid ? pr : 0;
-                const int j = prv / (NDY * 3), tl = prv - j * (NDY * 3), d = tl / 3, dx = tl - 3 * d;
+                const int j = prv / 3, dx = prv - 3 * j;
                 const int pj = dx * L.w + j;
                 const float* wrow = xt + pj * L.xlen;
-                const float* gs = Gs + ((size_t)d * p.W + xs0[pj]) * HB_CB + q16 * 4;
-                f32x2_t alo = {0.f, 0.f}, ahi = {0.f, 0.f};
-                for (int n = n0; n < n1; ++n) {                  // (zero weights past the item's range; rows past W are never read: xs0 + xlen - 1 may
-                    const float wx = wrow[n];                    //  exceed the row only where the weight is 0 - the address is clamped)
-                    const f32x4 gv = *reinterpret_cast<const f32x4*>(gs + (size_t)min(n, p.W - 1 - xs0[pj]) * HB_CB);
+                const int xs = xs0[pj], nmax = p.W - 1 - xs;       // (weights past the item's range are 0; the row address is clamped)
+                const float* gs = Gs + (size_t)xs * HB_CB + q16 * 4;
+                f32x2_t alo[NDY], ahi[NDY];
+#pragma unroll
+                for (int d = 0; d < NDY; ++d) { alo[d] = f32x2_t{0.f, 0.f}; ahi[d] = f32x2_t{0.f, 0.f}; }
+                for (int n = n0; n < n1; ++n) {
+                    const float wx = wrow[n];
                     const f32x2_t w2 = {wx, wx};
-                    alo = __builtin_elementwise_fma(w2, f32x2_t{gv.x, gv.y}, alo);
-                    ahi = __builtin_elementwise_fma(w2, f32x2_t{gv.z, gv.w}, ahi);
+                    const float* gp = gs + (size_t)min(n, nmax) * HB_CB;
+#pragma unroll
+                    for (int d = 0; d < NDY; ++d) {
+                        const f32x4 gv = *reinterpret_cast<const f32x4*>(gp + (size_t)d * p.W * HB_CB);
+                        alo[d] = __builtin_elementwise_fma(w2, f32x2_t{gv.x, gv.y}, alo[d]);
+                        ahi[d] = __builtin_elementwise_fma(w2, f32x2_t{gv.z, gv.w}, ahi[d]);
+                    }
                 }
-                for (int o = 16; o < (16 << lg); o <<= 1) {
-                    alo.x += __shfl_xor(alo.x, o); alo.y += __shfl_xor(alo.y, o); ahi.x += __shfl_xor(ahi.x, o); ahi.y += __shfl_xor(ahi.y, o);
-                }
-                if (valid && part == 0 && q16 * 4 < cbn) {
-                    T* dst = zb + (int64_t)j * L.cs + ((dy0 + d) * 3 + dx) * p.C;
-                    if (sizeof(T) == 2) {
-                        uint2 o; o.x = f2bf_pk(alo.x, alo.y); o.y = f2bf_pk(ahi.x, ahi.y);
-                        *reinterpret_cast<uint2*>(dst) = o;
-                    } else {
-                        *reinterpret_cast<f32x4*>(dst) = f32x4{alo.x, alo.y, ahi.x, ahi.y};
+#pragma unroll
+                for (int d = 0; d < NDY; ++d) {
+                    for (int o = 16; o < (16 << lg); o <<= 1) {
+                        alo[d].x += __shfl_xor(alo[d].x, o); alo[d].y += __shfl_xor(alo[d].y, o);
+                        ahi[d].x += __shfl_xor(ahi[d].x, o); ahi[d].y += __shfl_xor(ahi[d].y, o);
+                    }
+                    if (valid && part == 0 && q16 * 4 < cbn) {
+                        T* dst = zb + (int64_t)j * L.cs + ((dy0 + d) * 3 + dx) * p.C;
+                        if (sizeof(T) == 2) {
+                            uint2 o; o.x = f2bf_pk(alo[d].x, alo[d].y); o.y = f2bf_pk(ahi[d].x, ahi[d].y);
+                            *reinterpret_cast<uint2*>(dst) = o;
+                        } else {
+                            *reinterpret_cast<f32x4*>(dst) = f32x4{alo[d].x, alo[d].y, ahi[d].x, ahi[d].y};
+                        }
                     }
                 }
             }
@@ -530,7 +546,7 @@ extern "C" int salt_hyper_stencil(const salt_hyper_stencil_args* a, void* stream
         p.nlev = a->nlev;
         int nr_max = 1, nc_max = 1;
         for (int k = 0; k < a->nlev; ++k) {
-            p.lev[k].z = a->z[k].p; p.lev[k].h = a->z[k].H; p.lev[k].w = a->z[k].W; p.lev[k].cs = a->z[k].cs; p.lev[k].R = a->R[k]; p.lev[k].blk0 = 0; p.lev[k].blk_lg = 0; p.lev[k].xlen = 0;
+            p.lev[k].z = a->z[k].p; p.lev[k].h = a->z[k].H; p.lev[k].w = a->z[k].W; p.lev[k].cs = a->z[k].cs; p.lev[k].R = a->R[k]; p.lev[k].blk0 = 0; p.lev[k].nblk = 0; p.lev[k].blk_lg = 0; p.lev[k].xlen = 0;
             const int nr = (HS_TH + 1) / a->R[k] + 3, nc = (HS_TW + 1) / a->R[k] + 3;      // low-resolution rows / columns a (TH + 2) / (TW + 2)-wide window can touch
             nr_max = nr > nr_max ? nr : nr_max; nc_max = nc > nc_max ? nc : nc_max;
             if ((int64_t)a->z[k].H * a->z[k].W * a->z[k].cs >= (1LL << 31)) SALT_FAIL(SALT_E_UNSUPPORTED, "hyper_stencil: level image too large for 32-bit offsets");
@@ -567,19 +583,27 @@ extern "C" int salt_hyper_stencil(const salt_hyper_stencil_args* a, void* stream
     const int nslot = cdiv(y.W, 128), ti = nslot == 1 ? 2 : 1;
     int64_t nb = 0;
     int nrows = 1, xt_floats = 0;
-    for (int k = 0; k < a->nlev; ++k) {
-        p.lev[k].z = a->z[k].p; p.lev[k].h = a->z[k].H; p.lev[k].w = a->z[k].W; p.lev[k].cs = a->z[k].cs; p.lev[k].R = a->R[k]; p.lev[k].blk0 = (unsigned)nb;
-        const int ndy = nslot == 1 ? 3 : 1;
+    int order[4] = {0, 1, 2, 3};                                // coarsest level first: its workgroups stream the most rows
+    for (int i = 0; i < a->nlev; ++i)
+        for (int j = i + 1; j < a->nlev; ++j)
+            if (a->R[order[j]] > a->R[order[i]]) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
+    for (int q = 0; q < a->nlev; ++q) {
+        const int k = order[q];
+        HsLevel& L = p.lev[q];
+        L.z = a->z[k].p; L.h = a->z[k].H; L.w = a->z[k].W; L.cs = a->z[k].cs; L.R = a->R[k]; L.blk0 = (unsigned)nb;
         int lg = 0;
-        while (lg < 2 && 16 * ndy * 3 * a->z[k].W * (2 << lg) <= HB_NT) ++lg;
-        p.lev[k].blk_lg = lg;
-        nb += (int64_t)y.B * cdiv(a->z[k].H, ti) * p.cblocks;
+        while (lg < 2 && 16 * 3 * a->z[k].W * (2 << lg) <= HB_NT) ++lg;
+        L.blk_lg = lg;
+        const int64_t nl = (int64_t)y.B * cdiv(a->z[k].H, ti) * p.cblocks;
+        if (nl >= (1LL << 28)) SALT_FAIL(SALT_E_UNSUPPORTED, "hyper_stencil: too many rows");
+        L.nblk = (unsigned)nl;
+        nb += (nl + 7) / 8 * 8;
         // rows a block of ti low-resolution rows can reference (hs_range; align_corners: (H - 1) / (h - 1) > R rows per step), + 2 for the tap shift
         const int step = a->align_corners ? (a->z[k].H > 1 ? cdiv(y.H - 1, a->z[k].H - 1) : y.H) : a->R[k];
         const int nr = (ti + 1) * step + 8;
         const int stepx = a->align_corners ? (a->z[k].W > 1 ? cdiv(y.W - 1, a->z[k].W - 1) : y.W) : a->R[k];
-        p.lev[k].xlen = 2 * stepx + 8 < y.W ? 2 * stepx + 8 : y.W;      // columns a gather range can span (hs_range + the tap shift)
-        const int xtf = 3 * a->z[k].W * (p.lev[k].xlen + 1);
+        L.xlen = 2 * stepx + 8 < y.W ? 2 * stepx + 8 : y.W;      // columns a gather range can span (hs_range + the tap shift)
+        const int xtf = 3 * a->z[k].W * (L.xlen + 1);
         xt_floats = xtf > xt_floats ? xtf : xt_floats;
         nrows = nr > nrows ? nr : nrows;
         if ((int64_t)a->z[k].H * a->z[k].W * a->z[k].cs >= (1LL << 31)) SALT_FAIL(SALT_E_UNSUPPORTED, "hyper_stencil: level image too large for 32-bit offsets");
@@ -587,7 +611,7 @@ extern "C" int salt_hyper_stencil(const salt_hyper_stencil_args* a, void* stream
     p.nrows_pad = cdiv(nrows, HB_UY) * HB_UY;
     p.xt_floats = (xt_floats + 3) & ~3;
     if (nb >= (1LL << 30)) SALT_FAIL(SALT_E_UNSUPPORTED, "hyper_stencil: too many rows");
-    p.nblocks = (unsigned)nb; p.per_xcd = (unsigned)((nb + 7) / 8);
+    p.nblocks = (unsigned)nb; p.per_xcd = (unsigned)(nb / 8);
     const size_t lds = (size_t)(nslot == 1 ? 3 : 1) * y.W * HB_CB * 4 + (size_t)p.xt_floats * 4 + (size_t)p.nrows_pad * 8 * 4;
     if (lds > 160 * 1024) SALT_FAIL(SALT_E_LDS, "hyper_stencil: the adjoint needs %zu bytes of LDS", lds);
     void (*kern)(HsbKP) = nullptr;

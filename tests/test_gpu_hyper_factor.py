@@ -287,3 +287,32 @@ def test_tapgemm_pack_and_sliced_reduce_layouts():
     want = torch.zeros(D0, D1, 3, 3)
     want[:, c0:c0 + cn] = slab.sum(0)[0].view(9, D0, cn).permute(1, 2, 0).reshape(D0, cn, 3, 3)
     assert_close(grad.cpu(), want, 1e-6, 'tap-GEMM reduce')
+
+
+@pytest.mark.parametrize('shape', [(64, 64, 3), (512, 512, 2), (96, 40, 8), (64, 320, 1)])
+def test_wgrad_reduce9_is_bit_identical_to_the_per_element_kernel(shape, monkeypatch):
+    """wgrad_reduce9_kernel (a thread per (a, b) pair writes its nine taps as 36 contiguous bytes) against wgrad_reduce8_kernel (a thread per
+    slab element): the SAME slabs presented with the taps in reverse order take the per-element kernel (the launch is routed by the raster
+    order of tap_kh / tap_kw) and must produce the same bits, plain and accumulating, full tensor and channel slice (ldb)."""
+    abi = _abi()
+    monkeypatch.setenv('SALT_WGRAD_REDUCE9', '1')          # opt-in kernel (measured no faster: DESIGN 10)
+    Ca, Cb, ns = shape
+    g = torch.Generator().manual_seed(Ca + Cb)
+    slab = torch.randn(ns, 9, Ca, Cb, generator=g)
+    ldb = Cb + 24
+    res = {}
+    for order in ('raster', 'reverse'):
+        taps = list(range(9)) if order == 'raster' else list(range(8, -1, -1))
+        sd = slab[:, taps].contiguous().to(DEV)
+        grad = torch.full((Ca, ldb, 3, 3), 0.5, device=DEV)
+        for acc in (0, 1):
+            S = abi.STRUCTS['salt_wgrad_reduce_args']()
+            abi.fill(S, partials=sd.data_ptr(), nsplit=ns, ntaps=9, Ca=Ca, Cb=Cb, KH=3, KW=3, tap_kh=[t // 3 for t in taps], tap_kw=[t % 3 for t in taps],
+                     grad=grad.data_ptr() + 4 * 8 * 9, accumulate=acc, ldb=ldb)
+            abi.check(abi.lib.salt_wgrad_reduce(ctypes.byref(S), None), 'reduce')
+        torch.cuda.synchronize()
+        res[order] = grad.cpu()
+    assert torch.equal(res['raster'], res['reverse'])
+    want = torch.full((Ca, ldb, 3, 3), 0.5)
+    want[:, 8:8 + Cb] = 2 * slab.sum(0).permute(1, 2, 0).reshape(Ca, Cb, 3, 3)
+    assert_close(res['raster'], want, 1e-6, 'reduce9 vs torch')
