@@ -27,7 +27,10 @@ inline bool vec_ok(const salt_view& v, int ve) {
 }
 inline int ew_blocks(int64_t units) {
     static const int64_t cap = getenv("SALT_EW_BLOCKS") ? atoi(getenv("SALT_EW_BLOCKS")) : 768;      // round 3: 768 (1024 before; every workgroup of the consumer-side finalize kernels pays the statistics prologue)
-    int64_t b = (units + 255) / 256; return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+    // SALT_EW_MIN_UNITS (A/B, round 5): at least this many 16-byte units per thread - fewer workgroups on the small tensors, where every
+    // workgroup's statistics prologue (8 shards x 2 C + 1 doubles from L2, fp64 division + square root per channel) outweighs its stream
+    static const int64_t min_units = getenv("SALT_EW_MIN_UNITS") ? atoi(getenv("SALT_EW_MIN_UNITS")) : 1;
+    int64_t b = (units + 256 * min_units - 1) / (256 * min_units); return (int)(b < 1 ? 1 : (b > cap ? cap : b));
 }
 
 #ifndef SALT_BNB_UNITS

@@ -21,6 +21,9 @@
 namespace {
 
 constexpr int HS_TH = 32, HS_TW = 16, HS_CB = 64, HS_NT = 1024;     // forward: pixel tile, channel block and threads of a workgroup
+#ifndef HS_ABLATE
+#define HS_ABLATE 0          // timing ablations of the forward kernel (tools/build_variant.sh hyper ... -DHS_ABLATE=n): 1 no stage H, 2 no stage V, 4 no z loads
+#endif
 constexpr int HS_TWL = 4;                                           // log2(HS_TW).  (32 x 8 tiles on 512-thread workgroups, two per CU, measured 3 % SLOWER:
                                                                     //  the rounds are VALU / LDS bound, not latency bound - DESIGN 7)
 constexpr int HS_VR = HS_TH * HS_TW * (HS_CB / 8) / HS_NT;          // rows of a column a thread accumulates in stage V (4)
@@ -195,9 +198,12 @@ __global__ __launch_bounds__(HS_NT) void hyper_stencil_fwd_kernel(HsKP p) {
         const int l = rr / 3, dy = rr - 3 * l;
         const bool more = rr + 1 < nrounds, newlev = more && dy == 2;
         if (newlev) level_setup(l + 1);
+#if !(HS_ABLATE & 4)
         if (more) pf_issue(newlev ? 0 : dy + 1);
+#endif
         const HsCoef* rowt = tabs + (l & 1) * TABN;
         const HsCoef* colt = rowt + HS_TH + 2;
+#if !(HS_ABLATE & 1)
         {   // stage H: hbuf[i][hx][4 cq ..] = sum_dx (1 - lam) z[i][j0(hx + dx)][dx] + lam z[i][j1(hx + dx)][dx]
             int o0[3], o1[3]; f32x2_t w0[3], w1[3];
 #pragma unroll
@@ -220,11 +226,13 @@ __global__ __launch_bounds__(HS_NT) void hyper_stencil_fwd_kernel(HsKP p) {
                 *reinterpret_cast<f32x4*>(hbuf + hbuf_off(i, hx, cq)) = v;
             }
         }
+#endif
         __syncthreads();                                       // B: hbuf complete, zp free
         if (more) {
             pf_store();
             if (newlev) tables_write(l + 1);                   // (the other parity: stage V below still reads this level's rows)
         }
+#if !(HS_ABLATE & 2)
         {   // stage V: acc[k] += (1 - lam) hbuf[i0(row k + dy)] + lam hbuf[i1(..)] (branch-free: both patch rows are read for every step)
 #pragma unroll
             for (int k = 0; k < HS_VR; ++k) {
@@ -244,6 +252,7 @@ __global__ __launch_bounds__(HS_NT) void hyper_stencil_fwd_kernel(HsKP p) {
                 }
             }
         }
+#endif
         nr = G.nr; nc = G.nc;
         __syncthreads();                                       // A: zp (+ tables) of the next round visible, hbuf free
     }
