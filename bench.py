@@ -376,6 +376,9 @@ def conv_roofline(model, B, channels, dtype, loss, reps):
     return roof, ops, total_ms, side, sum(g[1] for g in groups.values()) / reps, dn
 
 
+RANK_MS = []
+
+
 def train_config(workload, dtype, B, loss, steps, warmup, dev, rank=0, world=1, reps=1):
     """Build the model of one training configuration, run `warmup` + `steps` timed fused steps on resident data; -> (model, batches, s)."""
     from salt_amd.models import SegmentationModel
@@ -407,8 +410,13 @@ def train_config(workload, dtype, B, loss, steps, warmup, dev, rank=0, world=1, 
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    global RANK_MS
+    RANK_MS = [1e3 * elapsed / steps]
     if world > 1:
         te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(te) for _ in range(world)]
+        dist.all_gather(every, te)
+        RANK_MS = [round(1e3 * float(t[0]) / steps, 4) for t in every]      # every rank's own clock around the same K steps
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te[0])
     return model, batches, elapsed, float(loss_v['sum'])
@@ -565,6 +573,7 @@ def extra_configs(dev, steps=12, warmup=4):
 
 
 RCCL_LOG = '/tmp/salt_rccl_%d.log' % os.getpid()
+RCCL_MAX_NCHANNELS = None
 
 
 def init_rccl(rank):
@@ -574,6 +583,9 @@ def init_rccl(rank):
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29511')
     os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
+    from salt_amd.parallel import configure_rccl_env
+    global RCCL_MAX_NCHANNELS
+    RCCL_MAX_NCHANNELS = configure_rccl_env()          # NCCL_MAX_NCHANNELS (default 32: one CU per channel - parallel.py has the reasoning)
     sys.stdout.flush()
     saved = os.dup(1)
     os.dup2(2, 1)
@@ -716,6 +728,8 @@ def main():
         # after its last backward kernel (the collectives of the earlier buckets ran underneath backward)
         ex = model.dp.exposed_allreduce_ms()
         out['rccl_ranks'] = dist.get_world_size() if dist.is_initialized() else 1
+        out['per_rank_ms_per_step'] = {'min': min(RANK_MS), 'max': max(RANK_MS), 'all': RANK_MS}
+        out['rccl_max_nchannels'] = RCCL_MAX_NCHANNELS      # NCCL_MAX_NCHANNELS in effect (None: RCCL's default); rccl_info has what RCCL reports
         if rank == 0:
             out['rccl_info'] = rccl_summary()
         out['allreduce'] = {'buckets': len(list(model.dp._plans.values())[0]) if model.dp._plans else 0,

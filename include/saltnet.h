@@ -846,6 +846,15 @@ int salt_program_run_timed(const salt_program_entry* entries, int begin, int end
 int salt_program_run_streams(const salt_program_entry* entries, int begin, int end, void* main_stream, void* side_stream);
 /* join_at_end == 0: the caller orders its consumers after BOTH streams itself (bucketed all-reduce between backward segments) */
 int salt_program_run_streams_ex(const salt_program_entry* entries, int begin, int end, void* main_stream, void* side_stream, int join_at_end);
+/* ... with MARKS: before entry marks[m] (ascending, begin <= marks[m] <= end) is issued, ev_main[m] is recorded on the main stream and
+ * ev_side[m] on the side stream (hipEvent_t handles from salt_event_create).  The data-parallel backward (one process per GPU, replaces
+ * nn.DataParallel of models.py:81-85) learns this way that an all-reduce bucket's gradients are final WITHOUT cutting the program into
+ * one call per bucket (each cut cost a flush of the pending side-stream entries and the completion-signal fork hand-off). */
+int salt_program_run_streams_marks(const salt_program_entry* entries, int begin, int end, void* main_stream, void* side_stream, int join_at_end,
+                                   const int* marks, int nmarks, void* const* ev_main, void* const* ev_side);
+int salt_event_create(void** event_out);            /* a hipEvent_t without timing */
+int salt_event_destroy(void* event);
+int salt_stream_wait_event(void* stream, void* event);
 int salt_graph_capture(const salt_program_entry* entries, int n, void* stream, void** graph_exec_out);
 /* whole-step capture: every salt_program_run* call between begin and end on `stream` (and on the side stream the two-stream executor
  * forks to) is recorded instead of executed; `stream` must not be the default stream */

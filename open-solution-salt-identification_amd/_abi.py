@@ -113,6 +113,12 @@ lib.salt_graph_launch.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 lib.salt_graph_begin.argtypes = [ctypes.c_void_p]
 lib.salt_graph_end.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]
 lib.salt_graph_destroy.argtypes = [ctypes.c_void_p]
+lib.salt_program_run_streams_ex.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+lib.salt_program_run_streams_marks.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                               ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p)]
+lib.salt_event_create.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+lib.salt_event_destroy.argtypes = [ctypes.c_void_p]
+lib.salt_stream_wait_event.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 
 DECLARED_SYMBOLS = [p[0] for p in _PROTOS] + ['salt_last_error']
 

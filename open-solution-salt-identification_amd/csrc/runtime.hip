@@ -100,7 +100,32 @@ extern "C" int salt_program_run_streams(const salt_program_entry* e, int begin, 
 }
 
 extern "C" int salt_program_run_streams_ex(const salt_program_entry* e, int begin, int end, void* main_stream, void* side_stream, int join_at_end) {
-    if (!side_stream || side_stream == main_stream) return salt_program_run_range(e, begin, end, main_stream);
+    return salt_program_run_streams_marks(e, begin, end, main_stream, side_stream, join_at_end, nullptr, 0, nullptr, nullptr);
+}
+
+extern "C" int salt_event_create(void** out) {
+    if (!out) SALT_FAIL(SALT_E_BADARG, "event_create: null");
+    hipEvent_t ev = nullptr;
+    const hipError_t err = hipEventCreateWithFlags(&ev, hipEventDisableTiming | fork_event_flags());
+    if (err != hipSuccess) SALT_FAIL((int)err, "hipEventCreate: %s", hipGetErrorString(err));
+    *out = ev;
+    return SALT_OK;
+}
+extern "C" int salt_event_destroy(void* ev) { if (ev) (void)hipEventDestroy((hipEvent_t)ev); return SALT_OK; }
+extern "C" int salt_stream_wait_event(void* stream, void* ev) {
+    if (!ev) SALT_FAIL(SALT_E_BADARG, "stream_wait_event: null event");
+    const hipError_t err = hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0);
+    if (err != hipSuccess) SALT_FAIL((int)err, "hipStreamWaitEvent: %s", hipGetErrorString(err));
+    return SALT_OK;
+}
+
+extern "C" int salt_program_run_streams_marks(const salt_program_entry* e, int begin, int end, void* main_stream, void* side_stream, int join_at_end,
+                                              const int* marks, int nmarks, void* const* ev_main, void* const* ev_side) {
+    if (nmarks < 0 || (nmarks > 0 && (!marks || !ev_main || !ev_side))) SALT_FAIL(SALT_E_BADARG, "program: marks");
+    if (!side_stream || side_stream == main_stream) {
+        if (nmarks) SALT_FAIL(SALT_E_BADARG, "program: marks need the two-stream executor");
+        return salt_program_run_range(e, begin, end, main_stream);
+    }
     if (!e || begin < 0 || end < begin) SALT_FAIL(SALT_E_BADARG, "program: bad range");
     if (g_events.ensure()) SALT_FAIL(SALT_E_BADARG, "hipEventCreate failed");
     hipStream_t ms = (hipStream_t)main_stream, ss = (hipStream_t)side_stream;
@@ -108,7 +133,16 @@ extern "C" int salt_program_run_streams_ex(const salt_program_entry* e, int begi
     if (one_stream) {
         (void)hipEventRecord(g_events.ev[1], ss);                 // whatever the caller enqueued on the side stream before (weight packs)
         (void)hipStreamWaitEvent(ms, g_events.ev[1], 0);
-        return salt_program_run_range(e, begin, end, main_stream);
+        int b0 = begin;
+        for (int m = 0; m < nmarks; ++m) {
+            const int pos = marks[m] < b0 ? b0 : (marks[m] > end ? end : marks[m]);
+            const int rc = salt_program_run_range(e, b0, pos, main_stream);
+            if (rc) return rc;
+            (void)hipEventRecord((hipEvent_t)ev_main[m], ms);
+            (void)hipEventRecord((hipEvent_t)ev_side[m], ss);
+            b0 = pos;
+        }
+        return salt_program_run_range(e, b0, end, main_stream);
     }
     bool main_dirty = true, side_used = false;       // main_dirty: main has work the side stream has not been ordered after
     // Fork coalescing (SALT_FORK_EVERY = K > 1): side-stream entries are held back until K groups of them are pending, then issued
@@ -143,7 +177,18 @@ extern "C" int salt_program_run_streams_ex(const salt_program_entry* e, int begi
         npending = 0; groups = 0; side_used = true; ++nflush;
         return 0;
     };
+    int mk = 0;
+    auto do_marks = [&](int i) -> int {          // every mark at position i: both queues' events, behind everything issued so far
+        while (mk < nmarks && marks[mk] <= i) {
+            const int rc = flush(); if (rc) return rc;
+            (void)hipEventRecord((hipEvent_t)ev_main[mk], ms);
+            (void)hipEventRecord((hipEvent_t)ev_side[mk], ss);
+            ++mk;
+        }
+        return 0;
+    };
     for (int i = begin; i < end; ++i) {
+        if (mk < nmarks) { const int rc = do_marks(i); if (rc) return rc; }
         const bool side = e[i].stream == 1;
         if (fork_every > 1) {
             if (side) {
@@ -180,6 +225,7 @@ extern "C" int salt_program_run_streams_ex(const salt_program_entry* e, int begi
         else main_dirty = true;
     }
     { const int rc = flush(); if (rc) return rc; }
+    if (mk < nmarks) { const int rc = do_marks(end); if (rc) return rc; }
     if (side_used && join_at_end) {
         (void)hipEventRecord(g_events.ev[1], ss);
         (void)hipStreamWaitEvent(ms, g_events.ev[1], 0);

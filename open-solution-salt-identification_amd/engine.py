@@ -110,16 +110,21 @@ class Program:
     def __len__(self):
         return len(self.ops)
 
-    def run(self, stream=None, begin=0, end=None, side=None, join=True):
+    def run(self, stream=None, begin=0, end=None, side=None, join=True, marks=None):
         """Enqueue ops [begin, end).  With ``side`` (a torch.cuda.Stream) ops tagged stream=1 run on it concurrently; ``join=False``
-        leaves the side stream un-joined at the end of the range (the caller orders its consumers after both streams)."""
+        leaves the side stream un-joined at the end of the range (the caller orders its consumers after both streams).
+        ``marks`` = (positions int array, n, main-event array, side-event array) prepared by parallel.DataParallel: the executor records
+        the two events of a mark before it issues the entry at that position (salt_program_run_streams_marks)."""
         if self._entries is None:
             self.finalize()
         end = len(self.ops) if end is None else end
         st = _stream_ptr(stream)
         if side is None and 3 in self.streams[begin:end]:
             raise SaltError('program %s joins the side stream (data-gradient weight packs): run it with side=engine.side_stream' % self.name)
-        if side is not None:
+        if side is not None and marks is not None:
+            rc = lib.salt_program_run_streams_marks(ctypes.cast(self._entries, ctypes.c_void_p), begin, end, st, ctypes.c_void_p(side.cuda_stream),
+                                                    1 if join else 0, marks[0], marks[1], marks[2], marks[3])
+        elif side is not None:
             rc = lib.salt_program_run_streams_ex(ctypes.cast(self._entries, ctypes.c_void_p), begin, end, st, ctypes.c_void_p(side.cuda_stream),
                                                  1 if join else 0)
         else:

@@ -25,6 +25,26 @@ import torch.distributed as dist
 
 DEFAULT_BUCKET_BYTES = 32 << 20
 DEFAULT_TAIL_BYTES = 4 << 20
+# RCCL's device kernels take ONE workgroup (= one CU) per channel.  The convolution kernels of this build are whole-CU workgroups
+# (conv_ws / conv_ls / conv_wgrad_ls: 160 KB of LDS or > 256 registers per SIMD lane pair - DESIGN 4), so every channel RCCL opens is a
+# CU the backward pass it overlaps cannot use, and a workgroup of ours waits for a CU RCCL holds.  RCCL's own default on this part is
+# 64 channels for the 1-rank communicator (bench.py: rccl_info) - a quarter of the chip.  The 7 xGMI links of a GPU carry ~153 GB/s
+# each and a channel moves ~20-25 GB/s, so 32 channels (1/8 of the CUs) already cover the links a ring / direct exchange can use at
+# once; the ~120 MB of gradients per step are then ~0.4 ms of collectives underneath ~3.5 ms of backward.  Exposed as a knob because
+# nobody can rehearse the 8-GPU run here: SALT_RCCL_MAX_NCHANNELS (0 = leave RCCL alone), or set NCCL_MAX_NCHANNELS yourself (wins).
+DEFAULT_RCCL_MAX_NCHANNELS = 32
+
+
+def configure_rccl_env():
+    """Set NCCL_MAX_NCHANNELS (unless the user did) BEFORE the process group is created - RCCL reads it when the communicator comes up.
+    -> the value in effect, or None when RCCL's default is left alone."""
+    if 'NCCL_MAX_NCHANNELS' in os.environ:
+        return int(os.environ['NCCL_MAX_NCHANNELS'])
+    n = int(os.environ.get('SALT_RCCL_MAX_NCHANNELS', str(DEFAULT_RCCL_MAX_NCHANNELS)))
+    if n > 0:
+        os.environ['NCCL_MAX_NCHANNELS'] = str(n)
+        return n
+    return None
 
 
 def plan_buckets(ready, total, bucket_bytes=DEFAULT_BUCKET_BYTES, tail_bytes=DEFAULT_TAIL_BYTES):
@@ -65,6 +85,8 @@ class DataParallel:
         self.rank, self.world, self.bucket_bytes = rank, world, bucket_bytes
         self._comm_stream = None
         self._plans = {}
+        self._events = {}
+        self._marks = {}
         self.measure = False            # bench.py: record an event pair around the final wait for the collectives
         self.exposed_events = []
         self.timeline = False           # bench.py / tools/dp_overhead.py: timing events per bucket (ready / all-reduce done) and at backward end
@@ -85,6 +107,8 @@ class DataParallel:
             if torch.cuda.is_available():
                 torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')))
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            if torch.cuda.is_available() and backend in (None, 'nccl'):
+                configure_rccl_env()
             dist.init_process_group(backend or ('nccl' if torch.cuda.is_available() else 'gloo'))
         return DataParallel.from_env()
 
@@ -165,6 +189,59 @@ class DataParallel:
         key = id(net)
         if key not in self._plans:
             self._plans[key] = plan_buckets(net.g.grad_ready, eng.n_live, self.bucket_bytes)
+            # ONE event per bucket and queue, created once (round 4 allocated two torch.cuda.Event objects per bucket per step)
+            self._events[key] = [(torch.cuda.Event(), torch.cuda.Event()) for _ in self._plans[key]]
+            self._marks[key] = self._make_marks(self._plans[key], len(net.bwd))
+        if self.timeline or os.environ.get('SALT_DP_SEGMENTS'):
+            return self._backward_segments(eng, net, key)
+        # ---- ONE executor call for the whole backward program: the executor records each bucket's two events (compute queue, weight-
+        # gradient queue) when it reaches the bucket's position - no cut of the program per bucket (round 4: + 2 % on one rank before
+        # any wire time, most of it the per-segment flush / lost fork hand-off) - and the collectives are issued behind those events
+        from ._abi import lib, check
+        import ctypes
+        pos, n, evm, evs, handles = self._marks[key]
+        cur = torch.cuda.current_stream()
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream()
+        comm = self._comm_stream
+        net.bwd.run(side=eng.side_stream, marks=(pos, n, evm, evs))
+        works = []
+        with torch.cuda.stream(comm):
+            for (lo, hi, _), (hm, hs) in zip(self._plans[key], handles):
+                check(lib.salt_stream_wait_event(ctypes.c_void_p(comm.cuda_stream), hm), 'stream_wait_event')
+                check(lib.salt_stream_wait_event(ctypes.c_void_p(comm.cuda_stream), hs), 'stream_wait_event')
+                works.append(None if self.skip_collectives else self._all_reduce(eng.grads[lo:hi]))
+        if self.measure:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(cur)
+        for w in works:
+            if w is not None:
+                w.wait()
+        cur.wait_stream(comm)
+        if self.measure:
+            e1.record(cur)
+            self.exposed_events.append((e0, e1))
+
+    def _make_marks(self, plan, n_ops):
+        """ctypes arrays for salt_program_run_streams_marks: ascending positions + one native event per bucket and queue"""
+        import ctypes
+        from ._abi import lib, check
+        n = len(plan)
+        pos = (ctypes.c_int * n)(*[min(max(r, 0), n_ops) for _, _, r in plan])
+        for a, b in zip(pos, list(pos)[1:]):
+            assert a <= b, 'bucket positions must ascend'
+        evm, evs = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)()
+        handles = []
+        for i in range(n):
+            hm, hs = ctypes.c_void_p(), ctypes.c_void_p()
+            check(lib.salt_event_create(ctypes.byref(hm)), 'event_create'); check(lib.salt_event_create(ctypes.byref(hs)), 'event_create')
+            evm[i], evs[i] = hm.value, hs.value
+            handles.append((hm, hs))
+        return pos, n, evm, evs, handles
+
+    def _backward_segments(self, eng, net, key):
+        """round 4's form - the backward program cut into one executor call per bucket - kept for the per-bucket timing timeline
+        (timeline=True needs timing events recorded from Python) and as an A/B (SALT_DP_SEGMENTS=1)"""
         if self._comm_stream is None:
             self._comm_stream = torch.cuda.Stream()
         cur = torch.cuda.current_stream()
@@ -175,14 +252,14 @@ class DataParallel:
         if self.timeline:
             tl = [torch.cuda.Event(enable_timing=True), [], None, None]
             tl[0].record(cur)
-        for lo, hi, ridx in self._plans[key]:
+        for (lo, hi, ridx), (ev_plain, ev_side) in zip(self._plans[key], self._events[key]):
             ridx = min(max(ridx, pos), n_ops)
             if ridx > pos:
                 # no join between segments: the main stream keeps running ahead of the weight-gradient stream; the bucket's
                 # gradients come from both, so the communication stream waits for both
                 net.bwd.run(begin=pos, end=ridx, side=eng.side_stream, join=False)
                 pos = ridx
-            ev, ev_side = torch.cuda.Event(enable_timing=tl is not None), torch.cuda.Event()
+            ev = torch.cuda.Event(enable_timing=True) if tl is not None else ev_plain
             ev.record(cur)
             ev_side.record(eng.side_stream)
             with torch.cuda.stream(comm):
@@ -236,5 +313,9 @@ class DataParallel:
                 out['buckets'][j]['allreduce_done_ms'] += (t0.elapsed_time(done) - span) / n
         out['backward_ms'] = round(out['backward_ms'], 4); out['wait_after_backward_ms'] = round(out['wait_after_backward_ms'], 4)
         for b in out['buckets']:
+            # all-reduce bus bandwidth (the nccl-tests convention: 2 (N - 1) / N x bytes / time) from "gradients final" to "collective done":
+            # an UPPER bound on the collective's own duration (it may have queued behind the previous bucket's), so a LOWER bound on the rate
+            dur = b['allreduce_done_ms'] - b['ready_ms']
+            b['busbw_GBps_lower_bound'] = round(2.0 * (self.world - 1) / self.world * b['mbytes'] / dur, 1) if (dur > 0 and self.world > 1) else None
             b['ready_ms'] = round(b['ready_ms'], 4); b['allreduce_done_ms'] = round(b['allreduce_done_ms'], 4)
         return out

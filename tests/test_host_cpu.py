@@ -171,11 +171,14 @@ def test_gloo_ranks_gradient_average_and_bucket_plan(tmp_path, world):
     trainer decisions."""
     script = tmp_path / 'worker.py'
     script.write_text(_WORKER % {'root': ROOT, 'out': str(tmp_path)})
-    port = 29500 + (os.getpid() % 500) + world
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % world, '--master-addr', '127.0.0.1',
-           '--master-port', str(port), str(script)]
     env = dict(os.environ, OMP_NUM_THREADS='1')
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    for attempt in range(2):                     # (a rendezvous port left in TIME_WAIT by an earlier run: one retry on another port)
+        port = 29500 + (os.getpid() % 500) + world + 37 * attempt
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=%d' % world, '--master-addr', '127.0.0.1',
+               '--master-port', str(port), str(script)]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+        if r.returncode == 0:
+            break
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert all((tmp_path / ('rank%d.ok' % k)).exists() for k in range(world))
 
