@@ -793,9 +793,10 @@ def main():
     fit_pending = not args.no_iou and rank == 0 and world == 1
 
     if rank == 0 and 'roofline_by_class' in out:           # the fused Adam + L2 kernel (28 bytes per parameter), timed after the evaluation
-        for name, _, ms in model.optimizer.prog.run_timed():
-            if name == 'adam' and ms > 0:
-                by = 28.0 * model.model.engine().n_live
+        aprog = model.optimizer._adam_pack_program() or model.optimizer.prog      # (bf16: Adam also writes the forward weight packs, 2 more bytes per packed parameter)
+        for name, _, ms in aprog.run_timed():
+            if name in ('adam', 'adam_pack') and ms > 0:
+                by = (28.0 + (2.0 if name == 'adam_pack' else 0.0)) * model.model.engine().n_live
                 out['roofline_by_class']['adam'] = {'launches_per_step': 1, 'ms_per_step': round(ms, 3), 'bound': 'hbm', 'achieved': round(by / (ms * 1e-3) / 1e9, 1),
                                                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 

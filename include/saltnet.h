@@ -706,6 +706,32 @@ typedef struct {
 } salt_adam_args;
 int salt_adam(const salt_adam_args*, void* stream);
 
+/* Adam + L2 AND the bf16 forward weight packs in one pass (round 5).  The forward packs of the 3x3 / 1x1 layers (97 % of a ResNet's
+ * parameters) are re-derived from the fp32 masters after every optimizer step (salt_pack_batched: 405 MB of traffic, the first launch of
+ * the next step on the critical queue).  Here the thread that updates 8 input channels x all taps of one output channel - 8 KK contiguous
+ * floats of the master - also stores their KK 16-byte packed pieces: the same values salt_pack_batched would write, bit for bit.
+ * `jobs` are the salt_pack_conv_weight_args of those layers (salt_pack_job_is_vec(job) != 0, each weight at most once, every `w` inside
+ * [param, param + n)); `rest` lists the ranges of the flat buffer no job covers (everything else takes the plain update of salt_adam). */
+typedef struct {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    int64_t n;
+    const float* hyper;       /* as salt_adam_args.hyper */
+    const void* jobs;         /* DEVICE array of salt_pack_conv_weight_args */
+    const int* job_block0;    /* DEVICE [njobs + 1]: prefix of salt_pack_job_blocks */
+    int njobs;
+    int pack_blocks;
+    const int64_t* rest;      /* DEVICE [nrest][2]: (first element, element count), both multiples of 4 */
+    const int* rest_block0;   /* DEVICE [nrest + 1]: prefix of ceil(count / 1024) */
+    int nrest;
+    int rest_blocks;
+} salt_adam_pack_args;
+int salt_adam_pack(const salt_adam_pack_args*, void* stream);
+/* != 0 for the jobs salt_adam_pack can write on the way: salt_pack_batched's vector path, 3x3 layers (KH KW = 9) */
+int salt_pack_job_is_vec(const salt_pack_conv_weight_args*);
+
 typedef struct {              /* advance step counter and bias corrections on device (graph-replay safe) */
     float* hyper;             /* as above */
     int64_t* step;            /* device [1] */

@@ -68,6 +68,16 @@ __device__ __forceinline__ void bil_src(int d, int R, int n, int ac, int& i0, in
     lam = s - (float)i0;
 }
 
+// Adam + L2 on four consecutive parameters (models.py:74-75,289-297: optim.Adam with weight decay in the gradient).  ONE definition for
+// adam_kernel (loss.hip) and adam_pack_kernel (conv_mfma.hip): the two must produce the same bits.
+__device__ __forceinline__ void adam4(f32x4& pp, const f32x4& gg, f32x4& mm, f32x4& vv, float b1, float b2, float eps, float wd, float gs, float step_size, float rs) {
+#define SALT_ADAM1V(X) { const float gr = __fmaf_rn(wd, pp.X, __fmul_rn(gg.X, gs)); mm.X = __fmaf_rn(1.f - b1, gr, __fmul_rn(b1, mm.X)); \
+                         vv.X = __fmaf_rn(__fmul_rn(1.f - b2, gr), gr, __fmul_rn(b2, vv.X)); \
+                         pp.X = __fsub_rn(pp.X, __fdiv_rn(__fmul_rn(step_size, mm.X), __fmaf_rn(sqrtf(vv.X), rs, eps))); }
+    SALT_ADAM1V(x) SALT_ADAM1V(y) SALT_ADAM1V(z) SALT_ADAM1V(w)
+#undef SALT_ADAM1V
+}
+
 // ---- host-side helpers
 void salt_set_error(const char* fmt, ...);
 // Fork hand-off (runtime.hip): when the two-stream executor is about to fork the side stream right after a main-stream

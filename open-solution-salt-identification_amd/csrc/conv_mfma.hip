@@ -1895,6 +1895,76 @@ __global__ __launch_bounds__(256) void pack_batched_kernel(const salt_pack_conv_
     }
 }
 
+// ------------------------------------------------------------------------------------------ Adam + forward packs in one pass
+// (saltnet.h: salt_adam_pack.)  Job blocks: pack_vec's thread mapping - a thread owns 8 input channels x KK taps of one output channel,
+// 8 KK contiguous fp32 of the master in the flat buffer: it runs the Adam update over them as 2 KK float4 groups (the same arithmetic, in
+// the same order, as adam_kernel in loss.hip: bit-identical parameters and moments) and stores the KK packed pieces from the updated
+// values.  Rest blocks: the plain update over the ranges no job covers.
+struct AdamPackKP {
+    float* p; const float* g; float* m; float* v; const float* hyper;
+    const salt_pack_conv_weight_args* jobs; const int* job_block0; int njobs, pack_blocks;
+    const int64_t* rest; const int* rest_block0; int nrest;
+};
+// A job block = 64 segments; a segment = the 32 input channels x 9 taps of one output channel = 288 CONTIGUOUS floats of the master.
+// Phase 1: the block's 4 608 float4 groups are updated in memory order (coalesced 1 152-byte runs - a thread per (output channel, 8 input
+// channels) walking its own 288 bytes left every load of the four arrays at a 288-byte lane stride: 0.76 ms for the network instead of
+// 0.13) and the new parameters are parked in LDS; phase 2: pack_vec's thread mapping reads them back and stores the packed pieces.
+constexpr int AP_SEG = 64, AP_SEGF = 288;
+__global__ __launch_bounds__(256) void adam_pack_kernel(AdamPackKP k) {
+    extern __shared__ __attribute__((aligned(16))) float ap_sm[];              // [AP_SEG][AP_SEGF]
+    const float lr = k.hyper[0], b1 = k.hyper[1], b2 = k.hyper[2], eps = k.hyper[3], wd = k.hyper[4], bc1 = k.hyper[5], bc2 = k.hyper[6], gs = k.hyper[7];
+    const float step_size = lr / bc1, rs = 1.f / sqrtf(bc2);
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < k.pack_blocks) {
+        int lo = 0, hi = k.njobs - 1;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (k.job_block0[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+        const salt_pack_conv_weight_args& a = k.jobs[lo];
+        const int N = a.D0, C = a.D1, nseg = N * (C / 32);
+        const int seg0 = ((int)blockIdx.x - k.job_block0[lo]) * AP_SEG;
+        const int64_t wbase = a.w - k.p;
+#pragma unroll 3
+        for (int it = 0; it < AP_SEG * AP_SEGF / 4 / 256; ++it) {
+            const int f = tid + 256 * it, sl = f / (AP_SEGF / 4), fi = f - sl * (AP_SEGF / 4), seg = seg0 + sl;
+            if (seg < nseg) {
+                const int chunk = seg / N, n = seg - chunk * N;
+                const int64_t off = wbase + ((int64_t)n * C + chunk * 32) * 9 + 4 * fi;
+                f32x4 pp = *reinterpret_cast<const f32x4*>(k.p + off);
+                const f32x4 gg = *reinterpret_cast<const f32x4*>(k.g + off);
+                f32x4 mm = *reinterpret_cast<const f32x4*>(k.m + off), vv = *reinterpret_cast<const f32x4*>(k.v + off);
+                adam4(pp, gg, mm, vv, b1, b2, eps, wd, gs, step_size, rs);
+                *reinterpret_cast<f32x4*>(k.p + off) = pp; *reinterpret_cast<f32x4*>(k.m + off) = mm; *reinterpret_cast<f32x4*>(k.v + off) = vv;
+                *reinterpret_cast<f32x4*>(ap_sm + sl * AP_SEGF + 4 * fi) = pp;
+            }
+        }
+        __syncthreads();
+        const int sl = tid >> 2, q = tid & 3, seg = seg0 + sl;
+        if (seg >= nseg) return;
+        const int chunk = seg / N, n = seg - chunk * N;
+        const float* v = ap_sm + sl * AP_SEGF + q * 72;                          // 8 channels x 9 taps of this thread
+        bf16_t* out = reinterpret_cast<bf16_t*>(a.wp);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            u32x4 o;
+            o.x = f2bf_pk(v[0 * 9 + t], v[1 * 9 + t]); o.y = f2bf_pk(v[2 * 9 + t], v[3 * 9 + t]);
+            o.z = f2bf_pk(v[4 * 9 + t], v[5 * 9 + t]); o.w = f2bf_pk(v[6 * 9 + t], v[7 * 9 + t]);
+            *reinterpret_cast<u32x4*>(out + (((int64_t)chunk * 9 + t) * N + n) * 32 + q * 8) = o;
+        }
+        return;
+    }
+    const int rb = (int)blockIdx.x - k.pack_blocks;
+    int lo = 0, hi = k.nrest - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (k.rest_block0[mid] <= rb) lo = mid; else hi = mid - 1; }
+    const int64_t first = k.rest[2 * lo], count = k.rest[2 * lo + 1];
+    const int64_t e = (int64_t)(rb - k.rest_block0[lo]) * 1024 + tid * 4;
+    if (e >= count) return;
+    const int64_t off = first + e;
+    f32x4 pp = *reinterpret_cast<const f32x4*>(k.p + off);
+    const f32x4 gg = *reinterpret_cast<const f32x4*>(k.g + off);
+    f32x4 mm = *reinterpret_cast<const f32x4*>(k.m + off), vv = *reinterpret_cast<const f32x4*>(k.v + off);
+    adam4(pp, gg, mm, vv, b1, b2, eps, wd, gs, step_size, rs);
+    *reinterpret_cast<f32x4*>(k.p + off) = pp; *reinterpret_cast<f32x4*>(k.m + off) = mm; *reinterpret_cast<f32x4*>(k.v + off) = vv;
+}
+
 // ------------------------------------------------------------------------------------------ weight gradient
 // dW[t][a][b] = sum_p P[p,a] * Q[pad(p*q_step + tap_t), b].  Workgroup = 64(a) x 64(b) block for all taps of
 // the launch over a slice of the pixel tiles (split-K); 4 waves as 2(a) x 2(b), each 32x32 per tap.
@@ -3035,6 +3105,34 @@ extern "C" int salt_pack_job_blocks(const salt_pack_conv_weight_args* a) {
     if (!a->transpose) return (int)(((int64_t)N * cdiv(C, KCE) * KCE + 255) / 256);      // one thread per (n, padded channel) pair
     const int64_t total = (int64_t)cdiv(C, KCE) * a->ntaps * N * KCE;
     return (int)((total + PACK_EPB - 1) / PACK_EPB);
+}
+
+extern "C" int salt_pack_job_is_vec(const salt_pack_conv_weight_args* a) {      // (salt_adam_pack fuses the 3x3 layers; the few 1x1 vector packs stay with salt_pack_batched)
+    return a && !a->transpose && a->KH * a->KW == 9 && pack_vec_ok(*a, a->dtype) ? 1 : 0;
+}
+
+extern "C" int salt_adam_pack(const salt_adam_pack_args* a, void* stream) {
+    if (!a || !a->param || !a->grad || !a->exp_avg || !a->exp_avg_sq || !a->hyper || a->n < 0 || a->njobs < 0 || a->nrest < 0 || a->pack_blocks < 0 ||
+        a->rest_blocks < 0 || (a->njobs && (!a->jobs || !a->job_block0)) || (a->nrest && (!a->rest || !a->rest_block0)))
+        SALT_FAIL(SALT_E_BADARG, "adam_pack: bad args");
+    if ((reinterpret_cast<uintptr_t>(a->param) | reinterpret_cast<uintptr_t>(a->grad) | reinterpret_cast<uintptr_t>(a->exp_avg) | reinterpret_cast<uintptr_t>(a->exp_avg_sq)) & 15)
+        SALT_FAIL(SALT_E_BADARG, "adam_pack: buffers must be 16-byte aligned");
+    const int64_t blocks = (int64_t)a->pack_blocks + a->rest_blocks;
+    if (blocks == 0) return SALT_OK;
+    if (blocks >= (1LL << 31)) SALT_FAIL(SALT_E_UNSUPPORTED, "adam_pack: too many blocks");
+    AdamPackKP k;
+    k.p = a->param; k.g = a->grad; k.m = a->exp_avg; k.v = a->exp_avg_sq; k.hyper = a->hyper;
+    k.jobs = reinterpret_cast<const salt_pack_conv_weight_args*>(a->jobs); k.job_block0 = a->job_block0; k.njobs = a->njobs; k.pack_blocks = a->pack_blocks;
+    k.rest = a->rest; k.rest_block0 = a->rest_block0; k.nrest = a->nrest;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(adam_pack_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) SALT_FAIL((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(adam_pack_kernel, dim3((unsigned)blocks), dim3(256), AP_SEG * AP_SEGF * sizeof(float), (hipStream_t)stream, k);
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
 }
 
 extern "C" int salt_pack_batched(const salt_pack_batched_args* a, void* stream) {

@@ -608,12 +608,10 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     const float step_size = lr / bc1, rs = 1.f / sqrtf(bc2);
     const int64_t n4 = n >> 2;
     for (int64_t i = blockIdx.x * 256LL + threadIdx.x; i < n4; i += gridDim.x * 256LL) {
-        float4 pp = reinterpret_cast<float4*>(p)[i], gg = reinterpret_cast<const float4*>(g)[i];
-        float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
-#define SALT_ADAM1(X) { const float gr = gg.X * gs + wd * pp.X; mm.X = b1 * mm.X + (1.f - b1) * gr; vv.X = b2 * vv.X + (1.f - b2) * gr * gr; \
-                        pp.X -= step_size * mm.X / (sqrtf(vv.X) * rs + eps); }
-        SALT_ADAM1(x) SALT_ADAM1(y) SALT_ADAM1(z) SALT_ADAM1(w)
-        reinterpret_cast<float4*>(p)[i] = pp; reinterpret_cast<float4*>(m)[i] = mm; reinterpret_cast<float4*>(v)[i] = vv;
+        f32x4 pp = reinterpret_cast<const f32x4*>(p)[i], mm = reinterpret_cast<const f32x4*>(m)[i], vv = reinterpret_cast<const f32x4*>(v)[i];
+        const f32x4 gg = reinterpret_cast<const f32x4*>(g)[i];
+        adam4(pp, gg, mm, vv, b1, b2, eps, wd, gs, step_size, rs);             // (common.h: shared with adam_pack_kernel - same bits)
+        reinterpret_cast<f32x4*>(p)[i] = pp; reinterpret_cast<f32x4*>(m)[i] = mm; reinterpret_cast<f32x4*>(v)[i] = vv;
     }
     for (int64_t i = (n4 << 2) + blockIdx.x * 256LL + threadIdx.x; i < n; i += gridDim.x * 256LL) {
         const float gr = g[i] * gs + wd * p[i];

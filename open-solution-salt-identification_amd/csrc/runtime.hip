@@ -20,7 +20,7 @@ void salt_set_error(const char* fmt, ...) {
 
 extern "C" const char* salt_last_error(void) { return g_err; }
 
-extern "C" int salt_abi_version(void) { return 21; }
+extern "C" int salt_abi_version(void) { return 22; }
 
 extern "C" int salt_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name_len) {
     int dev = 0;
@@ -341,6 +341,7 @@ extern "C" int salt_abi_struct_sizes(int* out, int n) {
     (int)sizeof(salt_lovasz_args),
     (int)sizeof(salt_bce_dice_args),
     (int)sizeof(salt_adam_args),
+    (int)sizeof(salt_adam_pack_args),
     (int)sizeof(salt_adam_tick_args),
     (int)sizeof(salt_zero_args),
     (int)sizeof(salt_tta_mean_args),

@@ -63,6 +63,56 @@ class FusedAdam(torch.optim.Optimizer):
         self.prog.add('adam', param=eng.flat.data_ptr(), grad=eng.grads.data_ptr(), exp_avg=self.exp_avg.data_ptr(),
                       exp_avg_sq=self.exp_avg_sq.data_ptr(), n=eng.n_live, hyper=self.hyper.data_ptr())
         self.prog.finalize()
+        self._pack_prog, self._pack_gen = None, None
+
+    def _adam_pack_program(self):
+        """Adam + the bf16 forward weight packs in ONE launch (salt_adam_pack): the thread that updates 8 input channels x all taps of an
+        output channel also stores their packed pieces, so the pack launch that opened every step on the critical queue (405 MB of
+        traffic re-deriving what Adam had just written) shrinks to the few layers without a vector pack.  None when there is nothing to
+        fuse (fp32 engines, no compiled network yet, SALT_ADAM_PACK=0).  Rebuilt whenever the engine's pack tables are."""
+        import os
+        import numpy as np
+        eng = self._eng
+        if eng.dtype != 'bf16' or os.environ.get('SALT_ADAM_PACK', '1') == '0':
+            return None
+        if getattr(eng, '_pack_batched_n', -1) != len(eng._pack_ops):
+            eng._build_pack_batch()
+            eng._packed_version = eng._packed_bwd_version = -1
+        if self._pack_gen == eng._pack_generation:
+            return self._pack_prog
+        self._pack_gen, self._pack_prog = eng._pack_generation, None
+        jobs = eng._adam_jobs
+        if not jobs:
+            return None
+        import ctypes
+        from ._abi import lib
+        base = eng.flat.data_ptr()
+        blocks = [lib.salt_pack_job_blocks(ctypes.byref(j)) for j in jobs]
+        pref = np.concatenate([[0], np.cumsum(blocks)]).astype(np.int32)
+        covered = sorted(((j.w - base) // 4, j.D0 * j.D1 * j.KH * j.KW) for j in jobs)
+        rest, pos = [], 0
+        for first, cnt in covered:
+            if first % 4 or cnt % 4 or first < pos:
+                return None                              # (cannot happen for whole 32-channel chunks; plain Adam + full packs then)
+            if first > pos:
+                rest.append((pos, first - pos))
+            pos = first + cnt
+        if pos < eng.n_live:
+            rest.append((pos, eng.n_live - pos))
+        rblocks = [(c + 1023) // 1024 for _, c in rest]
+        rpref = np.concatenate([[0], np.cumsum(rblocks)]).astype(np.int32) if rest else np.zeros(1, np.int32)
+        dev = eng.device
+        self._pack_tables = [torch.frombuffer(bytearray(b''.join(bytes(j) for j in jobs)), dtype=torch.uint8).to(dev), torch.from_numpy(pref).to(dev),
+                             torch.tensor(rest if rest else [[0, 0]], dtype=torch.int64).to(dev), torch.from_numpy(rpref).to(dev)]
+        t = self._pack_tables
+        prog = Program('adam_pack')
+        prog.add('adam_tick', hyper=self.hyper.data_ptr(), step=self.step_t.data_ptr())
+        prog.add('adam_pack', param=eng.flat.data_ptr(), grad=eng.grads.data_ptr(), exp_avg=self.exp_avg.data_ptr(), exp_avg_sq=self.exp_avg_sq.data_ptr(),
+                 n=eng.n_live, hyper=self.hyper.data_ptr(), jobs=t[0].data_ptr(), job_block0=t[1].data_ptr(), njobs=len(jobs), pack_blocks=int(pref[-1]),
+                 rest=t[2].data_ptr(), rest_block0=t[3].data_ptr(), nrest=len(rest), rest_blocks=int(rpref[-1]))
+        prog.finalize()
+        self._pack_prog = prog
+        return prog
 
     def _sync_hyper(self):
         g = self.param_groups[0]
@@ -80,9 +130,12 @@ class FusedAdam(torch.optim.Optimizer):
             raise SaltError('FusedAdam needs the HipNetwork it optimises (model=...)')
         self._bind()
         self._sync_hyper()
-        self.prog.run()
+        fused = self._adam_pack_program()
+        (fused or self.prog).run()
         self.steps += 1
         self._eng.touch(weights=True, stats=False)
+        if fused is not None:
+            self._eng._adam_packed_version = self._eng.wver      # Engine.refresh: only the remaining forward packs are stale
 
     def state_dict(self):
         g = {k: v for k, v in self.param_groups[0].items() if k != 'params'}

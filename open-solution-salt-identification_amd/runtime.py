@@ -282,9 +282,24 @@ class Engine:
                 prog.add('pack_batched', jobs=table.data_ptr(), job_block0=pref_t.data_ptr(), njobs=len(sel), total_blocks=int(pref[-1]),
                          dtype=DT_CODE[self.dtype])
             return prog
-        fwd = batch([s for s, k in zip(jobs, self._pack_keys) if not self._pack_is_bwd[k]], 'pack')
+        fwd_jobs = [s for s, k in zip(jobs, self._pack_keys) if not self._pack_is_bwd[k]]
+        fwd = batch(fwd_jobs, 'pack')
         fwd.extend(others)
         fwd.finalize()
+        # the forward packs FusedAdam writes itself while it updates the weights (salt_adam_pack): vector-path jobs, one per weight, whose
+        # master lives in the flat buffer; `_pack_batched_rest` = what a refresh right behind such an optimizer step still has to run
+        lo, hi = self.flat.data_ptr(), self.flat.data_ptr() + 4 * self.n_live
+        seen, self._adam_jobs = set(), []
+        for s in fwd_jobs:
+            if lib.salt_pack_job_is_vec(ctypes.byref(s)) and lo <= s.w < hi and s.w not in seen:
+                seen.add(s.w)
+                self._adam_jobs.append(s)
+        ids = {id(s) for s in self._adam_jobs}
+        rest = batch([s for s in fwd_jobs if id(s) not in ids], 'pack_rest')
+        rest.extend(others)
+        rest.finalize()
+        self._pack_batched_rest = rest
+        self._adam_packed_version = None                 # (new / moved pack tensors: the next refresh runs every job)
         bwd = batch([s for s, k in zip(jobs, self._pack_keys) if self._pack_is_bwd[k]], 'pack_bwd')
         bwd.finalize()
         self._pack_batched, self._pack_batched_bwd = fwd, bwd
@@ -301,7 +316,8 @@ class Engine:
             self._build_pack_batch()
             self._packed_version = self._packed_bwd_version = -1
         if self._packed_version != self.wver:
-            self._pack_batched.run()
+            # the optimizer step that produced this weight version wrote the vector-path forward packs itself (FusedAdam -> salt_adam_pack)
+            (self._pack_batched_rest if getattr(self, '_adam_packed_version', None) == self.wver else self._pack_batched).run()
             self._packed_version = self.wver
         if train and not defer_bwd and self._packed_bwd_version != self.wver and len(self._pack_batched_bwd):
             # ordered after the optimizer step on the main stream; the backward program's first data-gradient joins (engine.py)
