@@ -167,8 +167,17 @@ def op_bytes(name, s, es):
     return 0.0
 
 
-PMC_FILE = 'profiles/r04_pmc_traffic.json'
-INSTEP_FILE = 'profiles/r04_instep.json'        # tools/prof_instep.py: kernel time per class INSIDE the step (rocprofv3 kernel trace)
+def _latest_profile(name):
+    """Newest committed evidence file of that kind (rounds are re-measured with tools/rNN_evidence.sh)."""
+    for tag in ('r05', 'r05a', 'r04'):
+        p = 'profiles/%s_%s' % (tag, name)
+        if os.path.exists(os.path.join(ROOT, p)):
+            return p
+    return 'profiles/r05_%s' % name
+
+
+PMC_FILE = _latest_profile('pmc_traffic.json')
+INSTEP_FILE = _latest_profile('instep.json')    # tools/prof_instep.py: kernel time per class INSIDE the step (rocprofv3 kernel trace)
 
 
 def pmc_commit():
@@ -182,7 +191,7 @@ def pmc_commit():
 def pmc_traffic(kernel):
     """HBM bytes per launch, averaged over the kernels named in the tuple `kernel`, from the committed rocprofv3 --pmc passes (PMC_FILE;
     tools/pmc_traffic.sh regenerates it - PMC counters cannot be read from inside the timed process).  None when the file is absent."""
-    for path in (os.path.join(ROOT, PMC_FILE), os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')):
+    for path in (os.path.join(ROOT, PMC_FILE), os.path.join(ROOT, 'profiles', 'r04_pmc_traffic.json')):
         try:
             ks = json.load(open(path))['kernels']
             sel = [v for k, v in ks.items() if k in kernel]

@@ -278,7 +278,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvKP& p, const TileCoord& 
         // Fast path (whole tile inside the grid, whole aligned channel pieces, no fold): 32-bit offsets, no per-piece bounds / mode
         // tests, fully unrolled so that the LDS reads and (accumulate / BatchNorm-backward) loads of all pieces are in flight together.
         // The general loop below spent ~70 instructions per 16-byte piece: the epilogue of a 9.66-GFLOP layer took 4.5 us of 19 us
-        // WITHOUT its stores (tools/k1_ablate.sh).
+        // WITHOUT its stores (round-2 variant builds: tools/build_variant.sh -DSALT_K1_DBG=n).
         const bool fast_store = SALT_K1_FAST_STORE && full_tile && !p.fold_fused && !p.strip && y_vec && (n0 + BN <= p.Cout) && p.y_small;
         if (fast_store) {
             const int pc = tid % PPO, n = n0 + pc * VE;
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvKP p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // compile-time ablations (tools/k1_ablate.sh): 1 return after the prologue, 2 no chunk loop, 4 no epilogue
+    // compile-time ablations (round-2 variant builds: tools/build_variant.sh -DSALT_K1_DBG=n): 1 return after the prologue, 2 no chunk loop, 4 no epilogue
     if (SALT_K1_DBG & 1) {
         int t = 0;
 #pragma unroll
@@ -1471,7 +1471,7 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
     if (id == 0 && v2_ok && v2_env && ((a->cfg & 0xff) == 0 || ((a->cfg & 0xff) >= 9 && (a->cfg & 0xff) <= 13))) {
         if (v2_env >= 6) id = v2_env;
         else {
-            // measured (tools/v2_sweep.sh, tools/v2_ablate.sh): the LDS-DMA kernel wins where conv_mfma_kernel's 128x32 tiles cannot
+            // measured (round-2 variant builds, DESIGN_history.md): the LDS-DMA kernel wins where conv_mfma_kernel's 128x32 tiles cannot
             // fill the chip with 64-channel tiles - the 8x8 maps (2048-3200 pixels, 512-768 channels: 24.0 -> 18.1 us) - ties on the
             // 16x16 / 32x32 maps and loses on the large maps, whose few channel chunks leave nothing to pipeline.  1 (default): the
             // few-pixel layers only; 2: + the 16x16 maps; 3: every eligible layer.

@@ -45,7 +45,7 @@
 #define SALT_LS_PREFETCH 1       // conv_ls_kernel MODE 2: the (+)= / BatchNorm-backward operand tiles of an item are requested BEFORE its chunk loop (0: in the epilogue)
 #endif
 #ifndef SALT_LS_ABLATE
-#define SALT_LS_ABLATE 0         // conv_ls_kernel timing ablations (tools/ls_ablate.sh; results are wrong): 1 no fragment reads / MFMAs, 2 no DMA, 4 no epilogue
+#define SALT_LS_ABLATE 0         // conv_ls_kernel timing ablations (SRC=conv_ws tools/build_variant.sh <name> -DSALT_LS_ABLATE=n; results are wrong): 1 no fragment reads / MFMAs, 2 no DMA, 4 no epilogue
 #endif
 #ifndef SALT_WS_CLK
 #define SALT_WS_CLK 0            // 1: per-workgroup s_memtime stamps into g_ws_clk (tools/ws_clocks.py; timing build only)

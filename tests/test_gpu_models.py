@@ -31,7 +31,7 @@ def _grad_report(net, ref_grads):
 
     Whole-network gradients are only piecewise continuous: one ReLU / max-pool decision that flips under fp32
     summation-order noise moves a conv weight gradient by ~1/sqrt(pixels) ~ 1e-3..1e-2 (torch's own fp32 result is
-    that far from its float64 result, see tools/diag_vanilla.py), so the element-wise 1e-7 agreement of the block
+    that far from its float64 result, measured in round 1), so the element-wise 1e-7 agreement of the block
     tests cannot hold here; L2 / cosine measures are the meaningful whole-net statistics."""
     eng = net.engine()
     worst, dots, n1, n2, n = (0.0, ''), 0.0, 0.0, 0.0, 0
@@ -211,7 +211,7 @@ def test_vanilla_unet_matches_oracle_c1_shape():
     from oracle import nets as ON, specs as OS, losses as OL
     # default (torch) initialisation: every BatchNorm channel is well conditioned, so fp32 gradients are comparable
     # to ~1e-5.  (The closed-form golden weights leave a few near-constant channels whose 1/sqrt(var+eps) = 316
-    # amplifies fp32 summation-order noise to ~1e-2 in torch itself: tools/diag_vanilla.py, DESIGN.md.)
+    # amplifies fp32 summation-order noise to ~1e-2 in torch itself: DESIGN.md 5.)
     net = A.VanillaUNet(2, 1, 16, 4)
     spec = OS.spec_vanilla_unet()
     assert list(spec.keys()) == list(net.state_dict().keys())
