@@ -551,6 +551,15 @@ typedef struct {
     const float* shift;
     int relu;
     double* fin_acc;          /* forward, train: [8][2 C + 1] fp64 shards (sum, sum of squares, count) of y, as salt_conv_args.fin_acc without a ticket */
+    /* forward, eval: the logit head nn.Conv2d(C, head_cout, 1) (architectures/unet.py:84-87: final = Sequential(Conv2dBnRelu, Conv2d 1x1),
+     * its only consumer) applied to the epilogue's values as they would be STORED (rounded to dtype) - salt_head1x1's arithmetic and
+     * summation order, bit-identical to running it on y.  With head_y_nchw set, y.p may be NULL: y (2 x 2.1 GB of traffic at
+     * [64,256,256,256]) is then never written or read.  C = 64, 128, 256 (bf16: also 512); head_cout 1..2. */
+    const float* head_w;      /* [head_cout][C] fp32 or NULL */
+    const float* head_b;      /* [head_cout] or NULL */
+    float* head_y_nchw;       /* fp32 [B, head_cout, H, W] */
+    int head_cout;
+    float* head_ws;           /* C > 64: fp32 workspace of B (C / 64) head_cout H W elements (per-channel-block values, joined in salt_head1x1's tree order) */
 } salt_hyper_stencil_args;
 int salt_hyper_stencil(const salt_hyper_stencil_args*, void* stream);
 

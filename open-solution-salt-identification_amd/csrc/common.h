@@ -68,6 +68,17 @@ __device__ __forceinline__ void bil_src(int d, int R, int n, int ac, int& i0, in
     lam = s - (float)i0;
 }
 
+// The logit head's per-lane dot product (salt_head1x1's vector kernels and salt_hyper_stencil's fused head): the rounding sequence is
+// PINNED - one multiply, then fused multiply-adds in channel order - so that every kernel that applies the head produces the same bits
+// (left to the compiler, one kernel got v_pk_mul + v_pk_add and the other v_fmac for the same source line).
+template <int N>
+__device__ __forceinline__ float head_dot(const float* f, const float* w) {
+    float a = __fmul_rn(f[0], w[0]);
+#pragma unroll
+    for (int j = 1; j < N; ++j) a = __fmaf_rn(f[j], w[j], a);
+    return a;
+}
+
 // Adam + L2 on four consecutive parameters (models.py:74-75,289-297: optim.Adam with weight decay in the gradient).  ONE definition for
 // adam_kernel (loss.hip) and adam_pack_kernel (conv_mfma.hip): the two must produce the same bits.
 __device__ __forceinline__ void adam4(f32x4& pp, const f32x4& gg, f32x4& mm, f32x4& vv, float b1, float b2, float eps, float wd, float gs, float step_size, float rs) {

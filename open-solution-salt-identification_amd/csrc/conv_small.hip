@@ -297,9 +297,7 @@ __global__ __launch_bounds__(256) void head1x1_vec_co_kernel(salt_view x, const 
             unpack16<T>(raw[q], f);
 #pragma unroll
             for (int o = 0; o < CO; ++o) {
-                acc[o] = 0.f;
-#pragma unroll
-                for (int j = 0; j < VE; ++j) acc[o] += f[j] * wr[o][j];     // same order as head1x1_vec_kernel: bit-identical
+                acc[o] = head_dot<VE>(f, wr[o]);                             // same pinned sequence as head1x1_vec_kernel: bit-identical
             }
 #pragma unroll
             for (int o = 0; o < CO; ++o)
@@ -339,10 +337,7 @@ __global__ void head1x1_vec_kernel(salt_view x, const float* w, const float* bia
             float f[VE];
             unpack16<T>(*reinterpret_cast<const u32x4*>((const T*)x.p + pix * x.cs + cv * VE), f);
 #pragma unroll
-            for (int o = 0; o < 4; ++o) if (o < Cout) {
-#pragma unroll
-                for (int j = 0; j < VE; ++j) acc[o] += f[j] * wr[o][j];
-            }
+            for (int o = 0; o < 4; ++o) if (o < Cout) acc[o] = head_dot<VE>(f, wr[o]);
         }
 #pragma unroll
         for (int o = 0; o < 4; ++o)

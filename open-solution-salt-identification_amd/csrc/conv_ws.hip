@@ -931,6 +931,8 @@ struct L1KP {
     const bf16_t* res; int res_cs;
     int step, IH, IW, OH, OW, tiles_x, tiles_y;   // step 2 (projection shortcuts): 16 x 16 OUTPUT-pixel tiles, input pixel = 2 x output pixel
     double* fin_acc;                              // MODE 1: train-mode BatchNorm statistics of the result (fp64 shards, salt_conv_args.fin_acc)
+    int item_major;                               // more channel blocks than workgroups per XCD (the hypercolumn's tap GEMMs, C -> 9 C): `slots` workgroups per XCD
+                                                  // walk the XCD's (pixel tile, channel block) items tile-major with stride `slots` (MODE 0, no per-channel constants)
 };
 
 // MODE 0: eval / plain epilogue; 1: + train-mode BatchNorm statistics (the projection shortcuts of a ResNet in training)
@@ -953,11 +955,14 @@ __global__ __launch_bounds__(512) void conv1x1_ls_kernel(L1KP p) {
     const int khalf = lane >> 5, l31 = lane & 31;
 
     const int xcd = blockIdx.x & 7, jwg = blockIdx.x >> 3;
-    if (jwg >= p.slots * p.n_tiles) return;
-    const int nt = jwg % p.n_tiles, slot = jwg / p.n_tiles, n0 = nt * BN;
+    const bool im = p.item_major != 0;
+    if (jwg >= (im ? p.slots : p.slots * p.n_tiles)) return;
+    const int nt = im ? 0 : jwg % p.n_tiles, slot = im ? 0 : jwg / p.n_tiles;
+    int n0 = nt * BN;                             // (item-major: set per item)
     const int t_lo = xcd * p.per_xcd;
     const int t_hi = min(t_lo + p.per_xcd, p.ntiles);
-    const int n_items = (t_lo + slot < t_hi) ? (t_hi - t_lo - slot + p.slots - 1) / p.slots : 0;
+    const int n_items = im ? (jwg < (t_hi - t_lo) * p.n_tiles ? ((t_hi - t_lo) * p.n_tiles - jwg + p.slots - 1) / p.slots : 0)
+                           : ((t_lo + slot < t_hi) ? (t_hi - t_lo - slot + p.slots - 1) / p.slots : 0);
     if (n_items <= 0) return;
     const int G = n_items * p.nsc;
     if (tid < BN) {
@@ -997,7 +1002,9 @@ __global__ __launch_bounds__(512) void conv1x1_ls_kernel(L1KP p) {
         auto issue_next = [&]() {
             const bool live = ig < G;
             const int buf = (ig % D) * CH_BYTES;
-            const long long tile = t_lo + slot + (long long)ik * p.slots;
+            long long tile = t_lo + slot + (long long)ik * p.slots;
+            int n0i = n0;
+            if (im) { const int item = jwg + ik * p.slots, q = item / p.n_tiles; tile = t_lo + q; n0i = (item - q * p.n_tiles) * BN; }
             long long pix0 = tile * 256;                                              // first input pixel of the tile (wave-uniform)
             if (p.step == 2) {
                 const int tx = (int)(tile % p.tiles_x); const long long r = tile / p.tiles_x;
@@ -1005,7 +1012,7 @@ __global__ __launch_bounds__(512) void conv1x1_ls_kernel(L1KP p) {
                 pix0 = (b * p.IH + ty * 32) * p.IW + tx * 32;
             }
             const T* xc = p.x + pix0 * p.x_cs + ic * (32 * V);
-            const T* wc = p.w + ((long long)ic * V * p.Cout + n0) * 32;
+            const T* wc = p.w + ((long long)ic * V * p.Cout + n0i) * 32;
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
                 const int pi = lw + NLW * i;
@@ -1047,7 +1054,8 @@ __global__ __launch_bounds__(512) void conv1x1_ls_kernel(L1KP p) {
             for (int j = 0; j < NI; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        const unsigned tile = (unsigned)(t_lo + slot + k * p.slots);
+        unsigned tile = (unsigned)(t_lo + slot + k * p.slots);
+        if (im) { const int item = jwg + k * p.slots, q = item / p.n_tiles; tile = (unsigned)(t_lo + q); n0 = (item - q * p.n_tiles) * BN; }
         unsigned pix[MI];
         if (p.step == 2) {
             const unsigned tx = tile % (unsigned)p.tiles_x, r = tile / (unsigned)p.tiles_x, ty = r % (unsigned)p.tiles_y, b = r / (unsigned)p.tiles_y;
@@ -1489,7 +1497,8 @@ int conv1x1_ls_variant(const salt_conv_args* a) {
     int ni = Cout % 64 == 0 ? 2 : 1;
     const int force_ni = asked ? (a->cfg >> 16) & 3 : 0;
     if (force_ni == 1 || (force_ni == 2 && Cout % 64 == 0)) ni = force_ni;
-    if (Cout / (32 * ni) > wpx) return 0;
+    // more channel blocks than workgroups per XCD: the item-major walk (plain epilogue only - no per-channel constants, no statistics)
+    if (Cout / (32 * ni) > wpx && (a->fin_acc || a->bias || a->scale || a->shift)) return 0;
     if (!asked && (npix / 256) * (Cout / (32 * ni)) < ws_cus() / 2) return 0;        // too few items to fill the chip
     return ni;
 }
@@ -1510,12 +1519,13 @@ int conv1x1_ls_launch(const salt_conv_args* a, hipStream_t st) {
     int wpx = ws_cus() / 8;
     const int cap = (a->cfg >> 8) & 0xff;
     k.n_tiles = k.Cout / (32 * ni);
-    if (cap && wpx > cap) wpx = cap > k.n_tiles ? cap : k.n_tiles;
+    k.item_major = k.n_tiles > wpx || ((a->cfg & 0xff) == 11 && ((a->cfg >> 18) & 1) && !(a->fin_acc || a->bias || a->scale || a->shift));   // (bit 18: tests walk it on small tensors)
+    if (cap && wpx > cap) wpx = (k.item_major || cap > k.n_tiles) ? cap : k.n_tiles;
     k.per_xcd = cdiv(k.ntiles, 8);
-    k.slots = wpx / k.n_tiles;
-    if (k.slots > k.per_xcd) k.slots = k.per_xcd;
+    k.slots = k.item_major ? wpx : wpx / k.n_tiles;
+    if (!k.item_major && k.slots > k.per_xcd) k.slots = k.per_xcd;
     if (k.slots < 1) k.slots = 1;
-    const int wgs = k.slots * k.n_tiles * 8;
+    const int wgs = (k.item_major ? k.slots : k.slots * k.n_tiles) * 8;
     return ni == 2 ? l1_launch<2>(k, wgs, st) : l1_launch<1>(k, wgs, st);
 }
 

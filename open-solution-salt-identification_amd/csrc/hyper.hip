@@ -40,6 +40,7 @@ struct HsKP {
     double* fin_acc;
     int tiles_x, tiles_y, cblocks, nr_max, nc_max;
     unsigned nblocks, per_xcd;
+    const float* head_w; const float* head_b; float* head_y; float* head_ws; int head_co;     // eval: the 1x1 logit head on the stored values (per channel block; head_sum_kernel joins the blocks)
 };
 
 template <typename T> __device__ __forceinline__ void ld8(const T* p, float* f);
@@ -94,36 +95,37 @@ __device__ __forceinline__ HsLevel hs_level(const HsKP& p, int l) {          // 
 // after it), stage H interpolates horizontally at the patch rows (thread = column, channel quad, every fourth row), stage V vertically
 // into the accumulators (thread = 4 rows of a column x 8 channels, a two-row register window sliding down the patch).  Two barriers
 // per round; no global latency inside a round.
-template <typename T, int NPF>
+template <typename T, int NPF, bool FH>
 __global__ __launch_bounds__(HS_NT) void hyper_stencil_fwd_kernel(HsKP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char hs_smem[];
     constexpr int VE = 16 / (int)sizeof(T), PPC = HS_CB / VE;
-    const int tid = threadIdx.x;
     // consecutive workgroup ids go round-robin over the 8 XCDs: every XCD takes a contiguous range of tiles (a level's z of the images
     // it works on stays in ITS L2)
     const unsigned lid = (blockIdx.x & 7u) * p.per_xcd + (blockIdx.x >> 3);
     if (lid >= p.nblocks) return;
     unsigned r = lid;
+    constexpr bool fh = FH;                                      // fused logit head (eval)
     const int cb = (int)(r % (unsigned)p.cblocks); r /= (unsigned)p.cblocks;
     const int tx = (int)(r % (unsigned)p.tiles_x); r /= (unsigned)p.tiles_x;
     const int ty = (int)(r % (unsigned)p.tiles_y);
     const int b = (int)(r / (unsigned)p.tiles_y);
-    const int Y0 = ty * HS_TH, X0 = tx * HS_TW, c0 = cb * HS_CB;
-    const int cbn = min(HS_CB, p.C - c0);
+    const int Y0 = ty * HS_TH, X0 = tx * HS_TW;
 
     const size_t hbuf_bytes = (size_t)p.nr_max * HS_TW * HS_CB * 4, zp_bytes = (size_t)p.nr_max * p.nc_max * 3 * HS_CB * 4;
     float* hbuf = reinterpret_cast<float*>(hs_smem);                                            // [nr_max][HS_TW][HS_CB] fp32
     float* zp = reinterpret_cast<float*>(hs_smem + hbuf_bytes);                                 // [nr][nc][3][HS_CB] fp32 (converted once, at the store: stage H reads every element ~5 times)
     HsCoef* tabs = reinterpret_cast<HsCoef*>(hs_smem + hbuf_bytes + zp_bytes);                  // [2 parities][rows HS_TH + 2 | columns HS_TW + 2]
     constexpr int TABN = HS_TH + 2 + HS_TW + 2;
-
+    float* hwl = reinterpret_cast<float*>(tabs + 2 * TABN);                                     // fused head: the block's weights [2][HS_CB] (global latency off the epilogue)
+    const int tid = threadIdx.x;
     // stage V / epilogue role: HS_VR rows (HS_VR vq ..) of column vx, channels 8 cp8 .. 8 cp8 + 7
     const int cp8 = tid & 7, vx = (tid >> 3) & (HS_TW - 1), vq = tid >> (3 + HS_TWL);
     // stage H role: column hx, channel quad cq, patch rows hi, hi + HS_NT / (16 HS_TW), ..
     const int hx = (tid >> 4) & (HS_TW - 1), cq = tid & 15, hi = tid >> (4 + HS_TWL);
-    const bool cok = cp8 * 8 < cbn;
     const int X = X0 + vx;
-
+    const int c0 = cb * HS_CB;
+    const int cbn = min(HS_CB, p.C - c0);
+    const bool cok = cp8 * 8 < cbn;
     float acc[HS_VR][8];
 #pragma unroll
     for (int k = 0; k < HS_VR; ++k) {
@@ -186,12 +188,20 @@ __global__ __launch_bounds__(HS_NT) void hyper_stencil_fwd_kernel(HsKP p) {
             }
     };
 
+    float hwv = 0.f;                                           // fused head: this thread's weight, parked in LDS behind the first patch (one global latency, not two)
+    if constexpr (FH) {
+        if (tid >= 256 && tid < 256 + 2 * HS_CB) {
+            const int o = (tid - 256) / HS_CB, n = (tid - 256) % HS_CB;
+            if (o < p.head_co && n < cbn) hwv = p.head_w[o * p.C + c0 + n];
+        }
+    }
     const int nrounds = 3 * p.nlev;
     level_setup(0);
     int nr = G.nr, nc = G.nc;                                  // geometry of the round being COMPUTED (G runs one round ahead)
     tables_write(0);
     pf_issue(0);
     pf_store();
+    if constexpr (FH) { if (tid >= 256 && tid < 256 + 2 * HS_CB) hwl[tid - 256] = hwv; }
     __syncthreads();
 #pragma unroll 1
     for (int rr = 0; rr < nrounds; ++rr) {
@@ -278,11 +288,48 @@ __global__ __launch_bounds__(HS_NT) void hyper_stencil_fwd_kernel(HsKP p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[k][e] = fmaxf(acc[k][e], 0.f);
         }
-        st8<T>(reinterpret_cast<T*>(p.y) + (((int64_t)b * p.H + Y) * p.W + X) * p.y_cs + c0 + cp8 * 8, acc[k]);
+        if (p.y) st8<T>(reinterpret_cast<T*>(p.y) + (((int64_t)b * p.H + Y) * p.W + X) * p.y_cs + c0 + cp8 * 8, acc[k]);
+        if constexpr (!FH) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { s8[e] += acc[k][e]; q8[e] += acc[k][e] * acc[k][e]; }
+            for (int e = 0; e < 8; ++e) { s8[e] += acc[k][e]; q8[e] += acc[k][e] * acc[k][e]; }
+        }
     }
-    if (p.fin_acc) {
+    if constexpr (FH) {
+        // salt_head1x1 on the values as stored (head1x1_vec_co_kernel: a lane's channels in order, then a butterfly over the lanes of a
+        // pixel - here its steps inside the 64-channel block; the steps across channel blocks are head_sum_kernel's, in the same tree order).
+        // The loop's last barrier has passed: hbuf is free and stages the block's [class][HS_TH x HS_TW] values for row-wise stores.
+#pragma unroll 1
+        for (int o = 0; o < p.head_co; ++o) {
+            float hw[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) hw[e] = hwl[o * HS_CB + cp8 * 8 + e];
+#pragma unroll
+            for (int k = 0; k < HS_VR; ++k) {
+                float fv[8];
+                if constexpr (sizeof(T) == 2) { const u32x4 pk = pack16<bf16_t>(acc[k]); unpack16<bf16_t>(pk, fv); }
+                else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) fv[e] = acc[k][e];
+                }
+                float pl;
+                if constexpr (sizeof(T) == 2) pl = head_dot<8>(fv, hw);                          // head1x1's lane = 8 bf16 channels ..
+                else pl = __fadd_rn(head_dot<4>(fv, hw), head_dot<4>(fv + 4, hw + 4));            // .. or 4 fp32 channels, two lanes joined by its first butterfly step
+                if (!cok) pl = 0.f;
+#pragma unroll
+                for (int sft = 1; sft < 8; sft <<= 1) pl += __shfl_xor(pl, sft);
+                if (cp8 == 0) hbuf[o * (HS_TH * HS_TW) + (HS_VR * vq + k) * HS_TW + vx] = pl;
+            }
+        }
+        __syncthreads();
+        const int o = tid >> 9, pix = tid & (HS_TH * HS_TW - 1);
+        const int Y = Y0 + (pix >> HS_TWL), Xo = X0 + (pix & (HS_TW - 1));
+        if (o < p.head_co && Y < p.H && Xo < p.W) {
+            const float v = hbuf[o * (HS_TH * HS_TW) + pix];
+            if (p.cblocks == 1) p.head_y[(((int64_t)b * p.head_co + o) * p.H + Y) * p.W + Xo] = v + (p.head_b ? p.head_b[o] : 0.f);
+            else p.head_ws[((((int64_t)b * p.cblocks + cb) * p.head_co + o) * p.H + Y) * p.W + Xo] = v;
+        }
+    }
+    if (!FH && p.fin_acc) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
 #pragma unroll
@@ -309,6 +356,22 @@ __global__ __launch_bounds__(HS_NT) void hyper_stencil_fwd_kernel(HsKP p) {
             }
         }
     }
+}
+
+// The fused head's butterfly steps ACROSS channel blocks (head1x1's lane distance 8, 16, 32: block c takes block c ^ 1, the pair takes
+// the pair c ^ 2, ..) + bias: logits [B, co, H, W] from the per-block values [B, blocks, co, H, W] hyper_stencil_fwd_kernel<.., true> left.
+__global__ __launch_bounds__(256) void head_sum_kernel(const float* __restrict__ ws, const float* __restrict__ bias, float* __restrict__ y, int nblk, int co, int64_t hw, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;          // (b, o, pixel)
+    if (i >= total) return;
+    const int64_t bo = i / hw, px = i - bo * hw, b = bo / co;
+    const int o = (int)(bo - b * co);
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = c < nblk ? ws[((b * nblk + c) * co + o) * hw + px] : 0.f;
+    if (nblk > 1) { v[0] += v[1]; v[2] += v[3]; v[4] += v[5]; v[6] += v[7]; }
+    if (nblk > 2) { v[0] += v[2]; v[4] += v[6]; }
+    if (nblk > 4) v[0] += v[4];
+    y[i] = v[0] + (bias ? bias[o] : 0.f);
 }
 
 // ------------------------------------------------------------------------------------------ adjoint
@@ -522,7 +585,19 @@ __global__ __launch_bounds__(HB_NT) void hyper_stencil_bwd_kernel(HsbKP p) {
 }
 
 static int hs_check(const salt_hyper_stencil_args* a) {
-    if (!a || a->nlev < 1 || a->nlev > 4 || !view_ok(a->y)) SALT_FAIL(SALT_E_BADARG, "hyper_stencil: bad args");
+    if (!a || a->nlev < 1 || a->nlev > 4) SALT_FAIL(SALT_E_BADARG, "hyper_stencil: bad args");
+    {
+        salt_view yv = a->y;
+        if (!yv.p && a->head_y_nchw && !a->backward) yv.p = const_cast<float*>(a->head_w);      // (the fused head may drop y: only its shape is used)
+        if (!view_ok(yv)) SALT_FAIL(SALT_E_BADARG, "hyper_stencil: bad y view");
+    }
+    if (a->head_y_nchw) {
+        const int ncb = (a->y.C + 63) / 64;
+        // (the shapes salt_head1x1's vector kernels take: C a power of two, at most 64 lanes of 16 bytes per pixel - their summation tree is the one reproduced)
+        if (a->backward || a->fin_acc || !a->head_w || a->head_cout < 1 || a->head_cout > 2 || a->y.C % 64 || (ncb != 1 && ncb != 2 && ncb != 4 && ncb != 8) ||
+            a->y.C > (a->dtype == SALT_F32 ? 256 : 512) || (ncb > 1 && !a->head_ws))
+            SALT_FAIL(SALT_E_UNSUPPORTED, "hyper_stencil: the fused head is an eval-mode epilogue for head_cout 1..2 and C = 64, 128, 256 (bf16: 512)");
+    }
     const int es = a->dtype == SALT_F32 ? 4 : 2;
     if (a->dtype != SALT_F32 && a->dtype != SALT_BF16) SALT_FAIL(SALT_E_BADARG, "hyper_stencil: dtype %d", a->dtype);
     const salt_view& y = a->y;
@@ -565,15 +640,17 @@ extern "C" int salt_hyper_stencil(const salt_hyper_stencil_args* a, void* stream
         p.scale = a->scale; p.shift = a->shift; p.relu = a->relu; p.fin_acc = a->fin_acc;
         if ((a->scale == nullptr) != (a->shift == nullptr)) SALT_FAIL(SALT_E_BADARG, "hyper_stencil: scale and shift come together");
         p.tiles_x = cdiv(y.W, HS_TW); p.tiles_y = cdiv(y.H, HS_TH); p.cblocks = cdiv(y.C, HS_CB); p.nr_max = nr_max; p.nc_max = nc_max;
+        p.head_w = a->head_w; p.head_b = a->head_b; p.head_y = a->head_y_nchw; p.head_co = a->head_cout;
+        p.head_ws = a->head_ws;
         const int64_t nb = (int64_t)y.B * p.tiles_x * p.tiles_y * p.cblocks;
         if (nb >= (1LL << 30)) SALT_FAIL(SALT_E_UNSUPPORTED, "hyper_stencil: too many tiles");
         p.nblocks = (unsigned)nb; p.per_xcd = (unsigned)((nb + 7) / 8);
-        const size_t lds = (size_t)nr_max * HS_TW * HS_CB * 4 + (size_t)nr_max * nc_max * 3 * HS_CB * 4 + 2 * (HS_TH + 2 + HS_TW + 2) * sizeof(HsCoef);
+        const size_t lds = (size_t)nr_max * HS_TW * HS_CB * 4 + (size_t)nr_max * nc_max * 3 * HS_CB * 4 + 2 * (HS_TH + 2 + HS_TW + 2) * sizeof(HsCoef) + 2 * HS_CB * 4;
         if (lds > 160 * 1024) SALT_FAIL(SALT_E_LDS, "hyper_stencil: needs %zu bytes of LDS", lds);
         const int npf = cdiv(nr_max * nc_max * 3 * (HS_CB * (int)es / 16), HS_NT);      // 16-byte pieces of a round per thread
         void (*kern)(HsKP) = nullptr;
-        if (a->dtype == SALT_F32) kern = npf <= 4 ? hyper_stencil_fwd_kernel<float, 4> : nullptr;
-        else kern = npf <= 2 ? hyper_stencil_fwd_kernel<bf16_t, 2> : nullptr;
+        if (a->dtype == SALT_F32) kern = npf <= 4 ? (p.head_y ? hyper_stencil_fwd_kernel<float, 4, true> : hyper_stencil_fwd_kernel<float, 4, false>) : nullptr;
+        else kern = npf <= 2 ? (p.head_y ? hyper_stencil_fwd_kernel<bf16_t, 2, true> : hyper_stencil_fwd_kernel<bf16_t, 2, false>) : nullptr;
         if (!kern) SALT_FAIL(SALT_E_UNSUPPORTED, "hyper_stencil: %d pieces per thread", npf);
         if (lds > 64 * 1024) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -581,6 +658,11 @@ extern "C" int salt_hyper_stencil(const salt_hyper_stencil_args* a, void* stream
         }
         hipLaunchKernelGGL(kern, dim3(p.per_xcd * 8), dim3(HS_NT), lds, st, p);
         SALT_CHECK_LAUNCH();
+        if (p.head_y && p.cblocks > 1) {
+            const int64_t hw = (int64_t)y.H * y.W, total = (int64_t)y.B * p.head_co * hw;
+            hipLaunchKernelGGL(head_sum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p.head_ws, p.head_b, p.head_y, p.cblocks, p.head_co, hw, total);
+            SALT_CHECK_LAUNCH();
+        }
         return SALT_OK;
     }
     if (a->scale || a->fin_acc) SALT_FAIL(SALT_E_BADARG, "hyper_stencil: the adjoint has no epilogue");

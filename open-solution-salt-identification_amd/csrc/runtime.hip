@@ -20,7 +20,7 @@ void salt_set_error(const char* fmt, ...) {
 
 extern "C" const char* salt_last_error(void) { return g_err; }
 
-extern "C" int salt_abi_version(void) { return 22; }
+extern "C" int salt_abi_version(void) { return 23; }
 
 extern "C" int salt_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name_len) {
     int dev = 0;

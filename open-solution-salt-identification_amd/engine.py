@@ -745,6 +745,13 @@ class Graph:
             return False                                # the transposed tap-GEMM pack places whole chunks
         return all(R >= 4 and R & (R - 1) == 0 and R <= 32 and H % R == 0 and W % R == 0 for R in Rs)
 
+    def hyper_head_ok(self, C, hconv):
+        """Can salt_hyper_stencil's epilogue apply the logit head ``hconv`` (eval; saltnet.h: 1..2 classes, 1 / 2 / 4 / 8 channel blocks)?"""
+        if self.train or os.environ.get('SALT_HYPER_HEAD', '1') == '0':
+            return False
+        co, ci, kh, kw = hconv.weight.shape
+        return (kh, kw) == (1, 1) and ci == C and 1 <= co <= 2 and C in ((64, 128, 256) if self.dtype == 'f32' else (64, 128, 256, 512))
+
     def hyper_level(self, x, conv, c0, name='hyper.z'):
         """z = [W[:, c0 : c0 + x.C, kh, kw]]_taps x  at x's (LOW) resolution: one 1x1 convolution x.C -> 9 Cout whose output channel
         t Cout + o is tap t of output channel o of the 3x3 convolution ``conv`` restricted to the input channels of this level.
@@ -757,7 +764,9 @@ class Graph:
         z = self.new_act(x.B, x.H, x.W, len(taps) * Cout, name)
         # cfg 11 | 1 << 16: ask for conv1x1_ls_kernel with 32-channel items wherever it applies - the heuristic sends these few-pixel
         # launches to conv_mfma_kernel's 128 x 32 tiles (a serial chain of K / 32 staged chunks per workgroup: 30 us for 0.15 GFLOP)
-        ask = 11 | (1 << 16)
+        # (with thousands of 64-channel items - the 256 x 256 inference shapes - 64-channel items halve the re-reads of x instead)
+        items64 = (x.B * x.H * x.W // 256) * (len(taps) * Cout // 64)
+        ask = 11 | ((1 << 16) if items64 < 2048 else 0)
         self._conv_launch(self.fwd, x.view(), pk.data_ptr(), [(0, 0)], 1, 0, z.view(), x.H, x.W, cfg=ask)
         z.on_side = self.fwd.default_stream == 1
         if self.train:
@@ -773,10 +782,13 @@ class Graph:
             self.tape.append(backward)
         return z
 
-    def conv_hyper(self, x, zs, Rs, conv, bn, relu=True, out=None, name='final'):
+    def conv_hyper(self, x, zs, Rs, conv, bn, relu=True, out=None, name='final', head=None):
         """Conv2dBnRelu over the hypercolumn (architectures/unet.py:84-87,101-109; base.py:21-37) with the levels of ``zs`` factored out:
         y = conv3x3_replicate(x; W[:, :x.C]) + bias, then salt_hyper_stencil adds sum_k stencil_k(z_k) (and takes the BatchNorm
-        statistics of the sum in training / applies the folded BatchNorm + ReLU in eval); x holds the full-resolution channels only."""
+        statistics of the sum in training / applies the folded BatchNorm + ReLU in eval); x holds the full-resolution channels only.
+        ``head`` = (nn.Conv2d(Cout, classes, 1), fp32 NCHW logits), eval only: the block's only consumer in the reference's ``final``
+        Sequential (architectures/unet.py:84-87) is applied by the stencil's epilogue (salt_hyper_stencil_args.head_*; same values as
+        salt_head1x1 on the stored activation, which is then never written) and None is returned."""
         eng = self.engine
         Cout, Cin, KH, KW = conv.weight.shape
         assert (KH, KW) == (3, 3) and bn is not None and x.C <= Cin and all(z.C == 9 * Cout for z in zs)
@@ -786,7 +798,9 @@ class Graph:
         d1 = (0, x.C)
         pk = eng.packed(conv, tk, transposed=False, d1=d1)
         bias = conv.bias.data_ptr() if conv.bias is not None else None
-        if out is None:
+        if head is not None and (self.train or not self.hyper_head_ok(Cout, head[0])):
+            raise SaltError('conv_hyper: the fused head is an eval-mode epilogue (ask hyper_head_ok first)')
+        if out is None and head is None:
             out = self.new_act(x.B, x.H, x.W, Cout, name)
         ac = int(bool(getattr(getattr(self.engine, 'module', None), 'align_corners', False)))
         y = self.new_act(x.B, x.H, x.W, Cout, name + '.y')
@@ -797,6 +811,16 @@ class Graph:
         if self.train:
             prod = self.fwd.add('hyper_stencil', y=y.view(), **st)
             w = self._bn_train_fwd(y, bn, relu, None, out, 0, None, None, producer=prod)
+        elif head is not None:
+            w = eng.bn_work(bn)
+            hconv, logits = head
+            yv = y.view()
+            yv.p = None                                  # shape only: the activated block output is never stored
+            self.fwd.add('hyper_stencil', y=yv, scale=w['scale'].data_ptr(), shift=w['shift'].data_ptr(), relu=int(relu),
+                         head_w=hconv.weight.data_ptr(), head_b=hconv.bias.data_ptr() if hconv.bias is not None else None,
+                         head_y_nchw=logits.data_ptr(), head_cout=hconv.weight.shape[0],
+                         head_ws=self.alloc((x.B * (Cout // 64) * hconv.weight.shape[0] * x.H * x.W,), torch.float32).data_ptr() if Cout > 64 else None, **st)
+            return None
         else:
             w = eng.bn_work(bn)
             self.fwd.add('hyper_stencil', y=out.view(), scale=w['scale'].data_ptr(), shift=w['shift'].data_ptr(), relu=int(relu), **st)

@@ -86,6 +86,34 @@ def test_conv1x1_ls_vs_torch_and_conv_mfma(case):
     assert d <= 8e-3, d                                                     # same products, same bf16 rounding points: at most one ulp apart
 
 
+CASES_ITEM_MAJOR = [
+    # (case, extra cfg bits): more channel blocks than workgroups per XCD - the hypercolumn's tap GEMMs C -> 9 C (engine.hyper_level) -
+    # walk (pixel tile, channel block) items tile-major; bit 18 asks for that walk on small tensors, bit 16 for 32-channel items
+    ((2, 16, 16, 256, 2304, False, False, False, 0, 0), 0),               # 36 blocks of 64 channels > 32 workgroups per XCD
+    ((2, 16, 16, 256, 2304, False, False, False, 0, 0), 1 << 16),         # 72 blocks of 32
+    ((8, 16, 16, 64, 192, True, False, False, 0, 3), 1 << 18),            # residual, 3 workgroups per XCD
+    ((4, 16, 16, 128, 576, False, False, True, 32, 5), (1 << 18) | (1 << 16)),   # (+)=, strided views, a ragged last round of items
+    ((16, 16, 16, 64, 64, False, False, False, 0, 7), 1 << 18),           # ONE channel block, items = tiles
+]
+
+
+@pytest.mark.parametrize('case,bits', CASES_ITEM_MAJOR)
+def test_conv1x1_ls_item_major_walk_vs_torch_and_conv_mfma(case, bits):
+    y, ref, kid, y0 = _conv1x1(case, 11 | bits)
+    assert kid == 11, kid
+    Cout, slack = case[4], case[8]
+    got = y[..., :Cout]
+    assert torch.isfinite(got).all()
+    err = float((got - ref).abs().max() / ref.abs().max())
+    assert err <= 1e-2, err
+    if slack:
+        assert torch.equal(y[..., Cout:], y0[..., Cout:])
+    y1, _, kid1, _ = _conv1x1(case, 1)
+    assert kid1 == 1
+    d = float((y1[..., :Cout] - got).abs().max() / ref.abs().max())
+    assert d <= 8e-3, d
+
+
 def test_conv1x1_ls_is_picked_for_the_bottleneck_shapes():
     """Without a request the plan hands the big eval-mode 1x1 launches (enough items for the chip) to the streaming kernel and keeps
     the rest on conv_mfma_kernel."""

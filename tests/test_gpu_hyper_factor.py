@@ -50,6 +50,84 @@ def _nhwc_taps(z):
     return z.permute(0, 3, 4, 1, 2).reshape(B, h, w, T9 * C).contiguous()
 
 
+HEAD_CASES = [
+    # B, C, H, W, levels, classes
+    (2, 64, 32, 48, (4, 8, 16), 2),       # the ResNet34 model's width: one channel block
+    (1, 256, 40, 36, (4,), 2),            # ResNet101 / 152: four channel blocks (three butterfly steps across them), partial pixel tiles
+    (1, 128, 64, 32, (16, 4), 1),         # two blocks, one class
+    (1, 512, 16, 16, (4, 8), 2),          # eight blocks
+]
+
+
+@pytest.mark.parametrize('case', HEAD_CASES)
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_stencil_fused_logit_head_is_bit_identical_to_stencil_then_head1x1(case, dtype):
+    """Eval: final = Sequential(Conv2dBnRelu, Conv2d(C, classes, 1)) (architectures/unet.py:84-87).  salt_hyper_stencil's epilogue applies
+    the 1x1 head to the values it would store; the logits must equal salt_head1x1 on the stored activation bit for bit (same products,
+    same summation tree), with and without y being written."""
+    abi = _abi()
+    B, C, H, W, Rs, CO = case
+    if dtype == 'f32' and C > 256:
+        pytest.skip('fp32: salt_head1x1 leaves its vector kernels above 64 lanes per pixel')
+    tdt = torch.float32 if dtype == 'f32' else torch.bfloat16
+    dt = 0 if dtype == 'f32' else 1
+    g = torch.Generator().manual_seed(7 + C)
+    zd = [_nhwc_taps(torch.randn(B, 9, C, H // R, W // R, generator=g)).to(DEV, tdt) for R in Rs]
+    yi = torch.randn(B, H, W, C, generator=g).to(DEV, tdt)
+    sc, sh = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
+    hw, hb = (torch.randn(CO, C, generator=g) * C ** -0.5).to(DEV), torch.randn(CO, generator=g).to(DEV)
+    # unfused: stencil (eval epilogue) -> y, then salt_head1x1
+    y = torch.zeros_like(yi)
+    S = abi.STRUCTS['salt_hyper_stencil_args']()
+    abi.fill(S, dtype=dt, nlev=len(Rs), z=[_view(z) for z in zd], R=list(Rs), y_in=_view(yi), y=_view(y), backward=0, align_corners=0,
+             scale=sc.data_ptr(), shift=sh.data_ptr(), relu=1)
+    abi.check(abi.lib.salt_hyper_stencil(ctypes.byref(S), None), 'hyper_stencil')
+    ref = torch.full((B, CO, H, W), float('nan'), device=DEV)
+    Hd = abi.STRUCTS['salt_head1x1_args']()
+    from salt_amd.engine import null_view
+    abi.fill(Hd, dtype=dt, x=_view(y), w=hw.data_ptr(), bias=hb.data_ptr(), Cout=CO, y_nchw=ref.data_ptr(), y=null_view())
+    abi.check(abi.lib.salt_head1x1(ctypes.byref(Hd), None), 'head1x1')
+    # fused, y written too
+    y2 = torch.zeros_like(yi)
+    got = torch.full((B, CO, H, W), float('nan'), device=DEV)
+    ws = torch.full((B * (C // 64) * CO * H * W,), float('nan'), device=DEV)
+    abi.fill(S, y=_view(y2), head_w=hw.data_ptr(), head_b=hb.data_ptr(), head_y_nchw=got.data_ptr(), head_cout=CO, head_ws=ws.data_ptr() if C > 64 else None)
+    abi.check(abi.lib.salt_hyper_stencil(ctypes.byref(S), None), 'hyper_stencil + head')
+    torch.cuda.synchronize()
+    assert torch.equal(y2, y)
+    assert torch.isfinite(ref).all()
+    assert torch.equal(got, ref), float((got - ref).abs().max())
+    # fused, y dropped (shape-only view)
+    got2 = torch.full((B, CO, H, W), float('nan'), device=DEV)
+    yv = _view(y2)
+    yv.p = None
+    abi.fill(S, y=yv, head_y_nchw=got2.data_ptr())
+    abi.check(abi.lib.salt_hyper_stencil(ctypes.byref(S), None), 'hyper_stencil + head, no y')
+    torch.cuda.synchronize()
+    assert torch.equal(got2, ref)
+    # and against torch on the stored activation
+    want = torch.einsum('bhwc,oc->bohw', y.float().cpu(), hw.cpu()) + hb.cpu().view(1, CO, 1, 1)
+    assert_close(got.cpu(), want, 2e-5, 'fused head vs torch')
+
+
+def test_stencil_fused_head_refuses_what_it_cannot_do():
+    abi = _abi()
+    y = torch.zeros(1, 16, 16, 192, device=DEV)          # three channel blocks: the butterfly across blocks needs a power of two
+    z = torch.zeros(1, 4, 4, 9 * 192, device=DEV)
+    lg = torch.zeros(1, 2, 16, 16, device=DEV)
+    w = torch.zeros(2, 192, device=DEV)
+    S = abi.STRUCTS['salt_hyper_stencil_args']()
+    ws = torch.zeros(3 * 2 * 256, device=DEV)
+    abi.fill(S, dtype=0, nlev=1, z=[_view(z)], R=[4], y_in=_view(y), y=_view(y), backward=0, align_corners=0, head_w=w.data_ptr(),
+             head_y_nchw=lg.data_ptr(), head_cout=2, head_ws=ws.data_ptr())
+    assert abi.lib.salt_hyper_stencil(ctypes.byref(S), None) != 0
+    y = torch.zeros(1, 16, 16, 64, device=DEV)
+    z = torch.zeros(1, 4, 4, 9 * 64, device=DEV)
+    acc = torch.zeros(8 * 129, dtype=torch.float64, device=DEV)
+    abi.fill(S, z=[_view(z)], y_in=_view(y), y=_view(y), fin_acc=acc.data_ptr())       # train-mode statistics + head: no
+    assert abi.lib.salt_hyper_stencil(ctypes.byref(S), None) != 0
+
+
 STENCIL_CASES = [
     # B, C, H, W, levels
     (2, 64, 32, 48, (4, 8, 16)),
