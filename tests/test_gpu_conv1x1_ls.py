@@ -114,6 +114,35 @@ def test_conv1x1_ls_item_major_walk_vs_torch_and_conv_mfma(case, bits):
     assert d <= 8e-3, d
 
 
+CASES_XS = [
+    # conv1x1_xs_kernel (cfg bit 19): the input tile stays in LDS, the workgroup walks every 64-channel block of it
+    (2, 16, 16, 256, 2304, False, False, False, 0, 0),       # the C4 tap GEMM's channel counts: 4 chunks, 36 blocks, one tile per workgroup
+    (16, 16, 16, 128, 576, False, False, False, 0, 1),       # 8 workgroups, two tiles each: the tile buffer is fenced and refilled
+    (24, 16, 16, 64, 192, False, False, False, 0, 1),        # three tiles each, one chunk
+    (4, 16, 16, 192, 320, False, False, False, 64, 0),       # strided views, 3 chunks, 5 blocks
+]
+
+
+@pytest.mark.parametrize('case', CASES_XS)
+def test_conv1x1_xs_vs_torch_and_conv_mfma(case):
+    y, ref, kid, y0 = _conv1x1(case, 11 | (1 << 19))
+    assert kid == 11, kid
+    Cout, slack = case[4], case[8]
+    got = y[..., :Cout]
+    assert torch.isfinite(got).all()
+    err = float((got - ref).abs().max() / ref.abs().max())
+    assert err <= 1e-2, err
+    if slack:
+        assert torch.equal(y[..., Cout:], y0[..., Cout:])
+    y1, _, kid1, _ = _conv1x1(case, 1)
+    assert kid1 == 1
+    d = float((y1[..., :Cout] - got).abs().max() / ref.abs().max())
+    assert d <= 8e-3, d
+    # and the streaming kernel's result for the same launch, bit for bit (same MFMA sequence per output, same rounding)
+    y2, _, _, _ = _conv1x1(case, 11)
+    assert torch.equal(y2[..., :Cout], got)
+
+
 def test_conv1x1_ls_is_picked_for_the_bottleneck_shapes():
     """Without a request the plan hands the big eval-mode 1x1 launches (enough items for the chip) to the streaming kernel and keeps
     the rest on conv_mfma_kernel."""
