@@ -39,10 +39,16 @@ cp $O/pmc_traffic_${tag}.json $O/${tag}_pmc_traffic.json
 python tools/op_profile.py --top 400 > $O/${tag}_c2_ops.txt 2>/dev/null
 python tools/c4_ops.py --top 60 > $O/${tag}_c4_ops.txt 2>/dev/null
 python tools/dp_overhead.py 30 > $O/${tag}_dp_overhead.json 2>/dev/null
-{ python tools/hyper_bench.py; python tools/hyper_bench.py --c4; } 2>&1 | grep -v amdgpu > $O/${tag}_hyper_bench.txt
+{ python tools/hyper_bench.py; python tools/hyper_bench.py --c4; python tools/hyper_bench.py --eval; python tools/hyper_bench.py --c4 --eval; } 2>&1 | grep -v amdgpu > $O/${tag}_hyper_bench.txt
 for rep in 1 2; do for f in 4 0; do
   echo "== SALT_HYPER_FACTOR=$f"
   SALT_HYPER_FACTOR=$f python bench.py --steps 40 --warmup 10 --no-cpu-baseline --no-iou --no-configs 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('C2', d['value'], d['ms_per_step'])"
   SALT_HYPER_FACTOR=$f python tools/bench_c4.py 2>/dev/null | cut -c1-220
 done; done > $O/${tag}_hyper_ab.txt 2>&1
+# C4 only: the logit head in the stencil's epilogue, the x-stationary tap GEMM (alternated, 3 rounds)
+for rep in 1 2 3; do
+  for v in "SALT_HYPER_HEAD=1 SALT_CONV_1X1_XS=1" "SALT_HYPER_HEAD=0 SALT_CONV_1X1_XS=1" "SALT_HYPER_HEAD=1 SALT_CONV_1X1_XS=0"; do
+    echo "== $v"; env $v python tools/bench_c4.py 2>/dev/null | cut -c1-220
+  done
+done > $O/${tag}_c4_ab.txt 2>&1
 ls $O | grep "^${tag}_"
