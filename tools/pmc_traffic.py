@@ -20,7 +20,7 @@ def per_kernel(path, counter):
          "join %s s on d.kernel_id=s.id where p.name='%s' group by d.id order by d.start" % (pe, pi, kd, ks, counter))
     rows = list(c.execute(q))
     # keep the dispatches of complete optimizer steps after the first Adam launch (skips warm-up compile / first-touch effects)
-    marks = [i for i, r in enumerate(rows) if 'adam_kernel' in r[0]]
+    marks = [i for i, r in enumerate(rows) if ('adam_kernel' in r[0] or 'adam_pack_kernel' in r[0])]
     ntrain = int(os.environ.get('SALT_PMC_TRAIN_STEPS', '0'))          # warm-up + timed steps of the profiled run: what follows is not a training step
     if ntrain:
         marks = marks[:ntrain]
@@ -31,8 +31,8 @@ def per_kernel(path, counter):
         k = name.replace('_ZN12_GLOBAL__N_1', '').replace('.kd', '')
         if 'conv_wgrad' in k:                     # every weight-gradient kernel (conv_wgrad_ls_kernel, the fast / generic ones) is one class
             k = 'conv_wgrad_kernel'
-        for base in ('conv_ws_kernel', 'conv1x1_ls_kernel', 'conv_ls_kernel', 'conv_thin_kernel', 'conv_mfma_kernel', 'conv_glds_kernel', 'conv_wgrad_kernel', 'bn_bwd_reduce', 'bn_bwd_apply', 'bn_bwd_finalize', 'bn_finalize', 'affine_act',
-                     'wgrad_reduce', 'adam_kernel', 'pad_fold', 'lovasz', 'bilinear_fwd', 'bilinear_bwd', 'pack_batched', 'head1x1', 'scse', 'se_'):
+        for base in ('conv_ws_kernel', 'conv1x1_ls_kernel', 'conv1x1_xs_kernel', 'conv_ls_kernel', 'conv_thin_kernel', 'conv_mfma_kernel', 'conv_glds_kernel', 'conv_wgrad_kernel', 'bn_bwd_reduce', 'bn_bwd_apply', 'bn_bwd_finalize', 'bn_finalize', 'affine_act',
+                     'wgrad_reduce', 'adam_kernel', 'adam_pack_kernel', 'hyper_stencil', 'pad_fold', 'lovasz', 'bilinear_fwd', 'bilinear_bwd', 'pack_batched', 'head1x1', 'scse', 'se_'):
             if base in k:
                 k = base
                 break

@@ -9,7 +9,7 @@ from collections import defaultdict
 
 CLASSES = [('conv_wgrad', ('conv_wgrad',)), ('conv', ('conv_ws_kernel', 'conv_ls_kernel', 'conv1x1_ls_kernel', 'conv_thin_kernel', 'conv_mfma_kernel', 'conv_glds_kernel')),
            ('wgrad_reduce', ('wgrad_reduce',)), ('bn_bwd', ('bn_bwd',)), ('affine_act', ('affine_act',)), ('bilinear', ('bilinear',)),
-           ('scse', ('scse', 'se_fc', 'gap_partial')), ('lovasz', ('lovasz',)), ('adam', ('adam_kernel',)), ('pack', ('pack_batched',)),
+           ('scse', ('scse', 'se_fc', 'gap_partial')), ('lovasz', ('lovasz',)), ('adam', ('adam_kernel', 'adam_pack_kernel')), ('pack', ('pack_batched',)),
            ('head', ('head1x1',)), ('hyper_stencil', ('hyper_stencil',))]
 
 
@@ -19,7 +19,7 @@ def main(path, skip, ntrain, commit):
     kd = [x for x in t if 'kernel_dispatch' in x][0]
     ks = [x for x in t if 'kernel_symbol' in x][0]
     rows = list(c.execute("select s.kernel_name, d.start, d.end from %s d join %s s on d.kernel_id=s.id order by d.start" % (kd, ks)))
-    marks = [i for i, r in enumerate(rows) if 'adam_kernel' in r[0]][:ntrain]
+    marks = [i for i, r in enumerate(rows) if ('adam_kernel' in r[0] or 'adam_pack_kernel' in r[0])][:ntrain]
     steps = [(marks[i] + 1, marks[i + 1] + 1) for i in range(skip, len(marks) - 1)]
     n = len(steps)
     agg = defaultdict(lambda: [0, 0.0])

@@ -11,7 +11,7 @@ def main(path, which=-3):
     ks = [x for x in t if 'kernel_symbol' in x][0]
     rows = list(c.execute("select s.kernel_name,d.start,d.end,d.grid_size_x,d.grid_size_y,d.workgroup_size_x,d.queue_id from %s d join %s s "
                           "on d.kernel_id=s.id order by d.start" % (kd, ks)))
-    marks = [i for i, r in enumerate(rows) if 'adam_kernel' in r[0]]
+    marks = [i for i, r in enumerate(rows) if ('adam_kernel' in r[0] or 'adam_pack_kernel' in r[0])]
     b, e = marks[which] + 1, marks[which + 1] + 1
     t0 = rows[b][1]
     for r in rows[b:e]:

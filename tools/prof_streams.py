@@ -14,7 +14,7 @@ kd = [x for x in t if 'kernel_dispatch' in x][0]; ks = [x for x in t if 'kernel_
 cols = [r[1] for r in c.execute('pragma table_info(%s)' % kd)]
 qcol = 'queue_id' if 'queue_id' in cols else ('stream_id' if 'stream_id' in cols else None)
 rows = list(c.execute("select s.kernel_name, d.start, d.end, d.%s from %s d join %s s on d.kernel_id=s.id order by d.start" % (qcol, kd, ks)))
-marks = [i for i, r in enumerate(rows) if 'adam_kernel' in r[0]]
+marks = [i for i, r in enumerate(rows) if ('adam_kernel' in r[0] or 'adam_pack_kernel' in r[0])]
 if ntrain:
     marks = marks[:ntrain]
 steps = [(marks[i] + 1, marks[i + 1] + 1) for i in range(skip, len(marks) - 1)]

@@ -15,7 +15,7 @@ def main(path, skip=8, ntrain=0):
     kd = [x for x in t if 'kernel_dispatch' in x][0]
     ks = [x for x in t if 'kernel_symbol' in x][0]
     rows = list(c.execute("select s.kernel_name, d.start, d.end from %s d join %s s on d.kernel_id=s.id order by d.start" % (kd, ks)))
-    marks = [i for i, r in enumerate(rows) if 'adam_kernel' in r[0]]
+    marks = [i for i, r in enumerate(rows) if ('adam_kernel' in r[0] or 'adam_pack_kernel' in r[0])]
     if ntrain:
         marks = marks[:ntrain]
     if len(marks) < skip + 2:
