@@ -658,15 +658,20 @@ struct LsKP {
     long long x_plane;               // salt_conv_args.x_plane: chunk c is the half (c & 1) of the dense 64-channel plane x + (c >> 1) * x_plane
 };
 
-// NLW loader waves (waves 4 .. 4 + NLW - 1) + 4 MFMA waves (waves 0 .. 3)
-template <int NI, int MODE, int NLW = SALT_LS_NLW>
+// NLW loader waves (waves 4 .. 4 + NLW - 1) + 4 MFMA waves (waves 0 .. 3).
+// MT = 2 (round 5, MODE 0, NI = 2: the eval-mode layers with hundreds of input channels): an item is TWO pixel tiles of the workgroup's
+// walk under ONE stream of weight chunks - a 64-channel chunk of weights is 36 of the 57 KB a chunk moves, the loader waves' issue rate
+// (and a ring of two 57 KB chunks against the DMA latency) is what held these layers at 46 - 50 % of the MFMA peak; per (tap, k-step) stage
+// 6 fragment reads feed 8 MFMAs instead of 4 : 4, and a chunk is 144 MFMAs per wave between two barriers instead of 72.
+template <int NI, int MODE, int NLW = SALT_LS_NLW, int MT = 1>
 __global__ __launch_bounds__(256 + 64 * NLW) void conv_ls_kernel(LsKP p) {
     typedef bf16_t T;
     constexpr int BN = 32 * NI, NT = 9, MI = 2;
-    constexpr int HPC = 21, WPC = NT * BN / 16, PC = HPC + WPC;           // DMA pieces (1 KB) of one chunk: halo rows, then weights
+    constexpr int HPC = 21, WPC = NT * BN / 16, PC = MT * HPC + WPC;      // DMA pieces (1 KB) of one chunk: halo rows (of MT tiles), then weights
     constexpr int NS = (PC + NLW - 1) / NLW;                            // DMA instructions per loader wave and chunk
     constexpr int D = NI == 1 ? SALT_LS_D1 : 2;                                  // ring depth
-    constexpr int H_BYTES = HPC * 1024, CH_BYTES = PC * 1024;
+    constexpr int HT_BYTES = HPC * 1024, H_BYTES = MT * HT_BYTES, CH_BYTES = PC * 1024;
+    static_assert(MT == 1 || (MODE == 0 && NI == 2), "two-tile items: plain epilogue, 64-channel blocks");
     constexpr int OFF_DUMMY = D * CH_BYTES, OFF_CONST = OFF_DUMMY + 1024;
     static_assert(OFF_CONST + 4 * BN * 4 <= 160 * 1024, "LDS budget");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -685,11 +690,12 @@ __global__ __launch_bounds__(256 + 64 * NLW) void conv_ls_kernel(LsKP p) {
     const int nt = jwg % p.n_tiles, slot = jwg / p.n_tiles, n0 = nt * BN;
     const int t_lo = xcd * p.per_xcd;
     const int t_hi = min(t_lo + p.per_xcd, p.ntiles);
-    const int n_items = (t_lo + slot < t_hi) ? (t_hi - t_lo - slot + p.slots - 1) / p.slots : 0;
+    const int n_my = (t_lo + slot < t_hi) ? (t_hi - t_lo - slot + p.slots - 1) / p.slots : 0;      // pixel tiles of this workgroup
+    const int n_items = (n_my + MT - 1) / MT;
     if (n_items <= 0) return;
     const int G = n_items * p.nchunk;                                    // chunks of this workgroup, in stream order
     struct TC { int b, oy0, ox0; };
-    auto coords = [&](int k) {
+    auto coords = [&](int k) {                                           // k-th pixel tile of the walk (item k / MT, tile k % MT of it)
         const int t = t_lo + slot + k * p.slots;
         TC c; const int tx = t % p.tiles_x; const int r = t / p.tiles_x;
         c.ox0 = tx << 4; c.oy0 = (r % p.tiles_y) << 4; c.b = r / p.tiles_y; return c;
@@ -727,30 +733,35 @@ __global__ __launch_bounds__(256 + 64 * NLW) void conv_ls_kernel(LsKP p) {
         for (int i = 0; i < NS; ++i) {
             const int pi = lw + NLW * i;
             w_rel[i] = 0; h_off[i] = -1;
-            if (pi >= HPC && pi < PC) {
-                const int R = (pi - HPC) * 16 + (lane >> 2);               // row t * BN + n of the chunk's weight block
+            if (pi >= MT * HPC && pi < PC) {
+                const int R = (pi - MT * HPC) * 16 + (lane >> 2);          // row t * BN + n of the chunk's weight block
                 const int t = R / BN, n = R - t * BN;
                 w_rel[i] = (t * p.Cout + n0 + n) * 32 + ((lane ^ (R >> 2)) & 3) * 8;
             }
         }
         const T* xb = p.x;
-        auto item_offsets = [&](int k) {                                  // halo source offsets of item k relative to its image
-            const TC c = coords(k);
-            xb = p.x + (int64_t)c.b * p.H * p.W * p.x_cs;
-            const int iy0 = c.oy0 + p.min_dy, ix0 = c.ox0 + p.min_dx;
+        auto item_offsets = [&](int k) {                                  // halo source offsets of item k relative to its image (MT = 2: to p.x - the host bounds the tensor to 2^31 elements)
             const bool clamp = p.pad_mode != 0;
+            TC cm[MT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) cm[m] = coords(min(MT * k + m, n_my - 1));
+            if (MT == 1) xb = p.x + (int64_t)cm[0].b * p.H * p.W * p.x_cs;
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
                 const int pi = lw + NLW * i;
-                if (pi < HPC) {
-                    const int row = pi * 16 + (lane >> 2);
+                if (pi < MT * HPC) {
+                    const int m = MT == 1 ? 0 : (pi >= HPC ? 1 : 0), hp = pi - m * HPC;
+                    const TC c = cm[m];
+                    const int iy0 = c.oy0 + p.min_dy, ix0 = c.ox0 + p.min_dx;
+                    const int row = hp * 16 + (lane >> 2);
                     const int hy = (int)__umulhi((unsigned)row, 238609295u);      // row / 18
                     const int hx = row - hy * 18;
                     const int iy = iy0 + hy, ix = ix0 + hx;
                     const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.W - 1);
                     const bool inside = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-                    const bool valid = (row < 324) & (clamp | inside);
-                    h_off[i] = valid ? (iyc * p.W + ixc) * p.x_cs + ((lane ^ (row >> 2)) & 3) * 8 : -1;
+                    const bool valid = (row < 324) & (clamp | inside) & (MT * k + m < n_my);
+                    const int img = MT == 1 ? 0 : c.b * p.H * p.W * p.x_cs;
+                    h_off[i] = valid ? img + (iyc * p.W + ixc) * p.x_cs + ((lane ^ (row >> 2)) & 3) * 8 : -1;
                 }
             }
         };
@@ -766,7 +777,7 @@ __global__ __launch_bounds__(256 + 64 * NLW) void conv_ls_kernel(LsKP p) {
                 const int pi = lw + NLW * i;
                 const void* src = zp;
                 int dst = OFF_DUMMY;
-                if (live && pi < HPC) { if (h_off[i] >= 0) src = xc + h_off[i]; dst = buf + pi * 1024; }
+                if (live && pi < MT * HPC) { if (h_off[i] >= 0) src = xc + h_off[i]; dst = buf + pi * 1024; }
                 else if (live && pi < PC) { src = wc + w_rel[i]; dst = buf + pi * 1024; }
                 if (!(SALT_LS_ABLATE & 2)) dma(src, dst);
             }
@@ -793,17 +804,19 @@ __global__ __launch_bounds__(256 + 64 * NLW) void conv_ls_kernel(LsKP p) {
         }
         const WsEpi ep = {p.y, p.bnb_y, p.bnb_a, p.y_cs, p.bnb_cs, p.bnb_acs, p.relu, p.accumulate, p.bnb_relu,
                           p.bias || p.scale || p.shift || p.relu, sums, p.res, p.res_cs};
-        struct Frag { u32x4 a[MI], b[NI]; };
+        struct Frag { u32x4 a[MT][MI], b[NI]; };
         int g = 0;
 #pragma unroll 1
         for (int k = 0; k < n_items; ++k) {
-            f32x16 acc[MI][NI];
+            f32x16 acc[MT][MI][NI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int j = 0; j < NI; ++j)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                    for (int j = 0; j < NI; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[m][i][j][r] = 0.f;
             int a_addr[NT][MI], b_addr[NI];
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
@@ -818,17 +831,20 @@ __global__ __launch_bounds__(256 + 64 * NLW) void conv_ls_kernel(LsKP p) {
 #pragma unroll
                 for (int j = 0; j < NI; ++j) b_addr[j] = H_BYTES + ws_swz(j * 32 + lb, khalf);
             }
-            const TC cc = coords(k);
-            unsigned pix[MI];
+            unsigned pix[MT][MI];
 #pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int m = wm * 64 + i * 32 + ws_perm(l31);
-                pix[i] = (unsigned)((cc.b * p.OH + cc.oy0 + (m >> 4)) * p.OW + cc.ox0 + (m & 15));
+            for (int mt = 0; mt < MT; ++mt) {
+                const TC cc = coords(min(MT * k + mt, n_my - 1));
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const int m = wm * 64 + i * 32 + ws_perm(l31);
+                    pix[mt][i] = (unsigned)((cc.b * p.OH + cc.oy0 + (m >> 4)) * p.OW + cc.ox0 + (m & 15));
+                }
             }
             constexpr bool PRE = MODE == 2 && SALT_LS_PREFETCH != 0;
             WsOps<PRE ? NI : 1> ops;
             constexpr bool PRE_OLD = NI == 1;                              // (NI = 2: 96 more registers do not fit beside the accumulators)
-            if constexpr (PRE) ws_prefetch_operands<NI, PRE_OLD>(ep, pix, n0, khalf, ops);
+            if constexpr (PRE) ws_prefetch_operands<NI, PRE_OLD>(ep, pix[0], n0, khalf, ops);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll 1
             for (int c = 0; c < p.nchunk; ++c, ++g) {
@@ -840,28 +856,32 @@ __global__ __launch_bounds__(256 + 64 * NLW) void conv_ls_kernel(LsKP p) {
                 auto load_frag = [&](int s, Frag& f) {                      // s = (tap, k-step), a constant after unrolling
                     const int t = s >> 1, hx = (s & 1) << 5;
 #pragma unroll
-                    for (int i = 0; i < MI; ++i) f.a[i] = *reinterpret_cast<const u32x4*>(hb + (a_addr[t][i] ^ hx));
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int i = 0; i < MI; ++i) f.a[m][i] = *reinterpret_cast<const u32x4*>(hb + m * HT_BYTES + (a_addr[t][i] ^ hx));
 #pragma unroll
                     for (int j = 0; j < NI; ++j) f.b[j] = *reinterpret_cast<const u32x4*>(hb + t * (BN * 64) + (b_addr[j] ^ hx));
                 };
                 auto mma_frag = [&](const Frag& f) {                         // operands swapped: rows of D = output channels
 #pragma unroll
-                    for (int i = 0; i < MI; ++i)
+                    for (int m = 0; m < MT; ++m)
 #pragma unroll
-                        for (int j = 0; j < NI; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.b[j]), __builtin_bit_cast(bf16x8, f.a[i]), acc[i][j], 0, 0, 0);
+                        for (int i = 0; i < MI; ++i)
+#pragma unroll
+                            for (int j = 0; j < NI; ++j)
+                                acc[m][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.b[j]), __builtin_bit_cast(bf16x8, f.a[m][i]), acc[m][i][j], 0, 0, 0);
                 };
                 constexpr int NST = NT * 2;
                 Frag f[3];
                 load_frag(0, f[0]);
                 load_frag(1, f[1]);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2 * (MI + NI), 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * (MT * MI + NI), 0);
 #pragma unroll
                 for (int s2 = 0; s2 < NST; ++s2) {
                     if (s2 + 2 < NST) load_frag(s2 + 2, f[(s2 + 2) % 3]);
                     mma_frag(f[s2 % 3]);
-                    if (s2 + 2 < NST) __builtin_amdgcn_sched_group_barrier(0x100, MI + NI, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, MI * NI, 0);
+                    if (s2 + 2 < NST) __builtin_amdgcn_sched_group_barrier(0x100, MT * MI + NI, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, MT * MI * NI, 0);
                 }
             }
             __builtin_amdgcn_s_setprio(0);
@@ -869,31 +889,39 @@ __global__ __launch_bounds__(256 + 64 * NLW) void conv_ls_kernel(LsKP p) {
             if (SALT_LS_ABLATE & 4) {                                      // keep the accumulators alive without the epilogue
                 float tsum = 0.f;
 #pragma unroll
-                for (int i = 0; i < MI; ++i)
+                for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int j = 0; j < NI; ++j)
+                    for (int i = 0; i < MI; ++i)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) tsum += acc[i][j][r];
+                        for (int j = 0; j < NI; ++j)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) tsum += acc[m][i][j][r];
                 if (tsum == 123.456f) p.y[0] = f2bf(tsum);
                 continue;
             }
-            if constexpr (PRE) ws_epilogue_tile<NI, MODE, false>(ep, acc, pix, geo, n0, reinterpret_cast<const float*>(smem + OFF_CONST), rs0, rs1, khalf, l31, &ops, PRE_OLD);
-            else ws_epilogue_tile<NI, MODE, false>(ep, acc, pix, geo, n0, reinterpret_cast<const float*>(smem + OFF_CONST), rs0, rs1, khalf, l31);
+            if constexpr (PRE) ws_epilogue_tile<NI, MODE, false>(ep, acc[0], pix[0], geo, n0, reinterpret_cast<const float*>(smem + OFF_CONST), rs0, rs1, khalf, l31, &ops, PRE_OLD);
+            else {
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    if (MT * k + m < n_my)                                  // (wave-uniform: an odd walk ends on half an item)
+                        ws_epilogue_tile<NI, MODE, false>(ep, acc[m], pix[m], geo, n0, reinterpret_cast<const float*>(smem + OFF_CONST), rs0, rs1, khalf, l31);
+            }
         }
     }
     if (MODE != 0 && sums) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         ws_sums_flush<NI, MODE, 4>(rs0, rs1, !loader, wm, reinterpret_cast<float*>(smem), n0, p.Cout, p.fin_acc, p.bnb_acc,
-                                   nt == 0 ? (double)n_items * 256.0 : 0.0, khalf, l31);
+                                   nt == 0 ? (double)n_my * 256.0 : 0.0, khalf, l31);
     }
 }
 
-template <int NI, int MODE>
+template <int NI, int MODE, int MT = 1>
 int ls_launch_mode(const LsKP& k, int wgs, hipStream_t st) {
-    constexpr int BN = 32 * NI, PC = 21 + 9 * BN / 16, D = NI == 1 ? SALT_LS_D1 : 2;
+    constexpr int BN = 32 * NI, PC = MT * 21 + 9 * BN / 16, D = NI == 1 ? SALT_LS_D1 : 2;
     constexpr int LDS = D * PC * 1024 + 1024 + 4 * BN * 4;
-    auto kern = conv_ls_kernel<NI, MODE>;
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+    auto kern = conv_ls_kernel<NI, MODE, SALT_LS_NLW, MT>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -906,9 +934,10 @@ int ls_launch_mode(const LsKP& k, int wgs, hipStream_t st) {
 }
 
 template <int NI>
-int ls_launch(const LsKP& k, int wgs, hipStream_t st) {
+int ls_launch(const LsKP& k, int wgs, hipStream_t st, int mt = 1) {
     if (k.fin_acc) return ls_launch_mode<NI, 1>(k, wgs, st);
     if (k.bnb_acc) return ls_launch_mode<NI, 2>(k, wgs, st);
+    if constexpr (NI == 2) { if (mt == 2) return ls_launch_mode<2, 0, 2>(k, wgs, st); }
     return ls_launch_mode<NI, 0>(k, wgs, st);
 }
 
@@ -1636,7 +1665,17 @@ int conv_ls_launch(const salt_conv_args* a, hipStream_t st) {
     k.slots = wpx / k.n_tiles;
     if (k.slots > k.per_xcd) k.slots = k.per_xcd;
     const int wgs = k.slots * k.n_tiles * 8;
-    return ni == 2 ? ls_launch<2>(k, wgs, st) : ls_launch<1>(k, wgs, st);
+    // two-tile items (MT = 2): plain epilogue, 64-channel blocks, >= 24 chunks of input channels and >= 4 tiles per workgroup.  Same-box
+    // per-layer A/B on the ResNet152 pass: 3072 / 2048 / 1280 input channels 6 - 9 % faster, 768 1 %, 512 even, 256 (8 chunks:
+    // two epilogues and the two-tile item set-up per 8 chunks) 12 - 20 % SLOWER.  SALT_CONV_LS_MT=1: off; per launch cfg bit 20 asks for it, bit 21 forbids it (tests, A/B)
+    static const int mt_env = getenv("SALT_CONV_LS_MT") ? atoi(getenv("SALT_CONV_LS_MT")) : 2;
+    const bool asked = (a->cfg & 0xff) == 10;
+    int mt = 1;
+    if (ni == 2 && !k.fin_acc && !k.bnb_acc) {
+        if (asked && ((a->cfg >> 20) & 1)) mt = 2;
+        else if (!(asked && ((a->cfg >> 21) & 1)) && mt_env == 2 && k.nchunk >= 24 && k.per_xcd >= 4 * k.slots) mt = 2;
+    }
+    return ni == 2 ? ls_launch<2>(k, wgs, st, mt) : ls_launch<1>(k, wgs, st);
 }
 
 

@@ -192,6 +192,8 @@ def test_ws_equals_conv_mfma_kernel_on_a_residual_block(case):
 
 @pytest.mark.parametrize('case', [(2, 64, 32, 32, 64, 9 | (1 << 8)), (4, 64, 32, 32, 32, 9 | (1 << 8)), (4, 32, 32, 32, 64, 9 | (1 << 8)),
                                   (2, 128, 32, 32, 96, _ls(3, 1)), (2, 192, 32, 32, 128, _ls(2, 2)),
+                                  # two-tile items (cfg bit 20): one tile per workgroup (half an item), 4 tiles, 3 tiles across images
+                                  (2, 192, 32, 32, 128, _ls(2, 2) | (1 << 20)), (4, 256, 64, 32, 64, _ls(1, 2) | (1 << 20)), (3, 128, 48, 32, 128, _ls(2, 2) | (1 << 20)),
                                   (3, 64, 40, 24, 64, 9 | (1 << 8)), (2, 64, 101, 101, 64, 9 | (2 << 8)), (2, 32, 20, 50, 128, 9 | (2 << 8))])   # ragged grids
 def test_ws_eval_folded_bn_relu_vs_torch(case):
     """eval mode: bias + folded BatchNorm + ReLU in the epilogue (salt_conv_args.bias / scale / shift / relu)."""
@@ -221,6 +223,41 @@ def test_ws_eval_folded_bn_relu_vs_torch(case):
     with torch.no_grad():
         yr = F.relu(rb(rc(x)))
     assert_close(y, yr, TOLBF, 'eval y')
+
+
+@pytest.mark.parametrize('case', [(4, 256, 64, 32, 64, 1), (3, 128, 48, 32, 128, 2), (2, 320, 32, 48, 64, 1), (5, 128, 16, 16, 192, 3)])
+@pytest.mark.parametrize('replicate', [False, True])
+def test_ls_two_tile_items_are_bit_identical_to_single_tile_items(case, replicate):
+    """conv_ls_kernel MT = 2 (two pixel tiles per stream of weight chunks; cfg bit 20) against MT = 1 (bit 21): the same MFMA sequence
+    per output value, so the eval-mode results must be equal bit for bit - zero padding and the reference's replicate padding
+    (architectures/base.py:21-27), whole and half items, tiles of different images in one item."""
+    from gpu_harness import BlockRun
+    B, Cin, H, W, Cout, cap = case
+    conv, bn = nn.Conv2d(Cin, Cout, 3, 1, 0 if replicate else 1, bias=True), nn.BatchNorm2d(Cout)
+    mod = nn.Sequential(nn.ReplicationPad2d((0, 2, 2, 0)), conv, bn) if replicate else nn.Sequential(conv, bn)
+    with torch.no_grad():
+        conv.weight.copy_(_rand(conv.weight.shape, 1, (2.0 / (Cin * 9)) ** 0.5)); conv.bias.copy_(0.1 * _rand((Cout,), 6))
+        bn.weight.copy_(1 + 0.1 * _rand((Cout,), 2)); bn.bias.copy_(0.1 * _rand((Cout,), 3))
+        bn.running_mean.copy_(0.2 * _rand((Cout,), 7)); bn.running_var.copy_(1 + 0.3 * _rand((Cout,), 8).abs())
+    x = _rand((B, Cin, H, W), 4).bfloat16().float()
+    mod.eval()
+    ys = []
+    for bit in (20, 21):
+        def emit(g, a, bit=bit):
+            _force_cfg(g, _ls(cap, 2) | (1 << bit))
+            return g.conv(a, conv, bn, relu=True, replicate=replicate) if replicate else g.conv(a, conv, bn, relu=True)
+        run = BlockRun(mod, [x], emit, train=False, dtype='bf16')
+        assert _kernel_ids(run.g.fwd) == [10]
+        ys.append(run.forward())
+    assert torch.isfinite(ys[0]).all()
+    assert torch.equal(ys[0], ys[1])
+    with torch.no_grad():
+        rc = nn.Conv2d(Cin, Cout, 3, 1, 0 if replicate else 1, bias=True); rc.load_state_dict({k: v.detach().cpu() for k, v in conv.state_dict().items()})
+        rc.weight.copy_(rc.weight.bfloat16().float())
+        rb = nn.BatchNorm2d(Cout); rb.load_state_dict({k: v.detach().cpu() for k, v in bn.state_dict().items()}); rb.eval()
+        xin = nn.ReplicationPad2d((0, 2, 2, 0))(x) if replicate else x
+        yr = F.relu(rb(rc(xin)))
+    assert_close(ys[0], yr, TOLBF, 'two-tile items vs torch')
 
 
 @pytest.mark.parametrize('shape', [(2, 64, 32, 32, 64), (2, 32, 32, 48, 96), (1, 128, 16, 16, 128)])
