@@ -744,7 +744,7 @@ __global__ __launch_bounds__(256 + 64 * NLW) void conv_ls_kernel(LsKP p) {
             const bool clamp = p.pad_mode != 0;
             TC cm[MT];
 #pragma unroll
-            for (int m = 0; m < MT; ++m) cm[m] = coords(min(MT * k + m, n_my - 1));
+            for (int m = 0; m < MT; ++m) cm[m] = coords(MT == 1 ? k : min(MT * k + m, n_my - 1));
             if (MT == 1) xb = p.x + (int64_t)cm[0].b * p.H * p.W * p.x_cs;
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
@@ -759,7 +759,7 @@ __global__ __launch_bounds__(256 + 64 * NLW) void conv_ls_kernel(LsKP p) {
                     const int iy = iy0 + hy, ix = ix0 + hx;
                     const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.W - 1);
                     const bool inside = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-                    const bool valid = (row < 324) & (clamp | inside) & (MT * k + m < n_my);
+                    const bool valid = (row < 324) & (clamp | inside) & (MT == 1 || MT * k + m < n_my);
                     const int img = MT == 1 ? 0 : c.b * p.H * p.W * p.x_cs;
                     h_off[i] = valid ? img + (iyc * p.W + ixc) * p.x_cs + ((lane ^ (row >> 2)) & 3) * 8 : -1;
                 }
@@ -817,13 +817,15 @@ __global__ __launch_bounds__(256 + 64 * NLW) void conv_ls_kernel(LsKP p) {
                     for (int j = 0; j < NI; ++j)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[m][i][j][r] = 0.f;
-            int a_addr[NT][MI], b_addr[NI];
+            int a_addr[MT == 1 ? NT : 1][MI], b_addr[NI];
+            if constexpr (MT == 1) {
 #pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                int pb = pbase[i];
-                asm volatile("" : "+v"(pb));                               // per item: not kept live across the epilogue
+                for (int i = 0; i < MI; ++i) {
+                    int pb = pbase[i];
+                    asm volatile("" : "+v"(pb));                           // per item: not kept live across the epilogue
 #pragma unroll
-                for (int t = 0; t < NT; ++t) a_addr[t][i] = ws_swz(pb + p.tap_off[t], khalf);
+                    for (int t = 0; t < NT; ++t) a_addr[t][i] = ws_swz(pb + p.tap_off[t], khalf);
+                }
             }
             {
                 int lb = l31;
@@ -832,16 +834,19 @@ __global__ __launch_bounds__(256 + 64 * NLW) void conv_ls_kernel(LsKP p) {
                 for (int j = 0; j < NI; ++j) b_addr[j] = H_BYTES + ws_swz(j * 32 + lb, khalf);
             }
             unsigned pix[MT][MI];
+            auto set_pix = [&](int lx) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const TC cc = coords(min(MT * k + mt, n_my - 1));
+                for (int mt = 0; mt < MT; ++mt) {
+                    const TC cc = coords(MT == 1 ? k : min(MT * k + mt, n_my - 1));
 #pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    const int m = wm * 64 + i * 32 + ws_perm(l31);
-                    pix[mt][i] = (unsigned)((cc.b * p.OH + cc.oy0 + (m >> 4)) * p.OW + cc.ox0 + (m & 15));
+                    for (int i = 0; i < MI; ++i) {
+                        const int m = wm * 64 + i * 32 + ws_perm(lx);
+                        pix[mt][i] = (unsigned)((cc.b * p.OH + cc.oy0 + (m >> 4)) * p.OW + cc.ox0 + (m & 15));
+                    }
                 }
-            }
+            };
             constexpr bool PRE = MODE == 2 && SALT_LS_PREFETCH != 0;
+            if (PRE || MT == 1) set_pix(l31);
             WsOps<PRE ? NI : 1> ops;
             constexpr bool PRE_OLD = NI == 1;                              // (NI = 2: 96 more registers do not fit beside the accumulators)
             if constexpr (PRE) ws_prefetch_operands<NI, PRE_OLD>(ep, pix[0], n0, khalf, ops);
@@ -853,12 +858,19 @@ __global__ __launch_bounds__(256 + 64 * NLW) void conv_ls_kernel(LsKP p) {
                 asm volatile("" ::: "memory");
                 if (SALT_LS_ABLATE & 1) continue;
                 const unsigned char* hb = smem + (g % D) * CH_BYTES;
+                int pbc[MI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) { pbc[i] = pbase[i]; if (MT != 1) asm volatile("" : "+v"(pbc[i])); }      // (per chunk: or the addresses below are hoisted out of the chunk loop and spilled again)
                 auto load_frag = [&](int s, Frag& f) {                      // s = (tap, k-step), a constant after unrolling
                     const int t = s >> 1, hx = (s & 1) << 5;
 #pragma unroll
-                    for (int m = 0; m < MT; ++m)
+                    for (int i = 0; i < MI; ++i) {
+                        // (two-tile items: the 18 tap addresses do not fit beside 128 accumulator registers - kept, they were spilled and reloaded
+                        //  from scratch INSIDE this loop, 58 dependent loads per chunk - so they are formed per stage: 7 VALU per 4 MFMAs)
+                        const int ad = (MT == 1 ? a_addr[t][i] : ws_swz(pbc[i] + p.tap_off[t], khalf)) ^ hx;
 #pragma unroll
-                        for (int i = 0; i < MI; ++i) f.a[m][i] = *reinterpret_cast<const u32x4*>(hb + m * HT_BYTES + (a_addr[t][i] ^ hx));
+                        for (int m = 0; m < MT; ++m) f.a[m][i] = *reinterpret_cast<const u32x4*>(hb + m * HT_BYTES + ad);
+                    }
 #pragma unroll
                     for (int j = 0; j < NI; ++j) f.b[j] = *reinterpret_cast<const u32x4*>(hb + t * (BN * 64) + (b_addr[j] ^ hx));
                 };
@@ -872,19 +884,25 @@ __global__ __launch_bounds__(256 + 64 * NLW) void conv_ls_kernel(LsKP p) {
                                 acc[m][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.b[j]), __builtin_bit_cast(bf16x8, f.a[m][i]), acc[m][i][j], 0, 0, 0);
                 };
                 constexpr int NST = NT * 2;
-                Frag f[3];
+                constexpr int FR = MT == 1 ? 3 : 2;                         // fragment ring: two-tile items have 8 MFMAs (256 cycles) per stage to cover one stage of
+                Frag f[FR];                                                // LDS latency, and no registers for a third (the 24 it costs were spilled around the loop)
                 load_frag(0, f[0]);
-                load_frag(1, f[1]);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2 * (MT * MI + NI), 0);
+                if (FR == 3) load_frag(1, f[1]);
+                __builtin_amdgcn_sched_group_barrier(0x100, (FR - 1) * (MT * MI + NI), 0);
 #pragma unroll
                 for (int s2 = 0; s2 < NST; ++s2) {
-                    if (s2 + 2 < NST) load_frag(s2 + 2, f[(s2 + 2) % 3]);
-                    mma_frag(f[s2 % 3]);
-                    if (s2 + 2 < NST) __builtin_amdgcn_sched_group_barrier(0x100, MT * MI + NI, 0);
+                    if (s2 + FR - 1 < NST) load_frag(s2 + FR - 1, f[(s2 + FR - 1) % FR]);
+                    mma_frag(f[s2 % FR]);
+                    if (s2 + FR - 1 < NST) __builtin_amdgcn_sched_group_barrier(0x100, MT * MI + NI, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, MT * MI * NI, 0);
                 }
             }
             __builtin_amdgcn_s_setprio(0);
+            if (!(PRE || MT == 1)) {                                       // two-tile items: the store addresses are derived AFTER the chunk loop (hoisted above it they
+                int lx = l31;                                              // were spilled across it and reloaded one by one in the epilogue: 96 scratch loads per item)
+                asm volatile("" : "+v"(lx));
+                set_pix(lx);
+            }
             const WsLaneGeo geo = {{true, true}, false, false, false, false, 0, 0, 0, 0};
             if (SALT_LS_ABLATE & 4) {                                      // keep the accumulators alive without the epilogue
                 float tsum = 0.f;
@@ -903,7 +921,7 @@ __global__ __launch_bounds__(256 + 64 * NLW) void conv_ls_kernel(LsKP p) {
             else {
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
-                    if (MT * k + m < n_my)                                  // (wave-uniform: an odd walk ends on half an item)
+                    if (MT == 1 || MT * k + m < n_my)                       // (wave-uniform: an odd walk ends on half an item)
                         ws_epilogue_tile<NI, MODE, false>(ep, acc[m], pix[m], geo, n0, reinterpret_cast<const float*>(smem + OFF_CONST), rs0, rs1, khalf, l31);
             }
         }
@@ -1665,15 +1683,20 @@ int conv_ls_launch(const salt_conv_args* a, hipStream_t st) {
     k.slots = wpx / k.n_tiles;
     if (k.slots > k.per_xcd) k.slots = k.per_xcd;
     const int wgs = k.slots * k.n_tiles * 8;
-    // two-tile items (MT = 2): plain epilogue, 64-channel blocks, >= 24 chunks of input channels and >= 4 tiles per workgroup.  Same-box
-    // per-layer A/B on the ResNet152 pass: 3072 / 2048 / 1280 input channels 6 - 9 % faster, 768 1 %, 512 even, 256 (8 chunks:
-    // two epilogues and the two-tile item set-up per 8 chunks) 12 - 20 % SLOWER.  SALT_CONV_LS_MT=1: off; per launch cfg bit 20 asks for it, bit 21 forbids it (tests, A/B)
+    // two-tile items (MT = 2): plain epilogue, 64-channel blocks, >= 4 chunks of input channels and >= 4 tiles per workgroup.  Same-box
+    // per-layer A/B on the ResNet152 pass: every layer of the class 2 - 12 % faster, the class 17.7 -> 16.0 ms.  (The first
+    // version kept the 18 tap addresses in registers beside 128 accumulators: they were spilled and reloaded INSIDE the chunk loop and
+    // the layers with few chunks ran 12 - 20 % slower.)  SALT_CONV_LS_MT=1: off; SALT_CONV_LS_MT_MINCHUNK; cfg bit 20 asks, bit 21 forbids
     static const int mt_env = getenv("SALT_CONV_LS_MT") ? atoi(getenv("SALT_CONV_LS_MT")) : 2;
+    static const int mt_minchunk = getenv("SALT_CONV_LS_MT_MINCHUNK") ? atoi(getenv("SALT_CONV_LS_MT_MINCHUNK")) : 4;
+    // (the folded-BatchNorm epilogue marks the eval-mode layers: the plain data gradients of a B = 32 training step have 4 - 8 tiles per
+    //  workgroup and came out 0.25 % slower per step with two-tile items; SALT_CONV_LS_MT_TRAIN=1 lifts the restriction)
+    static const bool mt_train = getenv("SALT_CONV_LS_MT_TRAIN") != nullptr;
     const bool asked = (a->cfg & 0xff) == 10;
     int mt = 1;
     if (ni == 2 && !k.fin_acc && !k.bnb_acc) {
         if (asked && ((a->cfg >> 20) & 1)) mt = 2;
-        else if (!(asked && ((a->cfg >> 21) & 1)) && mt_env == 2 && k.nchunk >= 24 && k.per_xcd >= 4 * k.slots) mt = 2;
+        else if (!(asked && ((a->cfg >> 21) & 1)) && mt_env == 2 && k.nchunk >= mt_minchunk && k.per_xcd >= 4 * k.slots && (a->scale || mt_train)) mt = 2;
     }
     return ni == 2 ? ls_launch<2>(k, wgs, st, mt) : ls_launch<1>(k, wgs, st);
 }
