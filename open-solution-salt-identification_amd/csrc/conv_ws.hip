@@ -740,12 +740,14 @@ __global__ __launch_bounds__(256 + 64 * NLW) void conv_ls_kernel(LsKP p) {
             }
         }
         const T* xb = p.x;
-        auto item_offsets = [&](int k) {                                  // halo source offsets of item k relative to its image (MT = 2: to p.x - the host bounds the tensor to 2^31 elements)
+        const T* xb1 = p.x;                                               // MT = 2: the image of the item's second tile
+        auto item_offsets = [&](int k) {                                  // halo source offsets of item k relative to its image(s)
             const bool clamp = p.pad_mode != 0;
             TC cm[MT];
 #pragma unroll
             for (int m = 0; m < MT; ++m) cm[m] = coords(MT == 1 ? k : min(MT * k + m, n_my - 1));
-            if (MT == 1) xb = p.x + (int64_t)cm[0].b * p.H * p.W * p.x_cs;
+            xb = p.x + (int64_t)cm[0].b * p.H * p.W * p.x_cs;
+            if (MT == 2) xb1 = p.x + (int64_t)cm[MT - 1].b * p.H * p.W * p.x_cs;
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
                 const int pi = lw + NLW * i;
@@ -760,8 +762,7 @@ __global__ __launch_bounds__(256 + 64 * NLW) void conv_ls_kernel(LsKP p) {
                     const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.W - 1);
                     const bool inside = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
                     const bool valid = (row < 324) & (clamp | inside) & (MT == 1 || MT * k + m < n_my);
-                    const int img = MT == 1 ? 0 : c.b * p.H * p.W * p.x_cs;
-                    h_off[i] = valid ? img + (iyc * p.W + ixc) * p.x_cs + ((lane ^ (row >> 2)) & 3) * 8 : -1;
+                    h_off[i] = valid ? (iyc * p.W + ixc) * p.x_cs + ((lane ^ (row >> 2)) & 3) * 8 : -1;
                 }
             }
         };
@@ -771,13 +772,15 @@ __global__ __launch_bounds__(256 + 64 * NLW) void conv_ls_kernel(LsKP p) {
             if (live && ic == 0) item_offsets(ik);
             const int buf = (ig % D) * CH_BYTES;
             const T* wc = p.w + (int64_t)ic * NT * p.Cout * 32;
-            const T* xc = xb + (p.x_plane ? (long long)(ic >> 1) * p.x_plane + (ic & 1) * 32 : (long long)ic * 32);   // wave-uniform
+            const long long coff = p.x_plane ? (long long)(ic >> 1) * p.x_plane + (ic & 1) * 32 : (long long)ic * 32;
+            const T* xc = xb + coff;                                          // wave-uniform
+            const T* xc1 = xb1 + coff;
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
                 const int pi = lw + NLW * i;
                 const void* src = zp;
                 int dst = OFF_DUMMY;
-                if (live && pi < MT * HPC) { if (h_off[i] >= 0) src = xc + h_off[i]; dst = buf + pi * 1024; }
+                if (live && pi < MT * HPC) { if (h_off[i] >= 0) src = ((MT == 2 && pi >= HPC) ? xc1 : xc) + h_off[i]; dst = buf + pi * 1024; }
                 else if (live && pi < PC) { src = wc + w_rel[i]; dst = buf + pi * 1024; }
                 if (!(SALT_LS_ABLATE & 2)) dma(src, dst);
             }
@@ -1622,7 +1625,10 @@ static int ls_common_ok(const salt_conv_args* a) {
     }
     if (max_dy - min_dy != 2 || max_dx - min_dx != 2) return 0;
     auto small = [](const salt_view& v) { return !v.p || (int64_t)v.B * v.H * v.W * v.cs < (int64_t)1 << 31; };
-    if (!small(a->x) || !small(a->y) || !small(a->bnb_y) || !small(a->bnb_a) || !small(a->res)) return 0;
+    // x: the loaders address an IMAGE with 32-bit lane offsets behind a 64-bit base (round 5: the 512 -> 256 convolution over the 64-image
+    // 256 x 256 hypercolumn is 2^31 elements); everything the epilogue touches is addressed from the tensor's base with 32 bits
+    if ((int64_t)a->x.H * a->x.W * a->x.cs >= (int64_t)1 << 31 || (int64_t)a->x.B * a->x.H * a->x.W * a->x.cs >= (int64_t)1 << 40) return 0;
+    if (!small(a->y) || !small(a->bnb_y) || !small(a->bnb_a) || !small(a->res)) return 0;
     if (a->res.p && (a->res.cs % 8 || (reinterpret_cast<uintptr_t>(a->res.p) & 15) || a->accumulate || a->fin_acc || a->bnb_acc)) return 0;
     if (a->bnb_acc) {
         if (!view_ok(a->bnb_y) || a->bnb_y.B != a->y.B || a->bnb_y.H != a->y.H || a->bnb_y.W != a->y.W || a->bnb_y.C != Cout || a->bnb_y.cs % 8 ||
@@ -1683,20 +1689,21 @@ int conv_ls_launch(const salt_conv_args* a, hipStream_t st) {
     k.slots = wpx / k.n_tiles;
     if (k.slots > k.per_xcd) k.slots = k.per_xcd;
     const int wgs = k.slots * k.n_tiles * 8;
-    // two-tile items (MT = 2): plain epilogue, 64-channel blocks, >= 4 chunks of input channels and >= 4 tiles per workgroup.  Same-box
+    // two-tile items (MT = 2): plain epilogue, 64-channel blocks, >= 4 chunks of input channels and >= 16 tiles per workgroup (>= 4 from 24 chunks).  Same-box
     // per-layer A/B on the ResNet152 pass: every layer of the class 2 - 12 % faster, the class 17.7 -> 16.0 ms.  (The first
     // version kept the 18 tap addresses in registers beside 128 accumulators: they were spilled and reloaded INSIDE the chunk loop and
     // the layers with few chunks ran 12 - 20 % slower.)  SALT_CONV_LS_MT=1: off; SALT_CONV_LS_MT_MINCHUNK; cfg bit 20 asks, bit 21 forbids
     static const int mt_env = getenv("SALT_CONV_LS_MT") ? atoi(getenv("SALT_CONV_LS_MT")) : 2;
     static const int mt_minchunk = getenv("SALT_CONV_LS_MT_MINCHUNK") ? atoi(getenv("SALT_CONV_LS_MT_MINCHUNK")) : 4;
-    // (the folded-BatchNorm epilogue marks the eval-mode layers: the plain data gradients of a B = 32 training step have 4 - 8 tiles per
+    // (a bias / folded-BatchNorm / ReLU / residual epilogue marks the forward layers of an eval-mode network: the plain data gradients of a B = 32 training step have 4 - 8 tiles per
     //  workgroup and came out 0.25 % slower per step with two-tile items; SALT_CONV_LS_MT_TRAIN=1 lifts the restriction)
     static const bool mt_train = getenv("SALT_CONV_LS_MT_TRAIN") != nullptr;
     const bool asked = (a->cfg & 0xff) == 10;
     int mt = 1;
     if (ni == 2 && !k.fin_acc && !k.bnb_acc) {
         if (asked && ((a->cfg >> 20) & 1)) mt = 2;
-        else if (!(asked && ((a->cfg >> 21) & 1)) && mt_env == 2 && k.nchunk >= mt_minchunk && k.per_xcd >= 4 * k.slots && (a->scale || mt_train)) mt = 2;
+        else if (!(asked && ((a->cfg >> 21) & 1)) && mt_env == 2 && k.nchunk >= mt_minchunk && (a->scale || a->bias || a->relu || a->res.p || mt_train) &&
+                 (k.per_xcd >= 16 * k.slots || (k.per_xcd >= 4 * k.slots && k.nchunk >= 24))) mt = 2;       // (8 tiles per workgroup x 4 chunks - the training step's 128 -> 64 over the two full-resolution hypercolumn planes - came out 50 % slower)
     }
     return ni == 2 ? ls_launch<2>(k, wgs, st, mt) : ls_launch<1>(k, wgs, st);
 }
