@@ -159,6 +159,9 @@ __device__ __forceinline__ void ws_epilogue_tile(const WsEpi& p, f32x16 (&acc)[2
                                                  const WsOps<NI>* pre = nullptr, bool pre_old = true) {
     typedef bf16_t T;
     constexpr int MI = 2, BN = 32 * NI;
+    typedef const __attribute__((address_space(3))) float* cst_lds_t;
+    cst_lds_t cst_l = (cst_lds_t)cst + 8 * khalf;                              // this lane's half of every 16-channel group (MODE 2 reads below)
+    if (MODE == 2) asm volatile("" : "+v"(cst_l));
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         // operand tiles of the (+)= / BatchNorm-backward epilogue: 16-byte pieces at this lane's store addresses
@@ -274,12 +277,16 @@ __device__ __forceinline__ void ws_epilogue_tile(const WsEpi& p, f32x16 (&acc)[2
                 }
                 *reinterpret_cast<u32x4*>(p.y + (yo + 16 * gp)) = stored;
                 if (MODE == 2 && p.sums) {
-                    const int ch0 = 32 * j + 16 * gp + 8 * khalf;
+                    // the constants are read through ONE LDS base register + immediates: as generic-pointer arithmetic the compiler kept a
+                    // register per (array, j, gp) address - the table sits above the 64 KB an immediate reaches - spilled them at 256 VGPRs and
+                    // reloaded each from scratch behind `s_waitcnt vmcnt(0)`, i.e. behind the tile's own stores, eight times per tile
+                    const int ch0 = 32 * j + 16 * gp;
+                    const cst_lds_t cl = cst_l;
                     float mu[8], is[8], gq[8], yc[8];
-                    *reinterpret_cast<f32x4*>(mu) = *reinterpret_cast<const f32x4*>(cst + ch0);
-                    *reinterpret_cast<f32x4*>(mu + 4) = *reinterpret_cast<const f32x4*>(cst + ch0 + 4);
-                    *reinterpret_cast<f32x4*>(is) = *reinterpret_cast<const f32x4*>(cst + BN + ch0);
-                    *reinterpret_cast<f32x4*>(is + 4) = *reinterpret_cast<const f32x4*>(cst + BN + ch0 + 4);
+                    *reinterpret_cast<f32x4*>(mu) = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(cl + ch0);
+                    *reinterpret_cast<f32x4*>(mu + 4) = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(cl + ch0 + 4);
+                    *reinterpret_cast<f32x4*>(is) = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(cl + BN + ch0);
+                    *reinterpret_cast<f32x4*>(is + 4) = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(cl + BN + ch0 + 4);
                     unpack16<T>(stored, gq); unpack16<T>(yv[i][gp], yc);
                     if (p.bnb_a) {                                              // residual layer: the mask is the sign of the block output
                         float a8[8];
@@ -291,10 +298,10 @@ __device__ __forceinline__ void ws_epilogue_tile(const WsEpi& p, f32x16 (&acc)[2
                         }
                     } else {
                         float ks[8], sh[8];
-                        *reinterpret_cast<f32x4*>(ks) = *reinterpret_cast<const f32x4*>(cst + 2 * BN + ch0);
-                        *reinterpret_cast<f32x4*>(ks + 4) = *reinterpret_cast<const f32x4*>(cst + 2 * BN + ch0 + 4);
-                        *reinterpret_cast<f32x4*>(sh) = *reinterpret_cast<const f32x4*>(cst + 3 * BN + ch0);
-                        *reinterpret_cast<f32x4*>(sh + 4) = *reinterpret_cast<const f32x4*>(cst + 3 * BN + ch0 + 4);
+                        *reinterpret_cast<f32x4*>(ks) = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(cl + 2 * BN + ch0);
+                        *reinterpret_cast<f32x4*>(ks + 4) = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(cl + 2 * BN + ch0 + 4);
+                        *reinterpret_cast<f32x4*>(sh) = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(cl + 3 * BN + ch0);
+                        *reinterpret_cast<f32x4*>(sh + 4) = *reinterpret_cast<const __attribute__((address_space(3))) f32x4*>(cl + 3 * BN + ch0 + 4);
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
                             const float gg = (!p.bnb_relu || yc[e] * ks[e] + sh[e] > 0.f) ? gq[e] : 0.f;
