@@ -260,6 +260,36 @@ def test_ls_two_tile_items_are_bit_identical_to_single_tile_items(case, replicat
     assert_close(ys[0], yr, TOLBF, 'two-tile items vs torch')
 
 
+@pytest.mark.parametrize('case', [(4, 128, 64, 32, 1), (3, 192, 48, 32, 2)])
+def test_ls_two_tile_items_with_the_eval_residual_epilogue_are_bit_identical(case):
+    """eval-mode BasicBlock tail - conv, folded BatchNorm, + identity, ReLU in the convolution's epilogue (salt_conv_args.res) - on two-tile
+    items (cfg bit 20) against single-tile items (bit 21): the residual pieces are read at each tile's own store addresses."""
+    from gpu_harness import BlockRun
+    B, C, H, W, cap = case
+    conv, bn = nn.Conv2d(C, C, 3, 1, 1, bias=False), nn.BatchNorm2d(C)
+    mod = nn.Sequential(conv, bn)
+    with torch.no_grad():
+        conv.weight.copy_(_rand(conv.weight.shape, 1, (2.0 / (C * 9)) ** 0.5))
+        bn.weight.copy_(1 + 0.1 * _rand((C,), 2)); bn.bias.copy_(0.1 * _rand((C,), 3))
+        bn.running_mean.copy_(0.2 * _rand((C,), 7)); bn.running_var.copy_(1 + 0.3 * _rand((C,), 8).abs())
+    x = _rand((B, C, H, W), 4).bfloat16().float()
+    mod.eval()
+    ys = []
+    for bit in (20, 21):
+        def emit(g, a, bit=bit):
+            _force_cfg(g, _ls(cap, 2) | (1 << bit))
+            return g.conv(a, conv, bn, relu=True, res=a)
+        run = BlockRun(mod, [x], emit, train=False, dtype='bf16')
+        assert _kernel_ids(run.g.fwd) == [10]
+        ys.append(run.forward())
+    assert torch.equal(ys[0], ys[1])
+    with torch.no_grad():
+        rc = nn.Conv2d(C, C, 3, 1, 1, bias=False); rc.weight.copy_(conv.weight.detach().cpu().bfloat16().float())
+        rb = nn.BatchNorm2d(C); rb.load_state_dict({k: v.detach().cpu() for k, v in bn.state_dict().items()}); rb.eval()
+        yr = F.relu(rb(rc(x)) + x)
+    assert_close(ys[0], yr, 2 * TOLBF, 'residual epilogue vs torch')
+
+
 @pytest.mark.parametrize('shape', [(2, 64, 32, 32, 64), (2, 32, 32, 48, 96), (1, 128, 16, 16, 128)])
 def test_bn_apply_in_consumer_loader_forward_is_bit_identical(shape, monkeypatch):
     """salt_conv_args.in_fin / in_fin_acc / in_relu (the SALT_FWD_BN_FOLD switch: forward-only graphs): conv -> BN -> ReLU -> conv ->
