@@ -1705,12 +1705,13 @@ int conv_ls_launch(const salt_conv_args* a, hipStream_t st) {
     // (a bias / folded-BatchNorm / ReLU / residual epilogue marks the forward layers of an eval-mode network: the plain data gradients of a B = 32 training step have 4 - 8 tiles per
     //  workgroup and came out 0.25 % slower per step with two-tile items; SALT_CONV_LS_MT_TRAIN=1 lifts the restriction)
     static const bool mt_train = getenv("SALT_CONV_LS_MT_TRAIN") != nullptr;
+    static const int mt_mintiles = getenv("SALT_CONV_LS_MT_MINTILES") ? atoi(getenv("SALT_CONV_LS_MT_MINTILES")) : 16;
     const bool asked = (a->cfg & 0xff) == 10;
     int mt = 1;
     if (ni == 2 && !k.fin_acc && !k.bnb_acc) {
         if (asked && ((a->cfg >> 20) & 1)) mt = 2;
         else if (!(asked && ((a->cfg >> 21) & 1)) && mt_env == 2 && k.nchunk >= mt_minchunk && (a->scale || a->bias || a->relu || a->res.p || mt_train) &&
-                 (k.per_xcd >= 16 * k.slots || (k.per_xcd >= 4 * k.slots && k.nchunk >= 24))) mt = 2;       // (8 tiles per workgroup x 4 chunks - the training step's 128 -> 64 over the two full-resolution hypercolumn planes - came out 50 % slower)
+                 (k.per_xcd >= mt_mintiles * k.slots || (k.per_xcd >= 4 * k.slots && k.nchunk >= 24))) mt = 2;       // (8 tiles per workgroup x 4 chunks - the training step's 128 -> 64 over the two full-resolution hypercolumn planes - came out 50 % slower)
     }
     return ni == 2 ? ls_launch<2>(k, wgs, st, mt) : ls_launch<1>(k, wgs, st);
 }
