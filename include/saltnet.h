@@ -184,7 +184,8 @@ int salt_conv_stats_parts(const salt_conv_args*);
  * padding, eval epilogue or train-mode statistics through fin_acc).  `cfg` & 0xff:
  * 0 = heuristic, 1..8 = that config, 9 .. 13 = that kernel wherever it applies (else heuristic); (cfg >> 8) & 0xff caps the
  * workgroups per XCD of kernels 9 - 11 (0 = one per CU) and, for 10 / 11 when asked for, (cfg >> 16) & 3 fixes the output channels
- * per item to 32 x that (0 = by size). */
+ * per item to 32 x that (0 = by size).  Asked-for variants of those two kernels (tests / A-B; round 5): kernel 11 - bit 18 the item-major
+ * walk, bit 19 conv1x1_xs_kernel (input tile resident in LDS); kernel 10 - bit 20 two-tile items, bit 21 single tiles only. */
 int salt_conv_kernel_id(const salt_conv_args*);
 /* pixel tile of conv_mfma_kernel / conv_glds_kernel for these arguments (tests / tuning): tw | th << 8 | images << 16 | general << 24.
  * general = 1: a full-width strip of the extended grid of a fused-fold data gradient (th rows of tw = OW columns, or whole images)
