@@ -1184,6 +1184,9 @@ struct XsKP {
     const bf16_t* x; const bf16_t* w; bf16_t* y;
     int x_cs, y_cs, Cout, nsc;                   // nsc: chunks of 64 input channels (<= 4)
     int ntiles, n_blocks;                        // 256-pixel tiles, 64-channel blocks
+    const float* bias; const float* scale; const float* shift;      // eval epilogue (the Bottleneck expansions 64 -> 256 .. 256 -> 1024 of ResNet101 / 152:
+    int relu, accumulate;                        //  the same input tile under 4 channel blocks - 195 -> 137 us plain at 128 x 128 x 64 images)
+    const bf16_t* res; int res_cs;
 };
 
 __global__ __launch_bounds__(512) void conv1x1_xs_kernel(XsKP p) {
@@ -1194,7 +1197,7 @@ __global__ __launch_bounds__(512) void conv1x1_xs_kernel(XsKP p) {
     static_assert(WPC % NLW == 0 && (D - 2) * NSW <= 63, "pieces / vmcnt");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int XR = p.nsc * XCH;                                       // weight ring behind the tile
-    const int OFF_DUMMY = XR + D * W_BYTES, OFF_CONST = OFF_DUMMY + 1024;
+    const int OFF_DUMMY = XR + D * W_BYTES, OFF_CONST = OFF_DUMMY + 1024;     // constants: [n_blocks][4][BN] floats (bias, scale, shift, -) when there is an affine epilogue, else one block's defaults
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1205,7 +1208,15 @@ __global__ __launch_bounds__(512) void conv1x1_xs_kernel(XsKP p) {
     if (n_my <= 0) return;
     const int cpt = p.n_blocks * p.nsc;                               // chunks per tile
     const int G = n_my * cpt;
-    if (tid < 4 * BN) reinterpret_cast<float*>(smem + OFF_CONST)[tid] = (tid >= BN && tid < 2 * BN) ? 1.f : 0.f;      // (bias 0, scale 1, shift 0: the plain epilogue never reads them)
+    const bool affine = p.bias || p.scale || p.shift || p.relu;
+    {
+        float* sc = reinterpret_cast<float*>(smem + OFF_CONST);
+        const int nc = affine ? p.n_blocks * 4 * BN : 4 * BN;
+        for (int e = tid; e < nc; e += 512) {
+            const int blk = e / (4 * BN), r = e - blk * 4 * BN, which = r / BN, n = blk * BN + (r - which * BN);
+            sc[e] = which == 0 ? (p.bias ? p.bias[n] : 0.f) : which == 1 ? (p.scale ? p.scale[n] : 1.f) : which == 2 ? (p.shift ? p.shift[n] : 0.f) : 0.f;
+        }
+    }
 
     if (loader) {
         const unsigned char* zp = reinterpret_cast<const unsigned char*>(g_ws_zero);
@@ -1265,7 +1276,7 @@ __global__ __launch_bounds__(512) void conv1x1_xs_kernel(XsKP p) {
         }
         ws_wait_vm<0>();
     } else {
-        const WsEpi ep = {p.y, nullptr, nullptr, p.y_cs, 0, 0, 0, 0, 0, false, false, nullptr, 0};
+        const WsEpi ep = {p.y, nullptr, nullptr, p.y_cs, 0, 0, p.relu, p.accumulate, 0, affine, false, p.res, p.res_cs};
         int a_addr[MI], b_addr[NI];
 #pragma unroll
         for (int i = 0; i < MI; ++i) a_addr[i] = ws_swz(wm * 64 + i * 32 + l31, khalf);
@@ -1298,6 +1309,10 @@ __global__ __launch_bounds__(512) void conv1x1_xs_kernel(XsKP p) {
                     for (int j = 0; j < NI; ++j)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                // the residual / (+)= operand tile of the block is requested before its chunks (conv1x1_ls_kernel: a 64 -> 256 expansion is ONE chunk)
+                WsOps<NI> ops;
+                const bool pre_on = p.res != nullptr || p.accumulate;
+                if (pre_on) ws_prefetch_operands<NI, true>(ep, pix, nb * BN, khalf, ops);
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll 1
                 for (int c = 0; c < p.nsc; ++c, ++g) {
@@ -1326,14 +1341,18 @@ __global__ __launch_bounds__(512) void conv1x1_xs_kernel(XsKP p) {
                 }
                 __builtin_amdgcn_s_setprio(0);
                 const WsLaneGeo geo = {{true, true}, false, false, false, false, 0, 0, 0, 0};
-                ws_epilogue_tile<NI, 0, false>(ep, acc, pix, geo, nb * BN, reinterpret_cast<const float*>(smem + OFF_CONST), rs0, rs1, khalf, l31);
+                const float* cst = reinterpret_cast<const float*>(smem + OFF_CONST) + (affine ? nb * 4 * BN : 0);
+                if (pre_on) ws_epilogue_tile<NI, 0, false>(ep, acc, pix, geo, nb * BN, cst, rs0, rs1, khalf, l31, &ops, true);
+                else ws_epilogue_tile<NI, 0, false>(ep, acc, pix, geo, nb * BN, cst, rs0, rs1, khalf, l31);
             }
         }
     }
 }
 
 int xs_launch(const XsKP& k, int wgs, hipStream_t st) {
-    const int lds = k.nsc * 32 * 1024 + 3 * 8 * 1024 + 1024 + 4 * 64 * 4;
+    const bool affine = k.bias || k.scale || k.shift || k.relu;
+    const int lds = k.nsc * 32 * 1024 + 3 * 8 * 1024 + 1024 + (affine ? k.n_blocks : 1) * 4 * 64 * 4;
+    if (lds > 160 * 1024) SALT_FAIL(SALT_E_LDS, "conv1x1_xs: %d bytes of LDS", lds);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_xs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1758,12 +1777,16 @@ static bool conv1x1_xs_ok(const salt_conv_args* a) {
     static const int env = getenv("SALT_CONV_1X1_XS") ? atoi(getenv("SALT_CONV_1X1_XS")) : 1;
     const bool asked = (a->cfg & 0xff) == 11 && ((a->cfg >> 19) & 1);
     if (!env && !asked) return false;
-    if (a->in_step != 1 || a->bias || a->scale || a->shift || a->relu || a->res.p || a->accumulate || a->fin_acc) return false;
+    if (a->in_step != 1 || a->fin_acc) return false;
     const int Cin = a->x.C, Cout = a->y.C;
     if (Cin % 64 || Cin > 256 || Cout % 64) return false;
+    const bool affine = a->bias || a->scale || a->shift || a->relu;
+    if (Cin / 64 * 32 * 1024 + 25 * 1024 + (affine ? Cout / 64 : 1) * 1024 > 160 * 1024) return false;
     const int64_t tiles = (int64_t)a->y.B * a->y.H * a->y.W / 256;
     if (tiles >= (1 << 22)) return false;
-    return asked || (Cout / 64 >= 8 && tiles >= ws_cus());
+    // by size: the tap GEMMs (>= 8 blocks), and the Bottleneck expansions with <= 128 input channels per 4 blocks... measured (plain
+    // epilogue, 64 images): 64 -> 256 @128^2 195 -> 137 us, 128 -> 512 @64^2 93 -> 92, 256 -> 1024 @32^2 55 -> 52, 256 -> 64 @128^2 128 -> 137
+    return asked || (tiles >= ws_cus() && (Cout / 64 >= 8 || (Cout >= 4 * Cin && Cout / 64 >= 4)));
 }
 
 int conv1x1_ls_launch(const salt_conv_args* a, hipStream_t st) {
@@ -1774,6 +1797,8 @@ int conv1x1_ls_launch(const salt_conv_args* a, hipStream_t st) {
         k.x = reinterpret_cast<const bf16_t*>(a->x.p); k.w = reinterpret_cast<const bf16_t*>(a->w); k.y = reinterpret_cast<bf16_t*>(a->y.p);
         k.x_cs = a->x.cs; k.y_cs = a->y.cs; k.Cout = a->y.C; k.nsc = a->x.C / 64;
         k.ntiles = (int)((int64_t)a->y.B * a->y.H * a->y.W / 256); k.n_blocks = a->y.C / 64;
+        k.bias = a->bias; k.scale = a->scale; k.shift = a->shift; k.relu = a->relu; k.accumulate = a->accumulate;
+        k.res = reinterpret_cast<const bf16_t*>(a->res.p); k.res_cs = a->res.cs;
         int wgs = ws_cus();
         const int cap = (a->cfg >> 8) & 0xff;
         if (cap) wgs = cap * 8;

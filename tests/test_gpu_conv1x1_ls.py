@@ -120,6 +120,11 @@ CASES_XS = [
     (16, 16, 16, 128, 576, False, False, False, 0, 1),       # 8 workgroups, two tiles each: the tile buffer is fenced and refilled
     (24, 16, 16, 64, 192, False, False, False, 0, 1),        # three tiles each, one chunk
     (4, 16, 16, 192, 320, False, False, False, 64, 0),       # strided views, 3 chunks, 5 blocks
+    # the eval epilogue (Bottleneck conv3: folded BatchNorm, + identity, ReLU; per-block constants in LDS, residual tile requested per block)
+    (2, 16, 16, 64, 256, True, True, False, 0, 0),
+    (8, 16, 16, 128, 512, True, True, False, 64, 1),         # strided views, one tile per workgroup of 8
+    (16, 16, 16, 256, 1024, False, True, False, 0, 1),       # affine + ReLU without a residual, two tiles per workgroup
+    (4, 8, 8, 64, 128, False, True, True, 0, 0),             # (+)=
 ]
 
 
