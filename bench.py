@@ -123,6 +123,23 @@ def op_flops(name, s):
     return 0.0
 
 
+CONV_SYMBOL = {1: 'conv_mfma_kernel', 2: 'conv_mfma_kernel', 3: 'conv_mfma_kernel', 4: 'conv_mfma_kernel', 5: 'conv_mfma_kernel',
+               6: 'conv_glds_kernel', 7: 'conv_glds_kernel', 8: 'conv_glds_kernel', 9: 'conv_ws_kernel', 10: 'conv_ls_kernel',
+               11: 'conv1x1_ls_kernel', 12: 'conv_thin_kernel', 13: 'conv_stem16_kernel'}
+
+
+def op_symbol(name, s):
+    """kernel symbol a convolution / weight-gradient launch runs on (salt_conv_kernel_id / salt_conv_wgrad_kernel_id); None for the rest"""
+    import ctypes
+    from salt_amd._abi import lib
+    if name == 'conv':
+        return CONV_SYMBOL.get(int(lib.salt_conv_kernel_id(ctypes.byref(s))), 'conv_mfma_kernel')
+    if name == 'conv_wgrad':
+        return {1: 'conv_wgrad_ls_kernel', 2: 'conv_wgrad_thin_kernel', 3: 'conv_wgrad_fast_kernel', 4: 'conv_wgrad_fast32_kernel',
+                5: 'conv_wgrad_kernel', 6: 'conv_wgrad_full_kernel'}.get(int(lib.salt_conv_wgrad_kernel_id(ctypes.byref(s))), 'conv_wgrad_kernel')
+    return None
+
+
 def _vb(v, es):
     """bytes of one pass over the channels of a salt_view (0 for a NULL view)"""
     return float(v.B) * v.H * v.W * v.C * es if v.p else 0.0
@@ -342,6 +359,7 @@ def conv_roofline(model, B, channels, dtype, loss, reps):
     eng = model.model.engine()
     net = eng.net((B, channels, 128, 128), True)
     groups = {}
+    symbols = {}                                     # kernel symbol -> [ms, flops, launches] over the convolution / weight-gradient launches
     for _ in range(reps):
         eng.refresh(True)
         torch.cuda.synchronize()                     # the data-gradient weight packs run on the side stream
@@ -349,6 +367,10 @@ def conv_roofline(model, B, channels, dtype, loss, reps):
             for name, s, ms in prog.run_timed():
                 g = groups.setdefault(name, [0.0, 0.0, 0, 0.0])
                 g[0] += ms; g[1] += op_flops(name, s); g[2] += 1
+                sym = op_symbol(name, s)
+                if sym:
+                    y = symbols.setdefault(sym, [0.0, 0.0, 0])
+                    y[0] += ms; y[1] += op_flops(name, s); y[2] += 1
                 try:
                     g[3] += op_bytes(name, s, 2 if dtype == 'bf16' else 4)
                 except AttributeError:
@@ -365,6 +387,16 @@ def conv_roofline(model, B, channels, dtype, loss, reps):
             # x4 / x8 / x16 hypercolumn levels are contracted at their own resolution (salt_hyper_stencil), so this is LESS than the
             # reference network's algorithmic count for the same step (`flops` in the line has both); `frac` is priced on what ran
             'executed_gflop_per_step': round(dfl / reps / 1e9, 2)}
+    if symbols:
+        # the largest SINGLE kernel symbol of the step: `kernel` above names a class of five symbols; this is the one
+        # symbol with the most time, its own executed FLOP rate and fraction of the dense MFMA peak
+        sn, (sms, sfl, scnt) = max(symbols.items(), key=lambda kv: kv[1][0])
+        roof['kernel_symbol'] = {'symbol': sn, 'launches_per_step': scnt // reps, 'ms_per_step': round(sms / reps, 3),
+                                 'achieved': round(sfl / (sms * 1e-3) / 1e12, 1), 'unit': 'TFLOP/s', 'peak': peak,
+                                 'frac': round(sfl / (sms * 1e-3) / 1e12 / peak, 4), 'share_of_step': round(sms / reps / total_ms, 3)}
+        roof['by_symbol'] = {k: {'launches_per_step': v[2] // reps, 'ms_per_step': round(v[0] / reps, 3),
+                                 'achieved_tflops': round(v[1] / (v[0] * 1e-3) / 1e12, 1), 'frac': round(v[1] / (v[0] * 1e-3) / 1e12 / peak, 4)}
+                             for k, v in sorted(symbols.items(), key=lambda kv: -kv[1][0])}
     ops = {k: round(v[0] / reps, 3) for k, v in sorted(groups.items(), key=lambda kv: -kv[1][0])[:8]}
     side = sum(v[0] for k, v in groups.items() if k in ('conv_wgrad', 'wgrad_reduce', 'conv_first_wgrad', 'stem_grad_unfold')) / reps
     # per kernel class: matrix kernels against the dense MFMA peak of the compute dtype, streaming kernels as
@@ -386,6 +418,7 @@ def conv_roofline(model, B, channels, dtype, loss, reps):
 
 
 RANK_MS = []
+STEP_MS = []
 
 
 def train_config(workload, dtype, B, loss, steps, warmup, dev, rank=0, world=1, reps=1):
@@ -419,8 +452,20 @@ def train_config(workload, dtype, B, loss, steps, warmup, dev, rank=0, world=1, 
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    global RANK_MS
+    global RANK_MS, STEP_MS
     RANK_MS = [1e3 * elapsed / steps]
+    # SURVEY 8d asks for the MEDIAN step: a second leg behind the contract's timed region, one event per step on the compute stream
+    # (rank 0's own steps; >= 50 of them), reported beside the mean of the K timed steps
+    n_med = max(50, steps)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_med + 1)]
+    evs[0].record()
+    for i in range(n_med):
+        model._fit_loop(list(batches[(warmup + steps + i) % pool_batches]))
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    STEP_MS = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(n_med))
     if world > 1:
         te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         every = [torch.zeros_like(te) for _ in range(world)]
@@ -732,6 +777,14 @@ def main():
                                   % (wl_desc, B, args.loss),
                       'global_batch': B * world, 'image': [128, 128], 'parallelism': 'dp%d' % world},
            'final_loss': round(final_loss, 5)}
+    if STEP_MS:
+        n_ = len(STEP_MS)
+        out['ms_per_step_median'] = round(STEP_MS[n_ // 2], 3)
+        out['step_ms_distribution'] = {'steps': n_, 'median': round(STEP_MS[n_ // 2], 3), 'p10': round(STEP_MS[n_ // 10], 3), 'p90': round(STEP_MS[(9 * n_) // 10], 3),
+                                       'min': round(STEP_MS[0], 3), 'max': round(STEP_MS[-1], 3),
+                                       'note': 'a second leg of >= 50 steps behind the timed region, one HIP event per step on the compute stream (rank 0); '
+                                               '`ms_per_step` / `value` are the MEAN of the K timed steps the contract brackets with barrier + synchronize'}
+        out['value_at_median'] = round(world * B / (STEP_MS[n_ // 2] * 1e-3), 2)
     if world > 1 or model.dp._active():
         # how to read a scaling run: every rank is one RCCL rank; `exposed_allreduce_ms` is what the compute stream still waited for
         # after its last backward kernel (the collectives of the earlier buckets ran underneath backward)
@@ -769,6 +822,19 @@ def main():
         roof['traffic_unit'] = ('bytes per launch (rocprofv3 PMC FETCH_SIZE*2 + WRITE_SIZE, separate --pmc passes; file %s measured at commit %s - '
                                 'PMC counters cannot be read inside the timed process)' % (PMC_FILE, pmc_commit()))
         out['roofline_by_class'] = roof.pop('by_class')
+        if headline:
+            # whole-step HBM bytes: the rocprofv3 PMC counters (quoted from the committed file, commit inside) against the algorithmic
+            # bytes of the step (sum over convolutions of 3|x| + 2|y| activations + weight / optimizer bytes = 155.4 MB per
+            # image for this network at bf16, batch 32) - the ratio is what is left in re-reads, slabs and standalone BatchNorm passes
+            try:
+                pm = json.load(open(os.path.join(ROOT, PMC_FILE)))
+                cnt = (pm['step_total_MB']['read'] + pm['step_total_MB']['write']) * 1e6
+                alg = 155.4e6 * B
+                out['hbm_bytes_per_step'] = {'counter': round(cnt), 'algorithmic': round(alg), 'ratio': round(cnt / alg, 3),
+                                             'counter_GBps_at_this_step_time': round(cnt / (elapsed / args.steps) / 1e9, 1), 'hbm_peak_GBps': HBM_PEAK_GBS,
+                                             'quoted_from': PMC_FILE, 'commit': pm.get('commit')}
+            except (OSError, KeyError, ValueError):
+                out['hbm_bytes_per_step'] = None
         # the same class INSIDE the step (both queues running), from the committed rocprofv3 kernel trace: quoted, not measured here
         if headline:
             try:

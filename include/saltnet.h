@@ -212,6 +212,9 @@ typedef struct {
 } salt_conv_wgrad_args;
 int salt_conv_wgrad(const salt_conv_wgrad_args*, void* stream);
 int salt_conv_wgrad_nsplit(const salt_conv_wgrad_args*);
+/* which kernel family salt_conv_wgrad runs these arguments on (bench.py: roofline.kernel_symbol): 1 conv_wgrad_ls_kernel, 2
+ * conv_wgrad_thin_kernel, 3 conv_wgrad_fast_kernel / fast8, 4 conv_wgrad_fast32_kernel, 5 conv_wgrad_kernel (generic); < 0: no plan */
+int salt_conv_wgrad_kernel_id(const salt_conv_wgrad_args*);
 
 typedef struct {
     const float* partials;    /* [nsplit][ntaps][Ca][Cb] */

@@ -147,8 +147,9 @@ class TrainingMonitor(Callback):
 
     def on_batch_end(self, metrics, *args, **kwargs):
         # the loss stays on the device; it is only read back when something is logged (no per-step synchronisation)
+        # (round 6: kept as a list and summed ONCE per epoch - a `loss + sum` per step was one torch kernel on the step's queue)
         for name, loss in metrics.items():
-            self.epoch_loss_sum[name] = loss.detach() + self.epoch_loss_sum.get(name, 0.0)
+            self.epoch_loss_sum.setdefault(name, []).append(loss.detach() if torch.is_tensor(loss) else loss)
         self.epoch_batches += 1
         if self.batch_every and (self.batch_id % self.batch_every) == 0:
             for name, loss in metrics.items():
@@ -156,7 +157,8 @@ class TrainingMonitor(Callback):
         self.batch_id += 1
 
     def on_epoch_end(self, *args, **kwargs):
-        means = {k: _scalar(v) / max(self.epoch_batches, 1) for k, v in self.epoch_loss_sum.items()}
+        means = {k: _scalar(torch.stack([t.reshape(()) for t in v]).sum() if (v and torch.is_tensor(v[0])) else sum(v)) / max(self.epoch_batches, 1)
+                 for k, v in self.epoch_loss_sum.items()}
         self.history.append(means)
         if self.epoch_every and (self.epoch_id % self.epoch_every) == 0:
             for name, v in means.items():

@@ -3154,6 +3154,10 @@ extern "C" int salt_conv_wgrad_nsplit(const salt_conv_wgrad_args* a) {
     return ls > 0 ? ls : ns;
 }
 
+// salt_conv_wgrad_kernel_id: when set, launch_wgrad records which kernel family it would run (3 fast, 4 fast32, 5 generic) and returns
+static thread_local int* g_wgrad_probe = nullptr;
+#define SALT_WGRAD_PROBE(ID) if (g_wgrad_probe) { *g_wgrad_probe = (ID); return SALT_OK; }
+
 template <typename T>
 static int launch_wgrad(const WgradKP& k, hipStream_t st) {
     constexpr int ROWB = (sizeof(T) == 2) ? 192 : 256;
@@ -3169,6 +3173,7 @@ static int launch_wgrad(const WgradKP& k, hipStream_t st) {
                           ((reinterpret_cast<uintptr_t>(k.P) | reinterpret_cast<uintptr_t>(k.Q) | reinterpret_cast<uintptr_t>(k.partials)) & 15) == 0 &&
                           k.nb * k.hh * k.hw * 8 <= 10 * 256;
         if (fast) {
+            SALT_WGRAD_PROBE(3)
             bool row16 = k.ntaps == 9 && k.tw_log2 == 4 && k.th_log2 == 3 && k.nb == 1 && k.q_step == 1 && k.hw == 18;
             for (int t = 0; t < 9; ++t) row16 = row16 && k.tap_off[t] == (t / 3) * 18 + t % 3;       // raster tap order
             static const bool four_waves = getenv("SALT_WGRAD_W4") != nullptr;
@@ -3200,6 +3205,7 @@ static int launch_wgrad(const WgradKP& k, hipStream_t st) {
                            ((reinterpret_cast<uintptr_t>(k.P) | reinterpret_cast<uintptr_t>(k.Q) | reinterpret_cast<uintptr_t>(k.partials)) & 15) == 0 &&
                            k.nb * k.hh * k.hw * 8 <= 10 * 256;
         if (fast1) {
+            SALT_WGRAD_PROBE(3)
             auto kern = k.bmp == 64 ? conv_wgrad_fast_kernel<1, 4, false, false> : conv_wgrad_fast_kernel<1, 8, false, false>;
             if (lds > 64 * 1024) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 if (e != hipSuccess) SALT_FAIL((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e)); }
@@ -3208,6 +3214,7 @@ static int launch_wgrad(const WgradKP& k, hipStream_t st) {
             return SALT_OK;
         }
         if (fast64) {
+            SALT_WGRAD_PROBE(3)
             auto kern = k.pad_mode ? conv_wgrad_fast_kernel<9, 4, true, false> : conv_wgrad_fast_kernel<9, 4, false, false>;
             if (lds > 64 * 1024) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 if (e != hipSuccess) SALT_FAIL((int)e, "hipFuncSetAttribute: %s", hipGetErrorString(e)); }
@@ -3223,6 +3230,7 @@ static int launch_wgrad(const WgradKP& k, hipStream_t st) {
                     k.tw_log2 == 4 && k.th_log2 == 3 && k.nb == 1 && k.q_step == 1 && k.hw == 18 && k.hh == 10;
         for (int t = 0; t < 9 && fast; ++t) fast = k.tap_off[t] == (t / 3) * 18 + t % 3;
         if (fast) {
+            SALT_WGRAD_PROBE(4)
             static const bool nosplit = getenv("SALT_WGRAD32_NOSPLIT") != nullptr;
             const bool a32 = !nosplit && k.Ca <= 32, b32 = !nosplit && k.Cb <= 32;
             auto kern = k.pad_mode ? conv_wgrad_fast32_kernel<true> : conv_wgrad_fast32_kernel<false>;
@@ -3236,6 +3244,7 @@ static int launch_wgrad(const WgradKP& k, hipStream_t st) {
             return SALT_OK;
         }
     }
+    SALT_WGRAD_PROBE(5)
     WgradKP kg = k;
     if constexpr (sizeof(T) == 4) {
         static const bool no_ks = getenv("SALT_WGRAD32_NOSPLIT") != nullptr;
@@ -3255,6 +3264,18 @@ static int launch_wgrad(const WgradKP& k, hipStream_t st) {
 #undef SALT_WG
     SALT_CHECK_LAUNCH();
     return SALT_OK;
+}
+
+extern "C" int salt_conv_wgrad_kernel_id(const salt_conv_wgrad_args* a) {
+    WgradKP k; int ns = 0;
+    if (wgrad_plan(a, &k, &ns)) return -1;
+    if (conv_wgrad_thin(a, false, nullptr, nullptr) > 0) return 2;
+    if (conv_wgrad_ls(a, false, nullptr, nullptr) > 0) return 1;
+    int id = 0;
+    g_wgrad_probe = &id;
+    const int rc = a->dtype == SALT_F32 ? launch_wgrad<float>(k, nullptr) : launch_wgrad<bf16_t>(k, nullptr);
+    g_wgrad_probe = nullptr;
+    return rc ? -1 : id;
 }
 
 extern "C" int salt_conv_wgrad(const salt_conv_wgrad_args* a, void* stream) {

@@ -245,62 +245,72 @@ __global__ void se_parts_reduce_kernel(float* partials, int nparts, int width) {
 
 // FC backward: single block (sizes are B x C x R = tiny).  dgap[b][c] out; parameter grads written (not accumulated).
 // `partials` rows have already been reduced over parts (row 0 of every image holds the sums).
-__global__ __launch_bounds__(1024) void se_fc_bwd_kernel(const float* partials, int nparts, int B, int C, int R, const float* w1, const float* w2,
+// Round 6: the batch is walked in tiles of Bt images (Bt = B whenever the per-image vectors of the whole batch fit the 160 KB of LDS -
+// every case that ran before, bit for bit); a later tile ADDS its share of the parameter gradients to what the first tile stored (the
+// same thread owns the same output in every tile, so no atomics), which lifts the old limit of 51 images at C = 256 (R101 / R152
+// decoders at BASELINE C3's batch 64).
+__global__ __launch_bounds__(1024) void se_fc_bwd_kernel(const float* partials, int nparts, int Ball, int C, int R, const float* w1, const float* w2,
                                  const float* gap, const float* hidden, const float* gate_c,
                                  float* g_w1, float* g_b1, float* g_w2, float* g_b2, float* g_ws, float* g_bs, float* dgap, float inv_hw,
-                                 const double* acc, int stage_w) {
+                                 const double* acc, int stage_w, int Bt) {
     // everything the loops touch repeatedly is staged in LDS first (one coalesced sweep); the batch loops then run out of LDS
-    extern __shared__ float sm[];       // du [B][C], dh [B][R], gp [B][C], hd [B][R], ps [B][C+1] (spatial-SE sums)
-    float* du = sm; float* dh = du + B * C; float* gp = dh + B * R; float* hd = gp + B * C; float* ps = hd + B * R;
+    extern __shared__ float sm[];       // du [Bt][C], dh [Bt][R], gp [Bt][C], hd [Bt][R], ps [Bt][C+1] (spatial-SE sums)
+    float* du = sm; float* dh = du + Bt * C; float* gp = dh + Bt * R; float* hd = gp + Bt * C; float* ps = hd + Bt * R;
     // the FC weights: the batch loops below read them C / R times per output - staged too when the batch leaves room (stage_w), else read
     // from global as before round 4 (R101 / R152 decoders, C = 256, R = 16: batches 41 - 51 fit only without them)
-    float* lw1 = ps + B * (C + 1); float* lw2 = lw1 + R * C;
+    float* lw1 = ps + Bt * (C + 1); float* lw2 = lw1 + R * C;
     const float* sw1 = stage_w ? lw1 : w1; const float* sw2 = stage_w ? lw2 : w2;
     const int tid = threadIdx.x, nt = blockDim.x;
     if (stage_w) for (int i = tid; i < R * C; i += nt) { lw1[i] = w1[i]; lw2[i] = w2[i]; }
-    for (int i = tid; i < B * C; i += nt) {
-        const int b = i / C, c = i - b * C;
-        const float* row = partials + ((int64_t)b * nparts) * (2 * C + 1);
-        const double* arow = acc + (int64_t)b * (2 * C + 1);
-        const float g = gate_c[i];
-        du[i] = (acc ? (float)arow[c] : row[c]) * g * (1.f - g);
-        gp[i] = gap[i];
-        ps[b * (C + 1) + c] = acc ? (float)arow[C + c] : row[C + c];
-        if (c == 0) ps[b * (C + 1) + C] = acc ? (float)arow[2 * C] : row[2 * C];
-    }
-    for (int i = tid; i < B * R; i += nt) hd[i] = hidden[i];
-    __syncthreads();
-    for (int c = tid; c < C + 1; c += nt) {
-        float t = 0.f;
-        for (int b = 0; b < B; ++b) t += ps[b * (C + 1) + c];
-        if (c < C) g_ws[c] = t; else g_bs[0] = t;
-    }
-    for (int i = tid; i < B * R; i += nt) {
-        const int b = i / R, r = i - b * R;
-        float t = 0.f;
-        for (int c = 0; c < C; ++c) t += du[b * C + c] * sw2[c * R + r];
-        dh[i] = hd[i] > 0.f ? t : 0.f;
-    }
-    for (int i = tid; i < C * R; i += nt) {
-        const int c = i / R, r = i - c * R;
-        float t = 0.f;
-        for (int b = 0; b < B; ++b) t += du[b * C + c] * hd[b * R + r];
-        g_w2[i] = t;
-    }
-    for (int c = tid; c < C; c += nt) { float t = 0.f; for (int b = 0; b < B; ++b) t += du[b * C + c]; g_b2[c] = t; }
-    __syncthreads();
-    for (int i = tid; i < R * C; i += nt) {
-        const int r = i / C, c = i - r * C;
-        float t = 0.f;
-        for (int b = 0; b < B; ++b) t += dh[b * R + r] * gp[b * C + c];
-        g_w1[i] = t;
-    }
-    for (int r = tid; r < R; r += nt) { float t = 0.f; for (int b = 0; b < B; ++b) t += dh[b * R + r]; g_b1[r] = t; }
-    for (int i = tid; i < B * C; i += nt) {
-        const int b = i / C, c = i - b * C;
-        float t = 0.f;
-        for (int r = 0; r < R; ++r) t += dh[b * R + r] * sw1[r * C + c];
-        dgap[i] = t * inv_hw;
+    for (int b0 = 0; b0 < Ball; b0 += Bt) {
+        const int B = min(Bt, Ball - b0);
+        const bool first = b0 == 0;
+        if (!first) __syncthreads();                      // the previous tile's readers are done with the staged vectors
+        for (int i = tid; i < B * C; i += nt) {
+            const int b = i / C, c = i - b * C;
+            const float* row = partials + ((int64_t)(b0 + b) * nparts) * (2 * C + 1);
+            const double* arow = acc + (int64_t)(b0 + b) * (2 * C + 1);
+            const float g = gate_c[(int64_t)b0 * C + i];
+            du[i] = (acc ? (float)arow[c] : row[c]) * g * (1.f - g);
+            gp[i] = gap[(int64_t)b0 * C + i];
+            ps[b * (C + 1) + c] = acc ? (float)arow[C + c] : row[C + c];
+            if (c == 0) ps[b * (C + 1) + C] = acc ? (float)arow[2 * C] : row[2 * C];
+        }
+        for (int i = tid; i < B * R; i += nt) hd[i] = hidden[(int64_t)b0 * R + i];
+        __syncthreads();
+        for (int c = tid; c < C + 1; c += nt) {
+            float t = 0.f;
+            for (int b = 0; b < B; ++b) t += ps[b * (C + 1) + c];
+            float* o = c < C ? g_ws + c : g_bs;
+            *o = first ? t : *o + t;
+        }
+        for (int i = tid; i < B * R; i += nt) {
+            const int b = i / R, r = i - b * R;
+            float t = 0.f;
+            for (int c = 0; c < C; ++c) t += du[b * C + c] * sw2[c * R + r];
+            dh[i] = hd[i] > 0.f ? t : 0.f;
+        }
+        for (int i = tid; i < C * R; i += nt) {
+            const int c = i / R, r = i - c * R;
+            float t = 0.f;
+            for (int b = 0; b < B; ++b) t += du[b * C + c] * hd[b * R + r];
+            g_w2[i] = first ? t : g_w2[i] + t;
+        }
+        for (int c = tid; c < C; c += nt) { float t = 0.f; for (int b = 0; b < B; ++b) t += du[b * C + c]; g_b2[c] = first ? t : g_b2[c] + t; }
+        __syncthreads();
+        for (int i = tid; i < R * C; i += nt) {
+            const int r = i / C, c = i - r * C;
+            float t = 0.f;
+            for (int b = 0; b < B; ++b) t += dh[b * R + r] * gp[b * C + c];
+            g_w1[i] = first ? t : g_w1[i] + t;
+        }
+        for (int r = tid; r < R; r += nt) { float t = 0.f; for (int b = 0; b < B; ++b) t += dh[b * R + r]; g_b1[r] = first ? t : g_b1[r] + t; }
+        for (int i = tid; i < B * C; i += nt) {
+            const int b = i / C, c = i - b * C;
+            float t = 0.f;
+            for (int r = 0; r < R; ++r) t += dh[b * R + r] * sw1[r * C + c];
+            dgap[(int64_t)b0 * C + i] = t * inv_hw;
+        }
     }
 }
 
@@ -386,10 +396,16 @@ extern "C" int salt_scse_bwd(const salt_scse_bwd_args* a, void* stream) {
     if (a->nparts != nparts) SALT_FAIL(SALT_E_BADARG, "scse_bwd: nparts %d, expected %d", a->nparts, nparts);
     hipStream_t st = (hipStream_t)stream;
     const int C = a->x.C, B = a->x.B;
-    const size_t fc_base = (size_t)B * (3 * C + 2 * a->R + 1) * sizeof(float), fc_w = (size_t)2 * a->R * C * sizeof(float);
-    const int stage_w = fc_base + fc_w <= 160 * 1024;             // the FC weights ride along only when they fit beside the per-image vectors
-    const size_t fc_lds = fc_base + (stage_w ? fc_w : 0);
-    if (fc_lds > 160 * 1024) SALT_FAIL(SALT_E_LDS, "scse_bwd: batch*channels too large for the FC backward (%zu B)", fc_lds);
+    const size_t fc_img = (size_t)(3 * C + 2 * a->R + 1) * sizeof(float), fc_w = (size_t)2 * a->R * C * sizeof(float);
+    int stage_w = fc_img * B + fc_w <= 160 * 1024;                // the FC weights ride along only when they fit beside the per-image vectors
+    int Bt = B;
+    if (fc_img * B > 160 * 1024) {
+        // the batch does not fit: tiles of Bt images with the weights staged (round 6; C = 256 above 51 images per GPU failed before)
+        if (fc_w + fc_img > 160 * 1024) SALT_FAIL(SALT_E_LDS, "scse_bwd: %d channels x %d hidden units do not fit the FC backward", C, a->R);
+        stage_w = 1;
+        Bt = (int)((160 * 1024 - fc_w) / fc_img);
+    }
+    const size_t fc_lds = fc_img * Bt + (stage_w ? fc_w : 0);
     if (fc_lds > 64 * 1024) {
         static bool attr_set = false;
         if (!attr_set) {
@@ -410,7 +426,7 @@ extern "C" int salt_scse_bwd(const salt_scse_bwd_args* a, void* stream) {
             SALT_CHECK_LAUNCH();
         }
         hipLaunchKernelGGL(se_fc_bwd_kernel, dim3(1), dim3(1024), fc_lds, st, a->partials, nparts, B, C, a->R, a->w1, a->w2, a->gap, a->hidden,
-                           a->gate_c, a->g_w1, a->g_b1, a->g_w2, a->g_b2, a->g_ws, a->g_bs, a->dgap, 1.0f / (float)(a->x.H * a->x.W), a->acc, stage_w);
+                           a->gate_c, a->g_w1, a->g_b1, a->g_w2, a->g_b2, a->g_ws, a->g_bs, a->dgap, 1.0f / (float)(a->x.H * a->x.W), a->acc, stage_w, Bt);
         SALT_CHECK_LAUNCH();
         if (!a->skip_bcast) {                      // else: the consumer adds dgap[b][c] on the fly (salt_bn_bwd_args.da_bias)
             const int64_t units = view_pixels(a->dx) * (C / VE);

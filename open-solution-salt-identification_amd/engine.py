@@ -55,6 +55,8 @@ class Program:
         self.patches = []      # (struct, path, Scratch)
         self._entries = None
         self.marks = {}
+        self._pre_run = None           # callable(stream, begin) run before the entries are issued (Graph.finalize: shard hygiene)
+        self._post_run = None          # callable(begin, end) after they were issued
 
     def add(self, opname, stream=None, **fields):
         fn, S = OP_FUNCS['salt_' + opname]
@@ -118,6 +120,8 @@ class Program:
         if self._entries is None:
             self.finalize()
         end = len(self.ops) if end is None else end
+        if self._pre_run is not None:
+            self._pre_run(stream, begin)
         st = _stream_ptr(stream)
         if side is None and 3 in self.streams[begin:end]:
             raise SaltError('program %s joins the side stream (data-gradient weight packs): run it with side=engine.side_stream' % self.name)
@@ -138,6 +142,8 @@ class Program:
                 pass
             where = (' [%s]' % self.ops[m][0]) if m is not None and m < len(self.ops) else ''
             raise SaltError('program %s failed (%d)%s: %s' % (self.name, rc, where, msg))
+        if self._post_run is not None:
+            self._post_run(begin, end)
 
     def capture(self, stream):
         """Capture the whole program (single stream, tags ignored) into a hipGraph on ``stream`` (not the default stream)."""
@@ -166,15 +172,23 @@ class Program:
             self.finalize()
         n = len(self.ops)
         ms = (ctypes.c_float * max(n, 1))()
+        if self._pre_run is not None:
+            self._pre_run(stream, 0)
         check(lib.salt_program_run_timed(ctypes.cast(self._entries, ctypes.c_void_p), 0, n, _stream_ptr(stream), ms), 'run_timed')
+        if self._post_run is not None:
+            self._post_run(0, n)
         return [(self.ops[i][0], self.ops[i][2], float(ms[i])) for i in range(n)]
 
     def run_debug(self, stream=None):
         """Run op by op with a device sync after each (pinpoints a faulting kernel)."""
+        if self._pre_run is not None:
+            self._pre_run(stream, 0)
         st = _stream_ptr(stream)
         for i, (name, fn, s) in enumerate(self.ops):
             check(fn(ctypes.byref(s), st), '%s[%d] %s' % (self.name, i, name))
             torch.cuda.synchronize()
+        if self._post_run is not None:
+            self._post_run(0, len(self.ops))
 
 
 def _stream_ptr(stream):
@@ -385,6 +399,28 @@ class Graph:
                     fill(z, p=base[which], bytes=(nbf + nbb) if which == 'fwd' else 0)
             for st, field, w, off in self._fin_patches:
                 setattr(st, field, base[w] + off)
+            if not split and nbb and 'bwd' in self._fin_zero:
+                # The backward shards are accumulate-only and only the FORWARD program clears them: a backward program that is run
+                # again without a fresh forward pass (loss.backward(retain_graph=True) through autograd.py, a second loss's backward,
+                # bwd.run_timed in the profiling tools) would add its BatchNorm-backward sums on top of the previous run's.
+                # The programs keep a 'backward shards dirty' flag: forward clears it, backward sets it, and a backward run that finds
+                # it set clears its own half first (one salt_zero launch, only ever on that off-path case).
+                rz = Program('rezero_bwd_shards')
+                rz.add('zero', p=base['bwd'], bytes=nbb)
+                rz.finalize()
+                state = self._shard_state = {'dirty': False, 'rezeroed': 0}
+
+                def fwd_done(begin, end, state=state):
+                    if begin == 0:
+                        state['dirty'] = False
+
+                def bwd_begin(stream, begin, state=state, rz=rz):
+                    if begin == 0:
+                        if state['dirty']:
+                            rz.run(stream=stream)
+                            state['rezeroed'] += 1
+                        state['dirty'] = True
+                self.fwd._post_run, self.bwd._pre_run = fwd_done, bwd_begin
         return self
 
     def _fin_slot(self, which, ndoubles, *targets):

@@ -194,13 +194,27 @@ class SegmentationModel(Model):
             eng.run_step_graph(net, kind, weight, self.optimizer)
             self._graph_stepped = True
             return net.loss[0].clone()
-        net = eng.forward(X.contiguous().float(), True)
+        # round 6: no torch copy / fill / clone kernel inside the step.  A resident fp32 batch / target is READ IN PLACE (the programs'
+        # pointer fields are re-pointed for the duration of the enqueue calls, CompiledNet.bind), the loss scalar is written straight
+        # into a fresh 0-dim tensor that is returned as is (read lazily by whoever wants the number: callbacks.TrainingMonitor).
+        net = eng.net(tuple(X.shape), True)
         K = net.logits.shape[1]
-        net.target.copy_(target[:, :K])
-        net.loss_program(kind, weight).run()
-        self.dp.backward(eng, net, self.optimizer)
+        loss_prog = net.loss_program(kind, weight)
+        zero_copy = os.environ.get('SALT_STEP_ZERO_COPY', '1') != '0'
+        bx = zero_copy and net.bindable(X, net.x)
+        bt = zero_copy and net.bindable(target, net.target)
+        loss_t = torch.empty((1,), dtype=torch.float32, device=X.device) if zero_copy else None
+        try:
+            net.bind(x=X if bx else None, target=target if bt else None, loss=loss_t)
+            eng.forward(X if bx else X.contiguous().float(), True, bound=bx)
+            if not bt:
+                net.target.copy_(target[:, :K])
+            loss_prog.run()
+            self.dp.backward(eng, net, self.optimizer)
+        finally:
+            net.bind()                           # back to the static buffers (tools / tests that run the programs on their own)
         eng.eager_done.add((tuple(X.shape), kind))
-        return net.loss[0].clone()
+        return loss_t[0] if zero_copy else net.loss[0].clone()
 
     def transform(self, datagen, validation_datagen=None, *args, **kwargs):
         outputs = self._transform(datagen, validation_datagen)

@@ -19,6 +19,7 @@ step, and because gradients live in one flat buffer the all-reduce works on cont
 CPU (gloo) is supported for the bucket planner / reducer so the N>1 logic is testable without GPUs.
 """
 import os
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -30,14 +31,17 @@ DEFAULT_TAIL_BYTES = 4 << 20
 # CU the backward pass it overlaps cannot use, and a workgroup of ours waits for a CU RCCL holds.  RCCL's own default on this part is
 # 64 channels for the 1-rank communicator (bench.py: rccl_info) - a quarter of the chip.  The 7 xGMI links of a GPU carry ~153 GB/s
 # each and a channel moves ~20-25 GB/s, so 32 channels (1/8 of the CUs) already cover the links a ring / direct exchange can use at
-# once; the ~120 MB of gradients per step are then ~0.4 ms of collectives underneath ~3.5 ms of backward.  Exposed as a knob because
-# nobody can rehearse the 8-GPU run here: SALT_RCCL_MAX_NCHANNELS (0 = leave RCCL alone), or set NCCL_MAX_NCHANNELS yourself (wins).
-DEFAULT_RCCL_MAX_NCHANNELS = 32
+# once; the ~120 MB of gradients per step are then ~0.4 ms of collectives underneath ~3.5 ms of backward.  OPT-IN (round 6):
+# the cap is process-wide, applies to every communicator of the process and has never been measured on more than one rank, so RCCL is
+# left alone unless SALT_RCCL_MAX_NCHANNELS=<n> asks for it (or the user sets NCCL_MAX_NCHANNELS, which always wins); 32 is the
+# value the reasoning above suggests for an 8-GPU A/B.
+DEFAULT_RCCL_MAX_NCHANNELS = 0
+SUGGESTED_RCCL_MAX_NCHANNELS = 32
 
 
 def configure_rccl_env():
-    """Set NCCL_MAX_NCHANNELS (unless the user did) BEFORE the process group is created - RCCL reads it when the communicator comes up.
-    -> the value in effect, or None when RCCL's default is left alone."""
+    """SALT_RCCL_MAX_NCHANNELS=<n> (opt-in): export NCCL_MAX_NCHANNELS=<n> (unless the user set that variable) BEFORE the process group
+    is created - RCCL reads it when the communicator comes up.  -> the value in effect, or None when RCCL's default is left alone."""
     if 'NCCL_MAX_NCHANNELS' in os.environ:
         return int(os.environ['NCCL_MAX_NCHANNELS'])
     n = int(os.environ.get('SALT_RCCL_MAX_NCHANNELS', str(DEFAULT_RCCL_MAX_NCHANNELS)))
@@ -45,6 +49,15 @@ def configure_rccl_env():
         os.environ['NCCL_MAX_NCHANNELS'] = str(n)
         return n
     return None
+
+
+def _destroy_events(handles):
+    """salt_event_destroy on native event handles (ctypes.c_void_p) - weakref.finalize callback of a compiled net / drop_plans."""
+    from ._abi import lib
+    for h in handles:
+        if h is not None and h.value:
+            lib.salt_event_destroy(h)
+            h.value = None
 
 
 def plan_buckets(ready, total, bucket_bytes=DEFAULT_BUCKET_BYTES, tail_bytes=DEFAULT_TAIL_BYTES):
@@ -84,9 +97,11 @@ class DataParallel:
     def __init__(self, rank=0, world=1, bucket_bytes=DEFAULT_BUCKET_BYTES):
         self.rank, self.world, self.bucket_bytes = rank, world, bucket_bytes
         self._comm_stream = None
-        self._plans = {}
-        self._events = {}
-        self._marks = {}
+        # per compiled net (weak keys: a freed and re-created CompiledNet can never meet another net's stale mark positions through
+        # a recycled id()): bucket plan, the executor's marks (native events), torch events of the segmented form
+        self._plans = weakref.WeakKeyDictionary()
+        self._events = weakref.WeakKeyDictionary()
+        self._marks = weakref.WeakKeyDictionary()
         self.measure = False            # bench.py: record an event pair around the final wait for the collectives
         self.exposed_events = []
         self.timeline = False           # bench.py / tools/dp_overhead.py: timing events per bucket (ready / all-reduce done) and at backward end
@@ -118,7 +133,7 @@ class DataParallel:
             return
         with torch.no_grad():
             for t in list(model.parameters()) + list(model.buffers()):
-                dist.broadcast(t.data, src=0)
+                self._broadcast(t.data, src=0)
         if getattr(model, '_engine', None) is not None:
             model._engine.touch()
 
@@ -137,8 +152,25 @@ class DataParallel:
 
     def _all_reduce(self, t):
         """SUM all-reduce of one contiguous gradient range on the current stream (async work handle).  Tests substitute the
-        collective (e.g. x2 = the sum over two ranks that hold the same batch) to exercise the plan without a second GPU."""
+        collective (e.g. x2 = the sum over two ranks that hold the same batch) to exercise the plan without a second GPU.
+        gloo + device tensors (two ranks on ONE GPU - RCCL refuses two ranks on one device - or a CPU-only fabric): the range is staged
+        through the host ON THE CURRENT STREAM (the D2H copy waits for the bucket's events like a collective kernel would), summed by
+        gloo, and copied back; no work handle - the caller's stream wait orders the optimizer behind the copy."""
+        if t.is_cuda and dist.get_backend() == 'gloo':
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            t.copy_(h)
+            return None
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+
+    @staticmethod
+    def _broadcast(t, src=0):
+        if t.is_cuda and dist.get_backend() == 'gloo':
+            h = t.cpu()
+            dist.broadcast(h, src=src)
+            t.copy_(h)
+        else:
+            dist.broadcast(t, src=src)
 
     def allreduce_gradients(self, eng, optimizer=None):
         """Autograd-bridge branch of _fit_loop: one SUM all-reduce of the whole flat gradient buffer after backward; the 1/world
@@ -186,14 +218,17 @@ class DataParallel:
         if not self._active():
             net.bwd.run(side=eng.side_stream)
             return
-        key = id(net)
+        key = net
         if key not in self._plans:
             self._plans[key] = plan_buckets(net.g.grad_ready, eng.n_live, self.bucket_bytes)
-            # ONE event per bucket and queue, created once (round 4 allocated two torch.cuda.Event objects per bucket per step)
-            self._events[key] = [(torch.cuda.Event(), torch.cuda.Event()) for _ in self._plans[key]]
-            self._marks[key] = self._make_marks(self._plans[key], len(net.bwd))
         if self.timeline or os.environ.get('SALT_DP_SEGMENTS'):
+            if key not in self._events:
+                # ONE event per bucket and queue, created once (round 4 allocated two torch.cuda.Event objects per bucket per step)
+                self._events[key] = [(torch.cuda.Event(), torch.cuda.Event()) for _ in self._plans[key]]
             return self._backward_segments(eng, net, key)
+        if key not in self._marks:
+            self._marks[key] = self._make_marks(self._plans[key], len(net.bwd))
+            weakref.finalize(net, _destroy_events, [h for pair in self._marks[key][4] for h in pair])
         # ---- ONE executor call for the whole backward program: the executor records each bucket's two events (compute queue, weight-
         # gradient queue) when it reaches the bucket's position - no cut of the program per bucket (round 4: + 2 % on one rank before
         # any wire time, most of it the per-segment flush / lost fork hand-off) - and the collectives are issued behind those events
@@ -221,6 +256,13 @@ class DataParallel:
         if self.measure:
             e1.record(cur)
             self.exposed_events.append((e0, e1))
+
+    def drop_plans(self):
+        """Forget every bucket plan (tools re-plan with another bucket size); the native events of the dropped marks are destroyed."""
+        for m in list(self._marks.values()):
+            _destroy_events([h for pair in m[4] for h in pair])
+            del m[4][:]
+        self._plans.clear(); self._events.clear(); self._marks.clear()
 
     def _make_marks(self, plan, n_ops):
         """ctypes arrays for salt_program_run_streams_marks: ascending positions + one native event per bucket and queue"""

@@ -26,6 +26,21 @@ def _require_gpu(device):
         raise SaltError('the HIP path needs a GPU tensor/device (got %s); there is no CPU fallback' % device)
 
 
+def _ptr_fields(struct, ptr, out):
+    """(struct, field) of every pointer field of an argument struct (nested views / arrays included) that holds ``ptr``"""
+    for name, ct in struct._fields_:
+        v = getattr(struct, name)
+        if isinstance(v, ctypes.Structure):
+            _ptr_fields(v, ptr, out)
+        elif isinstance(v, ctypes.Array):
+            for e in v:
+                if isinstance(e, ctypes.Structure):
+                    _ptr_fields(e, ptr, out)
+        elif ct is ctypes.c_void_p and v == ptr:
+            out.append((struct, name))
+    return out
+
+
 class CompiledNet:
     """One static instance: input/target/logits buffers + forward/backward programs for fixed (B,C,H,W)."""
 
@@ -47,6 +62,50 @@ class CompiledNet:
         g.finalize()
         self.fwd, self.bwd = g.fwd, g.bwd
         self._loss_progs = {}
+        self._slots = {}               # 'x' | 'target' | 'loss' -> [(struct, field)] that hold the static buffer's address
+        self._bound = {}
+
+    # ------------------------------------------------------------------ zero-copy step inputs (round 6)
+    def _slot_list(self, which):
+        """Argument-struct pointer fields of this instance's programs that read the static input / target buffer or write the loss
+        scalar.  The executor reads an argument struct when it ENQUEUES the launch, so re-pointing such a field between two runs of a
+        program is a host-side store and nothing else: the fused step (models.SegmentationModel._fused_step) points them at the
+        caller's resident batch / target for the duration of its enqueue calls instead of copying 6 MB + 4 MB into the static
+        buffers first, and puts them back (hipGraph captures bake pointers in - they keep the copies)."""
+        buf = {'x': self.x, 'target': getattr(self, 'target', None), 'loss': getattr(self, 'loss', None)}[which]
+        progs = [self.fwd, self.bwd] + list(self._loss_progs.values())
+        key = (which, tuple(id(p) for p in progs))
+        if self._slots.get(which, (None,))[0] != key:
+            out = []
+            if buf is not None:
+                for prog in progs:
+                    for _, _, st in prog.ops:
+                        _ptr_fields(st, buf.data_ptr(), out)
+                        if self._bound.get(which, buf.data_ptr()) != buf.data_ptr():
+                            _ptr_fields(st, self._bound[which], out)
+            self._slots[which] = (key, out)
+        return self._slots[which][1]
+
+    def bind(self, **tensors):
+        """bind(x=t, target=t2, loss=t3): point the programs at these device tensors (None / omitted: the static buffer).  The caller
+        keeps the tensors alive until the step's launches are enqueued on the stream it later frees / overwrites them on."""
+        for which in ('x', 'target', 'loss'):
+            t = tensors.get(which)
+            buf = {'x': self.x, 'target': getattr(self, 'target', None), 'loss': getattr(self, 'loss', None)}[which]
+            if buf is None:
+                continue
+            ptr = buf.data_ptr() if t is None else t.data_ptr()
+            slots = self._slot_list(which)
+            if t is not None and (t.dtype != buf.dtype or tuple(t.shape) != tuple(buf.shape) or not t.is_contiguous() or t.device != buf.device or ptr % 16):
+                raise SaltError('bind(%s): needs a contiguous %s tensor of shape %s on %s' % (which, buf.dtype, tuple(buf.shape), buf.device))
+            for st, field in slots:
+                setattr(st, field, ptr)
+            self._bound[which] = ptr
+
+    @staticmethod
+    def bindable(t, buf):
+        return (t.dtype == buf.dtype and tuple(t.shape) == tuple(buf.shape) and t.is_contiguous() and t.device == buf.device
+                and t.data_ptr() % 16 == 0)
 
     def loss_program(self, kind, loss_scale):
         key = (kind, float(loss_scale))
@@ -409,10 +468,13 @@ class Engine:
         self._packed_version = self._packed_bwd_version = self.wver      # the graph packed the weights it started from ...
         self.touch(weights=True, stats=True)                             # ... and Adam / BatchNorm moved them
 
-    def forward(self, x, train):
+    def forward(self, x, train, bound=False):
+        """``bound``: the caller pointed the programs at ``x`` itself (CompiledNet.bind) - no copy into the static input buffer."""
         _require_gpu(x.device)
         net = self.net(x.shape, train)
-        net.x.copy_(x)
+        if not bound:
+            net.bind(x=None)
+            net.x.copy_(x)
         late = train and bool(os.environ.get('SALT_PACK_BWD_LATE'))   # round 2: the loss is ~65 us now, too short to hide the packs
         self.refresh(train, defer_bwd=late)
         net.fwd.run(side=None if os.environ.get('SALT_NO_FWD_SIDE') else self.side_stream)

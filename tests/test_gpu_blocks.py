@@ -399,3 +399,75 @@ def test_scse_kernels_vs_channel_and_spatial_se_goldens(dtype):
     assert_close(gx[0], xr.grad, gtol, 'gx')
     for k, g in grads.items():
         assert_close(g, leaves[k].grad, gtol * 2, 'g:' + k)
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_backward_program_is_idempotent_without_a_fresh_forward(dtype):
+    """the BatchNorm-backward fp64 shards are accumulate-only and cleared by the FORWARD program's salt_zero; a backward
+    program that runs twice behind ONE forward pass (loss.backward(retain_graph=True) through autograd.py, a second loss, the timed /
+    debug runs of the tools) must clear its own half first (Graph.finalize: 'backward shards dirty' flag) instead of doubling the sums."""
+    from gpu_harness import BlockRun, load_into
+    A = _mods()
+    fx = golden('F4_decoderblock_skip_train')
+    make, emit = BLOCKS['F4_decoderblock_skip']
+    m = make(A)
+    load_into(m, _fixture_state(fx, m))
+    m.train(True)
+    run = BlockRun(m, [T(fx['x']), T(fx['e0'])], emit(m), train=True, dtype=dtype)
+    run.forward()
+    gy = T(fx['gy']).to('cuda:0')
+    tol = 1e-4 if dtype == 'f32' else 2e-2          # (a doubled sum is an O(1) error; the fp64 atomics' arrival order is last bits)
+    gx1, g1 = run.backward(gy)
+    st = getattr(run.g, '_shard_state', None)
+    assert st is not None and st['dirty'] and st['rezeroed'] == 0
+    gx2, g2 = run.backward(gy)                       # no forward in between
+    assert st['rezeroed'] == 1
+    timed = run.g.bwd.run_timed()                    # the tools' path
+    torch.cuda.synchronize()
+    assert st['rezeroed'] == 2 and len(timed) == len(run.g.bwd)
+    gx3 = [t.cpu() for t in run.g.input_grads]
+    for a, b, c in zip(gx1, gx2, gx3):
+        assert_close(b, a, tol, 'dx after a second backward')
+        assert_close(c, a, tol, 'dx after a timed backward')
+    for k in g1:
+        assert_close(g2[k], g1[k], tol, k)
+    run.forward()
+    assert not st['dirty']
+    gx4, _ = run.backward(gy)
+    assert st['rezeroed'] == 2
+    assert_close(gx4[0], gx1[0], tol, 'dx after forward + backward')
+
+
+@pytest.mark.parametrize('B', [51, 64, 130])
+def test_scse_backward_batch_tiles_c256(B):
+    """se_fc_bwd_kernel is ONE workgroup whose per-image vectors had to fit 160 KB of LDS - C = 256 (the ResNet101 / 152
+    decoders, architectures/base.py:82-117) failed with SALT_E_LDS above 51 images per GPU, i.e. at BASELINE C3's batch 64.  Round 6
+    walks the batch in tiles; 51 still runs as ONE tile (the old path), 64 as 45 + 19, 130 as three tiles - all against the oracle's
+    composition of ChannelSELayer and SpatialSELayer (pinned by fixtures F4_channel_se / F4_spatial_se in tests/test_oracle_golden.py)."""
+    from torch import nn
+    from gpu_harness import BlockRun
+    from oracle import blocks as OB
+    A = _mods()
+    C = 256
+
+    class Both(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.channel_se = A.ChannelSELayer(C, reduction=16)
+            self.spatial_se = A.SpatialSELayer(C)
+    torch.manual_seed(B)
+    m = Both()
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = _rand((B, C, 8, 8), 31)
+    run = BlockRun(m, [x], lambda g, a: g.scse(a, m.channel_se, m.spatial_se), train=True, dtype='f32')
+    y = run.forward()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr = x.clone().requires_grad_(True)
+    yr = torch.relu(OB.channel_se(leaves, 'channel_se.', xr) + OB.spatial_se(leaves, 'spatial_se.', xr))
+    assert_close(y, yr.detach(), TOL32, 'y vs oracle')
+    gy = _rand(tuple(yr.shape), 32)
+    yr.backward(gy)
+    gx, grads = run.backward(gy.to('cuda:0'))
+    assert_close(gx[0], xr.grad, TOL32 * 2, 'gx')
+    for k, g in grads.items():
+        assert_close(g, leaves[k].grad, TOL32 * 4, 'g:' + k)

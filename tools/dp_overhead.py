@@ -37,7 +37,7 @@ def run(mode, n):
         dp.skip_collectives = True
     if mode == 'dp_1bucket':
         dp.bucket_bytes = 1 << 40
-    dp._plans.clear()
+    dp.drop_plans()
     dp.measure = False
     for i in range(4):
         model._fit_loop(list(batches[i % 8]))
@@ -57,7 +57,7 @@ print(json.dumps(res))
 os.environ['SALT_FORCE_DP_PATH'] = '1'
 dp.skip_collectives = False
 dp.bucket_bytes = parallel.DEFAULT_BUCKET_BYTES
-dp._plans.clear()
+dp.drop_plans()
 dp.timeline = True
 for i in range(10):
     model._fit_loop(list(batches[i % 8]))
