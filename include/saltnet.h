@@ -465,6 +465,53 @@ typedef struct {              /* backward of a = relu?(bn(y) (+res)) in train mo
 int salt_bn_bwd(const salt_bn_bwd_args*, void* stream);
 int salt_bn_bwd_parts(const salt_bn_bwd_args*);
 
+/* ------------------------------------------------------------------ train-mode BatchNorm + ReLU + 1x1 logit head in ONE pass (round 6)
+ * The reference's `final` Sequential (architectures/unet.py:84-87: Conv2dBnRelu -> nn.Conv2d(C, num_classes, 1)) in TRAINING: the
+ * activation a = relu(bn(y)) has exactly one reader, the 1x1 head, and the head's input gradient exactly one reader, the BatchNorm
+ * backward - so neither tensor needs to exist.  salt_head_bn finalizes the statistics shards of y's producer (consumer side, like
+ * salt_affine_act with fin_acc), applies scale / shift / ReLU to y on the way in, rounds to the storage dtype exactly where
+ * salt_affine_act would have stored, and writes the fp32 NCHW logits.  salt_head_bn_bwd is the matching backward in two passes
+ * over y: (1) head weight / bias gradients and the BatchNorm-backward sums of da = W^T dlogits (recomputed per pixel: rank
+ * num_classes) into fp64 shards, (2) dy = k (mask da - c1 - xhat c2) with the sums finalized in every workgroup's prologue (like
+ * salt_bn_bwd with partials_ready 3).  Replaces salt_affine_act + salt_head1x1 and salt_head1x1_bwd + salt_bn_bwd for that layer:
+ * 0.47 GB of traffic -> 0.21 GB at the C2 shape. */
+typedef struct {
+    int dtype;
+    salt_view y;              /* RAW convolution output (pre-BatchNorm) [B,H,W,C]; C / (16-byte piece) a power of two <= 64 */
+    const void* fin;          /* const salt_bn_finalize_args* of the layer */
+    const double* fin_acc;    /* [8][2 C + 1] fp64 statistics shards the producer of y added to (not cleared here) */
+    int relu;
+    const float* w;           /* head weight [Cout][C] fp32, Cout <= 4 */
+    const float* bias;        /* [Cout] or NULL */
+    int Cout;
+    float* y_nchw;            /* out: fp32 logits [B,Cout,H,W] */
+} salt_head_bn_args;
+int salt_head_bn(const salt_head_bn_args*, void* stream);
+
+typedef struct {
+    int dtype;
+    salt_view y;              /* raw convolution output, as in the forward call */
+    int relu;
+    const float* mean;        /* [C] batch statistics the forward call stored */
+    const float* invstd;
+    const float* gamma;
+    const float* beta;
+    const float* w;           /* head weight [Cout][C] */
+    int Cout;
+    const float* dy_nchw;     /* d loss / d logits, fp32 [B,Cout,H,W] */
+    float* partials;          /* workspace [nparts][Cout (C + 1)] */
+    int nparts;               /* as returned by salt_head_bn_bwd_parts */
+    float* gw;                /* out: head weight gradient [Cout][C] */
+    float* gb;                /* out: head bias gradient [Cout] or NULL */
+    double* fin_acc;          /* [8][2][C] fp64 shards of the BatchNorm-backward sums, zero on entry (salt_zero), left filled */
+    float* dgamma;            /* out [C] */
+    float* dbeta;             /* out [C] */
+    float* coef;              /* out [3][C] (k, c1, c2) or NULL */
+    salt_view dy;             /* out: grad wrt y */
+} salt_head_bn_bwd_args;
+int salt_head_bn_bwd(const salt_head_bn_bwd_args*, void* stream);
+int salt_head_bn_bwd_parts(const salt_head_bn_bwd_args*);
+
 typedef struct {              /* backward of a = relu(y (+res)) without BN, or plain masked copy */
     int dtype;
     salt_view da;

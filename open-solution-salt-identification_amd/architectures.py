@@ -436,7 +436,7 @@ class UNetResNet(HipNetwork):
             if fact:
                 ks = sorted(zs)
                 # eval: the 1x1 logit head is the block's only consumer - the stencil's epilogue applies it (SALT_HYPER_HEAD=0: separate launch)
-                fuse_head = g.hyper_head_ok(d, self.final[1])
+                fuse_head = g.head_bn_ok(d, self.final[1]) if g.train else g.hyper_head_ok(d, self.final[1])
                 f = g.conv_hyper(hyper, [zs[k] for k in ks], [dict((k_, R_) for R_, k_ in fact)[k] for k in ks], self.final[0].conv,
                                  self.final[0].batch_norm, relu=self.final[0].use_relu, head=(self.final[1], logits) if fuse_head else None)
                 if fuse_head:

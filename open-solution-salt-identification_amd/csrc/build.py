@@ -16,7 +16,7 @@ ROOT = os.path.dirname(PKG)
 INC = os.path.join(ROOT, 'include')
 OBJ = os.path.join(HERE, '_obj')
 LIB = os.path.join(PKG, 'libsaltnet_hip.so')
-SOURCES = ['runtime.hip', 'conv_mfma.hip', 'conv_ws.hip', 'conv_thin.hip', 'conv_wgrad_ls.hip', 'conv_small.hip', 'elementwise.hip', 'hyper.hip', 'se.hip', 'loss.hip', 'input.hip']
+SOURCES = ['runtime.hip', 'conv_mfma.hip', 'conv_ws.hip', 'conv_thin.hip', 'conv_wgrad_ls.hip', 'conv_small.hip', 'head_fused.hip', 'elementwise.hip', 'hyper.hip', 'se.hip', 'loss.hip', 'input.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + INC, '-I' + HERE, '-Wno-unused-value']
 
 

@@ -20,7 +20,7 @@ void salt_set_error(const char* fmt, ...) {
 
 extern "C" const char* salt_last_error(void) { return g_err; }
 
-extern "C" int salt_abi_version(void) { return 23; }
+extern "C" int salt_abi_version(void) { return 24; }
 
 extern "C" int salt_device_info(int* cu_count, int* lds_bytes, char* arch_name, int arch_name_len) {
     int dev = 0;
@@ -325,6 +325,8 @@ extern "C" int salt_abi_struct_sizes(int* out, int n) {
     (int)sizeof(salt_bn_fold_args),
     (int)sizeof(salt_affine_act_args),
     (int)sizeof(salt_bn_bwd_args),
+    (int)sizeof(salt_head_bn_args),
+    (int)sizeof(salt_head_bn_bwd_args),
     (int)sizeof(salt_relu_bwd_args),
     (int)sizeof(salt_maxpool2_args),
     (int)sizeof(salt_maxpool2_bwd_args),

@@ -788,6 +788,47 @@ class Graph:
         co, ci, kh, kw = hconv.weight.shape
         return (kh, kw) == (1, 1) and ci == C and 1 <= co <= 2 and C in ((64, 128, 256) if self.dtype == 'f32' else (64, 128, 256, 512))
 
+    def head_bn_ok(self, C, hconv):
+        """TRAIN mode: can the final block's BatchNorm apply + ReLU and the logit head ``hconv`` run as one pass over the raw convolution
+        output (salt_head_bn / salt_head_bn_bwd; saltnet.h: <= 4 classes, C a power-of-two number of 16-byte pieces <= 64, consumer-side
+        statistics shards)?  SALT_HEAD_BN=0 keeps the separate launches (A/B)."""
+        if not self.train or self._fin_mode() != 2 or os.environ.get('SALT_HEAD_BN', '1') == '0':
+            return False
+        co, ci, kh, kw = hconv.weight.shape
+        cpv = C // self.ve
+        return (kh, kw) == (1, 1) and ci == C and 1 <= co <= 4 and C % self.ve == 0 and 1 <= cpv <= 64 and cpv & (cpv - 1) == 0
+
+    def _head_bn(self, y, bn, relu, hconv, logits, producer):
+        """forward salt_head_bn behind ``producer`` (which adds y's statistics to the fp64 shards) + the tape entry of salt_head_bn_bwd,
+        which leaves dL/dy in y.grad: returned through ``self._head_bn_bwd`` - the caller's own backward closure calls it first."""
+        eng = self.engine
+        C = bn.num_features
+        w = eng.bn_work(bn)
+        nbt = bn.num_batches_tracked.data_ptr() if bn.num_batches_tracked is not None else None
+        F = fill(STRUCTS['salt_bn_finalize_args'](), C=C, gamma=bn.weight.data_ptr(), beta=bn.bias.data_ptr(), running_mean=bn.running_mean.data_ptr(),
+                 running_var=bn.running_var.data_ptr(), num_batches_tracked=nbt, momentum=bn.momentum, eps=bn.eps, mean=w['mean'].data_ptr(),
+                 invstd=w['invstd'].data_ptr(), scale=w['scale'].data_ptr(), shift=w['shift'].data_ptr())
+        self.keep.append(F)
+        Cout = hconv.weight.shape[0]
+        hb = self.fwd.add('head_bn', dtype=self.dt, y=y.view(), fin=ctypes.addressof(F), relu=int(relu), w=hconv.weight.data_ptr(),
+                          bias=hconv.bias.data_ptr() if hconv.bias is not None else None, Cout=Cout, y_nchw=logits.data_ptr())
+        self._fin_slot('fwd', 8 * (2 * C + 1), (producer, 'fin_acc'), (hb, 'fin_acc'))
+        self.dlogits = self.alloc(tuple(logits.shape), torch.float32)
+
+        def backward():
+            S = fill(STRUCTS['salt_head_bn_bwd_args'](), y=y.view())
+            nparts = lib.salt_head_bn_bwd_parts(ctypes.byref(S))
+            assert y.grad_state() == 0, 'conv output gradient has a single producer'
+            coef = self.f32(3 * C)
+            sb = self.bwd.add('head_bn_bwd', dtype=self.dt, y=y.view(), relu=int(relu), mean=w['mean'].data_ptr(), invstd=w['invstd'].data_ptr(),
+                              gamma=bn.weight.data_ptr(), beta=bn.bias.data_ptr(), w=hconv.weight.data_ptr(), Cout=Cout, dy_nchw=self.dlogits.data_ptr(),
+                              partials=Scratch('head', nparts * Cout * (C + 1) * 4), nparts=nparts, gw=self._gp(hconv.weight),
+                              gb=self._gp(hconv.bias) if hconv.bias is not None else None, dgamma=self._gp(bn.weight), dbeta=self._gp(bn.bias),
+                              coef=coef.data_ptr(), dy=y.gview())
+            self._fin_slot('bwd', 8 * 2 * C, (sb, 'fin_acc'))
+        self._head_bn_bwd = backward
+        return w
+
     def hyper_level(self, x, conv, c0, name='hyper.z'):
         """z = [W[:, c0 : c0 + x.C, kh, kw]]_taps x  at x's (LOW) resolution: one 1x1 convolution x.C -> 9 Cout whose output channel
         t Cout + o is tap t of output channel o of the 3x3 convolution ``conv`` restricted to the input channels of this level.
@@ -834,8 +875,8 @@ class Graph:
         d1 = (0, x.C)
         pk = eng.packed(conv, tk, transposed=False, d1=d1)
         bias = conv.bias.data_ptr() if conv.bias is not None else None
-        if head is not None and (self.train or not self.hyper_head_ok(Cout, head[0])):
-            raise SaltError('conv_hyper: the fused head is an eval-mode epilogue (ask hyper_head_ok first)')
+        if head is not None and not (self.head_bn_ok(Cout, head[0]) if self.train else self.hyper_head_ok(Cout, head[0])):
+            raise SaltError('conv_hyper: this head cannot be fused (ask hyper_head_ok / head_bn_ok first)')
         if out is None and head is None:
             out = self.new_act(x.B, x.H, x.W, Cout, name)
         ac = int(bool(getattr(getattr(self.engine, 'module', None), 'align_corners', False)))
@@ -844,6 +885,26 @@ class Graph:
         if any(getattr(z, 'on_side', False) for z in zs):
             self.join()
         st = dict(dtype=self.dt, nlev=len(zs), z=[z.view() for z in zs], R=list(Rs), y_in=y.view(), backward=0, align_corners=ac)
+        if self.train and head is not None:
+            # round 6: BatchNorm apply + ReLU + logit head in ONE pass over the raw sum (salt_head_bn): the block's activation and its
+            # gradient are never stored.  Backward: salt_head_bn_bwd writes dL/dy directly (head gradients + BatchNorm-backward sums in
+            # its first pass), then the stencil adjoint / weight gradient / data gradient as below.
+            prod = self.fwd.add('hyper_stencil', y=y.view(), **st)
+            w = self._head_bn(y, bn, relu, head[0], head[1], prod)
+            zs_, Rs_ = list(zs), list(Rs)
+
+            hb_bwd = self._head_bn_bwd
+
+            def backward():
+                hb_bwd()
+                for z in zs_:
+                    assert z.grad_state() == 0
+                self.bwd.add('hyper_stencil', dtype=self.dt, nlev=len(zs_), z=[z.gview() for z in zs_], R=Rs_, y_in=null_view(), y=y.gview(),
+                             backward=1, align_corners=ac)
+                self._wgrad(y.gview(), x.view(), td, tk, 1, 1, conv.weight, KH, KW, b_slice=(0, Cin))
+                self._dgrad(conv, x, y, taps, 1, True, KH, KW, d1=d1)
+            self.tape.append(backward)
+            return None
         if self.train:
             prod = self.fwd.add('hyper_stencil', y=y.view(), **st)
             w = self._bn_train_fwd(y, bn, relu, None, out, 0, None, None, producer=prod)

@@ -1,0 +1,145 @@
+"""salt_head_bn / salt_head_bn_bwd (round 6): the reference's `final` Sequential in TRAINING (architectures/unet.py:84-87: base.Conv2dBnRelu ->
+nn.Conv2d(C, num_classes, 1)) as one pass over the raw convolution output - BatchNorm finalize + apply + ReLU + 1x1 head forward, and
+head gradients + BatchNorm backward without the two tensors between them.
+
+(1) the two entry points alone, through the C-ABI, against torch autograd of  head(relu(batch_norm(y)))  on seeded tensors incl. ragged
+    pixel counts, non-power-of-two images, 1 - 4 classes, strided views, both dtypes;
+(2) the whole ResNet34 hypercolumn U-Net training step with the fusion on (default) against the same step with SALT_HEAD_BN=0 (the
+    separate salt_affine_act + salt_head1x1 / salt_head1x1_bwd + salt_bn_bwd launches): same rounding points, other summation order.
+The reference-generated goldens (F8 whole-network fixtures: eval logits, one training step) run on the fused default in
+tests/test_gpu_models.py."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+CASES = [
+    # B, H, W, C, Cout, relu, slack (pixel stride - C)
+    (2, 16, 16, 64, 2, 1, 0),
+    (3, 7, 9, 64, 2, 1, 0),          # ragged: 189 pixels, H W not a power of two
+    (1, 5, 3, 32, 1, 1, 0),
+    (2, 12, 20, 128, 3, 1, 64),      # strided view
+    (2, 8, 8, 256, 4, 0, 0),         # no ReLU, 4 classes
+    (5, 32, 32, 64, 2, 1, 0),        # several blocks per pass
+]
+
+
+def _run_case(case, dtype):
+    import salt_amd  # noqa: F401
+    from salt_amd._abi import STRUCTS, lib, fill, check
+    from salt_amd.engine import shaped_view
+    B, H, W, C, Cout, relu, slack = case
+    tdt = torch.float32 if dtype == 'f32' else torch.bfloat16
+    dt = 0 if dtype == 'f32' else 1
+    g = torch.Generator().manual_seed(B * 131 + C)
+    y = (torch.randn(B, H, W, C + slack, generator=g) * 1.5 + 0.3).to(tdt).to(DEV)
+    gamma = (1 + 0.2 * torch.randn(C, generator=g)).to(DEV); beta = (0.2 * torch.randn(C, generator=g)).to(DEV)
+    w = (torch.randn(Cout, C, generator=g) * C ** -0.5).to(DEV); bias = (0.1 * torch.randn(Cout, generator=g)).to(DEV)
+    dl = torch.randn(B, Cout, H, W, generator=g).to(DEV)
+    rm, rv, nbt = torch.zeros(C, device=DEV), torch.ones(C, device=DEV), torch.zeros(1, dtype=torch.int64, device=DEV)
+    mean, invstd, scale, shift = (torch.zeros(C, device=DEV) for _ in range(4))
+    # the producer's part: (sum, sum of squares, count) of the STORED y in fp64, spread over the 8 shards
+    yv = y[..., :C].double().reshape(-1, C)
+    M = yv.shape[0]
+    acc = torch.zeros(8, 2 * C + 1, dtype=torch.float64, device=DEV)
+    for s in range(8):
+        part = yv[s::8]
+        acc[s, :C] = part.sum(0); acc[s, C:2 * C] = (part * part).sum(0); acc[s, 2 * C] = part.shape[0]
+    Fa = fill(STRUCTS['salt_bn_finalize_args'](), C=C, gamma=gamma.data_ptr(), beta=beta.data_ptr(), running_mean=rm.data_ptr(), running_var=rv.data_ptr(),
+              num_batches_tracked=nbt.data_ptr(), momentum=0.1, eps=1e-5, mean=mean.data_ptr(), invstd=invstd.data_ptr(), scale=scale.data_ptr(), shift=shift.data_ptr())
+    logits = torch.zeros(B, Cout, H, W, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    yview = shaped_view(y.data_ptr(), B, H, W, C, C + slack)
+    check(lib.salt_head_bn(ctypes.byref(fill(STRUCTS['salt_head_bn_args'](), dtype=dt, y=yview, fin=ctypes.addressof(Fa), fin_acc=acc.data_ptr(), relu=relu,
+                                             w=w.data_ptr(), bias=bias.data_ptr(), Cout=Cout, y_nchw=logits.data_ptr())), st), 'head_bn')
+    S = fill(STRUCTS['salt_head_bn_bwd_args'](), y=yview)
+    nparts = lib.salt_head_bn_bwd_parts(ctypes.byref(S))
+    partials = torch.zeros(nparts * Cout * (C + 1), device=DEV)
+    gw, gb, dgamma, dbeta, coef = torch.zeros(Cout, C, device=DEV), torch.zeros(Cout, device=DEV), torch.zeros(C, device=DEV), torch.zeros(C, device=DEV), torch.zeros(3 * C, device=DEV)
+    acc_b = torch.zeros(8, 2, C, dtype=torch.float64, device=DEV)
+    dy = torch.zeros(B, H, W, C + slack, dtype=tdt, device=DEV)
+    check(lib.salt_head_bn_bwd(ctypes.byref(fill(STRUCTS['salt_head_bn_bwd_args'](), dtype=dt, y=yview, relu=relu, mean=mean.data_ptr(), invstd=invstd.data_ptr(),
+                                                 gamma=gamma.data_ptr(), beta=beta.data_ptr(), w=w.data_ptr(), Cout=Cout, dy_nchw=dl.data_ptr(),
+                                                 partials=partials.data_ptr(), nparts=nparts, gw=gw.data_ptr(), gb=gb.data_ptr(), fin_acc=acc_b.data_ptr(),
+                                                 dgamma=dgamma.data_ptr(), dbeta=dbeta.data_ptr(), coef=coef.data_ptr(),
+                                                 dy=shaped_view(dy.data_ptr(), B, H, W, C, C + slack))), st), 'head_bn_bwd')
+    torch.cuda.synchronize()
+    # torch reference on the stored operand (fp32 math; the bf16 path rounds a and dL/da to bf16 - emulated with straight-through casts)
+    yr = y[..., :C].float().cpu().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    gam, bet, wr, br = gamma.cpu().clone().requires_grad_(True), beta.cpu().clone().requires_grad_(True), w.cpu().clone().requires_grad_(True), bias.cpu().clone().requires_grad_(True)
+    rm_r, rv_r = torch.zeros(C), torch.ones(C)
+    a = F.batch_norm(yr, rm_r, rv_r, gam, bet, True, 0.1, 1e-5)
+    if relu:
+        a = F.relu(a)
+    if dtype == 'bf16':
+        class Rnd(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, t):
+                return t.bfloat16().float()
+
+            @staticmethod
+            def backward(ctx, gdy):
+                return gdy.bfloat16().float()
+        a = Rnd.apply(a)
+    out = F.conv2d(a, wr.view(Cout, C, 1, 1), br)
+    out.backward(dl.cpu())
+    res = dict(logits=(logits.cpu(), out.detach()), gw=(gw.cpu(), wr.grad), gb=(gb.cpu(), br.grad), dgamma=(dgamma.cpu(), gam.grad), dbeta=(dbeta.cpu(), bet.grad),
+               dy=(dy[..., :C].float().cpu(), yr.grad.permute(0, 2, 3, 1)), running_mean=(rm.cpu(), rm_r), running_var=(rv.cpu(), rv_r))
+    return res, int(nbt.item()), (dy[..., C:].float().abs().max().item() if slack else 0.0)
+
+
+@pytest.mark.parametrize('case', CASES)
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_head_bn_ops_vs_torch(case, dtype):
+    res, nbt, slack_max = _run_case(case, dtype)
+    assert nbt == 1 and slack_max == 0.0                                    # statistics updated once; nothing written outside the view's channels
+    tol = {'f32': dict(logits=2e-5, gw=5e-5, gb=2e-5, dgamma=1e-4, dbeta=1e-4, dy=1e-4, running_mean=1e-5, running_var=1e-5),
+           'bf16': dict(logits=3e-3, gw=3e-3, gb=2e-5, dgamma=3e-3, dbeta=3e-3, dy=1.5e-2, running_mean=1e-5, running_var=1e-5)}[dtype]
+    for k, (got, want) in res.items():
+        assert torch.isfinite(got).all(), k
+        err = float((got.double() - want.double()).abs().max() / (want.double().abs().max() + 1e-12))
+        assert err <= tol[k], '%s: max-rel error %.3e > %.1e' % (k, err, tol[k])
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_fused_final_block_equals_separate_launches(dtype, monkeypatch):
+    """The shipped training step (SegmentationModel._fit_loop) with the fused final block against SALT_HEAD_BN=0: same operands, same
+    rounding points, other summation partitions - logits, loss, every parameter after two steps."""
+    from test_gpu_fused_step import _segmentation_model
+    results = {}
+    for mode in ('fused', 'separate'):
+        if mode == 'separate':
+            monkeypatch.setenv('SALT_HEAD_BN', '0')
+        torch.manual_seed(21)
+        m = _segmentation_model('UNetResNet', 'lovasz', dtype=dtype, lr=1e-3)
+        m._to_device()
+        m.model.train()
+        g = torch.Generator().manual_seed(5)
+        X = torch.randn(4, 3, 64, 64, generator=g).to(DEV)
+        M = (torch.rand(4, 1, 64, 64, generator=g) > 0.6).float()
+        Tt = torch.cat([1 - M, M], 1).to(DEV)
+        l0 = float(m._fit_loop([X, Tt])['sum'])
+        torch.cuda.synchronize()
+        eng = m.model.engine()
+        net = eng.net((4, 3, 64, 64), True)
+        names = [n for n, _, _ in net.fwd.ops] + [n for n, _, _ in net.bwd.ops]
+        assert ('head_bn' in names and 'head_bn_bwd' in names) == (mode == 'fused'), names[-8:]
+        assert ('head1x1' in names) == (mode == 'separate')
+        logits0, grads0 = net.logits.cpu().clone(), eng.grads.cpu().clone()
+        l1 = float(m._fit_loop([X, Tt])['sum'])
+        torch.cuda.synchronize()
+        results[mode] = (l0, l1, logits0, grads0, eng.flat.cpu().clone(), len(names))
+    a, b = results['fused'], results['separate']
+    assert a[5] == b[5] - 2                                                   # one launch fewer in each direction
+
+    def rel(x, y):
+        return float((x.double() - y.double()).norm() / (y.double().norm() + 1e-30))
+    tol = 2e-5 if dtype == 'f32' else 4e-3
+    assert rel(a[2], b[2]) <= tol, rel(a[2], b[2])                             # first-step logits
+    assert abs(a[0] - b[0]) <= tol * max(1.0, abs(b[0])) and abs(a[1] - b[1]) <= 10 * tol * max(1.0, abs(b[1])), (a[:2], b[:2])
+    assert rel(a[3], b[3]) <= (2e-4 if dtype == 'f32' else 3e-2), rel(a[3], b[3])      # whole flat gradient of step 1
+    assert rel(a[4], b[4]) <= (1e-5 if dtype == 'f32' else 2e-4), rel(a[4], b[4])      # parameters after two steps
