@@ -678,6 +678,14 @@ typedef struct {
     salt_view y;
     double* gap_acc;          /* NULL, or [B][C] fp64 ZEROED by the caller: the pooling pass adds its channel sums there (atomics) and the
                                  apply pass derives the gates of its image in its prologue - two launches instead of three; gap_partials unused */
+    /* round 6 - x is the RAW output of a train-mode convolution whose BatchNorm + ReLU (base.Conv2dBnRelu, architectures/base.py:29-36)
+     * this launch applies on the way in: in_fin = the layer's const salt_bn_finalize_args*, in_fin_acc = the [8][2 C + 1] fp64 shards
+     * its producer added to (gap_acc path only).  The pooling pass finalizes the statistics (workgroup 0 stores mean / invstd / scale /
+     * shift and the running statistics), both passes evaluate a = round(relu(y scale + shift)) per element - the activation tensor
+     * and the salt_affine_act launch that would have written it do not exist.  salt_scse_bwd gets the same transform (in_scale ..). */
+    const void* in_fin;
+    const double* in_fin_acc;
+    int in_relu;
 } salt_scse_args;
 int salt_scse(const salt_scse_args*, void* stream);
 int salt_scse_parts(const salt_scse_args*);
@@ -710,6 +718,9 @@ typedef struct {
                                  FC backward reads them - no parts-reduction launch; partials unused */
     int skip_bcast;           /* 1: dx is left WITHOUT the channel-SE term dgap[b][c]; the consumer of dx adds it on the fly
                                  (salt_bn_bwd_args.da_bias = dgap) - one full pass over dx less */
+    const float* in_scale;    /* != NULL: x is the raw convolution output of salt_scse_args.in_fin; the forward call stored scale / shift */
+    const float* in_shift;
+    int in_relu;
 } salt_scse_bwd_args;
 int salt_scse_bwd(const salt_scse_bwd_args*, void* stream);
 

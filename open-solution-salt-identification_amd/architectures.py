@@ -161,8 +161,23 @@ class BasicBlock(EmitOnly):
         if self.downsample is not None:          # the projection shortcut is independent of conv1 -> conv2: side stream, joined at the add
             with g.side():
                 idt = g.conv(x, self.downsample[0], self.downsample[1], relu=False, name='down')
+        n0 = len(g.tape)
         a = g.conv(x, self.conv1, self.bn1, relu=True, name='block.conv1')
-        return g.conv(a, self.conv2, self.bn2, relu=True, res=idt, out=out, name='block.conv2')
+        y = g.conv(a, self.conv2, self.bn2, relu=True, res=idt, out=out, name='block.conv2')
+        _shortcut_gradient_first(g, n0, self.downsample)
+        return y
+
+
+def _shortcut_gradient_first(g, n0, downsample):
+    """Backward order inside a residual block with a projection shortcut (torchvision layout through architectures/encoders.py:38-45):
+    the tape runs in reverse, so by default the shortcut's closure - emitted first - runs LAST and its stride-2 1x1 data gradient
+    (every other pixel of the block input) is the last writer of dL/dx.  Moving it in front of the main branch's first convolution
+    makes that convolution's data gradient - a full-coverage launch - the last writer, which can then carry the BatchNorm-backward
+    sums of x's producer (Graph._bn_train_bwd) and saves that layer's reduction pass.  ``n0`` = tape length BEFORE the main branch was
+    emitted; the shortcut's closure sits at n0 - 1."""
+    if downsample is None or not g.train or os.environ.get('SALT_NO_SHORTCUT_FIRST') or n0 < 1 or len(g.tape) < n0 + 2:
+        return
+    g.tape.insert(n0, g.tape.pop(n0 - 1))        # [.., down, conv1, ..] -> [.., conv1, down, ..]: backward runs .., down, conv1
 
 
 class Bottleneck(EmitOnly):
@@ -185,9 +200,12 @@ class Bottleneck(EmitOnly):
         if self.downsample is not None:
             with g.side():
                 idt = g.conv(x, self.downsample[0], self.downsample[1], relu=False, name='down')
+        n0 = len(g.tape)
         a = g.conv(x, self.conv1, self.bn1, relu=True, name='bneck.conv1')
         a = g.conv(a, self.conv2, self.bn2, relu=True, name='bneck.conv2')
-        return g.conv(a, self.conv3, self.bn3, relu=True, res=idt, out=out, name='bneck.conv3')
+        y = g.conv(a, self.conv3, self.bn3, relu=True, res=idt, out=out, name='bneck.conv3')
+        _shortcut_gradient_first(g, n0, self.downsample)
+        return y
 
 
 class ResNet(EmitOnly):

@@ -403,10 +403,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvKP& p, const TileCoord& 
                 if (bnb) {                                         // host: bnb implies whole aligned pieces, out_step 1, no strip
                     float g[VE], yc[VE];
                     unpack16<T>(stored, g);
-                    unpack16<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.bnb_y) + (((int64_t)b * p.OHf + oy - (p.fold_fused ? p.fold_top : 0)) * p.OWf + ox) * p.bnb_cs + n), yc);
+                    unpack16<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.bnb_y) + (((int64_t)b * p.OHf + oy * p.out_step + out_oy - (p.fold_fused ? p.fold_top : 0)) * p.OWf + ox * p.out_step + out_ox) * p.bnb_cs + n), yc);
                     if (p.bnb_a) {                                 // residual layer: the mask is the sign of the forward output
                         float av[VE];
-                        unpack16<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.bnb_a) + (((int64_t)b * p.OHf + oy - (p.fold_fused ? p.fold_top : 0)) * p.OWf + ox) * p.bnb_acs + n), av);
+                        unpack16<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.bnb_a) + (((int64_t)b * p.OHf + oy * p.out_step + out_oy - (p.fold_fused ? p.fold_top : 0)) * p.OWf + ox * p.out_step + out_ox) * p.bnb_acs + n), av);
 #pragma unroll
                         for (int e = 0; e < VE; ++e) {
                             const float gg = (!p.bnb_relu || av[e] > 0.f) ? g[e] : 0.f;
@@ -1304,10 +1304,10 @@ __global__ __launch_bounds__(512, 2) void conv_glds_kernel(ConvKP p) {
                 if (bnb) {
                     float g[VE], yc[VE];
                     unpack16<T>(stored, g);
-                    unpack16<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.bnb_y) + (((int64_t)b * p.OHf + oy - (p.fold_fused ? p.fold_top : 0)) * p.OWf + ox) * p.bnb_cs + n), yc);
+                    unpack16<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.bnb_y) + (((int64_t)b * p.OHf + oy * p.out_step + out_oy - (p.fold_fused ? p.fold_top : 0)) * p.OWf + ox * p.out_step + out_ox) * p.bnb_cs + n), yc);
                     if (p.bnb_a) {
                         float av[VE];
-                        unpack16<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.bnb_a) + (((int64_t)b * p.OHf + oy - (p.fold_fused ? p.fold_top : 0)) * p.OWf + ox) * p.bnb_acs + n), av);
+                        unpack16<T>(*reinterpret_cast<const u32x4*>(reinterpret_cast<const T*>(p.bnb_a) + (((int64_t)b * p.OHf + oy * p.out_step + out_oy - (p.fold_fused ? p.fold_top : 0)) * p.OWf + ox * p.out_step + out_ox) * p.bnb_acs + n), av);
 #pragma unroll
                         for (int e = 0; e < VE; ++e) {
                             const float gg = (!p.bnb_relu || av[e] > 0.f) ? g[e] : 0.f;
@@ -1576,7 +1576,7 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
     k.m_tiles = tiles_b * k.tiles_y * k.tiles_x; k.n_tiles = cdiv(Cout, BN);
     k.nphase = a->nphase > 1 ? a->nphase : 1; k.m_tiles_ph = k.m_tiles; k.w_phase_elems = a->w_phase_elems;
     if (k.nphase > 1) {
-        if (k.nphase != 4 || a->out_step != 2 || a->strip || fold_fused || a->bnb_partials || a->bnb_acc || a->w_phase_elems <= 0 ||
+        if (k.nphase != 4 || a->out_step != 2 || a->strip || fold_fused || a->w_phase_elems <= 0 ||
             (a->OH - 1) * 2 + 1 >= a->y.H || (a->OW - 1) * 2 + 1 >= a->y.W)
             SALT_FAIL(SALT_E_BADARG, "conv: a phase-fused launch is 4 output-parity phases of an out_step 2 grid that fits y for every parity");
         k.m_tiles *= 4;
@@ -1601,8 +1601,12 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
     k.bnb_mean = a->bnb_mean; k.bnb_invstd = a->bnb_invstd; k.bnb_gamma = a->bnb_gamma; k.bnb_beta = a->bnb_beta;
     if (a->bnb_partials || a->bnb_acc) {
         const int ve = a->dtype == SALT_F32 ? 4 : 8;
-        if (a->strip || a->stats || a->fin_acc || a->out_step != 1 || a->out_oy || a->out_ox || (!fold_fused && (a->OH != a->y.H || a->OW != a->y.W)))
-            SALT_FAIL(SALT_E_BADARG, "conv: BatchNorm-backward sums need a plain (or fused-fold) full-grid launch");
+        // round 6: a phase-fused stride-2 launch (nphase 4: every output parity of an even grid, i.e. every pixel of y exactly once) also
+        // completes the gradient it writes - the data gradient of layerN.0.conv1 (architectures/encoders.py:38-45) carries the sums too
+        const bool all_phases = k.nphase == 4 && a->out_step == 2 && !a->out_oy && !a->out_ox && a->OH * 2 == a->y.H && a->OW * 2 == a->y.W;
+        if (a->strip || a->stats || a->fin_acc || ((a->out_step != 1 || a->out_oy || a->out_ox) && !all_phases) ||
+            (!fold_fused && !all_phases && (a->OH != a->y.H || a->OW != a->y.W)))
+            SALT_FAIL(SALT_E_BADARG, "conv: BatchNorm-backward sums need a plain (or fused-fold, or all-phases stride-2) full-grid launch");
         if (!view_ok(a->bnb_y) || a->bnb_y.B != a->y.B || a->bnb_y.H != a->y.H || a->bnb_y.W != a->y.W || a->bnb_y.C != a->y.C)
             SALT_FAIL(SALT_E_BADARG, "conv: bnb_y shape");
         if (!a->bnb_mean || !a->bnb_invstd || !a->bnb_gamma || !a->bnb_beta) SALT_FAIL(SALT_E_BADARG, "conv: bnb parameters missing");

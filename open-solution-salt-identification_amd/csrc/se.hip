@@ -14,9 +14,20 @@ template <typename T> struct P16 {
     static __device__ __forceinline__ void st(T* p, const float* f) { *reinterpret_cast<u32x4*>(p) = pack16<T>(f); }
 };
 
+// Input transform of the scSE kernels (salt_scse_args.in_fin): x is a raw convolution output and the element the operator sees is
+// a = round_to_storage(relu?(y scale + shift)) - ONE pinned expression in the three kernels that read x, so they agree bit for bit
+// with each other (and with what salt_affine_act would have stored, up to the contraction of its own multiply-add).
+template <typename T, int N>
+__device__ __forceinline__ void in_transform(float* f, const float* sc, const float* sh, int relu) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) { const float v = __fmaf_rn(f[j], sc[j], sh[j]); f[j] = relu ? fmaxf(v, 0.f) : v; }
+    if constexpr (sizeof(T) == 2) { const u32x4 v = pack16<T>(f); unpack16<T>(v, f); }
+}
+
 // per-image partial channel sums: partials[b][part][C]
-template <typename T>
-__global__ __launch_bounds__(256) void gap_partial_kernel(salt_view x, float* partials, int nparts, int pix_per_part, double* acc) {
+// FIN: x is raw - every workgroup finalizes the producer's statistics shards into LDS (fin_forward_consumer), workgroup 0 stores them
+template <typename T, bool FIN = false>
+__global__ __launch_bounds__(256) void gap_partial_kernel(salt_view x, float* partials, int nparts, int pix_per_part, double* acc, BnFin fin, int in_relu) {
     constexpr int N = P16<T>::N;
     extern __shared__ float sm[];
     const int C = x.C, cpv = C / N, R = 256 / cpv;
@@ -24,12 +35,20 @@ __global__ __launch_bounds__(256) void gap_partial_kernel(salt_view x, float* pa
     const int hw = x.H * x.W;
     const int p0 = part * pix_per_part, p1 = min(p0 + pix_per_part, hw);
     const int row = threadIdx.x / cpv, cv = threadIdx.x % cpv;
-    float s[N];
+    float s[N], sc[N], sh[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) s[j] = 0.f;
+    if constexpr (FIN) {
+        float* fs = sm + 256 * N;                          // [C] scale, [C] shift behind the row sums
+        fin_forward_consumer(fin, C, fs, fs + C, blockIdx.x == 0);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < N; ++j) { sc[j] = fs[cv * N + j]; sh[j] = fs[C + cv * N + j]; }
+    }
     for (int pix = p0 + row; pix < p1; pix += R) {
         float f[N];
         P16<T>::ld((const T*)x.p + ((int64_t)b * hw + pix) * x.cs + cv * N, f);
+        if constexpr (FIN) in_transform<T, N>(f, sc, sh, in_relu);
 #pragma unroll
         for (int j = 0; j < N; ++j) s[j] += f[j];
     }
@@ -52,7 +71,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void scse_apply_fc_kernel(salt_view x, const double* acc, int R, float inv_hw, const float* w1, const float* b1,
                                                             const float* w2, const float* b2, float* gap, float* hidden, float* gate_c,
                                                             const float* ws, const float* bs, float* gate_s, salt_view y, int cpv_log2,
-                                                            int nparts, int pix_per_part) {
+                                                            int nparts, int pix_per_part, const float* in_scale, const float* in_shift, int in_relu) {
     constexpr int N = P16<T>::N;
     extern __shared__ float sm[];       // [C] gap, [R] hidden, [C] gate
     const int C = x.C, cpv = 1 << cpv_log2, RW = 256 >> cpv_log2;
@@ -84,9 +103,9 @@ __global__ __launch_bounds__(256) void scse_apply_fc_kernel(salt_view x, const d
     const int p0 = part * pix_per_part, p1 = min(p0 + pix_per_part, hw);
     const int row = threadIdx.x >> cpv_log2, cv = threadIdx.x & (cpv - 1);
     const float bsv = bs[0];
-    float wsv[N], gc[N];
+    float wsv[N], gc[N], isc[N], ish[N];
 #pragma unroll
-    for (int j = 0; j < N; ++j) { wsv[j] = ws[cv * N + j]; gc[j] = sgate[cv * N + j]; }
+    for (int j = 0; j < N; ++j) { wsv[j] = ws[cv * N + j]; gc[j] = sgate[cv * N + j]; isc[j] = in_scale ? in_scale[cv * N + j] : 1.f; ish[j] = in_scale ? in_shift[cv * N + j] : 0.f; }
     const int iters = (p1 - p0 + RW - 1) / RW;
     for (int it = 0; it < iters; ++it) {
         const int pix = p0 + it * RW + row;
@@ -96,6 +115,7 @@ __global__ __launch_bounds__(256) void scse_apply_fc_kernel(salt_view x, const d
         float dot = 0.f;
         if (ok) {
             P16<T>::ld((const T*)x.p + gp * x.cs + cv * N, f);
+            if (in_scale) in_transform<T, N>(f, isc, ish, in_relu);
 #pragma unroll
             for (int j = 0; j < N; ++j) dot += f[j] * wsv[j];
         }
@@ -170,7 +190,7 @@ __global__ void scse_apply_kernel(salt_view x, const float* gate_c, const float*
 template <typename T>
 __global__ __launch_bounds__(256) void scse_bwd1_kernel(salt_view x, salt_view y, salt_view dy, const float* gate_c, const float* gate_s,
                                                         const float* ws, salt_view dx, int accumulate, float* partials, int nparts,
-                                                        int pix_per_part, int cpv_log2, double* acc) {
+                                                        int pix_per_part, int cpv_log2, double* acc, const float* in_scale, const float* in_shift, int in_relu) {
     constexpr int N = P16<T>::N;
     extern __shared__ float sm[];
     const int C = x.C, cpv = 1 << cpv_log2, R = 256 >> cpv_log2;
@@ -178,9 +198,10 @@ __global__ __launch_bounds__(256) void scse_bwd1_kernel(salt_view x, salt_view y
     const int hw = x.H * x.W;
     const int p0 = part * pix_per_part, p1 = min(p0 + pix_per_part, hw);
     const int row = threadIdx.x >> cpv_log2, cv = threadIdx.x & (cpv - 1);
-    float s_gc[N], s_ws[N], s_bs = 0.f, gc[N], wsv[N];
+    float s_gc[N], s_ws[N], s_bs = 0.f, gc[N], wsv[N], isc[N], ish[N];
 #pragma unroll
-    for (int j = 0; j < N; ++j) { s_gc[j] = 0.f; s_ws[j] = 0.f; gc[j] = gate_c[b * C + cv * N + j]; wsv[j] = ws[cv * N + j]; }
+    for (int j = 0; j < N; ++j) { s_gc[j] = 0.f; s_ws[j] = 0.f; gc[j] = gate_c[b * C + cv * N + j]; wsv[j] = ws[cv * N + j];
+                                  isc[j] = in_scale ? in_scale[cv * N + j] : 1.f; ish[j] = in_scale ? in_shift[cv * N + j] : 0.f; }
     const int iters = (p1 - p0 + R - 1) / R;
     for (int it = 0; it < iters; ++it) {
         const int pix = p0 + it * R + row;
@@ -191,6 +212,7 @@ __global__ __launch_bounds__(256) void scse_bwd1_kernel(salt_view x, salt_view y
         if (ok) {
             float yv[N];
             P16<T>::ld((const T*)x.p + gp * x.cs + cv * N, xv);
+            if (in_scale) in_transform<T, N>(xv, isc, ish, in_relu);
             P16<T>::ld((const T*)y.p + gp * y.cs + cv * N, yv);
             P16<T>::ld((const T*)dy.p + gp * dy.cs + cv * N, g);
             gs = gate_s[gp];
@@ -366,12 +388,23 @@ extern "C" int salt_scse(const salt_scse_args* a, void* stream) {
     SALT_DISPATCH_DTYPE(a->dtype, T, {
         if (!se_ok<T>(a->x) || !se_ok<T>(a->y)) SALT_FAIL(SALT_E_UNSUPPORTED, "scse: C=%d must be a power of two with 16-byte aligned rows", C);
         constexpr int VE = Elem<T>::VE;
-        hipLaunchKernelGGL(gap_partial_kernel<T>, dim3(a->x.B * nparts), dim3(256), 256 * VE * sizeof(float), st, a->x, a->gap_partials, nparts, per, a->gap_acc);
+        const salt_bn_finalize_args* f = static_cast<const salt_bn_finalize_args*>(a->in_fin);
+        if (f) {
+            if (!a->gap_acc || !a->in_fin_acc || f->C != C || !f->gamma || !f->beta || !f->mean || !f->invstd || !f->scale || !f->shift || C > 4096)
+                SALT_FAIL(SALT_E_BADARG, "scse: in_fin needs gap_acc, in_fin_acc and the complete salt_bn_finalize arguments of a %d-channel layer", C);
+            const BnFin fin{const_cast<double*>(a->in_fin_acc), nullptr, f->gamma, f->beta, f->running_mean, f->running_var, f->num_batches_tracked,
+                            f->momentum, f->eps, f->mean, f->invstd, f->scale, f->shift};
+            hipLaunchKernelGGL((gap_partial_kernel<T, true>), dim3(a->x.B * nparts), dim3(256), (256 * VE + 2 * C) * sizeof(float), st, a->x, a->gap_partials, nparts, per,
+                               a->gap_acc, fin, a->in_relu);
+        } else {
+            hipLaunchKernelGGL((gap_partial_kernel<T, false>), dim3(a->x.B * nparts), dim3(256), 256 * VE * sizeof(float), st, a->x, a->gap_partials, nparts, per, a->gap_acc,
+                               BnFin{}, 0);
+        }
         SALT_CHECK_LAUNCH();
         if (a->gap_acc) {
             hipLaunchKernelGGL(scse_apply_fc_kernel<T>, dim3(a->x.B * nparts), dim3(256), (2 * C + a->R) * sizeof(float), st, a->x, a->gap_acc, a->R,
                                1.0f / (float)(a->x.H * a->x.W), a->w1, a->b1, a->w2, a->b2, a->gap, a->hidden, a->gate_c, a->ws, a->bs, a->gate_s, a->y,
-                               ilog2_ceil(C / VE), nparts, per);
+                               ilog2_ceil(C / VE), nparts, per, f ? f->scale : nullptr, f ? f->shift : nullptr, a->in_relu);
             SALT_CHECK_LAUNCH();
             return SALT_OK;
         }
@@ -389,7 +422,7 @@ extern "C" int salt_scse(const salt_scse_args* a, void* stream) {
 
 extern "C" int salt_scse_bwd(const salt_scse_bwd_args* a, void* stream) {
     if (!a || !view_ok(a->x) || !view_ok(a->y) || !view_ok(a->dy) || !view_ok(a->dx) || !a->w1 || !a->w2 || !a->ws || !a->gap || !a->hidden ||
-        !a->gate_c || !a->gate_s || (!a->partials && !a->acc) || !a->g_w1 || !a->g_b1 || !a->g_w2 || !a->g_b2 || !a->g_ws || !a->g_bs || !a->dgap)
+        !a->gate_c || !a->gate_s || (!a->partials && !a->acc) || ((a->in_scale == nullptr) != (a->in_shift == nullptr)) || !a->g_w1 || !a->g_b1 || !a->g_w2 || !a->g_b2 || !a->g_ws || !a->g_bs || !a->dgap)
         SALT_FAIL(SALT_E_BADARG, "scse_bwd: bad args");
     int per = 0;
     const int nparts = scse_nparts(a->x, &per);
@@ -419,7 +452,7 @@ extern "C" int salt_scse_bwd(const salt_scse_bwd_args* a, void* stream) {
         constexpr int VE = Elem<T>::VE;
         const int cpv_log2 = ilog2_ceil(C / VE);
         hipLaunchKernelGGL(scse_bwd1_kernel<T>, dim3(B * nparts), dim3(256), (512 * VE + 256) * sizeof(float), st, a->x, a->y, a->dy, a->gate_c,
-                           a->gate_s, a->ws, a->dx, a->accumulate, a->partials, nparts, per, cpv_log2, a->acc);
+                           a->gate_s, a->ws, a->dx, a->accumulate, a->partials, nparts, per, cpv_log2, a->acc, a->in_scale, a->in_shift, a->in_relu);
         SALT_CHECK_LAUNCH();
         if (!a->acc) {
             hipLaunchKernelGGL(se_parts_reduce_kernel, dim3(B), dim3(256), 0, st, a->partials, nparts, 2 * C + 1);

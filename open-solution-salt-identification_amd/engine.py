@@ -370,6 +370,9 @@ class Graph:
         return self.alloc((max(int(n), 1),), torch.float32)
 
     def finalize(self):
+        for buf, reads in getattr(self, '_virtual_acts', []):
+            if buf.reads != reads:
+                raise SaltError('activation %s is applied on the fly by its only consumer (Graph._take_act_op) but another operator asked for its storage' % buf.name)
         sizes = {}
         for prog in (self.fwd, self.bwd):
             for _, _, sc in prog.patches:
@@ -594,6 +597,7 @@ class Graph:
         out.buf.bn_train_out = (out.c0, out.C)      # dL/d(out) is consumed by this layer's bn_bwd only: it may take a per-image bias (scse)
         sa = self.fwd.add('affine_act', dtype=self.dt, y=y.view(), scale=w['scale'].data_ptr(), shift=w['shift'].data_ptr(),
                           res=res.view() if res is not None else null_view(), relu=int(relu), a=out.view())
+        out.buf.act_op = (sa, out.buf.reads, out.c0, out.C)     # Graph.scse may take this operator over (the activation is then never stored)
         if F is not None:                        # the producer only adds to the shards; this operator finalizes them
             self.fwd.set_fields(sa, fin=ctypes.addressof(F))
             off = self._fin_slot('fwd', 8 * (2 * bn.num_features + 1), (producer, 'fin_acc'), (sa, 'fin_acc'))
@@ -622,7 +626,11 @@ class Graph:
         assert acc_y == 0, 'conv output gradient has a single producer'
         partials, ready = Scratch('bn_bwd', nparts * 2 * C * 4), 0
         wr = out.buf.grad_writers
-        if (wr and wr[-1][2] is not None and all((w_[0], w_[1]) == (out.c0, out.C) for w_ in wr) and C % self.ve == 0
+        # (round 6: only the LAST writer has to cover exactly this slice - earlier writers of the same buffer, e.g. the decoder's data
+        #  gradient over the whole concat buffer an encoder output lives in, are complete before it runs.  SALT_BNB_STRICT=1: round 5's rule)
+        same = (lambda w_: (w_[0], w_[1]) == (out.c0, out.C))
+        ok_wr = bool(wr) and same(wr[-1]) and (all(same(w_) for w_ in wr) or not os.environ.get('SALT_BNB_STRICT'))
+        if (ok_wr and wr[-1][2] is not None and C % self.ve == 0
                 and (res is None or not os.environ.get('SALT_NO_BNB_RES')) and not os.environ.get('SALT_NO_BNB_FUSE')):
             # the LAST writer of dL/d(out) is a plain data-gradient launch (it completes the gradient: earlier writers of the same
             # slice were accumulated): its epilogue also reduces this layer's BatchNorm-backward sums over its pixel tiles
@@ -1024,8 +1032,10 @@ class Graph:
             # ONE launch for all four phases (each its own packed weight block; taps a phase lacks are zero weights)
             td_u, phase_taps = fused
             pk_t, elems = eng.packed_phases(conv, phase_taps, transposed=True, bwd=True)
-            self._conv_launch(self.bwd, dy.gview(), pk_t.data_ptr(), td_u, 1, 0, x.gview(), x.H // 2, x.W // 2, out_step=2, accumulate=acc,
-                              nphase=4, w_phase_elems=elems, stream=self._bwd_pack_tag())
+            s = self._conv_launch(self.bwd, dy.gview(), pk_t.data_ptr(), td_u, 1, 0, x.gview(), x.H // 2, x.W // 2, out_step=2, accumulate=acc,
+                                  nphase=4, w_phase_elems=elems, stream=self._bwd_pack_tag())
+            if not x.plane_stride() and not os.environ.get('SALT_NO_BNB_PHASE'):
+                x.buf.grad_writers[-1][2] = s      # all four parities of an even grid: every pixel once - can carry the BatchNorm-backward sums (round 6)
             return
         if any(not sel for _, _, sel in phases) and not acc:
             self.fill(x, 0.0, grad=True)
@@ -1383,6 +1393,24 @@ class Graph:
             self.tape.append(backward)
         return out
 
+    def _take_act_op(self, x):
+        """x = relu?(bn(y)) written by the LAST forward operator (a consumer-side-finalize salt_affine_act without residual, main stream)
+        and read by nobody yet: remove that operator from the program and hand back (its argument struct, the layer's
+        salt_bn_finalize_args) - the caller's kernels apply the transform to y themselves.  Graph.finalize fails loudly if anybody asks
+        for a storage view of the activation afterwards."""
+        rec = getattr(x.buf, 'act_op', None)
+        if rec is None or not self.fwd.ops or self.fwd.ops[-1][0] != 'affine_act':
+            return None
+        sa, reads0, c0, C = rec
+        if (self.fwd.ops[-1][2] is not sa or (c0, C) != (x.c0, x.C) or x.c0 != 0 or x.C != x.buf.C or x.buf.reads != reads0 or not sa.fin or sa.res.p
+                or self.fwd.streams[-1] != 0 or x.buf.planes):
+            return None
+        self.fwd.ops.pop(); self.fwd.streams.pop()
+        self.fwd._entries = None
+        x.buf.act_op = None
+        self._virtual_acts = getattr(self, '_virtual_acts', []) + [(x.buf, x.buf.reads)]
+        return sa, STRUCTS['salt_bn_finalize_args'].from_address(sa.fin)
+
     # ------------------------------------------------------------------ scSE
     def scse(self, x, cse, sse, out=None, name=''):
         """relu(x*cSE(x) + x*sSE(x)); cse.fc = Sequential(Linear, ReLU, Linear, Sigmoid), sse.fc = Conv2d(C,1,1)."""
@@ -1391,14 +1419,30 @@ class Graph:
             out = self.new_act(x.B, x.H, x.W, x.C, name)
         l1, l2, cs = cse.fc[0], cse.fc[2], sse.fc
         R, C, B = l1.weight.shape[0], x.C, x.B
+        shards = self.train and self._fin_mode() == 2 and os.environ.get('SALT_SE_SHARDS', '1') != '0'   # per-image sums through the zeroed fp64 arena (see _fin_slot)
+        # round 6: x = relu(bn(conv)) whose ONLY reader is this operator (base.DecoderBlock: conv2 -> scSE, architectures/base.py:60-85) -
+        # the affine_act that would store it is taken back out of the program and the scSE kernels apply BatchNorm + ReLU to the raw
+        # convolution output on the way in (salt_scse_args.in_fin); backward reads the raw output through the same transform
+        taken = self._take_act_op(x) if (shards and os.environ.get('SALT_SE_IN_BN', '1') != '0') else None
+        if taken is not None:
+            sa, Fbn = taken
+            xv_ = sa.y                                   # the raw convolution output; never x.view(): the activation has no storage reader
+            in_kw = dict(in_fin=ctypes.addressof(Fbn), in_relu=int(sa.relu))
+            in_bwd = dict(in_scale=Fbn.scale, in_shift=Fbn.shift, in_relu=int(sa.relu))
+        else:
+            xv_, in_kw, in_bwd = None, {}, {}
+        xview = (lambda: xv_) if taken is not None else x.view
         S = STRUCTS['salt_scse_args']()
-        fill(S, x=x.view())
+        fill(S, x=xview())
         nparts = lib.salt_scse_parts(ctypes.byref(S))
         gap, hid, gc, gs = self.f32(B * C), self.f32(B * R), self.f32(B * C), self.f32(B * x.H * x.W)
-        sf = self.fwd.add('scse', dtype=self.dt, x=x.view(), w1=l1.weight.data_ptr(), b1=l1.bias.data_ptr(), w2=l2.weight.data_ptr(),
+        sf = self.fwd.add('scse', dtype=self.dt, x=xview(), w1=l1.weight.data_ptr(), b1=l1.bias.data_ptr(), w2=l2.weight.data_ptr(),
                           b2=l2.bias.data_ptr(), R=R, ws=cs.weight.data_ptr(), bs=cs.bias.data_ptr(), gap_partials=Scratch('se', B * nparts * (2 * C + 1) * 4),
-                          nparts=nparts, gap=gap.data_ptr(), hidden=hid.data_ptr(), gate_c=gc.data_ptr(), gate_s=gs.data_ptr(), y=out.view())
-        shards = self.train and self._fin_mode() == 2 and os.environ.get('SALT_SE_SHARDS', '1') != '0'   # per-image sums through the zeroed fp64 arena (see _fin_slot)
+                          nparts=nparts, gap=gap.data_ptr(), hidden=hid.data_ptr(), gate_c=gc.data_ptr(), gate_s=gs.data_ptr(), y=out.view(), **in_kw)
+        if taken is not None:
+            for i, q in enumerate(self._fin_patches):    # the statistics shards the dropped affine_act would have finalized
+                if q[0] is sa and q[1] == 'fin_acc':
+                    self._fin_patches[i] = (sf, 'in_fin_acc', q[2], q[3])
         if shards:
             self._fin_slot('fwd', B * C, (sf, 'gap_acc'))
         if self.train:
@@ -1406,11 +1450,11 @@ class Graph:
                 acc = x.grad_state()
                 dgap = self.f32(B * C)
                 gp = self._gp
-                sb = self.bwd.add('scse_bwd', dtype=self.dt, x=x.view(), y=out.view(), dy=out.gview(), w1=l1.weight.data_ptr(), w2=l2.weight.data_ptr(),
+                sb = self.bwd.add('scse_bwd', dtype=self.dt, x=xview(), y=out.view(), dy=out.gview(), w1=l1.weight.data_ptr(), w2=l2.weight.data_ptr(),
                                   R=R, ws=cs.weight.data_ptr(), gap=gap.data_ptr(), hidden=hid.data_ptr(), gate_c=gc.data_ptr(), gate_s=gs.data_ptr(),
                                   partials=Scratch('se', B * nparts * (2 * C + 1) * 4), nparts=nparts, g_w1=gp(l1.weight), g_b1=gp(l1.bias),
                                   g_w2=gp(l2.weight), g_b2=gp(l2.bias), g_ws=gp(cs.weight), g_bs=gp(cs.bias), dgap=dgap.data_ptr(),
-                                  dx=x.gview(), accumulate=acc)
+                                  dx=x.gview(), accumulate=acc, **in_bwd)
                 if shards:
                     self._fin_slot('bwd', B * (2 * C + 1), (sb, 'acc'))
                 # x = relu(bn(conv)): its only gradient consumer is that layer's bn_bwd, which can add the channel-SE term dgap[b][c]

@@ -471,3 +471,78 @@ def test_scse_backward_batch_tiles_c256(B):
     assert_close(gx[0], xr.grad, TOL32 * 2, 'gx')
     for k, g in grads.items():
         assert_close(g, leaves[k].grad, TOL32 * 4, 'g:' + k)
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+@pytest.mark.parametrize('shape', [(2, 16, 16, 16, 32), (3, 32, 8, 12, 64)])
+def test_projection_block_input_gradient_carries_bn_backward_sums(dtype, shape, monkeypatch):
+    """layerN.0 of the ResNet encoders (torchvision BasicBlock with a 1x1 stride-2 projection shortcut, architectures/encoders.py:38-45)
+    behind a Conv-BN-ReLU producer.  Round 6: the shortcut's backward is emitted BEFORE conv1's, so the LAST writer of dL/dx is conv1's
+    phase-fused stride-2 data gradient - every pixel once - and it carries the BatchNorm-backward sums of x's producer
+    (salt_conv_args.bnb_* on an nphase = 4 launch): that layer's bn_bwd runs without its reduction pass.  Values against torch autograd;
+    SALT_NO_SHORTCUT_FIRST=1 restores round 5's order (reduction pass in bn_bwd) and must give the same gradients."""
+    from gpu_harness import BlockRun
+    from torch import nn
+    A = _mods()
+    B, Cin, H, W, planes = shape
+    torch.manual_seed(7)
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv0 = nn.Conv2d(Cin, Cin, 3, 1, 1, bias=False)
+            self.bn0 = nn.BatchNorm2d(Cin)
+            down = nn.Sequential(nn.Conv2d(Cin, planes, 1, 2, bias=False), nn.BatchNorm2d(planes))
+            self.block = A.BasicBlock(Cin, planes, 2, down)
+    m = Net()
+    with torch.no_grad():
+        for p_ in m.parameters():
+            if p_.dim() == 1:
+                p_.copy_(1 + 0.2 * torch.randn_like(p_))
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    x = _rand((B, Cin, H, W), 41)
+    gy = _rand((B, planes, H // 2, W // 2), 42)
+    results = {}
+    for mode in ('shortcut_first', 'round5'):
+        if mode == 'round5':
+            monkeypatch.setenv('SALT_NO_SHORTCUT_FIRST', '1')
+        m.load_state_dict(sd)
+        m.train()
+
+        def emit(g, a):
+            h = g.conv(a, m.conv0, m.bn0, relu=True)
+            return m.block.emit(g, h)
+        run = BlockRun(m, [x], emit, train=True, dtype=dtype)
+        y = run.forward()
+        gx, grads = run.backward(gy.to('cuda:0'))
+        ready = [int(st.partials_ready) for name, _, st in run.g.bwd.ops if name == 'bn_bwd']
+        nph = [int(st.nphase) for name, _, st in run.g.bwd.ops if name == 'conv' and st.bnb_y.p]
+        results[mode] = (y, gx[0], grads, ready, nph)
+    fusable = Cin % (4 if dtype == 'f32' else 8) == 0
+    # backward order of the bn_bwd operators: block.bn2 (reduce: its da comes from the harness' layout op), [downsample.bn | block.bn1], bn0
+    assert results['shortcut_first'][3][-1] == (3 if fusable else 0) and results['round5'][3][-1] == 0, (results['shortcut_first'][3], results['round5'][3])
+    assert (4 in results['shortcut_first'][4]) == fusable and 4 not in results['round5'][4]
+    # torch reference (fp32)
+    ref = nn.ModuleDict(dict(conv0=nn.Conv2d(Cin, Cin, 3, 1, 1, bias=False), bn0=nn.BatchNorm2d(Cin), c1=nn.Conv2d(Cin, planes, 3, 2, 1, bias=False), b1=nn.BatchNorm2d(planes),
+                             c2=nn.Conv2d(planes, planes, 3, 1, 1, bias=False), b2=nn.BatchNorm2d(planes), d=nn.Conv2d(Cin, planes, 1, 2, bias=False), db=nn.BatchNorm2d(planes)))
+    mp = {'conv0': 'conv0', 'bn0': 'bn0', 'c1': 'block.conv1', 'b1': 'block.bn1', 'c2': 'block.conv2', 'b2': 'block.bn2', 'd': 'block.downsample.0', 'db': 'block.downsample.1'}
+    ref.load_state_dict({a_ + k[len(b_):]: v for a_, b_ in mp.items() for k, v in sd.items() if k.startswith(b_ + '.')})
+    ref.train()
+    xr = x.clone().requires_grad_(True)
+    h = F.relu(ref['bn0'](ref['conv0'](xr)))
+    yr = F.relu(ref['b2'](ref['c2'](F.relu(ref['b1'](ref['c1'](h))))) + ref['db'](ref['d'](h)))
+    yr.backward(gy)
+    tol = TOL32 if dtype == 'f32' else TOLBF
+    for mode in results:
+        y, gx, grads = results[mode][:3]
+        assert_close(y, yr, tol * (1 if dtype == 'f32' else 2), 'y ' + mode)
+        if dtype == 'f32':
+            assert_close(gx, xr.grad, tol * 8, 'dx ' + mode)
+        else:
+            l2 = float((gx.double() - xr.grad.double()).norm() / xr.grad.double().norm())
+            assert l2 <= 3 * tol, (mode, l2)
+    a, b = results['shortcut_first'], results['round5']
+    for k in a[2]:
+        if float(b[2][k].abs().max()) > 0:
+            l2 = float((a[2][k].double() - b[2][k].double()).norm() / b[2][k].double().norm())
+            assert l2 <= (1e-4 if dtype == 'f32' else 3e-2), (k, l2)
