@@ -458,7 +458,7 @@ typedef struct {              /* backward of a = relu?(bn(y) (+res)) in train mo
                               /* 2: the producer also finalized (salt_conv_args.bnb_fin): coef / dgamma / dbeta are ready, only the apply pass runs */
                               /* 3: the producer added the sums to fin_acc (salt_conv_args.bnb_acc without ticket): the apply pass finalizes them */
     double* fin_acc;          /* partials_ready == 0 and fin_acc != NULL: the reduction pass accumulates into [8][2][C] fp64 shards and its last block */
-    const float* da_bias;     /* NULL, or [B][C]: a per-image, per-channel constant added to da wherever it is read (partials_ready 0 only) */
+    const float* da_bias;     /* NULL, or [B][C]: a per-image, per-channel constant added to da wherever it is read (partials_ready 0, or 3 when the sums in fin_acc already include it) */
     uint32_t* fin_ticket;     /* finalizes (no partials, no finalize launch); both zero before the first call, left zero (see salt_conv_args.fin).
                                * fin_ticket == NULL: no in-launch finalize - the apply pass finalizes the shards; the caller clears them */
 } salt_bn_bwd_args;
@@ -721,6 +721,13 @@ typedef struct {
     const float* in_scale;    /* != NULL: x is the raw convolution output of salt_scse_args.in_fin; the forward call stored scale / shift */
     const float* in_shift;
     int in_relu;
+    /* bnb_acc != NULL (needs acc, in_scale, skip_bcast): dx is dL/da of the Conv-BN-ReLU layer that produced x (minus dgap, which that
+     * layer's salt_bn_bwd adds through da_bias) - the first pass also takes that layer's BatchNorm-backward sums per image and the
+     * FC backward writes (sum, sum xhat) INCLUDING the dgap term to shard 0 of bnb_acc ([8][2][C] fp64, zero on entry): the layer's
+     * salt_bn_bwd then runs with partials_ready 3 + da_bias and no reduction pass.  acc must then hold [B][6 C + 1] doubles. */
+    const float* bn_mean;
+    const float* bn_invstd;
+    double* bnb_acc;
 } salt_scse_bwd_args;
 int salt_scse_bwd(const salt_scse_bwd_args*, void* stream);
 

@@ -1292,7 +1292,9 @@ extern "C" int salt_bn_bwd(const salt_bn_bwd_args* a, void* stream) {
         const bool fin_apply = a->fin_acc != nullptr && !a->fin_ticket && (a->partials_ready == 0 || a->partials_ready == 3);
         if (a->partials_ready == 3 && !fin_apply) SALT_FAIL(SALT_E_BADARG, "bn_bwd: partials_ready 3 needs fin_acc and no fin_ticket");
         if (fin_apply && C > 4096) SALT_FAIL(SALT_E_BADARG, "bn_bwd: fin_acc supports <= 4096 channels");
-        if (a->da_bias && (a->partials_ready || view_pixels(a->y) >= ((int64_t)1 << 31))) SALT_FAIL(SALT_E_BADARG, "bn_bwd: da_bias needs the reduction pass of this call (partials_ready 0)");
+        // (partials_ready 3 + da_bias: the sums in fin_acc already include the bias term - salt_scse_bwd_args.bnb_acc, round 6)
+        if (a->da_bias && ((a->partials_ready && a->partials_ready != 3) || view_pixels(a->y) >= ((int64_t)1 << 31)))
+            SALT_FAIL(SALT_E_BADARG, "bn_bwd: da_bias needs the reduction pass of this call (partials_ready 0) or sums that include it (partials_ready 3)");
         const unsigned hw = (unsigned)(a->y.H * a->y.W);
         const int hw_shift = (hw & (hw - 1)) == 0 ? ilog2_ceil((int)hw) : -1;
         const BnbFin fin{fin_here ? a->fin_acc : nullptr, a->fin_ticket, a->dgamma, a->dbeta, a->coef, a->accumulate_param_grads, (double)view_pixels(a->y), a->da_bias, hw, hw_shift};

@@ -187,10 +187,16 @@ __global__ void scse_apply_kernel(salt_view x, const float* gate_c, const float*
 }
 
 // backward pass 1: dx = g*(gc+gs) + ds*ws ; per-(image,part) partial sums of g*x (-> d gate_c), ds*x (-> g_ws), ds (-> g_bs)
-template <typename T>
+// BNB (round 6; needs in_scale and acc): x is the raw output of the Conv-BN-ReLU layer in front of the block and dx is that layer's dL/da
+// (minus the per-image channel-SE constant dgap, which the layer's salt_bn_bwd adds on the fly) - so this pass also takes the four
+// per-image sums that layer's BatchNorm backward needs, and the FC backward kernel turns them into the layer's (sum, sum xhat) shards:
+//   A1 = sum m o, A2 = sum m o xhat (o = the stored dx), M0 = sum m, M1 = sum m xhat  =>  s1 = sum_b A1 + dgap M0, s2 = sum_b A2 + dgap M1
+// salt_bn_bwd then runs WITHOUT its reduction pass (partials_ready 3 + da_bias).  acc rows are [6 C + 1] wide in this mode.
+template <typename T, bool BNB = false>
 __global__ __launch_bounds__(256) void scse_bwd1_kernel(salt_view x, salt_view y, salt_view dy, const float* gate_c, const float* gate_s,
                                                         const float* ws, salt_view dx, int accumulate, float* partials, int nparts,
-                                                        int pix_per_part, int cpv_log2, double* acc, const float* in_scale, const float* in_shift, int in_relu) {
+                                                        int pix_per_part, int cpv_log2, double* acc, const float* in_scale, const float* in_shift, int in_relu,
+                                                        const float* bn_mean, const float* bn_invstd) {
     constexpr int N = P16<T>::N;
     extern __shared__ float sm[];
     const int C = x.C, cpv = 1 << cpv_log2, R = 256 >> cpv_log2;
@@ -199,19 +205,26 @@ __global__ __launch_bounds__(256) void scse_bwd1_kernel(salt_view x, salt_view y
     const int p0 = part * pix_per_part, p1 = min(p0 + pix_per_part, hw);
     const int row = threadIdx.x >> cpv_log2, cv = threadIdx.x & (cpv - 1);
     float s_gc[N], s_ws[N], s_bs = 0.f, gc[N], wsv[N], isc[N], ish[N];
+    float a1[N], a2[N], m0[N], m1[N], bmu[N], bis[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) { s_gc[j] = 0.f; s_ws[j] = 0.f; gc[j] = gate_c[b * C + cv * N + j]; wsv[j] = ws[cv * N + j];
-                                  isc[j] = in_scale ? in_scale[cv * N + j] : 1.f; ish[j] = in_scale ? in_shift[cv * N + j] : 0.f; }
+                                  isc[j] = in_scale ? in_scale[cv * N + j] : 1.f; ish[j] = in_scale ? in_shift[cv * N + j] : 0.f;
+                                  a1[j] = 0.f; a2[j] = 0.f; m0[j] = 0.f; m1[j] = 0.f;
+                                  bmu[j] = BNB ? bn_mean[cv * N + j] : 0.f; bis[j] = BNB ? bn_invstd[cv * N + j] : 0.f; }
     const int iters = (p1 - p0 + R - 1) / R;
     for (int it = 0; it < iters; ++it) {
         const int pix = p0 + it * R + row;
         const bool ok = pix < p1;
-        float xv[N], g[N];
+        float xv[N], g[N], xraw[N];
         float dgs = 0.f, gs = 0.f;
         const int64_t gp = (int64_t)b * hw + pix;
         if (ok) {
             float yv[N];
             P16<T>::ld((const T*)x.p + gp * x.cs + cv * N, xv);
+            if constexpr (BNB) {
+#pragma unroll
+                for (int j = 0; j < N; ++j) xraw[j] = xv[j];
+            }
             if (in_scale) in_transform<T, N>(xv, isc, ish, in_relu);
             P16<T>::ld((const T*)y.p + gp * y.cs + cv * N, yv);
             P16<T>::ld((const T*)dy.p + gp * dy.cs + cv * N, g);
@@ -235,6 +248,16 @@ __global__ __launch_bounds__(256) void scse_bwd1_kernel(salt_view x, salt_view y
 #pragma unroll
                 for (int j = 0; j < N; ++j) o[j] += old[j]; }
             P16<T>::st(dst, o);
+            if constexpr (BNB) {
+                if constexpr (sizeof(T) == 2) { const u32x4 v = pack16<T>(o); unpack16<T>(v, o); }     // the value salt_bn_bwd will read
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const float xh = (xraw[j] - bmu[j]) * bis[j];
+                    const bool on = !in_relu || __fmaf_rn(xraw[j], isc[j], ish[j]) > 0.f;       // the forward decision (in_transform's pre-activation)
+                    const float gg = on ? o[j] : 0.f, mm = on ? 1.f : 0.f;
+                    a1[j] += gg; a2[j] += gg * xh; m0[j] += mm; m1[j] += mm * xh;
+                }
+            }
         }
     }
     // block combine (fixed order)
@@ -244,14 +267,32 @@ __global__ __launch_bounds__(256) void scse_bwd1_kernel(salt_view x, salt_view y
     if (cv == 0) sb[row] = s_bs;
     __syncthreads();
     float* out = partials + ((int64_t)b * nparts + part) * (2 * C + 1);
+    const int AW = BNB ? 6 * C + 1 : 2 * C + 1;           // width of an image's row of `acc`
     // cross-row sums, one thread per output (rows in ascending order)
     for (int e = threadIdx.x; e < 2 * C + 1; e += 256) {
         float t = 0.f;
         if (e < C) { for (int r = 0; r < R; ++r) t += sg[r * C + e]; }
         else if (e < 2 * C) { for (int r = 0; r < R; ++r) t += sw[r * C + e - C]; }
         else { for (int r = 0; r < R; ++r) t += sb[r]; }
-        if (acc) unsafeAtomicAdd(acc + (int64_t)b * (2 * C + 1) + e, (double)t);   // per-image sums over the parts: no se_parts_reduce launch
+        if (acc) unsafeAtomicAdd(acc + (int64_t)b * AW + e, (double)t);   // per-image sums over the parts: no se_parts_reduce launch
         else out[e] = t;
+    }
+    if constexpr (BNB) {
+        __syncthreads();
+        float* q0 = sm; float* q1 = sm + 256 * N; float* q2 = sm + 512 * N; float* q3 = sm + 768 * N;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const int i = (row * cpv + cv) * N + j;
+            q0[i] = a1[j]; q1[i] = a2[j]; q2[i] = m0[j]; q3[i] = m1[j];
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < 4 * C; e += 256) {
+            const int k = e / C, c = e - k * C;
+            const float* q = sm + k * 256 * N;
+            float t = 0.f;
+            for (int r = 0; r < R; ++r) t += q[r * C + c];
+            unsafeAtomicAdd(acc + (int64_t)b * AW + 2 * C + 1 + e, (double)t);
+        }
     }
 }
 
@@ -274,7 +315,9 @@ __global__ void se_parts_reduce_kernel(float* partials, int nparts, int width) {
 __global__ __launch_bounds__(1024) void se_fc_bwd_kernel(const float* partials, int nparts, int Ball, int C, int R, const float* w1, const float* w2,
                                  const float* gap, const float* hidden, const float* gate_c,
                                  float* g_w1, float* g_b1, float* g_w2, float* g_b2, float* g_ws, float* g_bs, float* dgap, float inv_hw,
-                                 const double* acc, int stage_w, int Bt) {
+                                 const double* acc, int stage_w, int Bt, int AW, double* bnb_out) {
+    // AW: doubles per image row of `acc` (2 C + 1, or 6 C + 1 when scse_bwd1_kernel<.., BNB> also left A1, A2, M0, M1 there);
+    // bnb_out != NULL: shard 0 of the producer layer's BatchNorm-backward sums [2][C] (the other shards stay zero)
     // everything the loops touch repeatedly is staged in LDS first (one coalesced sweep); the batch loops then run out of LDS
     extern __shared__ float sm[];       // du [Bt][C], dh [Bt][R], gp [Bt][C], hd [Bt][R], ps [Bt][C+1] (spatial-SE sums)
     float* du = sm; float* dh = du + Bt * C; float* gp = dh + Bt * R; float* hd = gp + Bt * C; float* ps = hd + Bt * R;
@@ -291,7 +334,7 @@ __global__ __launch_bounds__(1024) void se_fc_bwd_kernel(const float* partials, 
         for (int i = tid; i < B * C; i += nt) {
             const int b = i / C, c = i - b * C;
             const float* row = partials + ((int64_t)(b0 + b) * nparts) * (2 * C + 1);
-            const double* arow = acc + (int64_t)(b0 + b) * (2 * C + 1);
+            const double* arow = acc + (int64_t)(b0 + b) * AW;
             const float g = gate_c[(int64_t)b0 * C + i];
             du[i] = (acc ? (float)arow[c] : row[c]) * g * (1.f - g);
             gp[i] = gap[(int64_t)b0 * C + i];
@@ -332,6 +375,29 @@ __global__ __launch_bounds__(1024) void se_fc_bwd_kernel(const float* partials, 
             float t = 0.f;
             for (int r = 0; r < R; ++r) t += dh[b * R + r] * sw1[r * C + c];
             dgap[(int64_t)b0 * C + i] = t * inv_hw;
+        }
+        if (bnb_out) {
+            __syncthreads();                              // this tile's dgap rows are visible to the whole workgroup
+            // 16 adjacent lanes share a channel, each takes every 16th image of the tile (five independent loads per image, all in flight
+            // together), then a 4-step butterfly: the first version - a thread per channel walking the whole tile - left 960 of the 1024
+            // threads idle behind a chain of 32 dependent round trips and cost 14 us per launch
+            constexpr int G = 16;
+            for (int i = tid; i < C * G; i += nt) {
+                const int c = i / G, gl = i % G;
+                double t1 = 0.0, t2 = 0.0;
+                for (int b = gl; b < B; b += G) {
+                    const double* arow = acc + (int64_t)(b0 + b) * AW + 2 * C + 1;
+                    const double dg = (double)dgap[(int64_t)(b0 + b) * C + c];
+                    t1 += arow[c] + dg * arow[2 * C + c];
+                    t2 += arow[C + c] + dg * arow[3 * C + c];
+                }
+#pragma unroll
+                for (int sft = 1; sft < G; sft <<= 1) { t1 += __shfl_xor(t1, sft); t2 += __shfl_xor(t2, sft); }
+                if (gl == 0) {
+                    bnb_out[c] = first ? t1 : bnb_out[c] + t1;
+                    bnb_out[C + c] = first ? t2 : bnb_out[C + c] + t2;
+                }
+            }
         }
     }
 }
@@ -429,6 +495,9 @@ extern "C" int salt_scse_bwd(const salt_scse_bwd_args* a, void* stream) {
     if (a->nparts != nparts) SALT_FAIL(SALT_E_BADARG, "scse_bwd: nparts %d, expected %d", a->nparts, nparts);
     hipStream_t st = (hipStream_t)stream;
     const int C = a->x.C, B = a->x.B;
+    const bool bnb = a->bnb_acc != nullptr;
+    if (bnb && (!a->acc || !a->in_scale || !a->bn_mean || !a->bn_invstd || !a->skip_bcast))
+        SALT_FAIL(SALT_E_BADARG, "scse_bwd: bnb_acc needs acc, the input transform (in_scale / in_shift), bn_mean / bn_invstd and skip_bcast");
     const size_t fc_img = (size_t)(3 * C + 2 * a->R + 1) * sizeof(float), fc_w = (size_t)2 * a->R * C * sizeof(float);
     int stage_w = fc_img * B + fc_w <= 160 * 1024;                // the FC weights ride along only when they fit beside the per-image vectors
     int Bt = B;
@@ -451,15 +520,19 @@ extern "C" int salt_scse_bwd(const salt_scse_bwd_args* a, void* stream) {
         if (!se_ok<T>(a->x) || !se_ok<T>(a->y) || !se_ok<T>(a->dy) || !se_ok<T>(a->dx)) SALT_FAIL(SALT_E_UNSUPPORTED, "scse_bwd: layout");
         constexpr int VE = Elem<T>::VE;
         const int cpv_log2 = ilog2_ceil(C / VE);
-        hipLaunchKernelGGL(scse_bwd1_kernel<T>, dim3(B * nparts), dim3(256), (512 * VE + 256) * sizeof(float), st, a->x, a->y, a->dy, a->gate_c,
-                           a->gate_s, a->ws, a->dx, a->accumulate, a->partials, nparts, per, cpv_log2, a->acc, a->in_scale, a->in_shift, a->in_relu);
+        if (bnb) hipLaunchKernelGGL((scse_bwd1_kernel<T, true>), dim3(B * nparts), dim3(256), 1024 * VE * sizeof(float), st, a->x, a->y, a->dy, a->gate_c,
+                                    a->gate_s, a->ws, a->dx, a->accumulate, a->partials, nparts, per, cpv_log2, a->acc, a->in_scale, a->in_shift, a->in_relu,
+                                    a->bn_mean, a->bn_invstd);
+        else hipLaunchKernelGGL((scse_bwd1_kernel<T, false>), dim3(B * nparts), dim3(256), (512 * VE + 256) * sizeof(float), st, a->x, a->y, a->dy, a->gate_c,
+                                a->gate_s, a->ws, a->dx, a->accumulate, a->partials, nparts, per, cpv_log2, a->acc, a->in_scale, a->in_shift, a->in_relu,
+                                nullptr, nullptr);
         SALT_CHECK_LAUNCH();
         if (!a->acc) {
             hipLaunchKernelGGL(se_parts_reduce_kernel, dim3(B), dim3(256), 0, st, a->partials, nparts, 2 * C + 1);
             SALT_CHECK_LAUNCH();
         }
         hipLaunchKernelGGL(se_fc_bwd_kernel, dim3(1), dim3(1024), fc_lds, st, a->partials, nparts, B, C, a->R, a->w1, a->w2, a->gap, a->hidden,
-                           a->gate_c, a->g_w1, a->g_b1, a->g_w2, a->g_b2, a->g_ws, a->g_bs, a->dgap, 1.0f / (float)(a->x.H * a->x.W), a->acc, stage_w, Bt);
+                           a->gate_c, a->g_w1, a->g_b1, a->g_w2, a->g_b2, a->g_ws, a->g_bs, a->dgap, 1.0f / (float)(a->x.H * a->x.W), a->acc, stage_w, Bt, bnb ? 6 * C + 1 : 2 * C + 1, bnb ? a->bnb_acc : nullptr);
         SALT_CHECK_LAUNCH();
         if (!a->skip_bcast) {                      // else: the consumer adds dgap[b][c] on the fly (salt_bn_bwd_args.da_bias)
             const int64_t units = view_pixels(a->dx) * (C / VE);

@@ -661,8 +661,14 @@ class Graph:
             if (bias[0], bias[1]) != (out.c0, out.C):
                 raise SaltError('gradient bias of %s covers channels [%d, %d), this BatchNorm backward reads [%d, %d)'
                                 % (out.buf.name, bias[0], bias[0] + bias[1], out.c0, out.c0 + out.C))
+            sums = bias[3] if len(bias) > 3 else None       # the scSE backward also took this layer's BatchNorm-backward sums (salt_scse_bwd_args.bnb_acc)
             if ready != 0:
                 raise SaltError('a per-image gradient bias needs the reduction pass of bn_bwd (the producer of dL/da is not a convolution)')
+            if sums is not None:
+                ready, producer = 3, sums
+                self.bwd.set_fields(s2, partials=None, partials_ready=3)
+                self.bwd.patches = [q for q in self.bwd.patches if q[0] is not s2 or q[1] != ('partials',)]
+                self.bwd.set_fields(sums, bn_mean=w['mean'].data_ptr(), bn_invstd=w['invstd'].data_ptr())
             self.bwd.set_fields(s2, da_bias=bias[2].data_ptr())
             out.buf.grad_bias = None
         if ready == 3:
@@ -1455,8 +1461,12 @@ class Graph:
                                   partials=Scratch('se', B * nparts * (2 * C + 1) * 4), nparts=nparts, g_w1=gp(l1.weight), g_b1=gp(l1.bias),
                                   g_w2=gp(l2.weight), g_b2=gp(l2.bias), g_ws=gp(cs.weight), g_bs=gp(cs.bias), dgap=dgap.data_ptr(),
                                   dx=x.gview(), accumulate=acc, **in_bwd)
+                # round 6: with the input transform the kernel holds everything the producer layer's BatchNorm backward sums over - it takes
+                # them too and that layer's bn_bwd loses its reduction pass (saltnet.h salt_scse_bwd_args.bnb_acc; SALT_SE_BNB=0: off)
+                carry = (taken is not None and shards and getattr(x.buf, 'bn_train_out', None) == (x.c0, x.C) and acc == 0
+                         and x.B * x.H * x.W < (1 << 31) and os.environ.get('SALT_SE_BIAS_FOLD', '1') != '0' and os.environ.get('SALT_SE_BNB', '1') != '0')
                 if shards:
-                    self._fin_slot('bwd', B * (2 * C + 1), (sb, 'acc'))
+                    self._fin_slot('bwd', B * ((6 if carry else 2) * C + 1), (sb, 'acc'))
                 # x = relu(bn(conv)): its only gradient consumer is that layer's bn_bwd, which can add the channel-SE term dgap[b][c]
                 # wherever it reads dL/dx - the broadcast-add pass over dx (read + write of the whole tensor) disappears
                 if (getattr(x.buf, 'bn_train_out', None) == (x.c0, x.C) and acc == 0 and x.B * x.H * x.W < (1 << 31)
@@ -1464,7 +1474,7 @@ class Graph:
                     if getattr(x.buf, 'grad_bias', None) is not None:
                         raise SaltError('two pending gradient biases on %s' % x.buf.name)
                     self.bwd.set_fields(sb, skip_bcast=1)
-                    x.buf.grad_bias = (x.c0, x.C, dgap)
+                    x.buf.grad_bias = (x.c0, x.C, dgap) + ((sb,) if carry else ())
                     self._bias_bufs = getattr(self, '_bias_bufs', []) + [x.buf]
             self.tape.append(backward)
         return out

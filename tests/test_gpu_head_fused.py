@@ -159,7 +159,9 @@ def test_scse_applies_the_producer_batchnorm_itself(dtype, monkeypatch):
     fx = golden('F4_decoderblock_skip_train')
     make, emit = BLOCKS['F4_decoderblock_skip']
     res = {}
-    for mode in ('fused', 'separate'):
+    for mode in ('fused', 'no_bnb', 'separate'):
+        if mode == 'no_bnb':
+            monkeypatch.setenv('SALT_SE_BNB', '0')       # input transform on, but the layer's bn_bwd keeps its own reduction pass
         if mode == 'separate':
             monkeypatch.setenv('SALT_SE_IN_BN', '0')
         m = make(A)
@@ -170,10 +172,14 @@ def test_scse_applies_the_producer_batchnorm_itself(dtype, monkeypatch):
         gx, grads = run.backward(T(fx['gy']).to(DEV))
         names = [n for n, _, _ in run.g.fwd.ops]
         sc = [s_ for n, _, s_ in run.g.fwd.ops if n == 'scse'][0]
-        assert bool(sc.in_fin) == (mode == 'fused')
+        assert bool(sc.in_fin) == (mode != 'separate')
+        sb = [s_ for n, _, s_ in run.g.bwd.ops if n == 'scse_bwd'][0]
+        bnb = [s_ for n, _, s_ in run.g.bwd.ops if n == 'bn_bwd']
+        # backward order: scse_bwd, then conv2's bn_bwd: apply-only (partials_ready 3, da_bias) when the scSE pass carried its sums
+        assert bool(sb.bnb_acc) == (mode == 'fused') and int(bnb[0].partials_ready) == (3 if mode == 'fused' else 0) and bool(bnb[0].da_bias)
         res[mode] = (y, gx, grads, names.count('affine_act'), {k: v.clone().cpu() for k, v in m.state_dict().items() if 'running' in k})
     a, b = res['fused'], res['separate']
-    assert a[3] == b[3] - 1
+    assert a[3] == b[3] - 1 and res['no_bnb'][3] == a[3]
     tol = 1e-5 if dtype == 'f32' else 1e-2
 
     def close(u, v, what, t=tol):
@@ -187,3 +193,9 @@ def test_scse_applies_the_producer_batchnorm_itself(dtype, monkeypatch):
             close(a[2][k], b[2][k], k, tol * 4)
     for k in a[4]:
         close(a[4][k], b[4][k], k, 1e-6)
+    c = res['no_bnb']
+    for u, v in zip(a[1], c[1]):
+        close(u, v, 'dx (sums carried by the scSE pass vs bn_bwd reduction pass)', tol * 4)
+    for k in a[2]:
+        if float(c[2][k].abs().max()) > 0:
+            close(a[2][k], c[2][k], k + ' (carried sums)', tol * 4)
