@@ -327,6 +327,8 @@ def dp_leg(workload, dtype, B, loss):
            'ms_per_step_all': [round(v, 3) for v in ms_dp], 'ms_per_step_plain_all': [round(v, 3) for v in ms_plain],
            'overhead_frac': round(min(ms_dp) / min(ms_plain) - 1.0, 4), 'images_per_s': round(B / min(ms_dp) * 1e3, 1),
            'buckets': len(list(m2.dp._plans.values())[0]) if m2.dp._plans else 0, 'rccl_info': rccl_summary(6),
+           'bucket_mbytes': [round((hi - lo) * 4 / 1e6, 2) for lo, hi, _ in (list(m2.dp._plans.values())[0] if m2.dp._plans else [])],
+           'rccl_max_nchannels': RCCL_MAX_NCHANNELS,
            'exposed_allreduce_ms_per_step': round(ex, 4) if ex is not None else None, 'bucket_timeline': m2.dp.bucket_timeline()}
     print(json.dumps(res))
     dist.destroy_process_group()
@@ -757,6 +759,9 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
     torch.cuda.set_device(local)
+    # one process per GPU: the launch thread and the loader thread of this rank stay on the cores of its GPU's NUMA node (parallel.py)
+    from salt_amd.parallel import pin_rank_threads
+    affinity = pin_rank_threads(local, int(os.environ.get('LOCAL_WORLD_SIZE', str(world))))
     if world > 1 or os.environ.get('SALT_FORCE_DP_PATH'):
         init_rccl(rank)
     if world != args.gpus:
@@ -777,6 +782,8 @@ def main():
                                   % (wl_desc, B, args.loss),
                       'global_batch': B * world, 'image': [128, 128], 'parallelism': 'dp%d' % world},
            'final_loss': round(final_loss, 5)}
+    out['host'] = {'logical_cpus': os.cpu_count(), 'cpu_affinity': affinity,
+                   'note': 'cpu_affinity: what parallel.pin_rank_threads gave this rank (cores of its GPU\'s NUMA node, split between the ranks that share it); None = left alone'}
     if STEP_MS:
         n_ = len(STEP_MS)
         out['ms_per_step_median'] = round(STEP_MS[n_ // 2], 3)

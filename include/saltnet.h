@@ -234,6 +234,19 @@ typedef struct {
 } salt_wgrad_reduce_args;
 int salt_wgrad_reduce(const salt_wgrad_reduce_args*, void* stream);
 
+/* round 6: the slab reductions of SEVERAL layers in one launch (the 53 reductions of the ResNet34 U-Net's backward pass were 53 launches
+ * of 4 - 25 us on the weight-gradient queue).  `jobs` = DEVICE array of njobs salt_wgrad_reduce_args (each with its own slab),
+ * `job_block0` = DEVICE prefix sums [njobs + 1] of salt_wgrad_reduce_job_blocks over the jobs; per element the same loads and the same
+ * summation order as salt_wgrad_reduce: bit-identical.  salt_wgrad_reduce_job_blocks validates a job (< 0: bad arguments). */
+typedef struct {
+    const void* jobs;
+    const int* job_block0;
+    int njobs;
+    int total_blocks;
+} salt_wgrad_reduce_batched_args;
+int salt_wgrad_reduce_batched(const salt_wgrad_reduce_batched_args*, void* stream);
+int salt_wgrad_reduce_job_blocks(const salt_wgrad_reduce_args*);
+
 /* fp32 master weight (reference layout) -> packed compute layout.
  * transpose=0: Wp[chunk][t][n=d0][c=d1]  from W[d0][d1][kh][kw]   (conv forward; convT dgrad)
  * transpose=1: Wp[chunk][t][n=d1][c=d0]                           (conv dgrad;   convT forward) */

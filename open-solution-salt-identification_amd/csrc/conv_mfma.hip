@@ -3022,7 +3022,73 @@ __global__ __launch_bounds__(256) void wgrad_reduce9_kernel(ReduceKP p) {
     for (int t = 0; t < 9; ++t) dst[t] = p.accumulate ? dst[t] + s[t] : s[t];
 }
 
+// salt_wgrad_reduce_batched: one launch over the reductions of several layers.  A block finds its job in the block-prefix table and
+// runs wgrad_reduce8_kernel's (nsplit <= 8: a thread per element, 256 elements per block) or wgrad_reduce_kernel's (4 split rows x 64
+// elements) body on it - the same loads, the same summation order, the same stores.
+__global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const salt_wgrad_reduce_args* jobs, const int* block0, int njobs) {
+    __shared__ float sm[4][64];
+    int lo = 0, hi = njobs;                                     // block0[lo] <= blockIdx.x < block0[hi]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)blockIdx.x >= block0[mid]) lo = mid; else hi = mid; }
+    const salt_wgrad_reduce_args& a = jobs[lo];
+    const int blk = (int)blockIdx.x - block0[lo];
+    const int64_t slab = (int64_t)a.ntaps * a.Ca * a.Cb;
+    const int ldb = a.ldb > 0 ? a.ldb : a.Cb;
+    int64_t i; float s; bool writer;
+    if (a.nsplit <= 8) {
+        i = (int64_t)blk * 256 + threadIdx.x;
+        writer = i < slab;
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (writer && k < a.nsplit) ? a.partials[k * slab + i] : 0.f;
+        s = (((v[0] + v[4]) + (v[1] + v[5])) + (v[2] + v[6])) + (v[3] + v[7]);
+    } else {
+        const int e = threadIdx.x & 63, row = threadIdx.x >> 6;
+        i = (int64_t)blk * 64 + e;
+        float s0 = 0.f, s1 = 0.f;
+        if (i < slab) {
+            int k = row;
+            for (; k + 4 < a.nsplit; k += 8) { s0 += a.partials[k * slab + i]; s1 += a.partials[(k + 4) * slab + i]; }
+            for (; k < a.nsplit; k += 4) s0 += a.partials[k * slab + i];
+        }
+        sm[row][e] = s0 + s1;
+        __syncthreads();
+        writer = row == 0 && i < slab;
+        s = sm[0][e] + sm[1][e] + sm[2][e] + sm[3][e];
+    }
+    if (!writer) return;
+    const int b = (int)(i % a.Cb);
+    int64_t r = i / a.Cb;
+    int ar = (int)(r % a.Ca);
+    int t = (int)(r / a.Ca);
+    if (a.a_mod) { t = ar / a.a_mod; ar -= t * a.a_mod; }
+    float* dst = a.grad + (((int64_t)ar * ldb + b) * a.KH + a.tap_kh[t]) * a.KW + a.tap_kw[t];
+    *dst = a.accumulate ? (*dst + s) : s;
+}
+
 }  // namespace
+
+extern "C" int salt_wgrad_reduce_job_blocks(const salt_wgrad_reduce_args* a) {
+    if (!a || a->ntaps < 1 || a->ntaps > SALT_MAX_TAPS || a->nsplit < 1 || a->Ca < 1 || a->Cb < 1 || a->KH < 1 || a->KW < 1) return -1;
+    int nt_tab = a->ntaps;
+    if (a->a_mod) {
+        if (a->a_mod < 0 || a->ntaps != 1 || a->Ca % a->a_mod || a->Ca / a->a_mod > SALT_MAX_TAPS) return -1;
+        nt_tab = a->Ca / a->a_mod;
+    }
+    if (a->ldb && a->ldb < a->Cb) return -1;
+    for (int t = 0; t < nt_tab; ++t)
+        if (a->tap_kh[t] < 0 || a->tap_kh[t] >= a->KH || a->tap_kw[t] < 0 || a->tap_kw[t] >= a->KW) return -1;
+    const int64_t slab = (int64_t)a->ntaps * a->Ca * a->Cb;
+    const int64_t blocks = a->nsplit <= 8 ? (slab + 255) / 256 : (slab + 63) / 64;
+    return blocks > 0x3fffffff ? -1 : (int)blocks;
+}
+
+extern "C" int salt_wgrad_reduce_batched(const salt_wgrad_reduce_batched_args* a, void* stream) {
+    if (!a || !a->jobs || !a->job_block0 || a->njobs < 1 || a->total_blocks < 1) SALT_FAIL(SALT_E_BADARG, "wgrad_reduce_batched: bad args");
+    hipLaunchKernelGGL(wgrad_reduce_batched_kernel, dim3((unsigned)a->total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const salt_wgrad_reduce_args*>(a->jobs), a->job_block0, a->njobs);
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}
 
 extern "C" int salt_conv(const salt_conv_args* a, void* stream) {
     Plan pl;

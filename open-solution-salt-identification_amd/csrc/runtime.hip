@@ -312,6 +312,7 @@ extern "C" int salt_abi_struct_sizes(int* out, int n) {
     (int)sizeof(salt_conv_args),
     (int)sizeof(salt_conv_wgrad_args),
     (int)sizeof(salt_wgrad_reduce_args),
+    (int)sizeof(salt_wgrad_reduce_batched_args),
     (int)sizeof(salt_pack_conv_weight_args),
     (int)sizeof(salt_pack_batched_args),
     (int)sizeof(salt_conv_first_args),

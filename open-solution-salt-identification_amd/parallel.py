@@ -51,6 +51,65 @@ def configure_rccl_env():
     return None
 
 
+def _cpulist(text):
+    out = []
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        a, _, b = part.partition('-')
+        out.extend(range(int(a), int(b or a) + 1))
+    return out
+
+
+def gpu_numa_node(index):
+    """NUMA node of GPU ``index`` (sysfs, through the PCI address torch reports); None when the platform does not say"""
+    try:
+        pr = torch.cuda.get_device_properties(index)
+        path = '/sys/bus/pci/devices/%04x:%02x:%02x.0/numa_node' % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        node = int(open(path).read())
+        return node if node >= 0 else None
+    except (OSError, ValueError, AttributeError, RuntimeError):
+        return None
+
+
+def pin_rank_threads(local_rank=0, local_world=1):
+    """One process per GPU means one launch thread + one loader thread per GPU on the SAME host: pin this process (and every thread it
+    starts later - torch's intra-op pool, the input pipeline's loader) to the cores of its GPU's NUMA node, the node's cores split evenly
+    between the ranks whose GPUs share it (the reference's nn.DataParallel ran ONE process with a thread per replica, models.py:81-85,
+    and num_workers loader processes, loaders.py:477-490).  SALT_NO_PIN=1: leave the affinity alone.
+    -> {'numa_node', 'cpus' (count), 'mask' (cpulist string), 'ranks_on_node'} or None when nothing was changed."""
+    if os.environ.get('SALT_NO_PIN') or not hasattr(os, 'sched_setaffinity'):
+        return None
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        ngpu = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        nodes = [gpu_numa_node(i) for i in range(ngpu)]
+        node = nodes[local_rank] if local_rank < len(nodes) else None
+        if node is not None:
+            cpus = [c for c in _cpulist(open('/sys/devices/system/node/node%d/cpulist' % node).read()) if c in set(allowed)]
+            peers = [r for r in range(local_world) if r < len(nodes) and nodes[r] == node]
+        else:
+            cpus, peers = allowed, list(range(local_world))
+        if not cpus:
+            return None
+        k = peers.index(local_rank) if local_rank in peers else 0
+        per = max(len(cpus) // max(len(peers), 1), 1)
+        mine = cpus[k * per:(k + 1) * per] or cpus
+        os.sched_setaffinity(0, mine)
+        runs, a = [], None
+        for c in mine + [None]:
+            if a is None:
+                a = b = c
+            elif c is not None and c == b + 1:
+                b = c
+            else:
+                runs.append('%d-%d' % (a, b) if b != a else '%d' % a)
+                a = b = c
+        return {'numa_node': node, 'cpus': len(mine), 'mask': ','.join(runs), 'ranks_on_node': len(peers)}
+    except (OSError, ValueError):
+        return None
+
+
 def _destroy_events(handles):
     """salt_event_destroy on native event handles (ctypes.c_void_p) - weakref.finalize callback of a compiled net / drop_plans."""
     from ._abi import lib
@@ -60,17 +119,27 @@ def _destroy_events(handles):
             h.value = None
 
 
-def plan_buckets(ready, total, bucket_bytes=DEFAULT_BUCKET_BYTES, tail_bytes=DEFAULT_TAIL_BYTES):
+DEFAULT_FIRST_FRACTION = 0.25       # the first collective is issued by this fraction of the backward program (0: size rule only)
+DEFAULT_FIRST_MIN_BYTES = 1 << 20
+
+
+def plan_buckets(ready, total, bucket_bytes=DEFAULT_BUCKET_BYTES, tail_bytes=DEFAULT_TAIL_BYTES, first_pos=None, first_min_bytes=DEFAULT_FIRST_MIN_BYTES):
     """ready: list of (offset, numel, ready_index) per parameter (offsets ascending in forward order; ready_index =
     backward-program position after which that gradient is final).  Returns buckets in issue order:
     [(lo, hi, ready_index)] covering [0,total); every bucket but the remainder holds >= bucket_bytes.  The remainder (the first
     layers of the encoder: their gradients are final only when backward ends, so their collective is the one left exposed)
-    is split once more so that the very last collective moves at most ``tail_bytes``."""
+    is split once more so that the very last collective moves at most ``tail_bytes``.
+    ``first_pos`` (round 6): the FIRST bucket is closed early - as soon as it holds ``first_min_bytes`` and the next parameter's
+    gradient would only be final after backward-program position ``first_pos`` - so that the wire starts working by then instead of
+    when 32 MB have piled up (the ResNet34 U-Net's decoder is 1 / 4 of its parameters: the size rule alone issued the first
+    collective 46 % into backward)."""
     items = sorted(ready, key=lambda r: r[0])
     cuts = []                                    # lower bounds of the buckets, descending
     hi = total
-    for off, n, _ in reversed(items):
-        if (hi - off) * 4 >= bucket_bytes:
+    for i in range(len(items) - 1, -1, -1):
+        off = items[i][0]
+        early = (first_pos is not None and not cuts and i > 0 and (hi - off) * 4 >= first_min_bytes and items[i - 1][2] > first_pos)
+        if (hi - off) * 4 >= bucket_bytes or early:
             cuts.append(off)
             hi = off
     if hi > 0:
@@ -94,6 +163,8 @@ def shard_batch(n, rank, world):
 
 
 class DataParallel:
+    affinity = None                     # what pin_rank_threads did for this process (bench.py prints it)
+
     def __init__(self, rank=0, world=1, bucket_bytes=DEFAULT_BUCKET_BYTES):
         self.rank, self.world, self.bucket_bytes = rank, world, bucket_bytes
         self._comm_stream = None
@@ -124,6 +195,8 @@ class DataParallel:
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             if torch.cuda.is_available() and backend in (None, 'nccl'):
                 configure_rccl_env()
+            if torch.cuda.is_available():
+                DataParallel.affinity = pin_rank_threads(int(os.environ.get('LOCAL_RANK', '0')), int(os.environ.get('LOCAL_WORLD_SIZE', str(world))))
             dist.init_process_group(backend or ('nccl' if torch.cuda.is_available() else 'gloo'))
         return DataParallel.from_env()
 
@@ -220,7 +293,9 @@ class DataParallel:
             return
         key = net
         if key not in self._plans:
-            self._plans[key] = plan_buckets(net.g.grad_ready, eng.n_live, self.bucket_bytes)
+            frac = float(os.environ.get('SALT_DP_FIRST_FRACTION', str(DEFAULT_FIRST_FRACTION)))
+            self._plans[key] = plan_buckets(net.g.grad_ready, eng.n_live, self.bucket_bytes,
+                                            first_pos=int(frac * len(net.bwd)) if frac > 0 else None)
         if self.timeline or os.environ.get('SALT_DP_SEGMENTS'):
             if key not in self._events:
                 # ONE event per bucket and queue, created once (round 4 allocated two torch.cuda.Event objects per bucket per step)

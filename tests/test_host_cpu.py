@@ -118,6 +118,34 @@ def test_bucket_planner_covers_flat_buffer_in_reverse_order():
     assert plan_buckets(ready, off, bucket_bytes=8 << 20, tail_bytes=0) == plan_buckets(ready, off, bucket_bytes=8 << 20, tail_bytes=1 << 40)
 
 
+def test_first_bucket_closes_early_and_rank_pinning_reports_a_mask():
+    """Round 6: (1) plan_buckets(first_pos=...) closes the FIRST bucket as soon as it holds 1 MB and the next gradient would
+    only be final after that backward-program position - the wire starts by ~25 % of backward instead of when 32 MB have piled up;
+    coverage / order invariants unchanged.  (2) pin_rank_threads splits the allowed cores between the ranks of a node and reports it."""
+    from salt_amd.parallel import plan_buckets, pin_rank_threads, _cpulist
+    ready, off = [], 0
+    sizes = [1000, 50_000, 3_000_000, 10, 9_000_000, 2_000_000, 64, 500_000, 300_000]
+    for i, n in enumerate(sizes):
+        ready.append((off, n, 100 - 10 * i))           # later parameters are ready earlier (positions 20, 30, ... from the end)
+        off += (n + 3) // 4 * 4
+    plain = plan_buckets(ready, off, bucket_bytes=32 << 20)
+    early = plan_buckets(ready, off, bucket_bytes=32 << 20, first_pos=25)
+    assert len(early) == len(plain) + 1 and early[0][2] <= 25 < plain[0][2]        # issued by position 25 instead of 60
+    assert (early[0][1] - early[0][0]) * 4 >= 1 << 20
+    for b in (plain, early):
+        assert b[0][1] == off and b[-1][0] == 0 and sum(hi - lo for lo, hi, _ in b) == off
+        assert all(a[0] == c[1] and c[2] >= a[2] for a, c in zip(b, b[1:]))
+    assert plan_buckets(ready, off, bucket_bytes=32 << 20, first_pos=10 ** 9) == plain      # nothing is final that late: size rule only
+    assert _cpulist('0-3,8,10-11\n') == [0, 1, 2, 3, 8, 10, 11]
+    before = os.sched_getaffinity(0)
+    try:
+        a = pin_rank_threads(1, 2)                       # no GPU here: the allowed cores are split between the two ranks of the node
+        if a is not None and len(before) >= 2:
+            assert a['ranks_on_node'] == 2 and a['cpus'] == len(before) // 2 and set(os.sched_getaffinity(0)) < set(before)
+    finally:
+        os.sched_setaffinity(0, before)
+
+
 _WORKER = r'''
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, %(root)r)
