@@ -400,7 +400,7 @@ def conv_roofline(model, B, channels, dtype, loss, reps):
                                  'achieved_tflops': round(v[1] / (v[0] * 1e-3) / 1e12, 1), 'frac': round(v[1] / (v[0] * 1e-3) / 1e12 / peak, 4)}
                              for k, v in sorted(symbols.items(), key=lambda kv: -kv[1][0])}
     ops = {k: round(v[0] / reps, 3) for k, v in sorted(groups.items(), key=lambda kv: -kv[1][0])[:8]}
-    side = sum(v[0] for k, v in groups.items() if k in ('conv_wgrad', 'wgrad_reduce', 'conv_first_wgrad', 'stem_grad_unfold')) / reps
+    side = sum(v[0] for k, v in groups.items() if k in ('conv_wgrad', 'wgrad_reduce', 'wgrad_reduce_batched', 'conv_first_wgrad', 'stem_grad_unfold')) / reps
     # per kernel class: matrix kernels against the dense MFMA peak of the compute dtype, streaming kernels as
     # algorithmic GB/s against the HBM peak; every launch timed alone with its own HIP event pair
     by_class = {}

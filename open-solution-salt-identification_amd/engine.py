@@ -331,6 +331,7 @@ class Graph:
         self._scratch_sfx = ''
         # fp64 statistics shards of the train-mode BatchNorm layers (SALT_BN_FIN=2): slices of one arena per program, cleared by ONE
         # salt_zero at the head of the program
+        self._pending_reduces, self._deferred_params, self._pending_bytes, self._reduce_batches = [], [], 0, []
         self._fin_bytes = {'fwd': 0, 'bwd': 0}
         self._fin_patches = []                   # (struct, field, 'fwd' | 'bwd', byte offset)
         self._fin_zero = {}
@@ -386,6 +387,13 @@ class Graph:
                     obj = getattr(obj, a)
                 setattr(obj, path[-1], self.scratch[sc.name].data_ptr())
             prog.finalize()
+        # device tables of the batched slab reductions (the jobs' slab pointers were patched just above)
+        import numpy as np
+        for op, jobs, blocks in self._reduce_batches:
+            table = torch.frombuffer(bytearray(b''.join(bytes(j) for j in jobs)), dtype=torch.uint8).to(self.device)
+            pref = torch.from_numpy(np.concatenate([[0], np.cumsum(blocks)]).astype(np.int32)).to(self.device)
+            self.keep += [table, pref]
+            fill(op, jobs=table.data_ptr(), job_block0=pref.data_ptr())
         # ONE arena for the fp64 statistics shards of both programs, cleared by ONE salt_zero at the head of the FORWARD program (a
         # training step runs forward -> loss -> backward exactly once each; the backward program's own clear - a 6 us launch at the
         # head of the critical queue - is dropped: its salt_zero entry stays in the program with 0 bytes, which launches nothing).
@@ -434,10 +442,51 @@ class Graph:
             self._fin_patches.append((st, field, which, off))
         return off
 
-    def _gp(self, param):
-        """Gradient pointer of a parameter; remembers that the current backward closure finalises it."""
-        self._touched.append(param)
+    def _gp(self, param, deferred=False):
+        """Gradient pointer of a parameter; remembers that the current backward closure finalises it (``deferred``: the NEXT batched
+        slab reduction does - Graph._flush_reduces records the position)."""
+        (self._deferred_params if deferred else self._touched).append(param)
         return self.engine.grad_ptr(param)
+
+    # ------------------------------------------------------------------ batched weight-gradient slab reductions (round 6)
+    def _reduce_batching(self):
+        """SALT_WGRAD_BATCH_MB=<n> (OPT-IN; default 0 = one salt_wgrad_reduce launch per layer): the slab reductions of consecutive layers
+        are collected - every layer then needs its OWN slab region (0.9 GB for the ResNet34 U-Net instead of one shared 25 MB workspace) -
+        and issued as ONE salt_wgrad_reduce_batched launch whenever the collected gradients reach n megabytes or 16 layers.  Built for
+        VERDICT r5 #3 and measured SLOWER on the step (same box: 5.06 ms per layer / 5.13 with per-layer slabs but a launch per layer /
+        5.16 at 4 MB / 5.19 at 40 MB, profiles/r06_wgrad_batch2_ab.txt): the shared 25 MB workspace is written and read back out of the
+        256 MB Infinity Cache, per-layer regions go to HBM - the slab round trip the counters show is cache traffic, not HBM time."""
+        return float(os.environ.get('SALT_WGRAD_BATCH_MB', '0')) if self.train else 0.0
+
+    def _queue_reduce(self, fields, weight, nbytes):
+        """one layer's reduction: argument struct now, launch with the next batch"""
+        S = STRUCTS['salt_wgrad_reduce_args']()
+        self._n_slab = getattr(self, '_n_slab', 0) + 1
+        sc = Scratch('wgrad#%d' % self._n_slab, nbytes)
+        plain = dict(fields)
+        plain['grad'] = self._gp(weight, deferred=True) + plain.pop('grad_off', 0)
+        fill(S, **plain)
+        self.bwd.patches.append((S, ('partials',), sc))
+        self.keep.append(S)
+        self._pending_reduces.append(S)
+        self._pending_bytes += plain['ntaps'] * plain['Ca'] * plain['Cb'] * 4                      # bytes of gradient this job finishes
+        if self._pending_bytes >= self._reduce_batching() * 1e6 or len(self._pending_reduces) >= 16:
+            self._flush_reduces()
+        return sc
+
+    def _flush_reduces(self):
+        if not getattr(self, '_pending_reduces', None):
+            return
+        jobs = self._pending_reduces
+        blocks = [lib.salt_wgrad_reduce_job_blocks(ctypes.byref(j)) for j in jobs]
+        if min(blocks) < 0:
+            raise SaltError('wgrad_reduce_batched: bad job')
+        op = self.bwd.add('wgrad_reduce_batched', stream=1, jobs=1, job_block0=1, njobs=len(jobs), total_blocks=int(sum(blocks)))
+        self._reduce_batches.append((op, jobs, blocks))
+        for p in self._deferred_params:
+            off, n = self.engine.grad_range(p)
+            self.grad_ready.append((off, n, len(self.bwd.ops)))
+        self._pending_reduces, self._deferred_params, self._pending_bytes = [], [], 0
 
     def build_backward(self):
         """Emit the backward program (reverse tape order).  Also records, per parameter, the program position
@@ -452,6 +501,7 @@ class Graph:
             for p in self._touched:
                 off, n = self.engine.grad_range(p)
                 self.grad_ready.append((off, n, len(self.bwd.ops)))
+        self._flush_reduces()
         self.tape = []
         for b in getattr(self, '_bias_bufs', []):        # every folded channel-SE term must have met its bn_bwd, or x.grad is incomplete
             if getattr(b, 'grad_bias', None) is not None:
@@ -952,11 +1002,14 @@ class Graph:
         """dW = sum_p P[p,:]^T Q[p*q_step + tap, :] -> weight.grad (reference layout [Ca][Cb][KH][KW]).
         ``b_slice`` = (first, row stride): Q covers only channels [first, first + Cb) of the weight's second axis (salt_wgrad_reduce_args.ldb).
         ``tapgemm`` = (rows, [(kh, kw)]): a 1x1 launch whose P channels are t * rows + a (salt_wgrad_reduce_args.a_mod) - Graph.hyper_level."""
-        gw = self._gp(weight)
+        batching = self._reduce_batching() > 0
+        gw = self.engine.grad_ptr(weight) if batching else self._gp(weight)
+        goff = 0
         Ca, Cb = p_view.C, q_view.C
         extra = {}
         if b_slice is not None:
-            gw += 4 * b_slice[0] * KH * KW
+            goff = 4 * b_slice[0] * KH * KW
+            gw += goff
             extra['ldb'] = b_slice[1]
         if tapgemm is not None:
             assert len(taps_dydx) == 1 and Ca == tapgemm[0] * len(tapgemm[1])
@@ -973,11 +1026,17 @@ class Graph:
             if ns < 0:
                 raise SaltError('wgrad plan failed: ' + lib.salt_last_error().decode())
             nbytes = ns * len(chunk) * Ca * Cb * 4
-            self.bwd.add('conv_wgrad', stream=1, dtype=self.dt, p=p_view, q=q_view, ntaps=len(chunk), tap_dy=[taps_dydx[j][0] for j in chunk],
-                         tap_dx=[taps_dydx[j][1] for j in chunk], q_step=q_step, pad_mode=pad_mode, partials=Scratch('wgrad', nbytes), nsplit=ns, q_plane=qp)
+            wg_op = self.bwd.add('conv_wgrad', stream=1, dtype=self.dt, p=p_view, q=q_view, ntaps=len(chunk), tap_dy=[taps_dydx[j][0] for j in chunk],
+                                 tap_dx=[taps_dydx[j][1] for j in chunk], q_step=q_step, pad_mode=pad_mode,
+                                 partials=None if batching else Scratch('wgrad', nbytes), nsplit=ns, q_plane=qp)
             rt = range(len(taps_khkw)) if tapgemm is not None else chunk
-            self.bwd.add('wgrad_reduce', stream=1, partials=Scratch('wgrad', nbytes), nsplit=ns, ntaps=len(chunk), Ca=Ca, Cb=Cb, KH=KH, KW=KW,
-                         tap_kh=[taps_khkw[j][0] for j in rt], tap_kw=[taps_khkw[j][1] for j in rt], grad=gw, accumulate=0, **extra)
+            rfields = dict(nsplit=ns, ntaps=len(chunk), Ca=Ca, Cb=Cb, KH=KH, KW=KW, tap_kh=[taps_khkw[j][0] for j in rt],
+                           tap_kw=[taps_khkw[j][1] for j in rt], accumulate=0, **extra)
+            if batching:
+                sc = self._queue_reduce(dict(rfields, grad_off=goff), weight, nbytes)
+                self.bwd.set_fields(wg_op, partials=sc)
+            else:
+                self.bwd.add('wgrad_reduce', stream=1, partials=Scratch('wgrad', nbytes), grad=gw, **rfields)
             first = False
 
     def _bwd_pack_tag(self):

@@ -192,3 +192,71 @@ torch.save(got, sys.argv[1])
             outs.append(torch.load(f.name))
     d = float((outs[0].double() - outs[1].double()).norm() / outs[1].double().norm())
     assert d <= 2e-5, d
+
+
+def test_batched_slab_reduction_is_bit_identical_to_the_per_layer_launches():
+    """salt_wgrad_reduce_batched (round 6): several layers' slab reductions in ONE launch - per element the same loads and summation order as
+    salt_wgrad_reduce, for nsplit <= 8 (thread per element), nsplit > 8 (4 split rows x 64 elements), a weight slice (ldb), a tap-GEMM slab
+    (a_mod), and accumulate - compared bit for bit."""
+    import numpy as np
+    import salt_amd  # noqa: F401
+    from salt_amd._abi import STRUCTS, lib, fill, check
+    g = torch.Generator().manual_seed(9)
+    jobs_spec = [  # nsplit, ntaps, Ca, Cb, KH, KW, ldb, a_mod, accumulate
+        (2, 9, 64, 64, 3, 3, 0, 0, 0), (8, 9, 40, 24, 3, 3, 0, 0, 1), (32, 9, 64, 32, 3, 3, 0, 0, 0), (13, 1, 96, 16, 1, 1, 0, 0, 0),
+        (4, 9, 32, 64, 3, 3, 160, 0, 0), (2, 1, 9 * 16, 24, 3, 3, 0, 16, 0), (128, 4, 16, 16, 4, 4, 0, 0, 1)]
+    st = torch.cuda.current_stream().cuda_stream
+    structs, outs_single, outs_batched = [], [], []
+    for k, (ns, nt, Ca, Cb, KH, KW, ldb, a_mod, acc) in enumerate(jobs_spec):
+        part = torch.randn(ns * nt * Ca * Cb, generator=g).cuda()
+        rows = a_mod if a_mod else Ca
+        width = ldb if ldb else Cb
+        base = torch.randn(rows * width * KH * KW, generator=g).cuda()
+        taps = [(t // KW, t % KW) for t in range(KH * KW)][:(Ca // a_mod if a_mod else nt)]
+        g1, g2 = base.clone(), base.clone()
+        mk = lambda gr: fill(STRUCTS['salt_wgrad_reduce_args'](), partials=part.data_ptr(), nsplit=ns, ntaps=nt, Ca=Ca, Cb=Cb, KH=KH, KW=KW,
+                             tap_kh=[t[0] for t in taps], tap_kw=[t[1] for t in taps], grad=gr.data_ptr(), accumulate=acc, ldb=ldb, a_mod=a_mod)
+        check(lib.salt_wgrad_reduce(ctypes.byref(mk(g1)), st), 'wgrad_reduce')
+        structs.append((mk(g2), part))
+        outs_single.append(g1); outs_batched.append(g2)
+    blocks = [lib.salt_wgrad_reduce_job_blocks(ctypes.byref(s_)) for s_, _ in structs]
+    assert min(blocks) > 0
+    table = torch.frombuffer(bytearray(b''.join(bytes(s_) for s_, _ in structs)), dtype=torch.uint8).cuda()
+    pref = torch.from_numpy(np.concatenate([[0], np.cumsum(blocks)]).astype(np.int32)).cuda()
+    check(lib.salt_wgrad_reduce_batched(ctypes.byref(fill(STRUCTS['salt_wgrad_reduce_batched_args'](), jobs=table.data_ptr(), job_block0=pref.data_ptr(),
+                                                           njobs=len(structs), total_blocks=int(sum(blocks)))), st), 'wgrad_reduce_batched')
+    torch.cuda.synchronize()
+    for k, (a_, b_) in enumerate(zip(outs_single, outs_batched)):
+        assert torch.equal(a_, b_), k
+    bad = fill(STRUCTS['salt_wgrad_reduce_args'](), partials=1, nsplit=1, ntaps=1, Ca=4, Cb=4, KH=1, KW=1, tap_kh=[3], tap_kw=[0], grad=1)
+    assert lib.salt_wgrad_reduce_job_blocks(ctypes.byref(bad)) < 0
+
+
+def test_training_step_with_batched_reductions_equals_per_layer_reductions(monkeypatch, deterministic_sums):
+    """The step with its slab reductions batched (SALT_WGRAD_BATCH_MB=12: a launch per ~12 MB of gradient, every layer its own slab - opt-in,
+    measured slower: engine.Graph._reduce_batching) against the default (a launch per layer, one shared slab workspace): the flat
+    gradient buffer and the parameters after two steps are bit-identical; the backward program is shorter."""
+    import sys
+    import os as _os
+    sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__)))
+    from test_gpu_fused_step import _segmentation_model
+    res = {}
+    for mode in ('batched', 'per_layer'):
+        monkeypatch.setenv('SALT_WGRAD_BATCH_MB', '12' if mode == 'batched' else '0')
+        torch.manual_seed(4)
+        m = _segmentation_model('UNetResNet', 'lovasz', dtype='bf16', lr=1e-3)
+        m._to_device(); m.model.train()
+        gg = torch.Generator().manual_seed(5)
+        X = torch.randn(4, 3, 128, 128, generator=gg).cuda()
+        M = (torch.rand(4, 1, 128, 128, generator=gg) > 0.6).float()
+        Tt = torch.cat([1 - M, M], 1).cuda()
+        ls = [float(m._fit_loop([X, Tt])['sum']) for _ in range(2)]
+        torch.cuda.synchronize()
+        eng = m.model.engine()
+        net = eng.net((4, 3, 128, 128), True)
+        names = [n for n, _, _ in net.bwd.ops]
+        res[mode] = (ls, eng.grads.clone(), eng.flat.clone(), names.count('wgrad_reduce'), names.count('wgrad_reduce_batched'), len(net.g.grad_ready))
+    a, b = res['batched'], res['per_layer']
+    assert a[4] >= 2 and a[4] <= 14 and b[4] == 0 and b[3] >= 50 and a[3] <= 2, (a[3:], b[3:])     # (the stem keeps its two own reductions)
+    assert a[0] == b[0] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    assert a[5] == b[5]                                                          # every parameter still has its gradient-ready position
