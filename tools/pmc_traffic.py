@@ -32,7 +32,7 @@ def per_kernel(path, counter):
         if 'conv_wgrad' in k:                     # every weight-gradient kernel (conv_wgrad_ls_kernel, the fast / generic ones) is one class
             k = 'conv_wgrad_kernel'
         for base in ('conv_ws_kernel', 'conv1x1_ls_kernel', 'conv1x1_xs_kernel', 'conv_ls_kernel', 'conv_thin_kernel', 'conv_mfma_kernel', 'conv_glds_kernel', 'conv_wgrad_kernel', 'bn_bwd_reduce', 'bn_bwd_apply', 'bn_bwd_finalize', 'bn_finalize', 'affine_act',
-                     'wgrad_reduce', 'adam_kernel', 'adam_pack_kernel', 'hyper_stencil', 'pad_fold', 'lovasz', 'bilinear_fwd', 'bilinear_bwd', 'pack_batched', 'head1x1', 'scse', 'se_'):
+                     'wgrad_reduce', 'adam_kernel', 'adam_pack_kernel', 'hyper_stencil', 'pad_fold', 'lovasz', 'bilinear_fwd', 'bilinear_bwd', 'pack_batched', 'head1x1', 'head_bn', 'scse', 'se_', 'gap_partial'):
             if base in k:
                 k = base
                 break

@@ -10,7 +10,7 @@ from collections import defaultdict
 CLASSES = [('conv_wgrad', ('conv_wgrad',)), ('conv', ('conv_ws_kernel', 'conv_ls_kernel', 'conv1x1_ls_kernel', 'conv_thin_kernel', 'conv_mfma_kernel', 'conv_glds_kernel')),
            ('wgrad_reduce', ('wgrad_reduce',)), ('bn_bwd', ('bn_bwd',)), ('affine_act', ('affine_act',)), ('bilinear', ('bilinear',)),
            ('scse', ('scse', 'se_fc', 'gap_partial')), ('lovasz', ('lovasz',)), ('adam', ('adam_kernel', 'adam_pack_kernel')), ('pack', ('pack_batched',)),
-           ('head', ('head1x1',)), ('hyper_stencil', ('hyper_stencil',))]
+           ('head', ('head1x1', 'head_bn')), ('hyper_stencil', ('hyper_stencil',))]
 
 
 def main(path, skip, ntrain, commit):
