@@ -741,8 +741,13 @@ typedef struct {
     const float* bn_mean;
     const float* bn_invstd;
     double* bnb_acc;
+    /* 1 (needs acc): salt_scse_bwd leaves the parameter gradients g_w1 .. g_bs to salt_scse_fc_grads (same arguments, any stream ordered
+     * behind this call - the weight-gradient queue) and computes dgap (+ the bnb_acc sums, spread over the shards by image) with one
+     * workgroup per image instead of one workgroup for the batch: the parameter gradients are nobody's input before the optimizer */
+    int defer_param_grads;
 } salt_scse_bwd_args;
 int salt_scse_bwd(const salt_scse_bwd_args*, void* stream);
+int salt_scse_fc_grads(const salt_scse_bwd_args*, void* stream);
 
 /* ------------------------------------------------------------------ losses
  * Lovasz hinge, per image, both channels flattened together, F.elu variant

@@ -315,7 +315,7 @@ __global__ void se_parts_reduce_kernel(float* partials, int nparts, int width) {
 __global__ __launch_bounds__(1024) void se_fc_bwd_kernel(const float* partials, int nparts, int Ball, int C, int R, const float* w1, const float* w2,
                                  const float* gap, const float* hidden, const float* gate_c,
                                  float* g_w1, float* g_b1, float* g_w2, float* g_b2, float* g_ws, float* g_bs, float* dgap, float inv_hw,
-                                 const double* acc, int stage_w, int Bt, int AW, double* bnb_out) {
+                                 const double* acc, int stage_w, int Bt, int AW, double* bnb_out, int write_dgap) {
     // AW: doubles per image row of `acc` (2 C + 1, or 6 C + 1 when scse_bwd1_kernel<.., BNB> also left A1, A2, M0, M1 there);
     // bnb_out != NULL: shard 0 of the producer layer's BatchNorm-backward sums [2][C] (the other shards stay zero)
     // everything the loops touch repeatedly is staged in LDS first (one coalesced sweep); the batch loops then run out of LDS
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(1024) void se_fc_bwd_kernel(const float* partials, 
             const int b = i / C, c = i - b * C;
             float t = 0.f;
             for (int r = 0; r < R; ++r) t += dh[b * R + r] * sw1[r * C + c];
-            dgap[(int64_t)b0 * C + i] = t * inv_hw;
+            if (write_dgap) dgap[(int64_t)b0 * C + i] = t * inv_hw;
         }
         if (bnb_out) {
             __syncthreads();                              // this tile's dgap rows are visible to the whole workgroup
@@ -398,6 +398,43 @@ __global__ __launch_bounds__(1024) void se_fc_bwd_kernel(const float* partials, 
                     bnb_out[C + c] = first ? t2 : bnb_out[C + c] + t2;
                 }
             }
+        }
+    }
+}
+
+// Round 6 - the CRITICAL half of the FC backward, one workgroup per image: du -> dh -> dgap[b][:] (what the producer layer's
+// salt_bn_bwd needs through da_bias) and, with bnb_out, that layer's BatchNorm-backward sums (fp64 atomics into shard b & 7).
+// se_fc_bwd_kernel is ONE workgroup walking the whole batch (18 - 24 us of latency chain on the queue the data gradients wait on);
+// the parameter gradients it also produces are nobody's input before the optimizer, so with salt_scse_bwd_args.defer_param_grads
+// they move to salt_scse_fc_grads (the weight-gradient queue) and only this kernel stays on the critical one.  Same arithmetic per
+// element as se_fc_bwd_kernel (du, dh, dgap in fp32, in the same order).
+__global__ __launch_bounds__(256) void se_dgap_kernel(int C, int R, const float* w1, const float* w2, const float* hidden, const float* gate_c,
+                                                      float* dgap, float inv_hw, const double* acc, int AW, double* bnb_out) {
+    extern __shared__ float sm[];                        // du [C], dh [R]
+    float* du = sm; float* dh = sm + C;
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+    const double* arow = acc + (int64_t)b * AW;
+    for (int c = tid; c < C; c += nt) {
+        const float g = gate_c[(int64_t)b * C + c];
+        du[c] = (float)arow[c] * g * (1.f - g);
+    }
+    __syncthreads();
+    for (int r = tid; r < R; r += nt) {
+        float t = 0.f;
+        for (int c = 0; c < C; ++c) t += du[c] * w2[c * R + r];
+        dh[r] = hidden[(int64_t)b * R + r] > 0.f ? t : 0.f;
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += nt) {
+        float t = 0.f;
+        for (int r = 0; r < R; ++r) t += dh[r] * w1[r * C + c];
+        const float dg = t * inv_hw;
+        dgap[(int64_t)b * C + c] = dg;
+        if (bnb_out) {
+            const double* q = arow + 2 * C + 1;
+            double* sh = bnb_out + (int64_t)(b & 7) * 2 * C;
+            unsafeAtomicAdd(sh + c, q[c] + (double)dg * q[2 * C + c]);
+            unsafeAtomicAdd(sh + C + c, q[C + c] + (double)dg * q[3 * C + c]);
         }
     }
 }
@@ -486,18 +523,10 @@ extern "C" int salt_scse(const salt_scse_args* a, void* stream) {
     return SALT_OK;
 }
 
-extern "C" int salt_scse_bwd(const salt_scse_bwd_args* a, void* stream) {
-    if (!a || !view_ok(a->x) || !view_ok(a->y) || !view_ok(a->dy) || !view_ok(a->dx) || !a->w1 || !a->w2 || !a->ws || !a->gap || !a->hidden ||
-        !a->gate_c || !a->gate_s || (!a->partials && !a->acc) || ((a->in_scale == nullptr) != (a->in_shift == nullptr)) || !a->g_w1 || !a->g_b1 || !a->g_w2 || !a->g_b2 || !a->g_ws || !a->g_bs || !a->dgap)
-        SALT_FAIL(SALT_E_BADARG, "scse_bwd: bad args");
-    int per = 0;
-    const int nparts = scse_nparts(a->x, &per);
-    if (a->nparts != nparts) SALT_FAIL(SALT_E_BADARG, "scse_bwd: nparts %d, expected %d", a->nparts, nparts);
-    hipStream_t st = (hipStream_t)stream;
+// the single-workgroup FC backward over the whole batch (parameter gradients; with write_dgap also dgap and, with bnb_out, the sums)
+static int launch_se_fc(const salt_scse_bwd_args* a, int nparts, hipStream_t st, int write_dgap, double* bnb_out) {
     const int C = a->x.C, B = a->x.B;
     const bool bnb = a->bnb_acc != nullptr;
-    if (bnb && (!a->acc || !a->in_scale || !a->bn_mean || !a->bn_invstd || !a->skip_bcast))
-        SALT_FAIL(SALT_E_BADARG, "scse_bwd: bnb_acc needs acc, the input transform (in_scale / in_shift), bn_mean / bn_invstd and skip_bcast");
     const size_t fc_img = (size_t)(3 * C + 2 * a->R + 1) * sizeof(float), fc_w = (size_t)2 * a->R * C * sizeof(float);
     int stage_w = fc_img * B + fc_w <= 160 * 1024;                // the FC weights ride along only when they fit beside the per-image vectors
     int Bt = B;
@@ -516,6 +545,32 @@ extern "C" int salt_scse_bwd(const salt_scse_bwd_args* a, void* stream) {
             attr_set = true;
         }
     }
+    hipLaunchKernelGGL(se_fc_bwd_kernel, dim3(1), dim3(1024), fc_lds, st, a->partials, nparts, B, C, a->R, a->w1, a->w2, a->gap, a->hidden,
+                       a->gate_c, a->g_w1, a->g_b1, a->g_w2, a->g_b2, a->g_ws, a->g_bs, a->dgap, 1.0f / (float)(a->x.H * a->x.W), a->acc, stage_w, Bt,
+                       bnb ? 6 * C + 1 : 2 * C + 1, bnb_out, write_dgap);
+    SALT_CHECK_LAUNCH();
+    return SALT_OK;
+}
+
+extern "C" int salt_scse_fc_grads(const salt_scse_bwd_args* a, void* stream) {
+    if (!a || !view_ok(a->x) || !a->w1 || !a->w2 || !a->gap || !a->hidden || !a->gate_c || !a->acc || !a->g_w1 || !a->g_b1 || !a->g_w2 || !a->g_b2 || !a->g_ws ||
+        !a->g_bs || !a->dgap) SALT_FAIL(SALT_E_BADARG, "scse_fc_grads: bad args");
+    return launch_se_fc(a, scse_nparts(a->x, nullptr), (hipStream_t)stream, 0, nullptr);
+}
+
+extern "C" int salt_scse_bwd(const salt_scse_bwd_args* a, void* stream) {
+    if (!a || !view_ok(a->x) || !view_ok(a->y) || !view_ok(a->dy) || !view_ok(a->dx) || !a->w1 || !a->w2 || !a->ws || !a->gap || !a->hidden ||
+        !a->gate_c || !a->gate_s || (!a->partials && !a->acc) || ((a->in_scale == nullptr) != (a->in_shift == nullptr)) || !a->g_w1 || !a->g_b1 || !a->g_w2 || !a->g_b2 || !a->g_ws || !a->g_bs || !a->dgap)
+        SALT_FAIL(SALT_E_BADARG, "scse_bwd: bad args");
+    int per = 0;
+    const int nparts = scse_nparts(a->x, &per);
+    if (a->nparts != nparts) SALT_FAIL(SALT_E_BADARG, "scse_bwd: nparts %d, expected %d", a->nparts, nparts);
+    hipStream_t st = (hipStream_t)stream;
+    const int C = a->x.C, B = a->x.B;
+    const bool bnb = a->bnb_acc != nullptr;
+    if (bnb && (!a->acc || !a->in_scale || !a->bn_mean || !a->bn_invstd || !a->skip_bcast))
+        SALT_FAIL(SALT_E_BADARG, "scse_bwd: bnb_acc needs acc, the input transform (in_scale / in_shift), bn_mean / bn_invstd and skip_bcast");
+    if (a->defer_param_grads && !a->acc) SALT_FAIL(SALT_E_BADARG, "scse_bwd: defer_param_grads needs the fp64 sums (acc)");
     SALT_DISPATCH_DTYPE(a->dtype, T, {
         if (!se_ok<T>(a->x) || !se_ok<T>(a->y) || !se_ok<T>(a->dy) || !se_ok<T>(a->dx)) SALT_FAIL(SALT_E_UNSUPPORTED, "scse_bwd: layout");
         constexpr int VE = Elem<T>::VE;
@@ -531,8 +586,14 @@ extern "C" int salt_scse_bwd(const salt_scse_bwd_args* a, void* stream) {
             hipLaunchKernelGGL(se_parts_reduce_kernel, dim3(B), dim3(256), 0, st, a->partials, nparts, 2 * C + 1);
             SALT_CHECK_LAUNCH();
         }
-        hipLaunchKernelGGL(se_fc_bwd_kernel, dim3(1), dim3(1024), fc_lds, st, a->partials, nparts, B, C, a->R, a->w1, a->w2, a->gap, a->hidden,
-                           a->gate_c, a->g_w1, a->g_b1, a->g_w2, a->g_b2, a->g_ws, a->g_bs, a->dgap, 1.0f / (float)(a->x.H * a->x.W), a->acc, stage_w, Bt, bnb ? 6 * C + 1 : 2 * C + 1, bnb ? a->bnb_acc : nullptr);
+        if (a->defer_param_grads) {
+            // only what the critical queue needs: dgap (+ the producer layer's BatchNorm-backward sums), one workgroup per image
+            hipLaunchKernelGGL(se_dgap_kernel, dim3(B), dim3(256), (size_t)(C + a->R) * sizeof(float), st, C, a->R, a->w1, a->w2, a->hidden, a->gate_c, a->dgap,
+                               1.0f / (float)(a->x.H * a->x.W), a->acc, bnb ? 6 * C + 1 : 2 * C + 1, bnb ? a->bnb_acc : nullptr);
+        } else {
+            const int rc = launch_se_fc(a, nparts, st, 1, bnb ? a->bnb_acc : nullptr);
+            if (rc) return rc;
+        }
         SALT_CHECK_LAUNCH();
         if (!a->skip_bcast) {                      // else: the consumer adds dgap[b][c] on the fly (salt_bn_bwd_args.da_bias)
             const int64_t units = view_pixels(a->dx) * (C / VE);

@@ -722,7 +722,8 @@ class Graph:
             self.bwd.set_fields(s2, da_bias=bias[2].data_ptr())
             out.buf.grad_bias = None
         if ready == 3:
-            self._fin_slot('bwd', 8 * 2 * C, (producer, 'bnb_acc'), (s2, 'fin_acc'))
+            peers = [(bias[4], 'bnb_acc')] if (bias is not None and len(bias) > 4 and bias[4] is not None) else []   # scse_fc_grads reads the same 6 C + 1 wide rows
+            self._fin_slot('bwd', 8 * 2 * C, (producer, 'bnb_acc'), (s2, 'fin_acc'), *peers)
         elif ready == 2:
             acc, ticket = self._fin_buffers(8 * 2 * C)
             self.bwd.set_fields(producer, bnb_fin=ctypes.addressof(s2), bnb_acc=acc, bnb_ticket=ticket)
@@ -1515,17 +1516,22 @@ class Graph:
                 acc = x.grad_state()
                 dgap = self.f32(B * C)
                 gp = self._gp
-                sb = self.bwd.add('scse_bwd', dtype=self.dt, x=xview(), y=out.view(), dy=out.gview(), w1=l1.weight.data_ptr(), w2=l2.weight.data_ptr(),
-                                  R=R, ws=cs.weight.data_ptr(), gap=gap.data_ptr(), hidden=hid.data_ptr(), gate_c=gc.data_ptr(), gate_s=gs.data_ptr(),
-                                  partials=Scratch('se', B * nparts * (2 * C + 1) * 4), nparts=nparts, g_w1=gp(l1.weight), g_b1=gp(l1.bias),
-                                  g_w2=gp(l2.weight), g_b2=gp(l2.bias), g_ws=gp(cs.weight), g_bs=gp(cs.bias), dgap=dgap.data_ptr(),
-                                  dx=x.gview(), accumulate=acc, **in_bwd)
+                # round 6: the FC parameter gradients (one workgroup over the whole batch: 18 - 24 us) are nobody's input before the optimizer -
+                # they run as their own operator on the weight-gradient queue; the critical queue keeps the per-image dgap kernel
+                defer = shards and os.environ.get('SALT_SE_FC_SIDE', '1') != '0'
+                kw = dict(dtype=self.dt, x=xview(), y=out.view(), dy=out.gview(), w1=l1.weight.data_ptr(), w2=l2.weight.data_ptr(),
+                          R=R, ws=cs.weight.data_ptr(), gap=gap.data_ptr(), hidden=hid.data_ptr(), gate_c=gc.data_ptr(), gate_s=gs.data_ptr(),
+                          partials=Scratch('se', B * nparts * (2 * C + 1) * 4), nparts=nparts, g_w1=gp(l1.weight), g_b1=gp(l1.bias),
+                          g_w2=gp(l2.weight), g_b2=gp(l2.bias), g_ws=gp(cs.weight), g_bs=gp(cs.bias), dgap=dgap.data_ptr(),
+                          dx=x.gview(), accumulate=acc, defer_param_grads=int(defer), **in_bwd)
+                sb = self.bwd.add('scse_bwd', **kw)
+                sg = self.bwd.add('scse_fc_grads', stream=1, **kw) if defer else None
                 # round 6: with the input transform the kernel holds everything the producer layer's BatchNorm backward sums over - it takes
                 # them too and that layer's bn_bwd loses its reduction pass (saltnet.h salt_scse_bwd_args.bnb_acc; SALT_SE_BNB=0: off)
                 carry = (taken is not None and shards and getattr(x.buf, 'bn_train_out', None) == (x.c0, x.C) and acc == 0
                          and x.B * x.H * x.W < (1 << 31) and os.environ.get('SALT_SE_BIAS_FOLD', '1') != '0' and os.environ.get('SALT_SE_BNB', '1') != '0')
                 if shards:
-                    self._fin_slot('bwd', B * ((6 if carry else 2) * C + 1), (sb, 'acc'))
+                    self._fin_slot('bwd', B * ((6 if carry else 2) * C + 1), (sb, 'acc'), *([(sg, 'acc')] if sg is not None else []))
                 # x = relu(bn(conv)): its only gradient consumer is that layer's bn_bwd, which can add the channel-SE term dgap[b][c]
                 # wherever it reads dL/dx - the broadcast-add pass over dx (read + write of the whole tensor) disappears
                 if (getattr(x.buf, 'bn_train_out', None) == (x.c0, x.C) and acc == 0 and x.B * x.H * x.W < (1 << 31)
@@ -1533,7 +1539,7 @@ class Graph:
                     if getattr(x.buf, 'grad_bias', None) is not None:
                         raise SaltError('two pending gradient biases on %s' % x.buf.name)
                     self.bwd.set_fields(sb, skip_bcast=1)
-                    x.buf.grad_bias = (x.c0, x.C, dgap) + ((sb,) if carry else ())
+                    x.buf.grad_bias = (x.c0, x.C, dgap) + ((sb, sg) if carry else ())
                     self._bias_bufs = getattr(self, '_bias_bufs', []) + [x.buf]
             self.tape.append(backward)
         return out

@@ -159,7 +159,8 @@ def test_scse_applies_the_producer_batchnorm_itself(dtype, monkeypatch):
     fx = golden('F4_decoderblock_skip_train')
     make, emit = BLOCKS['F4_decoderblock_skip']
     res = {}
-    for mode in ('fused', 'no_bnb', 'separate'):
+    for mode in ('fused', 'fc_main', 'no_bnb', 'separate'):
+        monkeypatch.setenv('SALT_SE_FC_SIDE', '0' if mode == 'fc_main' else '1')   # fc_main: parameter gradients + dgap in the single-workgroup kernel
         if mode == 'no_bnb':
             monkeypatch.setenv('SALT_SE_BNB', '0')       # input transform on, but the layer's bn_bwd keeps its own reduction pass
         if mode == 'separate':
@@ -176,7 +177,8 @@ def test_scse_applies_the_producer_batchnorm_itself(dtype, monkeypatch):
         sb = [s_ for n, _, s_ in run.g.bwd.ops if n == 'scse_bwd'][0]
         bnb = [s_ for n, _, s_ in run.g.bwd.ops if n == 'bn_bwd']
         # backward order: scse_bwd, then conv2's bn_bwd: apply-only (partials_ready 3, da_bias) when the scSE pass carried its sums
-        assert bool(sb.bnb_acc) == (mode == 'fused') and int(bnb[0].partials_ready) == (3 if mode == 'fused' else 0) and bool(bnb[0].da_bias)
+        assert bool(sb.bnb_acc) == (mode in ('fused', 'fc_main')) and int(bnb[0].partials_ready) == (3 if mode in ('fused', 'fc_main') else 0) and bool(bnb[0].da_bias)
+        assert ('scse_fc_grads' in [n for n, _, _ in run.g.bwd.ops]) == (mode != 'fc_main') and int(sb.defer_param_grads) == int(mode != 'fc_main')
         res[mode] = (y, gx, grads, names.count('affine_act'), {k: v.clone().cpu() for k, v in m.state_dict().items() if 'running' in k})
     a, b = res['fused'], res['separate']
     assert a[3] == b[3] - 1 and res['no_bnb'][3] == a[3]
@@ -193,6 +195,11 @@ def test_scse_applies_the_producer_batchnorm_itself(dtype, monkeypatch):
             close(a[2][k], b[2][k], k, tol * 4)
     for k in a[4]:
         close(a[4][k], b[4][k], k, 1e-6)
+    for u, v in zip(a[1], res['fc_main'][1]):
+        close(u, v, 'dx (per-image dgap kernel vs single-workgroup FC backward)', tol * 4)
+    for k in a[2]:
+        if float(res['fc_main'][2][k].abs().max()) > 0:
+            close(a[2][k], res['fc_main'][2][k], k + ' (FC gradients on the weight-gradient queue)', tol * 4)
     c = res['no_bnb']
     for u, v in zip(a[1], c[1]):
         close(u, v, 'dx (sums carried by the scSE pass vs bn_bwd reduction pass)', tol * 4)
