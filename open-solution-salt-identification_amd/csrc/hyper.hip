@@ -391,7 +391,7 @@ __device__ __forceinline__ float hs_wgt(int d, int R, int n, int ac, int i) {
     return (i0 == i ? 1.f - lam : 0.f) + (i1 == i ? lam : 0.f);
 }
 // conservative range of full-resolution coordinates d (before the tap shift) that reference low-resolution index i
-__device__ __forceinline__ void hs_range(int i, int R, int n, int N, int ac, int& lo, int& hi) {
+__host__ __device__ __forceinline__ void hs_range(int i, int R, int n, int N, int ac, int& lo, int& hi) {
     float flo, fhi;
     if (ac) {       // src = d (n - 1) / (N - 1) in (i - 1, i + 1); one coordinate of slack for the rounding of the fp32 scale
         const float s = n > 1 ? (float)(N - 1) / (float)(n - 1) : (float)N;
@@ -691,7 +691,17 @@ extern "C" int salt_hyper_stencil(const salt_hyper_stencil_args* a, void* stream
         nb += (nl + 7) / 8 * 8;
         // rows a block of ti low-resolution rows can reference (hs_range; align_corners: (H - 1) / (h - 1) > R rows per step), + 2 for the tap shift
         const int step = a->align_corners ? (a->z[k].H > 1 ? cdiv(y.H - 1, a->z[k].H - 1) : y.H) : a->R[k];
-        const int nr = (ti + 1) * step + 8;
+        int nr = (ti + 1) * step + 8;
+        // ... and the EXACT span of every row block with the kernel's own hs_range (if the bound above ever fell short of it the
+        // kernel's min(span, nrows_pad) would drop rows silently) - the larger of the two sizes the row-weight table
+        for (int i0 = 0; i0 < a->z[k].H; i0 += ti) {
+            int ylo, yhi, t0, t1;
+            hs_range(i0, a->R[k], a->z[k].H, y.H, a->align_corners, ylo, t0);
+            hs_range(i0 + ti - 1 < a->z[k].H - 1 ? i0 + ti - 1 : a->z[k].H - 1, a->R[k], a->z[k].H, y.H, a->align_corners, t1, yhi);
+            yhi += 2;
+            ylo = ylo > 0 ? ylo : 0; yhi = yhi < y.H - 1 ? yhi : y.H - 1;
+            if (yhi - ylo + 1 > nr) nr = yhi - ylo + 1;
+        }
         const int stepx = a->align_corners ? (a->z[k].W > 1 ? cdiv(y.W - 1, a->z[k].W - 1) : y.W) : a->R[k];
         L.xlen = 2 * stepx + 8 < y.W ? 2 * stepx + 8 : y.W;      // columns a gather range can span (hs_range + the tap shift)
         const int xtf = 3 * a->z[k].W * (L.xlen + 1);

@@ -136,6 +136,8 @@ STENCIL_CASES = [
     (1, 72, 64, 32, (16, 4)),         # a second, partial channel block
     (1, 64, 64, 256, (4, 16)),        # two column slots in the adjoint
     (1, 64, 128, 128, (4, 8, 16)),    # the C2 geometry
+    (1, 32, 96, 160, (32, 8)),        # non-square, R = 32 (with align_corners the adjoint's row span is (H - 1) / (h - 1) > R per step;
+                                      #  the host now sizes the row table from the kernel's own range function)
 ]
 
 
