@@ -661,6 +661,23 @@ class Graph:
 
     def _bn_train_bwd(self, y, bn, relu, res, out, w):
         """emit backward of out = relu?(bn(y) (+res)); returns nothing, leaves grad in y.grad (and res.grad)."""
+        hconv = getattr(out.buf, 'head_fused', None)
+        if hconv is not None:
+            # `out` was never stored: its only reader was the logit head (Graph.head took the affine_act over) - head gradients and this
+            # BatchNorm's backward from (y, dlogits) alone
+            if res is not None:
+                raise SaltError('fused head behind a residual BatchNorm')
+            C, Cout = bn.num_features, hconv.weight.shape[0]
+            S = fill(STRUCTS['salt_head_bn_bwd_args'](), y=y.view())
+            nparts = lib.salt_head_bn_bwd_parts(ctypes.byref(S))
+            assert y.grad_state() == 0, 'conv output gradient has a single producer'
+            sb = self.bwd.add('head_bn_bwd', dtype=self.dt, y=y.view(), relu=int(relu), mean=w['mean'].data_ptr(), invstd=w['invstd'].data_ptr(),
+                              gamma=bn.weight.data_ptr(), beta=bn.bias.data_ptr(), w=hconv.weight.data_ptr(), Cout=Cout, dy_nchw=self.dlogits.data_ptr(),
+                              partials=Scratch('head', nparts * Cout * (C + 1) * 4), nparts=nparts, gw=self._gp(hconv.weight),
+                              gb=self._gp(hconv.bias) if hconv.bias is not None else None, dgamma=self._gp(bn.weight), dbeta=self._gp(bn.bias),
+                              coef=self.f32(3 * C).data_ptr(), dy=y.gview())
+            self._fin_slot('bwd', 8 * 2 * C, (sb, 'fin_acc'))
+            return
         S = STRUCTS['salt_bn_bwd_args']()
         fill(S, y=y.view())
         nparts = lib.salt_bn_bwd_parts(ctypes.byref(S))
@@ -1334,6 +1351,21 @@ class Graph:
     # ------------------------------------------------------------------ logit head: 1x1 conv to <= 4 channels, fp32 NCHW out
     def head(self, x, conv, logits_nchw):
         Cout = conv.weight.shape[0]
+        # round 6: x = relu(bn(y)) stored by the last forward operator and read by nobody else (the `final` Sequential of every U-Net here:
+        # unet_models.py:131-138, architectures/unet.py:84-87) - BatchNorm apply + ReLU + head in one pass over y (salt_head_bn), the
+        # activation and its gradient are never stored; the producer layer's _bn_train_bwd emits salt_head_bn_bwd instead of salt_bn_bwd
+        taken = self._take_act_op(x) if self.head_bn_ok(x.C, conv) else None
+        if taken is not None:
+            sa, Fbn = taken
+            hb = self.fwd.add('head_bn', dtype=self.dt, y=sa.y, fin=ctypes.addressof(Fbn), relu=int(sa.relu), w=conv.weight.data_ptr(),
+                              bias=conv.bias.data_ptr() if conv.bias is not None else None, Cout=Cout, y_nchw=logits_nchw.data_ptr())
+            for i, q in enumerate(self._fin_patches):    # the statistics shards the dropped affine_act would have finalized
+                if q[0] is sa and q[1] == 'fin_acc':
+                    self._fin_patches[i] = (hb, 'fin_acc', q[2], q[3])
+            self.dlogits = self.alloc(tuple(logits_nchw.shape), torch.float32)
+            x.buf.head_fused = conv
+            self.tape.append(lambda: None)               # the head's backward is part of the producer layer's closure (Graph._bn_train_bwd)
+            return
         self.fwd.add('head1x1', dtype=self.dt, x=x.view(), w=conv.weight.data_ptr(), bias=conv.bias.data_ptr() if conv.bias is not None else None,
                      Cout=Cout, y_nchw=logits_nchw.data_ptr(), y=null_view())
         if self.train:

@@ -206,3 +206,37 @@ def test_scse_applies_the_producer_batchnorm_itself(dtype, monkeypatch):
     for k in a[2]:
         if float(c[2][k].abs().max()) > 0:
             close(a[2][k], c[2][k], k + ' (carried sums)', tol * 4)
+
+
+@pytest.mark.parametrize('arch,dtype', [('VanillaUNet', 'f32'), ('VanillaUNet', 'bf16')])
+def test_conv_bn_relu_final_blocks_fuse_through_graph_head(arch, dtype, monkeypatch):
+    """Graph.head takes over the BatchNorm apply + ReLU of a Conv-BN-ReLU block that feeds the 1x1 logit head whenever that block's statistics
+    travel through the fp64 shards (the vanilla U-Net of BASELINE C0 / C1; the k4 transposed convolutions in front of unet_models' heads
+    keep the per-tile partials protocol and the separate launches): one training step with the fusion against SALT_HEAD_BN=0 - same
+    loss, same gradients to summation order, one operator fewer in each direction."""
+    from test_gpu_fused_step import _segmentation_model
+    res = {}
+    for mode in ('fused', 'separate'):
+        monkeypatch.setenv('SALT_HEAD_BN', '1' if mode == 'fused' else '0')
+        torch.manual_seed(31)
+        m = _segmentation_model(arch, 'bce_dice', dtype=dtype, lr=1e-3)
+        m._to_device()
+        m.model.train()
+        ch = 1 if arch == 'VanillaUNet' else 3
+        g = torch.Generator().manual_seed(6)
+        X = torch.randn(4, ch, 64, 64, generator=g).to(DEV)
+        M = (torch.rand(4, 1, 64, 64, generator=g) > 0.6).float()
+        Tt = torch.cat([1 - M, M], 1).to(DEV)
+        loss = float(m._fit_loop([X, Tt])['sum'])
+        torch.cuda.synchronize()
+        eng = m.model.engine()
+        net = eng.net((4, ch, 64, 64), True)
+        names = [n for n, _, _ in net.fwd.ops] + [n for n, _, _ in net.bwd.ops]
+        assert ('head_bn' in names and 'head_bn_bwd' in names and 'head1x1' not in names) == (mode == 'fused'), [n for n in names if 'head' in n]
+        res[mode] = (loss, net.logits.cpu().clone(), eng.grads.cpu().clone(), len(names))
+    a, b = res['fused'], res['separate']
+    assert a[3] == b[3] - 2
+    rel = lambda u, v: float((u.double() - v.double()).norm() / (v.double().norm() + 1e-30))
+    tol = 2e-5 if dtype == 'f32' else 4e-3
+    assert abs(a[0] - b[0]) <= tol * max(1.0, abs(b[0])) and rel(a[1], b[1]) <= tol, (a[0], b[0], rel(a[1], b[1]))
+    assert rel(a[2], b[2]) <= (2e-4 if dtype == 'f32' else 3e-2), rel(a[2], b[2])
