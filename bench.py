@@ -574,6 +574,80 @@ def fit_e2e_leg(dev, workload, dtype, B, loss, n_train=3200, n_val=800, epochs=2
     return out
 
 
+# ----------------------------------------------------------------------------- host side of an 8-rank node, on a 1-GPU box
+def _core_share(k, n):
+    """the k-th of n equal slices of the cores of GPU 0's NUMA node (what parallel.pin_rank_threads gives rank k when n ranks share a node)"""
+    from salt_amd.parallel import gpu_numa_node, _cpulist
+    allowed = sorted(os.sched_getaffinity(0))
+    node = gpu_numa_node(0) if torch.cuda.is_available() else None
+    cpus = allowed
+    if node is not None:
+        try:
+            cpus = [c for c in _cpulist(open('/sys/devices/system/node/node%d/cpulist' % node).read()) if c in set(allowed)] or allowed
+        except OSError:
+            pass
+    per = max(len(cpus) // n, 1)
+    return node, cpus[k * per:(k + 1) * per] or cpus
+
+
+def host_load_child(k, B):
+    """CPU-only stand-in for the host work of ONE more rank of the node: the loader thread's gather of a shuffled uint8 batch into a staging
+    buffer + ~3.4 ms of launch-thread work per 5 ms step (a busy loop of ctypes calls into the library, which is what the executor's host side
+    is made of), on core share k of 8; runs until killed."""
+    import ctypes
+    import threading
+    _, mine = _core_share(k, 8)
+    os.sched_setaffinity(0, mine)
+    import salt_amd  # noqa: F401
+    from salt_amd._abi import lib
+    img, msk = synth_tiles(1600, seed=99 + k)
+    X8, M8 = np.clip(img * 255 + 0.5, 0, 255).astype(np.uint8), msk.astype(np.uint8)
+    sx, sm = np.empty((B,) + X8.shape[1:], np.uint8), np.empty((B,) + M8.shape[1:], np.uint8)
+    r = np.random.RandomState(k)
+
+    def loader():
+        while True:
+            t0 = time.perf_counter()
+            idx = r.randint(0, X8.shape[0], B)
+            np.take(X8, idx, axis=0, out=sx); np.take(M8, idx, axis=0, out=sm)
+            time.sleep(max(0.0, 0.005 - (time.perf_counter() - t0)))
+    threading.Thread(target=loader, daemon=True).start()
+    sys.stdout.write('ready\n'); sys.stdout.flush()
+    while True:
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.0034:
+            lib.salt_abi_version()
+        time.sleep(max(0.0, 0.005 - (time.perf_counter() - t0)))
+
+
+def host_contention(workload, dtype, B, loss):
+    """fit_e2e twice on core share 0 of 8 of the GPU's NUMA node: alone, then beside 7 host_load_child processes on shares 1..7 - the host
+    side of an 8-rank node as far as a 1-GPU box can show it.  Prints one JSON object."""
+    import subprocess
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(0)
+    node, mine = _core_share(0, 8)
+    os.sched_setaffinity(0, mine)
+    import salt_amd  # noqa: F401
+    alone = fit_e2e_leg(dev, workload, dtype, B, loss)
+    kids = [subprocess.Popen([sys.executable, os.path.abspath(__file__), '--host-load', str(k), '--batch', str(B)], stdout=subprocess.PIPE, text=True)
+            for k in range(1, 8)]
+    try:
+        for p in kids:
+            p.stdout.readline()                       # 'ready': tiles synthesised, loops running
+        time.sleep(1.0)
+        loaded = fit_e2e_leg(dev, workload, dtype, B, loss)
+    finally:
+        for p in kids:
+            p.kill()
+    keep = ('images_per_s', 'ms_per_step', 'host_ms_per_step', 'val_iou')
+    print(json.dumps({'what': 'SegmentationModel.fit() (fit_e2e) pinned to core share 0 of 8 of the GPU\'s NUMA node, alone and beside 7 CPU-only '
+                              'stand-ins for the other ranks\' host work (loader gather + 3.4 ms launch-thread busy loop per 5 ms) on shares 1..7',
+                      'numa_node': node, 'cores_per_rank': len(mine), 'logical_cpus': os.cpu_count(),
+                      'alone': {k: alone[k] for k in keep}, 'with_7_host_loads': {k: loaded[k] for k in keep},
+                      'ratio': round(loaded['images_per_s'] / alone['images_per_s'], 4)}))
+
+
 def extra_configs(dev, steps=12, warmup=4):
     """The other BASELINE.json configurations, measured in the same run (each a few hundred milliseconds): C1 vanilla fp32,
     ResNet34 fp32, C3's per-GPU shape (batch 64), C4 inference with 4-flip TTA."""
@@ -741,7 +815,16 @@ def main():
     ap.add_argument('--cpu-threads', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--cpu-batch', type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument('--selftest-launch', action='store_true', help=argparse.SUPPRESS)   # launcher self-test under gloo (no GPU)
+    ap.add_argument('--host-contention', action='store_true', help='ONLY the host-contention proxy of an 8-rank node on a 1-GPU box: fit_e2e on core share 0 of 8 '
+                    'while 7 CPU-only copies of a rank\'s host work (loader gather + a launch-thread busy loop) run on the other shares')
+    ap.add_argument('--host-load', type=int, default=-1, help=argparse.SUPPRESS)      # child mode of --host-contention: core share k of 8
     args = ap.parse_args()
+    if args.host_load >= 0:
+        host_load_child(args.host_load, args.batch)
+        return
+    if args.host_contention:
+        host_contention(args.workload, args.dtype, args.batch, args.loss)
+        return
     if args.dp_leg:
         dp_leg(args.workload, args.dtype, args.batch, args.loss)
         return

@@ -39,4 +39,6 @@ cp $O/pmc_traffic_${tag}.json $O/${tag}_pmc_traffic.json
 python tools/op_profile.py --top 400 > $O/${tag}_c2_ops.txt 2>/dev/null
 python tools/c4_ops.py --top 60 > $O/${tag}_c4_ops.txt 2>/dev/null
 python tools/dp_overhead.py 30 > $O/${tag}_dp_overhead.json 2>/dev/null
+python bench.py --host-contention 2>/dev/null | grep "^{" > $O/${tag}_host_contention.json
+for r in 1 2; do for v in 0 1; do SALT_FWD_BN_FOLD=$v python tools/fwd_fold_probe.py 2>&1 | tail -1; done; done > $O/${tag}_fwd_fold_probe.txt
 ls $O | grep "^${tag}_"
