@@ -185,12 +185,17 @@ def op_bytes(name, s, es):
 
 
 def _latest_profile(name):
-    """Newest committed evidence file of that kind (rounds are re-measured with tools/rNN_evidence.sh)."""
-    for tag in ('r05', 'r05a', 'r04'):
-        p = 'profiles/%s_%s' % (tag, name)
-        if os.path.exists(os.path.join(ROOT, p)):
-            return p
-    return 'profiles/r05_%s' % name
+    """Newest committed evidence file of that kind (rounds are re-measured with tools/rNN_evidence.sh): the highest round tag wins."""
+    import glob
+    import re
+    best = None
+    for path in glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]*_' + name)):
+        m = re.match(r'r(\d+)([a-z]?)_' + re.escape(name) + '$', os.path.basename(path))
+        if m:
+            key = (int(m.group(1)), m.group(2))
+            if best is None or key > best[0]:
+                best = (key, 'profiles/' + os.path.basename(path))
+    return best[1] if best else 'profiles/r06_%s' % name
 
 
 PMC_FILE = _latest_profile('pmc_traffic.json')
