@@ -474,6 +474,15 @@ typedef struct {              /* backward of a = relu?(bn(y) (+res)) in train mo
     const float* da_bias;     /* NULL, or [B][C]: a per-image, per-channel constant added to da wherever it is read (partials_ready 0, or 3 when the sums in fin_acc already include it) */
     uint32_t* fin_ticket;     /* finalizes (no partials, no finalize launch); both zero before the first call, left zero (see salt_conv_args.fin).
                                * fin_ticket == NULL: no in-launch finalize - the apply pass finalizes the shards; the caller clears them */
+    /* round 6 - secondary sums (apply pass with fin_acc and no ticket, dres written without accumulate_dres): the residual branch is the
+     * output of ANOTHER train-mode BatchNorm without ReLU (a ResNet projection shortcut, torchvision layout through
+     * architectures/encoders.py:38-45) whose dL/da is exactly the dres this call stores - the pass also takes that layer's
+     * BatchNorm-backward sums (sum dres, sum dres xhat_sec with xhat_sec from sec_y / sec_mean / sec_invstd) into the fp64 shards
+     * sec_acc [8][2][C] (zero on entry), so the shortcut's own salt_bn_bwd runs with partials_ready 3 and no reduction pass */
+    salt_view sec_y;
+    const float* sec_mean;
+    const float* sec_invstd;
+    double* sec_acc;
 } salt_bn_bwd_args;
 int salt_bn_bwd(const salt_bn_bwd_args*, void* stream);
 int salt_bn_bwd_parts(const salt_bn_bwd_args*);

@@ -352,9 +352,13 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* parti
 
 // FIN: coef is not read from memory - every workgroup finalizes the fp64 shards of the BatchNorm-backward sums itself
 // (fin_backward_consumer) into LDS; workgroup 0 stores dgamma / dbeta / coef.
-template <typename T, bool VEC, bool FIN = false>
+// secondary sums of the apply pass (salt_bn_bwd_args.sec_*): the BatchNorm-backward sums of the layer that produced the residual
+struct BnbSec { const void* y; int cs; const float* mean; const float* invstd; double* acc; };
+
+template <typename T, bool VEC, bool FIN = false, bool SEC = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(salt_view da, salt_view a, salt_view y, int relu, const float* mean, const float* invstd,
-                                    const float* gamma, const float* beta, const float* coef, salt_view dy, salt_view dres, int acc_dres, BnbFin fin) {
+                                    const float* gamma, const float* beta, const float* coef, salt_view dy, salt_view dres, int acc_dres, BnbFin fin,
+                                    BnbSec sec) {
     constexpr int N = Unit<T, VEC>::N;
     const int C = y.C, cpv = C / N;
     const int64_t units = (int64_t)y.B * y.H * y.W * cpv;
@@ -395,6 +399,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(salt_view da, salt_vi
             // products folded), mean, and scale / shift of the forward pass for the ReLU mask (the SAME expression affine_act evaluated, so
             // the mask is the forward decision).  Round 2 kept nine (118 VGPRs, 4 waves per SIMD).
             float mu[N], A[N], D[N], E[N], sc[N], sh[N];
+            float t1[N], t2[N], smu[N], sis[N];                    // SEC: this thread's part of (sum dres, sum dres xhat_sec) for its channel piece
+#pragma unroll
+            for (int j = 0; j < N; ++j) { t1[j] = 0.f; t2[j] = 0.f; smu[j] = SEC ? sec.mean[c0 + j] : 0.f; sis[j] = SEC ? sec.invstd[c0 + j] : 0.f; }
             const float* gptr = from_y ? gamma : mean;             // valid addresses either way: every load below is unconditional,
             const float* bptr = from_y ? beta : mean;              // so all of them are in flight together (one latency, not N)
             {
@@ -436,8 +443,31 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(salt_view da, salt_vi
                                 for (int j = 0; j < N; ++j) g[i][j] += old[i][j];
                             }
                             Unit<T, VEC>::st((T*)dres.p + pix[i] * dres.cs + c0, g[i]);
+                            if constexpr (SEC) {
+                                float ys[N];
+                                Unit<T, VEC>::ld((const T*)sec.y + pix[i] * sec.cs + c0, ys);
+                                if constexpr (sizeof(T) == 2 && VEC) { const u32x4 v = pack16<T>(g[i]); unpack16<T>(v, g[i]); }   // the stored value
+#pragma unroll
+                                for (int j = 0; j < N; ++j) { t1[j] += g[i][j]; t2[j] += g[i][j] * (ys[j] - smu[j]) * sis[j]; }
+                            }
                         }
                     }
+                }
+            }
+            if constexpr (SEC) {
+                // threads tid, tid + cpv, .. share a channel piece (host: 256 % cpv == 0): rows through LDS in fixed order, then one set of
+                // fp64 shard atomics per workgroup (the layout of the reduction pass: shard = workgroup id & 7)
+                float* red = fin_sm + 3 * C;
+                const int rows = 256 / cpv, row = threadIdx.x / cpv, pc = threadIdx.x % cpv;
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < N; ++j) { red[((row * cpv + pc) * N + j) * 2] = t1[j]; red[((row * cpv + pc) * N + j) * 2 + 1] = t2[j]; }
+                __syncthreads();
+                for (int e = threadIdx.x; e < 2 * C; e += 256) {
+                    const int st = e >= C ? 1 : 0, cl = e - st * C;
+                    float t = 0.f;
+                    for (int r = 0; r < rows; ++r) t += red[(r * C + cl) * 2 + st];
+                    fin_add(sec.acc + ((blockIdx.x & 7) * 2 + st) * C + cl, (double)t);
                 }
             }
             return;
@@ -1312,14 +1342,26 @@ extern "C" int salt_bn_bwd(const salt_bn_bwd_args* a, void* stream) {
             SALT_CHECK_LAUNCH();
         }
         const int64_t units = view_pixels(a->y) * cpv;
-        if (fin_apply) {
+        if (a->sec_acc) {
+            // secondary sums: the vectorised fixed-piece path of the consumer-finalize apply pass only
+            const int64_t grid_stride = (int64_t)ew_blocks(view_pixels(a->y) * cpv) * 256;
+            if (!fin_apply || !v || !a->dres.p || a->accumulate_dres || !a->sec_mean || !a->sec_invstd || !view_ok(a->sec_y) || !same_shape(a->sec_y, a->y) ||
+                !vec_ok(a->sec_y, ve) || 256 % cpv || grid_stride % cpv || a->da_bias)
+                SALT_FAIL(SALT_E_BADARG, "bn_bwd: secondary sums need the consumer-finalize apply pass (fin_acc, no ticket), a freshly written dres, aligned views and a channel-piece count that divides 256");
+            const BnbFin fa{a->fin_acc, nullptr, a->dgamma, a->dbeta, a->coef, a->accumulate_param_grads, (double)view_pixels(a->y), nullptr, hw, hw_shift};
+            const BnbSec sc{a->sec_y.p, a->sec_y.cs, a->sec_mean, a->sec_invstd, a->sec_acc};
+            const size_t ldss = (size_t)C * 3 * sizeof(float) + (size_t)256 * ve * 2 * sizeof(float);
+            hipEvent_t ev_ = salt_take_fork_event();
+            hipExtLaunchKernelGGL((bn_bwd_apply_kernel<T, true, true, true>), dim3(ew_blocks(view_pixels(a->y) * cpv)), dim3(256), ldss, st, nullptr, ev_, 0, a->da, a->a, a->y, a->relu,
+                                  a->mean, a->invstd, a->gamma, a->beta, nullptr, a->dy, a->dres, a->accumulate_dres, fa, sc);
+        } else if (fin_apply) {
             const BnbFin fa{a->fin_acc, nullptr, a->dgamma, a->dbeta, a->coef, a->accumulate_param_grads, (double)view_pixels(a->y), a->da_bias, hw, hw_shift};
             const size_t lds3 = (size_t)C * 3 * sizeof(float);
             hipEvent_t ev_ = salt_take_fork_event();
-            if (v) hipExtLaunchKernelGGL((bn_bwd_apply_kernel<T, true, true>), dim3(ew_blocks(units)), dim3(256), lds3, st, nullptr, ev_, 0, a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->gamma, a->beta, nullptr, a->dy, a->dres, a->accumulate_dres, fa);
-            else hipExtLaunchKernelGGL((bn_bwd_apply_kernel<T, false, true>), dim3(ew_blocks(units)), dim3(256), lds3, st, nullptr, ev_, 0, a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->gamma, a->beta, nullptr, a->dy, a->dres, a->accumulate_dres, fa);
+            if (v) hipExtLaunchKernelGGL((bn_bwd_apply_kernel<T, true, true>), dim3(ew_blocks(units)), dim3(256), lds3, st, nullptr, ev_, 0, a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->gamma, a->beta, nullptr, a->dy, a->dres, a->accumulate_dres, fa, BnbSec{});
+            else hipExtLaunchKernelGGL((bn_bwd_apply_kernel<T, false, true>), dim3(ew_blocks(units)), dim3(256), lds3, st, nullptr, ev_, 0, a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->gamma, a->beta, nullptr, a->dy, a->dres, a->accumulate_dres, fa, BnbSec{});
         } else {
-            EW_LAUNCH_EV(bn_bwd_apply_kernel, T, v, units, st, salt_take_fork_event(), a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->gamma, a->beta, a->coef, a->dy, a->dres, a->accumulate_dres, BnbFin{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.0, a->da_bias, hw, hw_shift});
+            EW_LAUNCH_EV(bn_bwd_apply_kernel, T, v, units, st, salt_take_fork_event(), a->da, a->a, a->y, a->relu, a->mean, a->invstd, a->gamma, a->beta, a->coef, a->dy, a->dres, a->accumulate_dres, BnbFin{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.0, a->da_bias, hw, hw_shift}, BnbSec{});
         }
     })
     SALT_CHECK_LAUNCH();

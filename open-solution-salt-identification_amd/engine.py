@@ -697,7 +697,15 @@ class Graph:
         #  gradient over the whole concat buffer an encoder output lives in, are complete before it runs.  SALT_BNB_STRICT=1: round 5's rule)
         same = (lambda w_: (w_[0], w_[1]) == (out.c0, out.C))
         ok_wr = bool(wr) and same(wr[-1]) and (all(same(w_) for w_ in wr) or not os.environ.get('SALT_BNB_STRICT'))
-        if (ok_wr and wr[-1][2] is not None and C % self.ve == 0
+        sec = wr[-1][2] if (ok_wr and isinstance(wr[-1][2], tuple) and wr[-1][2][0] == 'sec') else None
+        if sec is not None and not relu and res is None and self._fin_mode() == 2:
+            # round 6: dL/d(out) is the dres the main branch's bn_bwd wrote (this is a projection shortcut's BatchNorm): that apply pass
+            # took this layer's sums as well (salt_bn_bwd_args.sec_*) - apply-only here
+            partials, ready, producer = None, 3, sec[1]
+            self.bwd.set_fields(producer, sec_y=y.view(), sec_mean=w['mean'].data_ptr(), sec_invstd=w['invstd'].data_ptr())
+        elif sec is not None:
+            pass                                   # (a shape the secondary sums do not cover: this layer keeps its reduction pass)
+        elif (ok_wr and wr[-1][2] is not None and C % self.ve == 0
                 and (res is None or not os.environ.get('SALT_NO_BNB_RES')) and not os.environ.get('SALT_NO_BNB_FUSE')):
             # the LAST writer of dL/d(out) is a plain data-gradient launch (it completes the gradient: earlier writers of the same
             # slice were accumulated): its epilogue also reduces this layer's BatchNorm-backward sums over its pixel tiles
@@ -738,7 +746,13 @@ class Graph:
                 self.bwd.set_fields(sums, bn_mean=w['mean'].data_ptr(), bn_invstd=w['invstd'].data_ptr())
             self.bwd.set_fields(s2, da_bias=bias[2].data_ptr())
             out.buf.grad_bias = None
-        if ready == 3:
+        if res is not None and acc_res == 0 and ready == 3 and self._fin_mode() == 2 and C % self.ve == 0 and 256 % (C // self.ve) == 0 \
+                and getattr(res.buf, 'bn_train_out', None) == (res.c0, res.C) and bias is None and not res.plane_stride() \
+                and os.environ.get('SALT_BNB_SEC', '1') != '0':
+            res.buf.grad_writers[-1][2] = ('sec', s2)          # the residual's own BatchNorm (a projection shortcut) may ask this pass for its sums
+        if sec is not None and ready == 3 and producer is sec[1]:
+            self._fin_slot('bwd', 8 * 2 * C, (producer, 'sec_acc'), (s2, 'fin_acc'))
+        elif ready == 3:
             peers = [(bias[4], 'bnb_acc')] if (bias is not None and len(bias) > 4 and bias[4] is not None) else []   # scse_fc_grads reads the same 6 C + 1 wide rows
             self._fin_slot('bwd', 8 * 2 * C, (producer, 'bnb_acc'), (s2, 'fin_acc'), *peers)
         elif ready == 2:

@@ -546,3 +546,67 @@ def test_projection_block_input_gradient_carries_bn_backward_sums(dtype, shape, 
         if float(b[2][k].abs().max()) > 0:
             l2 = float((a[2][k].double() - b[2][k].double()).norm() / b[2][k].double().norm())
             assert l2 <= (1e-4 if dtype == 'f32' else 3e-2), (k, l2)
+
+
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_projection_shortcut_bn_backward_sums_ride_on_the_main_branch_apply_pass(dtype, monkeypatch):
+    """salt_bn_bwd_args.sec_* (round 6): in a residual block with a projection shortcut (torchvision BasicBlock, architectures/encoders.py:38-45)
+    the shortcut BatchNorm's dL/da IS the masked gradient the main branch's bn_bwd stores as dres - so that apply pass also takes the
+    shortcut layer's (sum, sum xhat) and the shortcut's bn_bwd loses its reduction pass.  Needs the main branch's sums to come from a
+    convolution (a layer behind the block), as in the encoders.  Against torch autograd and against SALT_BNB_SEC=0."""
+    from gpu_harness import BlockRun
+    from torch import nn
+    A = _mods()
+    B, Cin, H, W, planes = 3, 16, 16, 16, 32
+    torch.manual_seed(9)
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            down = nn.Sequential(nn.Conv2d(Cin, planes, 1, 2, bias=False), nn.BatchNorm2d(planes))
+            self.block = A.BasicBlock(Cin, planes, 2, down)
+            self.tail = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+            self.tail_bn = nn.BatchNorm2d(planes)
+    m = Net()
+    with torch.no_grad():
+        for p_ in m.parameters():
+            if p_.dim() == 1:
+                p_.copy_(1 + 0.2 * torch.randn_like(p_))
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    x = _rand((B, Cin, H, W), 51)
+    gy = _rand((B, planes, H // 2, W // 2), 52)
+    results = {}
+    for mode in ('sec', 'plain'):
+        monkeypatch.setenv('SALT_BNB_SEC', '1' if mode == 'sec' else '0')
+        m.load_state_dict(sd)
+        m.train()
+        run = BlockRun(m, [x], lambda g, a: g.conv(m.block.emit(g, a), m.tail, m.tail_bn, relu=True), train=True, dtype=dtype)
+        y = run.forward()
+        gx, grads = run.backward(gy.to('cuda:0'))
+        bnb = [st for name, _, st in run.g.bwd.ops if name == 'bn_bwd']
+        # backward order: tail_bn (reduce), block.bn2 (apply-only, sums from tail's data gradient), downsample.bn, block.bn1
+        assert int(bnb[1].partials_ready) == 3 and bool(bnb[1].sec_acc) == (mode == 'sec'), [int(b.partials_ready) for b in bnb]
+        assert int(bnb[2].partials_ready) == (3 if mode == 'sec' else 0)
+        results[mode] = (y, gx[0], grads)
+    ref = nn.ModuleDict(dict(c1=nn.Conv2d(Cin, planes, 3, 2, 1, bias=False), b1=nn.BatchNorm2d(planes), c2=nn.Conv2d(planes, planes, 3, 1, 1, bias=False),
+                             b2=nn.BatchNorm2d(planes), d=nn.Conv2d(Cin, planes, 1, 2, bias=False), db=nn.BatchNorm2d(planes),
+                             t=nn.Conv2d(planes, planes, 3, 1, 1, bias=False), tb=nn.BatchNorm2d(planes)))
+    mp = {'c1': 'block.conv1', 'b1': 'block.bn1', 'c2': 'block.conv2', 'b2': 'block.bn2', 'd': 'block.downsample.0', 'db': 'block.downsample.1', 't': 'tail', 'tb': 'tail_bn'}
+    ref.load_state_dict({a_ + k[len(b_):]: v for a_, b_ in mp.items() for k, v in sd.items() if k.startswith(b_ + '.')})
+    ref.train()
+    xr = x.clone().requires_grad_(True)
+    blk = F.relu(ref['b2'](ref['c2'](F.relu(ref['b1'](ref['c1'](xr))))) + ref['db'](ref['d'](xr)))
+    yr = F.relu(ref['tb'](ref['t'](blk)))
+    yr.backward(gy)
+    tol = TOL32 if dtype == 'f32' else TOLBF
+    inv = {v: k for k, v in mp.items()}
+    for mode, (y, gx, grads) in results.items():
+        assert_close(y, yr, tol * (1 if dtype == 'f32' else 2), 'y ' + mode)
+        l2 = float((gx.double() - xr.grad.double()).norm() / xr.grad.double().norm())
+        assert l2 <= (1e-4 if dtype == 'f32' else 3 * tol), (mode, l2)
+        for k, g_ in grads.items():
+            mod_name, _, pname = k.rpartition('.')
+            want = dict(ref[inv[mod_name]].named_parameters())[pname].grad
+            if float(want.abs().max()) > 1e-6:
+                l2 = float((g_.double() - want.double()).norm() / want.double().norm())
+                assert l2 <= (2e-4 if dtype == 'f32' else 4 * tol), (mode, k, l2)
