@@ -26,7 +26,7 @@ inline bool vec_ok(const salt_view& v, int ve) {
     return v.p == nullptr || ((v.C % ve) == 0 && (v.cs % ve) == 0 && (reinterpret_cast<uintptr_t>(v.p) & 15) == 0);
 }
 inline int ew_blocks(int64_t units) {
-    static const int64_t cap = getenv("SALT_EW_BLOCKS") ? atoi(getenv("SALT_EW_BLOCKS")) : 768;      // round 3: 768 (1024 before; every workgroup of the consumer-side finalize kernels pays the statistics prologue)
+    static const int64_t cap = getenv("SALT_EW_BLOCKS") ? atoi(getenv("SALT_EW_BLOCKS")) : 512;      // round 6: 512 = two workgroups per CU (same box: 1024 5.27, 768 5.27, 512 5.20, 384 5.21, 256 5.23, 192 5.34 ms; round 3: 768 - since then every workgroup of the consumer-side finalize kernels pays the statistics prologue)
     // SALT_EW_MIN_UNITS (A/B, round 5): at least this many 16-byte units per thread - fewer workgroups on the small tensors, where every
     // workgroup's statistics prologue (8 shards x 2 C + 1 doubles from L2, fp64 division + square root per channel) outweighs its stream
     static const int64_t min_units = getenv("SALT_EW_MIN_UNITS") ? atoi(getenv("SALT_EW_MIN_UNITS")) : 1;

@@ -15,6 +15,7 @@
 // have stored them, so the two paths differ only in summation order (tests/test_gpu_head_fused.py bounds it).
 #include "common.h"
 #include <hip/hip_ext.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -313,8 +314,9 @@ int head_bn_parts(const salt_view& x, int64_t* per) {
 }
 
 inline int head_bn_blocks(int64_t units) {
+    static const int64_t cap = getenv("SALT_HEAD_BLOCKS") ? atoi(getenv("SALT_HEAD_BLOCKS")) : 1024;
     int64_t b = (units + 255) / 256;
-    return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
 }
 
 }  // namespace

@@ -5,6 +5,7 @@
 // pass (dx direct terms + per-image partial sums), the FC backward, and one broadcast-add pass.
 // Channel count must be a power of two (64 / 256 in the reference's U-Nets); C/VE lanes share a pixel.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -475,8 +476,9 @@ __global__ void bcast_add_kernel(salt_view dx, const float* dgap) {
 
 int scse_nparts(const salt_view& x, int* per) {
     const int hw = x.H * x.W;
+    static const int max_parts = getenv("SALT_SE_PARTS") ? atoi(getenv("SALT_SE_PARTS")) : 16;      // workgroups per image (every one pays the FC / statistics prologue); round 6: 16 (x 32 images = two per CU; 64: +0.02 ms, 8: +0.06, 4: +0.24)
     int parts = cdiv(hw, 256);
-    if (parts > 64) parts = 64;
+    if (parts > max_parts) parts = max_parts;
     if (parts < 1) parts = 1;
     const int pp = cdiv(hw, parts);
     if (per) *per = pp;
