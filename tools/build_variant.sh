@@ -9,7 +9,7 @@ SRC=${SRC:-conv_mfma}
 C=open-solution-salt-identification_amd/csrc
 mkdir -p $C/_variants/obj_$name
 objs=""
-for f in runtime conv_mfma conv_ws conv_thin conv_wgrad_ls conv_small elementwise hyper se loss input; do
+for f in runtime conv_mfma conv_ws conv_thin conv_wgrad_ls conv_small head_fused elementwise hyper se loss input; do
   if [ $f = $SRC ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -I$C -Wno-unused-value "$@" -c $C/$f.hip -o $C/_variants/obj_$name/$f.o
     objs="$objs $C/_variants/obj_$name/$f.o"
