@@ -983,6 +983,9 @@ int salt_program_run_streams_ex(const salt_program_entry* entries, int begin, in
  * one call per bucket (each cut cost a flush of the pending side-stream entries and the completion-signal fork hand-off). */
 int salt_program_run_streams_marks(const salt_program_entry* entries, int begin, int end, void* main_stream, void* side_stream, int join_at_end,
                                    const int* marks, int nmarks, void* const* ev_main, void* const* ev_side);
+/* stream-tag 4 entries (the weight-gradient slab reductions) run on this stream in the plain eager two-stream run, beside the next
+ * conv_wgrad (two alternating slab buffers; events inside the executor); NULL (default): on the side stream.  Per host thread. */
+int salt_set_aux_stream(void* stream);
 int salt_event_create(void** event_out);            /* a hipEvent_t without timing */
 int salt_event_destroy(void* event);
 int salt_stream_wait_event(void* stream, void* event);

@@ -118,6 +118,7 @@ lib.salt_program_run_streams_marks.argtypes = [ctypes.c_void_p, ctypes.c_int, ct
                                                ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p)]
 lib.salt_event_create.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
 lib.salt_event_destroy.argtypes = [ctypes.c_void_p]
+lib.salt_set_aux_stream.argtypes = [ctypes.c_void_p]
 lib.salt_stream_wait_event.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
 
 DECLARED_SYMBOLS = [p[0] for p in _PROTOS] + ['salt_last_error']

@@ -80,13 +80,17 @@ unsigned fork_event_flags() {
 }
 struct EventPool {
     hipEvent_t ev[2] = {nullptr, nullptr};
+    hipEvent_t ax[3] = {nullptr, nullptr, nullptr};      // auxiliary stream: [0] side -> aux hand-over, [1], [2] "slab free again" ring
     int ensure() {
         for (int i = 0; i < 2; ++i)
             if (!ev[i] && hipEventCreateWithFlags(&ev[i], hipEventDisableTiming | fork_event_flags()) != hipSuccess) return -1;
+        for (int i = 0; i < 3; ++i)
+            if (!ax[i] && hipEventCreateWithFlags(&ax[i], hipEventDisableTiming | fork_event_flags()) != hipSuccess) return -1;
         return 0;
     }
 };
 thread_local EventPool g_events;
+thread_local hipStream_t g_aux_stream = nullptr;   // salt_set_aux_stream: where stream-tag-4 entries run (NULL: on the side stream)
 thread_local hipEvent_t g_fork_event = nullptr;
 const bool g_fork_handoff_env = !getenv("SALT_NO_FORK_HANDOFF");
 thread_local bool g_capturing = false;         // hipExtLaunchKernelGGL stop events are not capturable: plain event forks while a graph records
@@ -94,6 +98,8 @@ thread_local bool g_capturing = false;         // hipExtLaunchKernelGGL stop eve
 }  // namespace
 
 hipEvent_t salt_take_fork_event() { hipEvent_t e = g_fork_event; g_fork_event = nullptr; return e; }
+
+extern "C" int salt_set_aux_stream(void* stream) { g_aux_stream = (hipStream_t)stream; return SALT_OK; }
 
 extern "C" int salt_program_run_streams(const salt_program_entry* e, int begin, int end, void* main_stream, void* side_stream) {
     return salt_program_run_streams_ex(e, begin, end, main_stream, side_stream, 1);
@@ -177,6 +183,13 @@ extern "C" int salt_program_run_streams_marks(const salt_program_entry* e, int b
         npending = 0; groups = 0; side_used = true; ++nflush;
         return 0;
     };
+    // Auxiliary stream (round 6): entries tagged 4 - the weight-gradient slab reductions - run on a THIRD stream, each behind the side
+    // entry in front of it (its conv_wgrad) and beside the NEXT conv_wgrad, which writes the other of two alternating slab buffers; the
+    // side entry that reuses a slab waits for the reduction that read it two reductions ago.  Only in the plain eager two-stream run
+    // (no marks, no capture, join at the end, a fork per group); otherwise tag 4 is the side stream.
+    hipStream_t as = g_aux_stream;
+    const bool use_aux = as && as != ms && as != ss && !g_capturing && nmarks == 0 && join_at_end && fork_every <= 1;
+    int naux = 0;
     int mk = 0;
     auto do_marks = [&](int i) -> int {          // every mark at position i: both queues' events, behind everything issued so far
         while (mk < nmarks && marks[mk] <= i) {
@@ -189,7 +202,18 @@ extern "C" int salt_program_run_streams_marks(const salt_program_entry* e, int b
     };
     for (int i = begin; i < end; ++i) {
         if (mk < nmarks) { const int rc = do_marks(i); if (rc) return rc; }
-        const bool side = e[i].stream == 1;
+        if (use_aux && e[i].stream == 4) {
+            (void)hipEventRecord(g_events.ax[0], ss);            // behind the conv_wgrad that filled the slab
+            (void)hipStreamWaitEvent(as, g_events.ax[0], 0);
+            const int rc = e[i].fn(e[i].args, as);
+            if (rc) { char prev[400]; strncpy(prev, g_err, sizeof(prev) - 1); prev[sizeof(prev) - 1] = 0; salt_set_error("program entry %d failed (%d): %s", i, rc, prev); return rc; }
+            (void)hipEventRecord(g_events.ax[1 + (naux & 1)], as);
+            ++naux;
+            continue;
+        }
+        const bool side = e[i].stream == 1 || e[i].stream == 4;
+        if (use_aux && side && i + 1 < end && e[i + 1].stream == 4 && naux >= 2)
+            (void)hipStreamWaitEvent(ss, g_events.ax[1 + (naux & 1)], 0);      // the slab this launch writes was read by the reduction two back
         if (fork_every > 1) {
             if (side) {
                 if (npending == 64) { const int rc = flush(); if (rc) return rc; }
@@ -202,6 +226,7 @@ extern "C" int salt_program_run_streams_marks(const salt_program_entry* e, int b
         if ((e[i].stream == 2 && side_used) || e[i].stream == 3) {   // a main-stream entry that consumes side-stream results:
             (void)hipEventRecord(g_events.ev[1], ss);                 // 2 = produced inside this range, 3 = enqueued on the side
             (void)hipStreamWaitEvent(ms, g_events.ev[1], 0);          // stream before the call (data-gradient weight packs)
+            if (naux) { (void)hipEventRecord(g_events.ax[0], as); (void)hipStreamWaitEvent(ms, g_events.ax[0], 0); }
             side_used = false;
         }
         if (side && main_dirty) {
@@ -229,6 +254,11 @@ extern "C" int salt_program_run_streams_marks(const salt_program_entry* e, int b
     if (side_used && join_at_end) {
         (void)hipEventRecord(g_events.ev[1], ss);
         (void)hipStreamWaitEvent(ms, g_events.ev[1], 0);
+    }
+    if (naux) {                                                  // (use_aux implies join_at_end)
+        (void)hipEventRecord(g_events.ax[0], as);
+        (void)hipStreamWaitEvent(ms, g_events.ax[0], 0);
+        (void)hipStreamWaitEvent(ss, g_events.ax[0], 0);          // the next range's first slab writers
     }
     return SALT_OK;
 }

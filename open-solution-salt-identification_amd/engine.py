@@ -43,6 +43,17 @@ class Scratch:
         self.name, self.nbytes = name, int(nbytes)
 
 
+_AUX_STREAMS = {}
+
+
+def _aux_stream(side):
+    """The auxiliary stream that goes with a side stream (salt_set_aux_stream): one per side stream, created on first use."""
+    a = _AUX_STREAMS.get(side.cuda_stream)
+    if a is None:
+        a = _AUX_STREAMS[side.cuda_stream] = torch.cuda.Stream(device=side.device)
+    return a
+
+
 class Program:
     """A flat list of (operator, argument struct) pairs executed by salt_program_run."""
 
@@ -55,6 +66,7 @@ class Program:
         self.patches = []      # (struct, path, Scratch)
         self._entries = None
         self.marks = {}
+        self._has_aux = None           # any stream-tag-4 entry (slab reductions on the auxiliary stream)?
         self._pre_run = None           # callable(stream, begin) run before the entries are issued (Graph.finalize: shard hygiene)
         self._post_run = None          # callable(begin, end) after they were issued
 
@@ -129,6 +141,10 @@ class Program:
             rc = lib.salt_program_run_streams_marks(ctypes.cast(self._entries, ctypes.c_void_p), begin, end, st, ctypes.c_void_p(side.cuda_stream),
                                                     1 if join else 0, marks[0], marks[1], marks[2], marks[3])
         elif side is not None:
+            if self._has_aux is None:
+                self._has_aux = 4 in self.streams
+            if self._has_aux:
+                lib.salt_set_aux_stream(ctypes.c_void_p(_aux_stream(side).cuda_stream))
             rc = lib.salt_program_run_streams_ex(ctypes.cast(self._entries, ctypes.c_void_p), begin, end, st, ctypes.c_void_p(side.cuda_stream),
                                                  1 if join else 0)
         else:
@@ -332,6 +348,7 @@ class Graph:
         # fp64 statistics shards of the train-mode BatchNorm layers (SALT_BN_FIN=2): slices of one arena per program, cleared by ONE
         # salt_zero at the head of the program
         self._pending_reduces, self._deferred_params, self._pending_bytes, self._reduce_batches = [], [], 0, []
+        self._n_slab = 0
         self._fin_bytes = {'fwd': 0, 'bwd': 0}
         self._fin_patches = []                   # (struct, field, 'fwd' | 'bwd', byte offset)
         self._fin_zero = {}
@@ -1035,6 +1052,7 @@ class Graph:
         ``b_slice`` = (first, row stride): Q covers only channels [first, first + Cb) of the weight's second axis (salt_wgrad_reduce_args.ldb).
         ``tapgemm`` = (rows, [(kh, kw)]): a 1x1 launch whose P channels are t * rows + a (salt_wgrad_reduce_args.a_mod) - Graph.hyper_level."""
         batching = self._reduce_batching() > 0
+        aux = not batching and os.environ.get('SALT_REDUCE_AUX', '0') != '0'
         gw = self.engine.grad_ptr(weight) if batching else self._gp(weight)
         goff = 0
         Ca, Cb = p_view.C, q_view.C
@@ -1058,9 +1076,15 @@ class Graph:
             if ns < 0:
                 raise SaltError('wgrad plan failed: ' + lib.salt_last_error().decode())
             nbytes = ns * len(chunk) * Ca * Cb * 4
+            # two alternating slab workspaces: the reduction of pair k runs on the auxiliary stream beside conv_wgrad k + 1 (stream tag 4,
+            # runtime.hip); both stay in the Infinity Cache (2 x <= 25 MB)
+            slab = 'wgrad'
+            if aux:
+                slab = 'wgrad_' + 'ab'[self._n_slab & 1]
+                self._n_slab += 1
             wg_op = self.bwd.add('conv_wgrad', stream=1, dtype=self.dt, p=p_view, q=q_view, ntaps=len(chunk), tap_dy=[taps_dydx[j][0] for j in chunk],
                                  tap_dx=[taps_dydx[j][1] for j in chunk], q_step=q_step, pad_mode=pad_mode,
-                                 partials=None if batching else Scratch('wgrad', nbytes), nsplit=ns, q_plane=qp)
+                                 partials=None if batching else Scratch(slab, nbytes), nsplit=ns, q_plane=qp)
             rt = range(len(taps_khkw)) if tapgemm is not None else chunk
             rfields = dict(nsplit=ns, ntaps=len(chunk), Ca=Ca, Cb=Cb, KH=KH, KW=KW, tap_kh=[taps_khkw[j][0] for j in rt],
                            tap_kw=[taps_khkw[j][1] for j in rt], accumulate=0, **extra)
@@ -1068,7 +1092,7 @@ class Graph:
                 sc = self._queue_reduce(dict(rfields, grad_off=goff), weight, nbytes)
                 self.bwd.set_fields(wg_op, partials=sc)
             else:
-                self.bwd.add('wgrad_reduce', stream=1, partials=Scratch('wgrad', nbytes), grad=gw, **rfields)
+                self.bwd.add('wgrad_reduce', stream=4 if aux else 1, partials=Scratch(slab, nbytes), grad=gw, **rfields)
             first = False
 
     def _bwd_pack_tag(self):

@@ -39,3 +39,23 @@ for q, (tot, cnt, names) in sorted(perq.items(), key=lambda kv: -kv[1][0]):
     print('queue %s: busy %.1f us/step, %.0f dispatches/step' % (q, tot / n, cnt / n))
     for k, v in sorted(names.items(), key=lambda kv: -kv[1])[:12]:
         print('      %-50s %9.1f' % (k, v / n))
+# the end of the step: how far the weight-gradient queue runs past the main queue's last backward kernel (what Adam waits for)
+main_q = max(perq.items(), key=lambda kv: kv[1][0])[0]
+tails = defaultdict(float)
+for b, e in steps:
+    seg = rows[b:e]
+    adam = seg[-1]
+    last_main = max(r[2] for r in seg[:-1] if r[3] == main_q)
+    side = [r for r in seg[:-1] if r[3] != main_q]
+    last_side = max(r[2] for r in side) if side else last_main
+    tails['main queue: last kernel end -> adam start'] += (adam[1] - last_main) / 1e3
+    tails['other queues: last kernel end -> adam start'] += (adam[1] - last_side) / 1e3
+    tails['other queues run past the main queue by'] += (last_side - last_main) / 1e3
+for k, v in tails.items():
+    print('%-48s %9.1f us' % (k, v / n))
+b, e = steps[-1]
+seg = rows[b:e]
+t_end = seg[-1][2]
+print('# last 40 dispatches of the last step (us before the end of Adam): queue start end name')
+for name, s, en, q in seg[-40:]:
+    print('  q%-3s %8.1f %8.1f  %s' % (q, (s - t_end) / 1e3, (en - t_end) / 1e3, name.replace('_ZN12_GLOBAL__N_1', '').replace('.kd', '')[:60]))
