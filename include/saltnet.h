@@ -962,7 +962,8 @@ typedef struct {
     salt_op_fn fn;
     const void* args;
     int stream;               /* 0 = main, 1 = side, 2 = main after joining side work of this range, 3 = main after joining the side
-                                 stream unconditionally (work enqueued there before the call) - salt_program_run_streams */
+                                 stream unconditionally (work enqueued there before the call) - salt_program_run_streams;
+                                 4, 5 = auxiliary stream (salt_set_aux_stream), side stream without one */
     int reserved;
 } salt_program_entry;
 int salt_program_run(const salt_program_entry* entries, int n, void* stream);
@@ -983,8 +984,9 @@ int salt_program_run_streams_ex(const salt_program_entry* entries, int begin, in
  * one call per bucket (each cut cost a flush of the pending side-stream entries and the completion-signal fork hand-off). */
 int salt_program_run_streams_marks(const salt_program_entry* entries, int begin, int end, void* main_stream, void* side_stream, int join_at_end,
                                    const int* marks, int nmarks, void* const* ev_main, void* const* ev_side);
-/* stream-tag 4 entries (the weight-gradient slab reductions) run on this stream in the plain eager two-stream run, beside the next
- * conv_wgrad (two alternating slab buffers; events inside the executor); NULL (default): on the side stream.  Per host thread. */
+/* stream-tag 4 entries (the weight-gradient slab reductions; behind the side entry in front of them, two alternating slab buffers) and
+ * stream-tag 5 entries (optimizer updates of parameter ranges whose gradients are final; behind both queues) run on this stream in the
+ * plain eager two-stream run, joined into the main stream at the end of the range; NULL (default): on the side stream.  Per host thread. */
 int salt_set_aux_stream(void* stream);
 int salt_event_create(void** event_out);            /* a hipEvent_t without timing */
 int salt_event_destroy(void* event);

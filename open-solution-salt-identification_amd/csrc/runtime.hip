@@ -80,11 +80,11 @@ unsigned fork_event_flags() {
 }
 struct EventPool {
     hipEvent_t ev[2] = {nullptr, nullptr};
-    hipEvent_t ax[3] = {nullptr, nullptr, nullptr};      // auxiliary stream: [0] side -> aux hand-over, [1], [2] "slab free again" ring
+    hipEvent_t ax[4] = {nullptr, nullptr, nullptr, nullptr};   // auxiliary stream: [0] side -> aux hand-over, [1], [2] "slab free again" ring, [3] main -> aux
     int ensure() {
         for (int i = 0; i < 2; ++i)
             if (!ev[i] && hipEventCreateWithFlags(&ev[i], hipEventDisableTiming | fork_event_flags()) != hipSuccess) return -1;
-        for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < 4; ++i)
             if (!ax[i] && hipEventCreateWithFlags(&ax[i], hipEventDisableTiming | fork_event_flags()) != hipSuccess) return -1;
         return 0;
     }
@@ -183,13 +183,16 @@ extern "C" int salt_program_run_streams_marks(const salt_program_entry* e, int b
         npending = 0; groups = 0; side_used = true; ++nflush;
         return 0;
     };
-    // Auxiliary stream (round 6): entries tagged 4 - the weight-gradient slab reductions - run on a THIRD stream, each behind the side
+    // Auxiliary stream (round 6).  Entries tagged 4 - the weight-gradient slab reductions - run on a THIRD stream, each behind the side
     // entry in front of it (its conv_wgrad) and beside the NEXT conv_wgrad, which writes the other of two alternating slab buffers; the
-    // side entry that reuses a slab waits for the reduction that read it two reductions ago.  Only in the plain eager two-stream run
-    // (no marks, no capture, join at the end, a fork per group); otherwise tag 4 is the side stream.
+    // side entry that reuses a slab waits for the reduction that read it two reductions ago.  Entries tagged 5 - the optimizer's update
+    // of a parameter range whose gradients are final at that position (FusedAdam.backward_program) - run there behind everything both
+    // queues were given so far.  Only in the plain eager two-stream run (no marks, no capture, join at the end, a fork per group);
+    // otherwise tags 4 and 5 are the side stream (same order guarantees, no concurrency).
     hipStream_t as = g_aux_stream;
     const bool use_aux = as && as != ms && as != ss && !g_capturing && nmarks == 0 && join_at_end && fork_every <= 1;
     int naux = 0;
+    bool aux_used = false;
     int mk = 0;
     auto do_marks = [&](int i) -> int {          // every mark at position i: both queues' events, behind everything issued so far
         while (mk < nmarks && marks[mk] <= i) {
@@ -208,10 +211,18 @@ extern "C" int salt_program_run_streams_marks(const salt_program_entry* e, int b
             const int rc = e[i].fn(e[i].args, as);
             if (rc) { char prev[400]; strncpy(prev, g_err, sizeof(prev) - 1); prev[sizeof(prev) - 1] = 0; salt_set_error("program entry %d failed (%d): %s", i, rc, prev); return rc; }
             (void)hipEventRecord(g_events.ax[1 + (naux & 1)], as);
-            ++naux;
+            ++naux; aux_used = true;
             continue;
         }
-        const bool side = e[i].stream == 1 || e[i].stream == 4;
+        if (use_aux && e[i].stream == 5) {                       // behind BOTH queues (an optimizer update of parameters whose gradients are final here)
+            (void)hipEventRecord(g_events.ax[3], ms); (void)hipStreamWaitEvent(as, g_events.ax[3], 0);
+            (void)hipEventRecord(g_events.ax[0], ss); (void)hipStreamWaitEvent(as, g_events.ax[0], 0);
+            const int rc = e[i].fn(e[i].args, as);
+            if (rc) { char prev[400]; strncpy(prev, g_err, sizeof(prev) - 1); prev[sizeof(prev) - 1] = 0; salt_set_error("program entry %d failed (%d): %s", i, rc, prev); return rc; }
+            aux_used = true;
+            continue;
+        }
+        const bool side = e[i].stream == 1 || e[i].stream == 4 || e[i].stream == 5;
         if (use_aux && side && i + 1 < end && e[i + 1].stream == 4 && naux >= 2)
             (void)hipStreamWaitEvent(ss, g_events.ax[1 + (naux & 1)], 0);      // the slab this launch writes was read by the reduction two back
         if (fork_every > 1) {
@@ -226,7 +237,7 @@ extern "C" int salt_program_run_streams_marks(const salt_program_entry* e, int b
         if ((e[i].stream == 2 && side_used) || e[i].stream == 3) {   // a main-stream entry that consumes side-stream results:
             (void)hipEventRecord(g_events.ev[1], ss);                 // 2 = produced inside this range, 3 = enqueued on the side
             (void)hipStreamWaitEvent(ms, g_events.ev[1], 0);          // stream before the call (data-gradient weight packs)
-            if (naux) { (void)hipEventRecord(g_events.ax[0], as); (void)hipStreamWaitEvent(ms, g_events.ax[0], 0); }
+            if (aux_used) { (void)hipEventRecord(g_events.ax[0], as); (void)hipStreamWaitEvent(ms, g_events.ax[0], 0); }
             side_used = false;
         }
         if (side && main_dirty) {
@@ -255,7 +266,7 @@ extern "C" int salt_program_run_streams_marks(const salt_program_entry* e, int b
         (void)hipEventRecord(g_events.ev[1], ss);
         (void)hipStreamWaitEvent(ms, g_events.ev[1], 0);
     }
-    if (naux) {                                                  // (use_aux implies join_at_end)
+    if (aux_used) {                                              // (use_aux implies join_at_end)
         (void)hipEventRecord(g_events.ax[0], as);
         (void)hipStreamWaitEvent(ms, g_events.ax[0], 0);
         (void)hipStreamWaitEvent(ss, g_events.ax[0], 0);          // the next range's first slab writers

@@ -142,9 +142,9 @@ class Program:
                                                     1 if join else 0, marks[0], marks[1], marks[2], marks[3])
         elif side is not None:
             if self._has_aux is None:
-                self._has_aux = 4 in self.streams
+                self._has_aux = 4 in self.streams or 5 in self.streams
             if self._has_aux:
-                lib.salt_set_aux_stream(ctypes.c_void_p(_aux_stream(side).cuda_stream))
+                lib.salt_set_aux_stream(None if os.environ.get('SALT_NO_AUX_STREAM') else ctypes.c_void_p(_aux_stream(side).cuda_stream))
             rc = lib.salt_program_run_streams_ex(ctypes.cast(self._entries, ctypes.c_void_p), begin, end, st, ctypes.c_void_p(side.cuda_stream),
                                                  1 if join else 0)
         else:

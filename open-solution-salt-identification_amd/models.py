@@ -169,7 +169,7 @@ class SegmentationModel(Model):
         (name, loss_function, weight), target = self.loss_function[0], targets[0]
         kind = getattr(loss_function, 'native_kind', None)
         if kind is not None:
-            batch_loss = self._fused_step(X, target, kind, weight)
+            batch_loss = self._fused_step(X, target, kind, weight, adam_in_backward=True)     # (optimizer.step() follows below)
         else:                                   # any torch-differentiable loss: through the autograd bridge
             outputs_batch = self.model(X)
             batch_loss = loss_function(outputs_batch, target) * weight
@@ -181,7 +181,7 @@ class SegmentationModel(Model):
             self.optimizer.step()
         return {'sum': batch_loss}
 
-    def _fused_step(self, X, target, kind, weight):
+    def _fused_step(self, X, target, kind, weight, adam_in_backward=False):
         eng = self.model.engine(X.device)
         # 'first step of a shape ran eagerly' is remembered ON the engine (a rebuilt engine starts empty - no recycled id() can skip it)
         if self.step_graph and not self.dp._active() and (tuple(X.shape), kind) in eng.eager_done:
@@ -210,7 +210,15 @@ class SegmentationModel(Model):
             if not bt:
                 net.target.copy_(target[:, :K])
             loss_prog.run()
-            self.dp.backward(eng, net, self.optimizer)
+            bwd = None
+            if adam_in_backward and not self.dp._active() and getattr(self.optimizer, 'model', None) is self.model and hasattr(self.optimizer, 'begin_step'):
+                # one rank: the optimizer updates each parameter range as soon as its gradients are final, beside the rest of backward
+                self.optimizer.grad_scale = 1.0
+                bwd = self.optimizer.begin_step(net)
+            if bwd is not None:
+                bwd.run(side=eng.side_stream)
+            else:
+                self.dp.backward(eng, net, self.optimizer)
         finally:
             net.bind()                           # back to the static buffers (tools / tests that run the programs on their own)
         eng.eager_done.add((tuple(X.shape), kind))

@@ -5,6 +5,8 @@ Mirrors ``optim.Adam(weight_regularization(model, regularize, weight_decay_conv2
 biases included), classic Adam (not AdamW), torch defaults beta=(0.9,0.999), eps=1e-8.  The surface the
 reference's callbacks touch is kept: ``param_groups`` (lr is read AND written by the schedulers,
 callbacks.py:262-275), ``state_dict()``, ``zero_grad()``, ``step()``."""
+import weakref
+
 import torch
 
 from ._abi import SaltError
@@ -64,6 +66,9 @@ class FusedAdam(torch.optim.Optimizer):
                       exp_avg_sq=self.exp_avg_sq.data_ptr(), n=eng.n_live, hyper=self.hyper.data_ptr())
         self.prog.finalize()
         self._pack_prog, self._pack_gen = None, None
+        self._bwd_progs = weakref.WeakKeyDictionary()        # per compiled net: (key, (backward + early updates, tail) | None)
+        self._chunk_tables = []
+        self._pending_tail = None
 
     def _adam_pack_program(self):
         """Adam + the bf16 forward weight packs in ONE launch (salt_adam_pack): the thread that updates 8 input channels x all taps of an
@@ -99,6 +104,7 @@ class FusedAdam(torch.optim.Optimizer):
             pos = first + cnt
         if pos < eng.n_live:
             rest.append((pos, eng.n_live - pos))
+        self._rest_ranges = list(rest)
         rblocks = [(c + 1023) // 1024 for _, c in rest]
         rpref = np.concatenate([[0], np.cumsum(rblocks)]).astype(np.int32) if rest else np.zeros(1, np.int32)
         dev = eng.device
@@ -113,6 +119,121 @@ class FusedAdam(torch.optim.Optimizer):
         prog.finalize()
         self._pack_prog = prog
         return prog
+
+    # -- the update of a parameter range as soon as its gradients are final (round 6)
+    def _range_ops(self, prog, ranges, stream):
+        """Append to ``prog`` the Adam update (+ forward packs, bf16 engines) of the flat-buffer ``ranges`` [(lo, hi)]; False when a
+        range cuts a pack job or is not float4-aligned (the caller then keeps the one-launch step)."""
+        import numpy as np
+        eng = self._eng
+        fused = self._adam_pack_program()
+        for lo, hi in ranges:
+            if lo % 4 or (hi % 4 and hi != eng.n_live):
+                return False
+        if fused is None:
+            for lo, hi in ranges:
+                prog.add('adam', stream=stream, param=eng.flat.data_ptr() + 4 * lo, grad=eng.grads.data_ptr() + 4 * lo, exp_avg=self.exp_avg.data_ptr() + 4 * lo,
+                         exp_avg_sq=self.exp_avg_sq.data_ptr() + 4 * lo, n=hi - lo, hyper=self.hyper.data_ptr())
+            return True
+        import ctypes
+        from ._abi import lib
+        base = eng.flat.data_ptr()
+        jobs, rest = [], []
+        for j in eng._adam_jobs:
+            first, cnt = (j.w - base) // 4, j.D0 * j.D1 * j.KH * j.KW
+            inside = [lo <= first and first + cnt <= hi for lo, hi in ranges]
+            if any(inside):
+                jobs.append(j)
+            elif any(first < hi and lo < first + cnt for lo, hi in ranges):
+                return False
+        for first, cnt in self._rest_ranges:
+            for lo, hi in ranges:
+                a, b = max(first, lo), min(first + cnt, hi)
+                if a < b:
+                    if a % 4 or ((b - a) % 4 and b != eng.n_live):
+                        return False
+                    rest.append((a, b - a))
+        blocks = [lib.salt_pack_job_blocks(ctypes.byref(j)) for j in jobs]
+        pref = np.concatenate([[0], np.cumsum(blocks)]).astype(np.int32)
+        rblocks = [(c + 1023) // 1024 for _, c in rest]
+        rpref = np.concatenate([[0], np.cumsum(rblocks)]).astype(np.int32) if rest else np.zeros(1, np.int32)
+        dev = eng.device
+        t = [torch.frombuffer(bytearray(b''.join(bytes(j) for j in jobs) or b'\0'), dtype=torch.uint8).to(dev), torch.from_numpy(pref).to(dev),
+             torch.tensor(rest if rest else [[0, 0]], dtype=torch.int64).to(dev), torch.from_numpy(rpref).to(dev)]
+        self._chunk_tables.append(t)
+        prog.add('adam_pack', stream=stream, param=eng.flat.data_ptr(), grad=eng.grads.data_ptr(), exp_avg=self.exp_avg.data_ptr(),
+                 exp_avg_sq=self.exp_avg_sq.data_ptr(), n=eng.n_live, hyper=self.hyper.data_ptr(), jobs=t[0].data_ptr(), job_block0=t[1].data_ptr(),
+                 njobs=len(jobs), pack_blocks=int(pref[-1]), rest=t[2].data_ptr(), rest_block0=t[3].data_ptr(), nrest=len(rest), rest_blocks=int(rpref[-1]))
+        return True
+
+    def backward_program(self, net):
+        """-> (program, tail) or None.  ``program`` = the backward program of ``net`` with this optimizer's update of every parameter
+        range whose gradients are final before the program ends inserted at that position as auxiliary-stream entries (stream tag 5,
+        runtime.hip: behind everything both queues were given so far, beside what follows); ``tail`` = the update of the remaining
+        ranges, which :meth:`step` runs after the join.  The launches of the one-kernel step cut into ranges: every element takes the
+        same arithmetic (`adam4`), so parameters, moments and packs are bit-identical to it.  Why: Adam is a 0.17 ms streaming pass
+        (R34 hypercolumn) that used to run alone at the end of the step, while the backward's two queues leave most of the HBM
+        bandwidth unused; the decoder's and layer4's parameters - 3 / 4 of the network - are final 40 - 70 % into backward."""
+        import os
+        from .parallel import plan_buckets
+        self._bind()
+        self._adam_pack_program()
+        key = (self._eng._pack_generation, len(net.bwd), id(self._eng))
+        hit = self._bwd_progs.get(net)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        self._bwd_progs[net] = (key, None)
+        if not getattr(net.g, 'grad_ready', None):
+            return None
+        n_ops = len(net.bwd)
+        chunk = int(float(os.environ.get('SALT_ADAM_CHUNK_MB', '24')) * (1 << 20))
+        plan = plan_buckets(net.g.grad_ready, self._eng.n_live, bucket_bytes=chunk, tail_bytes=0)
+        margin = int(os.environ.get('SALT_ADAM_TAIL_OPS', '4'))          # a range final this close to the end gains nothing from its own launch
+        early = [(lo, hi, min(max(pos, 0), n_ops)) for lo, hi, pos in plan if pos < n_ops - margin and hi > lo]
+        late = [(lo, hi) for lo, hi, pos in plan if not pos < n_ops - margin and hi > lo]
+        if not early:
+            return None
+        if net.bwd._entries is None:
+            net.bwd.finalize()
+        self._chunk_tables = getattr(self, '_chunk_tables', [])
+        ins = Program('adam_ranges')
+        at = []
+        ins.add('adam_tick', stream=5, hyper=self.hyper.data_ptr(), step=self.step_t.data_ptr())
+        at.append(early[0][2])
+        for lo, hi, pos in early:
+            n0 = len(ins.ops)
+            if not self._range_ops(ins, [(lo, hi)], 5):
+                return None
+            at.extend([pos] * (len(ins.ops) - n0))
+        tail = Program('adam_tail')
+        if late and not self._range_ops(tail, late, 0):
+            return None
+        tail.finalize()
+        prog = Program('bwd+adam')
+        k = 0
+        for i in range(n_ops + 1):
+            while k < len(at) and at[k] <= i:
+                prog.ops.append(ins.ops[k]); prog.streams.append(ins.streams[k]); k += 1
+            if i < n_ops:
+                prog.ops.append(net.bwd.ops[i]); prog.streams.append(net.bwd.streams[i])
+        prog._pre_run, prog._post_run = net.bwd._pre_run, net.bwd._post_run
+        prog.finalize()
+        self._bwd_progs[net] = (key, (prog, tail))
+        return prog, tail
+
+    def begin_step(self, net):
+        """Called by the fused step BEFORE backward: -> the program to run instead of ``net.bwd`` (None: run ``net.bwd``, step() does
+        everything).  After it ran, :meth:`step` only runs the tail."""
+        import os
+        if self.model is None or os.environ.get('SALT_ADAM_IN_BWD', '0') == '0':
+            return None
+        self._bind()
+        self._sync_hyper()
+        progs = self.backward_program(net)
+        if progs is None:
+            return None
+        self._pending_tail = progs[1]
+        return progs[0]
 
     def _sync_hyper(self):
         g = self.param_groups[0]
@@ -129,9 +250,14 @@ class FusedAdam(torch.optim.Optimizer):
         if self.model is None:
             raise SaltError('FusedAdam needs the HipNetwork it optimises (model=...)')
         self._bind()
-        self._sync_hyper()
         fused = self._adam_pack_program()
-        (fused or self.prog).run()
+        if self._pending_tail is not None:                 # begin_step: the ranges that were final early took their update inside backward
+            tail, self._pending_tail = self._pending_tail, None
+            if len(tail):
+                tail.run()
+        else:
+            self._sync_hyper()
+            (fused or self.prog).run()
         self.steps += 1
         self._eng.touch(weights=True, stats=False)
         if fused is not None:

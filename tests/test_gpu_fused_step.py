@@ -378,3 +378,48 @@ def test_planar_hypercolumn_equals_interleaved(monkeypatch):
     gn = float(b[2].norm())
     assert float((a[2] - b[2]).norm()) <= 2e-3 * gn, (float((a[2] - b[2]).norm()), gn)
     assert float((a[1] - b[1]).norm()) <= 1e-4 * float(b[1].norm())
+
+
+@pytest.mark.parametrize('architecture,dtype', [('UNetResNet', 'bf16'), ('UNetResNet', 'f32'), ('VanillaUNet', 'f32')])
+def test_auxiliary_stream_modes_equal_the_plain_step(architecture, dtype, monkeypatch, deterministic_sums):
+    """Round 6, both opt-in (measured slower than the default on the C2 step) but shipped and therefore tested:
+    * `SALT_ADAM_IN_BWD=1`: `FusedAdam.backward_program` inserts the update of every parameter range whose gradients are final into the
+      backward program (stream tag 5: auxiliary stream, behind both queues) and `step()` only runs the remaining ranges.  Same arithmetic
+      per element: parameters, both moments and the step counter after four `_fit_loop` steps are bit-identical to the step that runs
+      Adam as ONE launch after backward; the reference is `optimizer.step()` after `batch_loss.backward()` (models.py:127-129).
+    * `SALT_REDUCE_AUX=1`: the weight-gradient slab reductions on the auxiliary stream (stream tag 4) over two alternating slabs -
+      the same kernels on the same values in another queue.
+    Also both with the auxiliary stream withheld (`SALT_NO_AUX_STREAM`: the tags fall back to the weight-gradient queue)."""
+    shape = (4, 3, 64, 64) if architecture == 'UNetResNet' else (4, 1, 64, 64)
+    g = torch.Generator().manual_seed(11)
+    X = torch.randn(*shape, generator=g).to(DEV)
+    M = (torch.rand(shape[0], 1, shape[2], shape[3], generator=g) > 0.6).float()
+    Tg = torch.cat([1 - M, M], 1).to(DEV)
+    modes = {'plain': {}, 'adam': {'SALT_ADAM_IN_BWD': '1', 'SALT_ADAM_CHUNK_MB': '8'}, 'reduce': {'SALT_REDUCE_AUX': '1'},
+             'both_no_aux': {'SALT_ADAM_IN_BWD': '1', 'SALT_ADAM_CHUNK_MB': '8', 'SALT_REDUCE_AUX': '1', 'SALT_NO_AUX_STREAM': '1'},
+             'both': {'SALT_ADAM_IN_BWD': '1', 'SALT_ADAM_CHUNK_MB': '8', 'SALT_REDUCE_AUX': '1'}}
+    res = {}
+    for mode, env in modes.items():
+        for k in ('SALT_ADAM_IN_BWD', 'SALT_ADAM_CHUNK_MB', 'SALT_REDUCE_AUX', 'SALT_NO_AUX_STREAM'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        torch.manual_seed(3)
+        m = _segmentation_model(architecture, dtype=dtype, lr=1e-3)
+        m._to_device(); m.model.train()
+        losses = [float(m._fit_loop([X, Tg])['sum']) for _ in range(4)]
+        torch.cuda.synchronize()
+        eng = m.model.engine()
+        net = eng.net(shape, True)
+        early = m.optimizer._bwd_progs.get(net)
+        res[mode] = (losses, eng.flat.clone(), m.optimizer.exp_avg.clone(), m.optimizer.exp_avg_sq.clone(), int(m.optimizer.step_t.item()),
+                     m.optimizer.steps, None if early is None or early[1] is None else (len(early[1][0]) - len(net.bwd), len(early[1][1])),
+                     net.bwd.streams.count(4))
+    assert res['plain'][6] is None and res['plain'][7] == 0 and res['reduce'][7] > 4
+    if architecture == 'UNetResNet':
+        assert res['adam'][6] is not None and res['adam'][6][0] >= 2, res['adam'][6]     # tick + at least one early range
+    for mode in modes:
+        assert res[mode][0] == res['plain'][0], (mode, res[mode][0], res['plain'][0])
+        for i in (1, 2, 3):
+            assert torch.equal(res[mode][i], res['plain'][i]), (mode, i)
+        assert res[mode][4] == 4 and res[mode][5] == 4
