@@ -444,6 +444,9 @@ def train_config(workload, dtype, B, loss, steps, warmup, dev, rank=0, world=1, 
     X, T = preprocess(img, msk, True, channels)
     X, T = X.to(dev), T.to(dev)
     batches = [(X[i * B:(i + 1) * B], T[i * B:(i + 1) * B]) for i in range(pool_batches)]
+    if os.environ.get('SALT_MAIN_PRIORITY'):                 # A/B: the step's compute stream with a HIP stream priority
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(torch.cuda.Stream(priority=int(os.environ['SALT_MAIN_PRIORITY'])))
     for i in range(warmup):
         model._fit_loop(list(batches[i % pool_batches]))
     torch.cuda.synchronize()

@@ -158,7 +158,8 @@ class Engine:
         self._packed_version = -1
         self._folded_version = None
         self.world = 1
-        self.side_stream = torch.cuda.Stream(device=device)     # weight-gradient kernels overlap the data-gradient chain
+        pr = os.environ.get('SALT_SIDE_PRIORITY')                # (A/B: HIP stream priority of the weight-gradient queue; lower number = served first)
+        self.side_stream = torch.cuda.Stream(device=device, priority=int(pr)) if pr else torch.cuda.Stream(device=device)     # weight-gradient kernels overlap the data-gradient chain
         self.eager_done = set()          # (shape, loss kind) whose first training step already ran eagerly (models.SegmentationModel._fused_step)
 
     # ------------------------------------------------------------------ flat parameter storage
