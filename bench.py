@@ -668,7 +668,9 @@ def extra_configs(dev, steps=12, warmup=4):
         net.x.copy_(batches[0][0]); net.target.copy_(batches[0][1])
         roof, _, _, _, fl, _ = conv_roofline(model, B, channels, dtype, 'lovasz', 1)
         roof.pop('by_class', None)
-        out[tag] = {'config': note, 'images_per_s': round(B * steps / elapsed, 1), 'ms_per_step': round(1e3 * elapsed / steps, 3), 'dtype': dtype,
+        med = STEP_MS[len(STEP_MS) // 2] if STEP_MS else None      # train_config's second leg: >= 50 further steps, one event per step
+        out[tag] = {'config': note, 'images_per_s': round(B * steps / elapsed, 1), 'ms_per_step': round(1e3 * elapsed / steps, 3),
+                    'ms_per_step_median_of_%d' % len(STEP_MS): round(med, 3) if med else None, 'dtype': dtype,
                     'steps': steps, 'warmup': warmup, 'step_tflops': round(fl / (elapsed / steps) / 1e12, 1),
                     'conv_tflops': roof['achieved'], 'conv_frac_of_mfma_peak': roof['frac'], 'mfma_peak_tflops': roof['peak']}
         del model, batches, net
