@@ -661,7 +661,7 @@ def extra_configs(dev, steps=12, warmup=4):
     ResNet34 fp32, C3's per-GPU shape (batch 64), C4 inference with 4-flip TTA."""
     out = {}
 
-    def one(tag, workload, dtype, B, note):
+    def one(tag, workload, dtype, B, note, steps=steps, warmup=warmup):
         model, batches, elapsed, _ = train_config(workload, dtype, B, 'lovasz', steps, warmup, dev)
         _, channels, _ = WORKLOADS[workload]
         net = model.model.engine().net((B, channels, 128, 128), True)
@@ -675,9 +675,11 @@ def extra_configs(dev, steps=12, warmup=4):
                     'conv_tflops': roof['achieved'], 'conv_frac_of_mfma_peak': roof['frac'], 'mfma_peak_tflops': roof['peak']}
         del model, batches, net
         torch.cuda.empty_cache()
-    one('C1_vanilla_f32_b32', 'vanilla', 'f32', 32, 'vanilla 4-level U-Net, 101x101 pad->128, batch 32, fp32, training step (Lovasz, Adam)')
+    # (timed regions of >= 0.25 s: the 12-step region of the 3 ms vanilla step once read 4.0 ms where every other run reads 3.1 - one
+    # host hiccup of 10 ms is 30 % of 37 ms)
+    one('C1_vanilla_f32_b32', 'vanilla', 'f32', 32, 'vanilla 4-level U-Net, 101x101 pad->128, batch 32, fp32, training step (Lovasz, Adam)', steps=80, warmup=8)
     one('R34_hyper_f32_b32', 'r34_hyper', 'f32', 32, 'ResNet34 hypercolumn U-Net, 128x128, batch 32, fp32 (exact-f32 MFMA), training step')
-    one('C3_R34_hyper_bf16_b64', 'r34_hyper', 'bf16', 64, 'ResNet34 hypercolumn U-Net + Lovasz hinge, 128x128, batch 64 per GPU, bf16, training step')
+    one('C3_R34_hyper_bf16_b64', 'r34_hyper', 'bf16', 64, 'ResNet34 hypercolumn U-Net + Lovasz hinge, 128x128, batch 64 per GPU, bf16, training step', steps=30, warmup=6)
     # C4: ResNet152 hypercolumn U-Net, 256x256, batch 16, 4-flip TTA inference (flip -> one forward of 64 -> sigmoid -> inverse flip -> mean
     # -> centre crop -> threshold), bf16
     from salt_amd import architectures as A, inference as I
