@@ -2935,7 +2935,11 @@ int wgrad_plan(const salt_conv_wgrad_args* a, WgradKP* k, int* nsplit_out) {
     // CUs from the data-gradient chain
     const int min_tiles = min_tiles_env > 0 ? min_tiles_env : (a->dtype == SALT_F32 ? 2 : 8);
     static const bool wgs_env = getenv("SALT_WGRAD_WGS") != nullptr;
-    int ns = ((a->dtype == SALT_F32 && !min_tiles_env && !wgs_env) ? 256 : target_wgs) / blocks_;
+    // bf16 (round 6): 128 workgroups per launch instead of 512.  Backward is bound by the kernel time of its two queues together
+    // (DESIGN 7): a weight-gradient launch that holds every CU slows the data-gradient chain beside it by more than its own shorter
+    // run is worth, and every split less is a 147 KB slab less to write and reduce.  Same box, C2 step: 512 5.05 - 5.08 ms, 256 5.00,
+    // 160 5.00, 128 4.97 - 4.99, 96 5.03, 64 5.13, 32 5.97 (profiles/r06_wgrad_wgs_ab.txt)
+    int ns = (wgs_env ? target_wgs : (a->dtype == SALT_F32 && !min_tiles_env) ? 256 : a->dtype == SALT_F32 ? target_wgs : 128) / blocks_;
     // the stem (64 x 16 channels, launched on the MAIN stream at the very end of backward, nothing left to overlap with): finer
     // split.  NOT for the other single-block layers: their launches share the chip with the data-gradient chain, and 256 instead
     // of 128 weight-gradient workgroups cost 6.17 -> 6.24 ms per step (and halving the tiles per split wherever a launch has fewer than
