@@ -2939,7 +2939,9 @@ int wgrad_plan(const salt_conv_wgrad_args* a, WgradKP* k, int* nsplit_out) {
     // (DESIGN 7): a weight-gradient launch that holds every CU slows the data-gradient chain beside it by more than its own shorter
     // run is worth, and every split less is a 147 KB slab less to write and reduce.  Same box, C2 step: 512 5.05 - 5.08 ms, 256 5.00,
     // 160 5.00, 128 4.97 - 4.99, 96 5.03, 64 5.13, 32 5.97 (profiles/r06_wgrad_wgs_ab.txt)
+    static const int wgs_big = getenv("SALT_WGRAD_WGS_BIG") ? atoi(getenv("SALT_WGRAD_WGS_BIG")) : 0;      // A/B: the 128 x 128 maps (>= 2048 pixel tiles)
     int ns = (wgs_env ? target_wgs : (a->dtype == SALT_F32 && !min_tiles_env) ? 256 : a->dtype == SALT_F32 ? target_wgs : 128) / blocks_;
+    if (wgs_big > 0 && k->ntiles >= 2048) ns = wgs_big / blocks_;
     // the stem (64 x 16 channels, launched on the MAIN stream at the very end of backward, nothing left to overlap with): finer
     // split.  NOT for the other single-block layers: their launches share the chip with the data-gradient chain, and 256 instead
     // of 128 weight-gradient workgroups cost 6.17 -> 6.24 ms per step (and halving the tiles per split wherever a launch has fewer than

@@ -573,11 +573,14 @@ int conv_wgrad_ls(const salt_conv_wgrad_args* a, bool launch, hipStream_t st, in
     k.total = cdiv(k.B, NB) * k.ncol * k.U;
     k.a_blocks = cdiv(k.Ca, 64); k.b_blocks = cdiv(k.Cb, 64);
     // split rule of wgrad_plan: a workgroup budget per launch and a minimum of pixels per split (every split costs a slab round trip)
-    static const int target_wgs = getenv("SALT_WGRAD_WGS") ? atoi(getenv("SALT_WGRAD_WGS")) : 512;
+    // round 6: 128 workgroups per launch instead of 512 (wgrad_plan in conv_mfma.hip has the measurements: backward is bound by the
+    // kernel time of both queues together, a weight-gradient launch on every CU slows the data-gradient chain beside it)
+    static const int target_wgs = getenv("SALT_WGRAD_WGS") ? atoi(getenv("SALT_WGRAD_WGS")) : 128;
+    static const int wgs_big = getenv("SALT_WGRAD_WGS_BIG") ? atoi(getenv("SALT_WGRAD_WGS_BIG")) : 0;      // A/B: the 128 x 128 maps
     static const int tpw = getenv("SALT_WGRAD_TPW") ? atoi(getenv("SALT_WGRAD_TPW")) : 8;          // in 128-pixel tiles, as before
     const int blocks = k.a_blocks * k.b_blocks;
     int upw_min = tpw * 8 / KU; if (upw_min < 1) upw_min = 1;
-    int ns = target_wgs / blocks;
+    int ns = ((wgs_big > 0 && (long long)k.total * KU >= 16384) ? wgs_big : target_wgs) / blocks;
     if (ns > k.total / upw_min) ns = k.total / upw_min;
     if (ns < 1) ns = 1;
     k.upw = cdiv(k.total, ns);
