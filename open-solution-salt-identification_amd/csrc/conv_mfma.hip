@@ -51,6 +51,7 @@ struct ConvKP {
     int m_tiles, n_tiles;
     int vt;                          // virtual taps of a 1x1 convolution: vt channel chunks staged per barrier round (1 = off)
     int nbuf;                        // conv_glds_kernel: depth of the LDS chunk ring (2 | 3)
+    int no_perm8;                    // conv_glds_kernel: A/B - natural lane -> pixel order on the 8 x 8 tiles (SALT_GLDS_NO_PERM8)
     int y_small;                     // y / bnb_y / bnb_a hold < 2^31 elements each: the epilogue may use 32-bit offsets
     // BatchNorm-backward sums of the stored tile (saltnet.h, salt_conv_args.bnb_*); bnb_partials == nullptr: off
     const void* bnb_y; const void* bnb_a; int bnb_cs, bnb_acs, bnb_relu;
@@ -827,6 +828,20 @@ __device__ __forceinline__ int lane_pixel_perm(int m) {                  // m in
     return (int)((0x73261540u >> ((m >> 2) * 4)) & 0xfu) * 4 + (m & 3);
 }
 
+// The same for 8 x 8 tiles of a 3 x 3 layer (halo pitch 10: the 8 x 8 maps, a whole image per 64 pixels; round 6 - the SQ counters of
+// the step showed SQ_LDS_BANK_CONFLICT at 55 % of this kernel's LDS cycles, profiles/r06_pmc_sq.json): image rows y and y + 4 are
+// 40 = 8 (mod 16) LDS rows apart, so a 16-lane group that covers 8 pixels of row y and 8 of row y + 4 touches 16 distinct rows mod 16
+// for any tap shift.  The two 32-pixel sub-tiles of an image take rows {0, 1, 4, 5} and {2, 3, 6, 7}; s = sub-tile parity.
+__device__ __forceinline__ int lane_pixel_perm8(int s, int m) {           // m in [0, 32) -> pixel of the 8 x 8 image
+    const int g = m >> 2;
+    const int row = 2 * s + (int)((0x50054114u >> (g * 4)) & 0xfu);
+    return row * 8 + ((g >> 1) & 1) * 4 + (m & 3);
+}
+// tile pixel of MFMA row `mr` of 32-pixel sub-tile `sub`: mode 0 natural, 1 lane_pixel_perm, 2 lane_pixel_perm8
+__device__ __forceinline__ int frag_pixel(int mode, int sub, int mr) {
+    return mode == 2 ? (sub >> 1) * 64 + lane_pixel_perm8(sub & 1, mr) : sub * 32 + (mode == 1 ? lane_pixel_perm(mr) : mr);
+}
+
 __device__ __forceinline__ void wait_vmcnt_upto(int n) {               // n is wave-uniform
     switch (n) {
         case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
@@ -968,11 +983,12 @@ __global__ __launch_bounds__(512, 2) void conv_glds_kernel(ConvKP p) {
     };
 
     // ---- fragment addressing
-    const bool perm = !p.gen && p.tw_log2 == 4;                          // 16-pixel tile rows: conflict-free lane -> pixel order
+    // conflict-free lane -> pixel order: 16-pixel tile rows (1), 8 x 8 tiles at halo pitch 10 (2)
+    const int perm = p.gen ? 0 : p.tw_log2 == 4 ? 1 : (MI % 2 == 0 && p.tw_log2 == 3 && p.th_log2 == 3 && p.hw == 10 && !p.no_perm8) ? 2 : 0;
     int pbase[MI];
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-        const int m = (mb * MI + i) * 32 + (perm ? lane_pixel_perm(l31) : l31);
+        const int m = frag_pixel(perm, mb * MI + i, l31);
         const TilePix tp = tile_pix(p, m);
         const int tx = tp.tx, ty = tp.ty, bl = tp.bl;
         pbase[i] = bl < p.nb ? bl * hhw + ty * p.hw + tx : 0;                         // (general tiles: a row past the last pixel reads halo row 0)
@@ -1183,7 +1199,7 @@ __global__ __launch_bounds__(512, 2) void conv_glds_kernel(ConvKP p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int mr = (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                    const int m = rowoff[o] + (perm ? lane_pixel_perm(mr) : mr);
+                    const int m = frag_pixel(perm, rowoff[o] >> 5, mr);
                     const TilePix tp = tile_pix(p, m);
                     const int tx = tp.tx, ty = tp.ty, bl = tp.bl;
                     const bool valid = (b0 + bl < p.B) && (oy0 + ty < p.OH) && (ox0 + tx < p.OW) && (ox0 + tx >= 0);
@@ -1214,7 +1230,7 @@ __global__ __launch_bounds__(512, 2) void conv_glds_kernel(ConvKP p) {
                 }
                 if (want_stats && ((vmask[o] >> r) & 1u)) ssum[o] += v;
                 const int mr = (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                const int ml = rowoff[o] + (perm ? lane_pixel_perm(mr) : mr);
+                const int ml = frag_pixel(perm, rowoff[o] >> 5, mr);
                 Elem<T>::st(sO + ml * PITCH + coloff[o] + l31, v);
             }
         }
@@ -1530,6 +1546,8 @@ int make_plan(const salt_conv_args* a, Plan* pl) {
             // (halo rows padded to whole 1-KB DMA instructions; 8 KB behind the ring take the surplus slots' copies)
             const int64_t buf = (int64_t)cdiv(phalo, 16) * 1024 + (int64_t)a->ntaps * (32 * cfg->NI) * 64;
             k.nbuf = 3 * buf + 8192 <= 160 * 1024 ? 3 : 2;
+            static const bool no_perm8 = getenv("SALT_GLDS_NO_PERM8") != nullptr;
+            k.no_perm8 = no_perm8 ? 1 : 0;
             if (cdiv(phalo, 16) > v2_namax(BM) || 2 * buf + 8192 > 160 * 1024) {
                 if (attempt == 0 && cfg->id != 8) { for (const auto& c : kCfgs) if (c.id == 8) cfg = &c; continue; }
                 // tiny maps (4 x 4 and below: a 128-pixel tile is 8+ images, each with its own halo ring): conv_mfma_kernel's tiles
