@@ -142,7 +142,12 @@ def test_fused_final_block_equals_separate_launches(dtype, monkeypatch):
     assert rel(a[2], b[2]) <= tol, rel(a[2], b[2])                             # first-step logits
     assert abs(a[0] - b[0]) <= tol * max(1.0, abs(b[0])) and abs(a[1] - b[1]) <= 10 * tol * max(1.0, abs(b[1])), (a[:2], b[:2])
     assert rel(a[3], b[3]) <= (2e-4 if dtype == 'f32' else 3e-2), rel(a[3], b[3])      # whole flat gradient of step 1
-    assert rel(a[4], b[4]) <= 2e-3, rel(a[4], b[4])      # parameters after two Adam steps (sign-like updates amplify last-bit gradient differences)
+    # parameters after two Adam steps.  Adam's first updates are sign-like (|update| <= lr whatever the gradient's size), so a last-bit
+    # difference in a near-zero gradient becomes a difference of up to 2 lr per step: the bound that holds by construction is
+    # 2 steps x 2 lr per element; the relative L2 is what is typical (fp32: few elements flip; bf16: 2e-3 .. 8e-3 depending on which
+    # rounding the summation order of the day realises - it moved from 1.9e-3 to 7.7e-3 when conv_glds_kernel's lane order changed)
+    assert float((a[4] - b[4]).abs().max()) <= 4 * 1e-3 * 1.01, float((a[4] - b[4]).abs().max())
+    assert rel(a[4], b[4]) <= (2e-3 if dtype == 'f32' else 2e-2), rel(a[4], b[4])
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
